@@ -1,0 +1,320 @@
+"""CPU oracle for the EGNN.forward hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+This file is a plain-numpy restatement of the algorithm in the reference
+(lucidrains/egnn-pytorch v0.2.8).  Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import it, and only as the *checker*: the shipped
+path (`egnn_pytorch_amd`) never imports anything under `oracle/` and raises when its HIP
+library is missing.
+
+Parity pin: the reference publishes no golden vectors.  This oracle is
+pinned instead against outputs of the reference itself, generated in the dev container by
+`tests/golden/make_golden.py` (imports `/root/reference`) and committed as
+`tests/golden/*.npz`; `tests/test_oracle_golden.py` checks the oracle against every one of
+them, and `tests/test_oracle_vs_reference.py` re-runs the live reference when it is
+present.
+
+Every function cites the reference lines it restates (paths relative to /root/reference).
+The arithmetic is deliberately the reference's *unfactorised* op order (materialised
+edge_input, one Linear over the concatenation) so that the oracle is an independent check
+of the factorised HIP path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RANK_MASKED = 1e5      # egnn_pytorch/egnn_pytorch.py:242
+RANK_SELF = -1.0       # egnn_pytorch/egnn_pytorch.py:255
+RANK_ADJ = 0.0         # egnn_pytorch/egnn_pytorch.py:256
+
+
+# --------------------------------------------------------------------------- helpers
+
+def silu(x):
+    """nn.SiLU  (egnn_pytorch/egnn_pytorch.py:56-60): x * sigmoid(x)."""
+    return x / (1.0 + np.exp(-x, dtype=x.dtype))
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x, dtype=x.dtype))
+
+
+def linear(x, w, b=None):
+    """nn.Linear: x @ w.T + b."""
+    y = x @ w.T
+    if b is not None:
+        y = y + b
+    return y
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    """nn.LayerNorm(dim) as used at egnn_pytorch/egnn_pytorch.py:191,335 (biased variance)."""
+    mu = x.mean(axis=-1, keepdims=True, dtype=x.dtype)
+    xc = x - mu
+    var = (xc * xc).mean(axis=-1, keepdims=True, dtype=x.dtype)
+    return xc / np.sqrt(var + x.dtype.type(eps)) * weight + bias
+
+
+def safe_div(num, den, eps=1e-8):
+    """egnn_pytorch/egnn_pytorch.py:13-16."""
+    res = num / np.maximum(den, num.dtype.type(eps))
+    res = np.where(den == 0, num.dtype.type(0), res)
+    return res
+
+
+def fourier_encode_dist(x, num_encodings):
+    """egnn_pytorch/egnn_pytorch.py:34-41.  x: (...,) -> (..., 2F+1) = [sin.., cos.., x]."""
+    x = x[..., None]
+    scales = (2.0 ** np.arange(num_encodings)).astype(x.dtype)
+    xs = x / scales
+    return np.concatenate([np.sin(xs), np.cos(xs), x], axis=-1)
+
+
+def pairwise(coors):
+    """egnn_pytorch/egnn_pytorch.py:232-233.
+
+    rel_coors[b,i,j,:] = coors[b,i] - coors[b,j];  rel_dist = sum_c rel^2.
+    For C == 3 the reference's CPU result is bit-identical to ((dx*dx + dy*dy) + dz*dz) with
+    separately rounded multiplies and adds; that order is pinned here.
+    """
+    rel = coors[:, :, None, :] - coors[:, None, :, :]
+    sq = rel * rel
+    dist = sq[..., 0]
+    for c in range(1, coors.shape[-1]):
+        dist = dist + sq[..., c]
+    return rel, dist
+
+
+def build_ranking(rel_dist, mask, adj_mat):
+    """egnn_pytorch/egnn_pytorch.py:237-256.  Returns (ranking (B,N,N), adj_mat without diagonal)."""
+    b, n, _ = rel_dist.shape
+    ranking = rel_dist.copy()
+    if mask is not None:
+        rank_mask = mask[:, :, None] & mask[:, None, :]
+        ranking[~rank_mask] = rel_dist.dtype.type(RANK_MASKED)
+    adj = None
+    if adj_mat is not None:
+        adj = np.broadcast_to(adj_mat, (b, n, n)).copy() if adj_mat.ndim == 2 else adj_mat.copy()
+        eye = np.eye(n, dtype=bool)[None]
+        adj = adj & ~eye
+        ranking[np.broadcast_to(eye, ranking.shape)] = rel_dist.dtype.type(RANK_SELF)
+        ranking[adj] = rel_dist.dtype.type(RANK_ADJ)
+    return ranking, adj
+
+
+def topk_smallest(ranking, k):
+    """Tensor.topk(k, dim=-1, largest=False) at egnn_pytorch/egnn_pytorch.py:258.
+
+    Values ascending.  Tie order: the reference's (ATen) order is implementation-defined;
+    the oracle and the HIP kernel both use ascending index."""
+    if k > ranking.shape[-1]:
+        raise RuntimeError("selected index k out of range")       # what torch.topk raises
+    idx = np.argsort(ranking, axis=-1, kind="stable")[..., :k]
+    val = np.take_along_axis(ranking, idx, axis=-1)
+    return val, idx
+
+
+def sparse_num_nearest(adj_mat):
+    """egnn_pytorch/egnn_pytorch.py:249: int(adj_mat.float().sum(-1).max()) -- computed BEFORE the
+    diagonal is cleared, so a set diagonal is counted."""
+    if adj_mat.size == 0:
+        return 0
+    return int(adj_mat.astype(np.float32).sum(axis=-1).max())
+
+
+# --------------------------------------------------------------------------- the layer
+
+class EGNNConfig:
+    """Constructor arguments of EGNN (egnn_pytorch/egnn_pytorch.py:149-168)."""
+
+    def __init__(self, dim, edge_dim=0, m_dim=16, fourier_features=0, num_nearest_neighbors=0,
+                 dropout=0.0, init_eps=1e-3, norm_feats=False, norm_coors=False,
+                 norm_coors_scale_init=1e-2, update_feats=True, update_coors=True,
+                 only_sparse_neighbors=False, valid_radius=float("inf"), m_pool_method="sum",
+                 soft_edges=False, coor_weights_clamp_value=None):
+        assert m_pool_method in {"sum", "mean"}
+        assert update_feats or update_coors
+        self.dim = dim
+        self.edge_dim = edge_dim
+        self.m_dim = m_dim
+        self.fourier_features = fourier_features
+        self.num_nearest_neighbors = num_nearest_neighbors
+        self.norm_feats = norm_feats
+        self.norm_coors = norm_coors
+        self.update_feats = update_feats
+        self.update_coors = update_coors
+        self.only_sparse_neighbors = only_sparse_neighbors
+        self.valid_radius = valid_radius
+        self.m_pool_method = m_pool_method
+        self.soft_edges = soft_edges
+        self.coor_weights_clamp_value = coor_weights_clamp_value
+
+
+def egnn_forward(cfg, params, feats, coors, edges=None, mask=None, adj_mat=None, prefix="",
+                 return_neighbors=False):
+    """EGNN.forward (egnn_pytorch/egnn_pytorch.py:224-341), eval mode (dropout = identity).
+
+    `params`: mapping of reference state_dict key -> ndarray (keys as listed in SURVEY.md §8b).
+    Returns (node_out, coors_out) and, if return_neighbors, also (nbhd_ranking, nbhd_indices)
+    (None on the dense path)."""
+    p = lambda k: params[prefix + k]
+    dt = feats.dtype
+    b, n, d = feats.shape
+    num_nearest = cfg.num_nearest_neighbors
+    valid_radius = cfg.valid_radius
+    use_nearest = num_nearest > 0 or cfg.only_sparse_neighbors                       # :230
+
+    rel_coors, rel_dist = pairwise(coors)                                           # :232-233
+    nbhd_ranking = nbhd_indices = None
+
+    if use_nearest:
+        ranking, _ = build_ranking(rel_dist, mask, adj_mat)                         # :237-256
+        if adj_mat is not None and cfg.only_sparse_neighbors:
+            adj_full = np.broadcast_to(adj_mat, (b, n, n)) if adj_mat.ndim == 2 else adj_mat
+            num_nearest = sparse_num_nearest(adj_full)                              # :249
+            valid_radius = 0                                                        # :250
+        nbhd_ranking, nbhd_indices = topk_smallest(ranking, num_nearest)            # :258
+        nbhd_mask = nbhd_ranking <= valid_radius                                    # :260
+        bi = np.arange(b)[:, None, None]
+        ii = np.arange(n)[None, :, None]
+        rel_coors = rel_coors[bi, ii, nbhd_indices]                                 # :262
+        rel_dist = rel_dist[bi, ii, nbhd_indices]                                   # :263
+        if edges is not None:
+            edges = edges[bi, ii, nbhd_indices]                                     # :266
+        feats_j = feats[bi, nbhd_indices]                                           # :275
+        k = num_nearest
+    else:
+        feats_j = np.broadcast_to(feats[:, None, :, :], (b, n, n, d))               # :277
+        k = n
+
+    if cfg.fourier_features > 0:
+        dist_feat = fourier_encode_dist(rel_dist, cfg.fourier_features)             # :270-272
+    else:
+        dist_feat = rel_dist[..., None]
+
+    feats_i = np.broadcast_to(feats[:, :, None, :], (b, n, k, d))                   # :279-280
+    edge_input = np.concatenate([feats_i, feats_j, dist_feat], axis=-1)             # :282
+    if edges is not None:
+        edge_input = np.concatenate([edge_input, edges], axis=-1)                   # :285
+
+    h = silu(linear(edge_input, p("edge_mlp.0.weight"), p("edge_mlp.0.bias")))      # :287 (:178-184)
+    m_ij = silu(linear(h, p("edge_mlp.3.weight"), p("edge_mlp.3.bias")))
+    del h, edge_input
+
+    if cfg.soft_edges:                                                              # :289-290
+        gate = sigmoid(linear(m_ij, p("edge_gate.0.weight"), p("edge_gate.0.bias")))
+        m_ij = m_ij * gate
+
+    emask = None
+    if mask is not None:                                                            # :292-300
+        mask_i = mask[:, :, None]
+        if use_nearest:
+            mask_j = mask[np.arange(b)[:, None, None], nbhd_indices]
+            emask = (mask_i & mask_j) & nbhd_mask
+        else:
+            emask = mask_i & mask[:, None, :]
+
+    if cfg.update_coors:                                                            # :302-317
+        cw = silu(linear(m_ij, p("coors_mlp.0.weight"), p("coors_mlp.0.bias")))
+        cw = linear(cw, p("coors_mlp.3.weight"), p("coors_mlp.3.bias"))[..., 0]
+        rc = rel_coors
+        if cfg.norm_coors:                                                          # CoorsNorm :67-77
+            nrm = np.sqrt((rc * rc).sum(axis=-1, keepdims=True, dtype=dt))
+            rc = rc / np.maximum(nrm, dt.type(1e-8)) * p("coors_norm.scale")
+        if emask is not None:
+            cw = np.where(emask, cw, dt.type(0))                                    # :308-309
+        if cfg.coor_weights_clamp_value is not None:                                # :311-313
+            cv = dt.type(cfg.coor_weights_clamp_value)
+            cw = np.clip(cw, -cv, cv)
+        coors_out = np.einsum("bij,bijc->bic", cw, rc).astype(dt) + coors           # :315
+    else:
+        coors_out = coors
+
+    if cfg.update_feats:                                                            # :319-339
+        if emask is not None:
+            m_ij = np.where(emask[..., None], m_ij, dt.type(0))                     # :320-322
+        if cfg.m_pool_method == "mean":
+            if emask is not None:
+                mask_sum = emask[..., None].sum(axis=-2).astype(dt)                 # :326-327
+                m_i = safe_div(m_ij.sum(axis=-2, dtype=dt), mask_sum)
+            else:
+                m_i = m_ij.mean(axis=-2, dtype=dt)                                  # :330
+        else:
+            m_i = m_ij.sum(axis=-2, dtype=dt)                                       # :333
+        normed = feats
+        if cfg.norm_feats:
+            normed = layer_norm(feats, p("node_norm.weight"), p("node_norm.bias"))  # :335
+        node_in = np.concatenate([normed, m_i], axis=-1)                            # :336
+        hid = silu(linear(node_in, p("node_mlp.0.weight"), p("node_mlp.0.bias")))
+        node_out = linear(hid, p("node_mlp.3.weight"), p("node_mlp.3.bias")) + feats  # :337
+    else:
+        node_out = feats
+
+    node_out = node_out.astype(dt, copy=False)
+    coors_out = coors_out.astype(dt, copy=False)
+    if return_neighbors:
+        return node_out, coors_out, nbhd_ranking, nbhd_indices
+    return node_out, coors_out
+
+
+def egnn_network_forward(depth, cfg, params, feats, coors, adj_mat=None, edges=None, mask=None,
+                         return_coor_changes=False):
+    """The EGNN_Network layer loop (egnn_pytorch/egnn_pytorch.py:442-454) for float `feats`
+    (no token / position / edge embeddings, no adjacency-degree expansion, no global attention:
+    those front-end pieces are outside the hot path).
+    `cfg` must have norm_feats=True (forced at :387).  State-dict prefix: layers.{l}.1."""
+    assert cfg.norm_feats
+    coor_changes = [coors]
+    for layer in range(depth):
+        feats, coors = egnn_forward(cfg, params, feats, coors, edges=edges, mask=mask,
+                                    adj_mat=adj_mat, prefix=f"layers.{layer}.1.")
+        coor_changes.append(coors)
+    if return_coor_changes:
+        return feats, coors, coor_changes
+    return feats, coors
+
+
+# --------------------------------------------------------------------------- parameter helpers
+
+def param_shapes(cfg):
+    """Shapes of the reference state_dict, in registration order."""
+    din = 2 * cfg.fourier_features + 2 * cfg.dim + cfg.edge_dim + 1                # :175
+    m = cfg.m_dim
+    shapes = {
+        "edge_mlp.0.weight": (2 * din, din), "edge_mlp.0.bias": (2 * din,),
+        "edge_mlp.3.weight": (m, 2 * din), "edge_mlp.3.bias": (m,),
+    }
+    if cfg.soft_edges:
+        shapes.update({"edge_gate.0.weight": (1, m), "edge_gate.0.bias": (1,)})
+    if cfg.norm_feats:
+        shapes.update({"node_norm.weight": (cfg.dim,), "node_norm.bias": (cfg.dim,)})
+    if cfg.norm_coors:
+        shapes.update({"coors_norm.scale": (1,)})
+    if cfg.update_feats:
+        shapes.update({"node_mlp.0.weight": (2 * cfg.dim, cfg.dim + m), "node_mlp.0.bias": (2 * cfg.dim,),
+                       "node_mlp.3.weight": (cfg.dim, 2 * cfg.dim), "node_mlp.3.bias": (cfg.dim,)})
+    if cfg.update_coors:
+        shapes.update({"coors_mlp.0.weight": (4 * m, m), "coors_mlp.0.bias": (4 * m,),
+                       "coors_mlp.3.weight": (1, 4 * m), "coors_mlp.3.bias": (1,)})
+    return shapes
+
+
+def random_params(cfg, seed, prefix="", dtype=np.float32, scale="xavier"):
+    """Seeded parameters at a scale that makes parity discriminating (the
+    reference's default std-1e-3 init makes feature parity vacuous)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shp in param_shapes(cfg).items():
+        if name.endswith("weight") and len(shp) == 2:
+            std = np.sqrt(2.0 / (shp[0] + shp[1])) if scale == "xavier" else 1e-3
+            out[prefix + name] = (rng.standard_normal(shp) * std).astype(dtype)
+        elif name == "node_norm.weight":
+            out[prefix + name] = (1.0 + 0.1 * rng.standard_normal(shp)).astype(dtype)
+        elif name == "node_norm.bias":
+            out[prefix + name] = (0.1 * rng.standard_normal(shp)).astype(dtype)
+        elif name == "coors_norm.scale":
+            out[prefix + name] = np.full(shp, 1e-2 if scale != "xavier" else 0.5, dtype=dtype)
+        else:   # Linear biases: U(+-1/sqrt(fan_in))
+            wshape = param_shapes(cfg)[name.replace("bias", "weight")]
+            bound = 1.0 / np.sqrt(wshape[1])
+            out[prefix + name] = rng.uniform(-bound, bound, shp).astype(dtype)
+    return out

@@ -1,0 +1,94 @@
+"""Oracle vs the LIVE reference (skipped where /root/reference is absent, e.g. on the GPU box).
+This is the differential pin of SURVEY.md §8c at BASELINE.json-like layer widths."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import egnn_oracle as O
+from tests._util import check_neighbors
+
+REF = os.environ.get("EGNN_REFERENCE", "/root/reference")
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "egnn_pytorch")),
+                                reason="live reference not present")
+
+
+def _ref():
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import egnn_pytorch
+    return egnn_pytorch
+
+
+def _xavier(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in module.parameters():
+            if p.ndim == 2:
+                p.copy_(torch.randn(p.shape, generator=g) * (2.0 / (p.shape[0] + p.shape[1])) ** 0.5)
+
+
+@pytest.mark.parametrize("kwargs,b,n,use_mask", [
+    (dict(dim=512, num_nearest_neighbors=32), 1, 192, True),      # north-star layer, reduced N
+    (dict(dim=512), 1, 48, False),                                # config 2 layer, reduced N
+    (dict(dim=128, num_nearest_neighbors=32, norm_feats=True), 2, 128, True),   # config 3 layer
+    (dict(dim=256, num_nearest_neighbors=32, norm_feats=True, norm_coors=True), 1, 128, True),  # config 5 layer
+])
+def test_layer(kwargs, b, n, use_mask):
+    ref = _ref()
+    torch.manual_seed(0)
+    layer = ref.EGNN(**kwargs).eval()
+    _xavier(layer, 11)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(b, n, kwargs["dim"], generator=g)
+    coors = torch.randn(b, n, 3, generator=g)
+    mask = None
+    if use_mask:
+        lens = torch.randint(n // 2, n + 1, (b,), generator=g)
+        mask = torch.arange(n)[None] < lens[:, None]
+    captured = []
+    orig = torch.Tensor.topk
+
+    def spy(t, *a, **kw):
+        out = orig(t, *a, **kw)
+        captured.append(out)
+        return out
+
+    torch.Tensor.topk = spy
+    try:
+        with torch.no_grad():
+            rn, rc = layer(feats, coors, mask=mask)
+    finally:
+        torch.Tensor.topk = orig
+    params = {k: v.numpy() for k, v in layer.state_dict().items()}
+    cfg = O.EGNNConfig(**kwargs)
+    node, co, nr, ni = O.egnn_forward(cfg, params, feats.numpy(), coors.numpy(),
+                                      mask=None if mask is None else mask.numpy(), return_neighbors=True)
+    if captured:
+        check_neighbors(captured[0][0].numpy(), captured[0][1].numpy().astype(np.int32),
+                        nr.astype(np.float32), ni.astype(np.int32))
+    np.testing.assert_allclose(node, rn.numpy(), atol=3e-5, rtol=0)
+    np.testing.assert_allclose(co, rc.numpy(), atol=3e-5, rtol=0)
+
+
+def test_sparse_chain_config4_layer():
+    ref = _ref()
+    n, b = 64, 2
+    layer = ref.EGNN(dim=512, edge_dim=4, only_sparse_neighbors=True).eval()
+    _xavier(layer, 3)
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn(b, n, 512, generator=g)
+    coors = torch.randn(b, n, 3, generator=g)
+    edges = torch.randn(b, n, n, 4, generator=g)
+    mask = torch.ones(b, n, dtype=torch.bool)
+    i = torch.arange(n)
+    adj = (i[:, None] - i[None, :]).abs() <= 1
+    with torch.no_grad():
+        rn, rc = layer(feats, coors, edges, mask, adj)
+    params = {k: v.numpy() for k, v in layer.state_dict().items()}
+    cfg = O.EGNNConfig(dim=512, edge_dim=4, only_sparse_neighbors=True)
+    node, co = O.egnn_forward(cfg, params, feats.numpy(), coors.numpy(), edges.numpy(), mask.numpy(), adj.numpy())
+    np.testing.assert_allclose(node, rn.numpy(), atol=3e-5, rtol=0)
+    np.testing.assert_allclose(co, rc.numpy(), atol=3e-5, rtol=0)
