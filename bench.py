@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""bench.py -- EGNN.forward throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one EGNN.forward over one batch of synthetic graphs: the north-star workload
+EGNN(dim=512, num_nearest_neighbors=32), B=64 graphs x N=1024 nodes per GPU, fp32, inference
+(eval / no_grad), inputs resident in HBM before the timed region.  Multi-GPU = independent graphs
+sharded over ranks (weak scaling: 64 graphs per GPU), no collective in the data path; the timed
+region is bracketed by barrier + synchronize and the max over ranks is taken.
+
+Rank 0 prints ONE JSON line: the driver contract plus
+  "roofline"     -- the dominant kernel against its roofline, duration measured live with events on
+                    the launch stream (the kernels are launched on torch's current stream);
+  "kernels"      -- the same for every kernel of the step;
+  "cpu_baseline" -- the CPU oracle (a port of the reference's algorithm, numpy) on a bounded sample
+                    of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# chip peaks: /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+HBM_PEAK_GBS = 8000.0          # HBM3E spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_* (f32 in / f32 acc), dense
+
+WORKLOADS = {
+    # name: (layer kwargs, graphs per GPU, nodes)
+    "north_star": (dict(dim=512, num_nearest_neighbors=32), 64, 1024),
+    "c2_dense": (dict(dim=512), 8, 256),
+}
+
+
+def model_counts(kwargs, b, n):
+    """Algorithmic bytes / executed flops per kernel for one step."""
+    dim = kwargs["dim"]
+    k = kwargs.get("num_nearest_neighbors", 0) or n
+    edge_dim = kwargs.get("edge_dim", 0)
+    m = kwargs.get("m_dim", 16)
+    din = 2 * dim + 1 + edge_dim
+    h = 2 * din
+    hp = (h + 31) // 32 * 32
+    bn, e = b * n, b * n * k
+    weights = 4 * (h * din + h + m * h + m + (dim + m) * 2 * dim + 2 * dim + 2 * dim * dim + dim + 4 * m * m + 9 * m + 1)
+    return {
+        # every edge reads its neighbour's feature row once, every node row read + written once
+        "edge_fused": dict(bound="hbm", bytes=4 * dim * (e + 2 * bn) + 4 * e + 24 * bn + bn + 4 * edge_dim * e + weights,
+                           flops=2.0 * e * hp * 16 + 2.0 * e * (16 * 64 + 64)),
+        "node_proj": dict(bound="mfma", flops=2.0 * bn * dim * 2 * hp, bytes=4 * (bn * dim + 2 * hp * dim + bn * 2 * hp)),
+        "node_mlp0": dict(bound="mfma", flops=2.0 * bn * (dim + m) * 2 * dim,
+                          bytes=4 * (bn * (dim + m) + 2 * dim * (dim + m) + bn * 2 * dim)),
+        "node_mlp1": dict(bound="mfma", flops=2.0 * bn * 2 * dim * dim, bytes=4 * (bn * 2 * dim + 2 * dim * dim + 2 * bn * dim)),
+        "node_prep": dict(bound="hbm", bytes=4 * 2 * bn * (dim + m), flops=8.0 * bn * dim),
+        # fused select: compulsory traffic is tiny; the comparable figure is one fp32 rank per ordered pair
+        "knn_select": dict(bound="hbm", bytes=4 * b * n * n, flops=8.0 * b * n * n),
+    }, dict(E=e, K=k, H=h, Hp=hp)
+
+
+def roofline_entry(name, counts, ms):
+    c = counts[name]
+    sec = ms * 1e-3
+    if c["bound"] == "hbm":
+        ach = c["bytes"] / sec / 1e9
+        return dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBS, 4), avg_ms=round(ms, 4), algorithmic_bytes=int(c["bytes"]))
+    ach = c["flops"] / sec / 1e12
+    return dict(kernel=name, bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), avg_ms=round(ms, 4), flops=c["flops"])
+
+
+def make_inputs(kwargs, b, n, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(b, n, kwargs["dim"], generator=g)
+    coors = torch.randn(b, n, 3, generator=g)
+    mask = torch.ones(b, n, dtype=torch.bool)          # throughput runs: all-True mask
+    return feats.to(device), coors.to(device), mask.to(device)
+
+
+def timed_region(step, steps, warmup, sync, barrier, reduce_max):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides;
+    returns the max over ranks of the elapsed seconds."""
+    for _ in range(warmup):
+        step()
+    sync()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    barrier()
+    sync()
+    return reduce_max(time.perf_counter() - t0)
+
+
+def cpu_baseline(kwargs, n, budget_s=25.0):
+    """The oracle (numpy port of the reference's unfactorised algorithm) on a bounded sample of the same
+    workload: B_cpu graphs of N nodes, default-scale weights, on this box's host cores."""
+    import numpy as np
+    from oracle import egnn_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    cfg = O.EGNNConfig(**kwargs)
+    params = O.random_params(cfg, seed=0)
+    rng = np.random.default_rng(0)
+    b_cpu = 1
+    feats = rng.standard_normal((b_cpu, n, kwargs["dim"])).astype(np.float32)
+    coors = rng.standard_normal((b_cpu, n, 3)).astype(np.float32)
+    mask = np.ones((b_cpu, n), bool)
+    best, reps, spent = None, 0, 0.0
+    while reps < 5 and (spent < budget_s * 0.6 or reps < 2):
+        t0 = time.perf_counter()
+        O.egnn_forward(cfg, params, feats, coors, mask=mask)
+        dt = time.perf_counter() - t0
+        spent += dt
+        reps += 1
+        best = dt if best is None else min(best, dt)
+    return dict(value=round(b_cpu / best, 4), unit="graphs/s", cores=int(threads), kind="port",
+                sample=f"oracle/egnn_oracle.py (numpy fp32), {b_cpu} graph x N={n}, min of {reps} runs, "
+                       f"{best:.2f} s per forward; host {os.cpu_count()} logical cores")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="north_star", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path to time")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
+
+    from egnn_pytorch_amd import EGNN, phase_timer
+
+    kwargs, b, n = WORKLOADS[args.workload]
+    torch.manual_seed(0)
+    layer = EGNN(**kwargs).to(device).eval()
+    if dist is not None:
+        from egnn_pytorch_amd.sharding import broadcast_parameters
+        broadcast_parameters(layer)                       # the only collective: one-off weight replication
+    feats, coors, mask = make_inputs(kwargs, b, n, device, seed=1000 + rank)   # this rank's shard of the batch
+
+    def step():
+        layer(feats, coors, mask=mask)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def reduce_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    elapsed = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, reduce_max)
+
+    # ---- per-kernel durations (events on the launch stream), outside the timed region
+    with phase_timer() as pt:
+        for _ in range(5):
+            step()
+    per_kernel = {k: sum(v) / len(v) for k, v in pt.summary().items()}
+
+    if rank == 0:
+        counts, shp = model_counts(kwargs, b, n)
+        kernels = [roofline_entry(k, counts, ms) for k, ms in sorted(per_kernel.items(), key=lambda kv: -kv[1])
+                   if k in counts]
+        dominant = dict(kernels[0])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dominant["kernel"])
+            except Exception:
+                traffic = None
+        dominant["traffic"] = traffic
+        graphs = world * b * args.steps
+        value = graphs / elapsed
+        out = {
+            "metric": "EGNN.forward graphs/sec", "value": round(value, 2), "unit": "graphs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "edges_per_s": round(value * n * shp["K"], 1),
+            "config": {"workload": f"EGNN(dim={kwargs['dim']}, k={shp['K']}) B={b}/GPU N={n} fp32 masked k-NN"
+                       if "num_nearest_neighbors" in kwargs else f"EGNN(dim={kwargs['dim']}) dense B={b}/GPU N={n} fp32",
+                       "graphs_per_gpu": b, "nodes": n, "neighbors": shp["K"], "global_batch": world * b,
+                       "parallelism": f"batch-shard x{world} (no data-path collective)"},
+            "roofline": dominant,
+            "kernels": kernels,
+            "sum_kernel_ms": round(sum(per_kernel.values()), 4),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kwargs, n)
+        print(json.dumps(out), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

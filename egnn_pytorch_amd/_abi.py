@@ -1,0 +1,110 @@
+"""ctypes binding of libegnn_hip.so (C ABI declared in include/egnn_hip.h).
+
+The library is the product: there is NO fallback.  If it is missing or does not export the
+symbols of the header this module raises, and every forward call raises with it.
+
+`import torch` happens before `ctypes.CDLL` on purpose: torch bundles its own libamdhip64.so.7
+(same SONAME as /opt/rocm's); loading torch first makes our library bind to the HIP runtime torch
+already initialised, so `torch.cuda.current_stream().cuda_stream` and `tensor.data_ptr()` are valid
+inside the library (two HIP runtimes in one process would make stream handles unusable).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+ABI_VERSION = 1
+_LIB_NAME = "libegnn_hip.so"
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+
+# every symbol include/egnn_hip.h declares
+SYMBOLS = (
+    "egnn_abi_version", "egnn_error_string", "egnn_padded_hidden", "egnn_knn_select_f32",
+    "egnn_adj_max_degree_u8", "egnn_linear_f32", "egnn_node_prep_f32", "egnn_edge_fused_f32",
+)
+
+
+class EdgeArgs(Structure):
+    """Mirror of `struct egnn_edge_args` (include/egnn_hip.h) -- field order and types must match."""
+    _fields_ = [
+        ("B", c_int32), ("N", c_int32), ("K", c_int32), ("dim", c_int32), ("m_dim", c_int32),
+        ("H", c_int32), ("Hp", c_int32), ("fourier", c_int32), ("edge_dim", c_int32),
+        ("S", c_int32), ("Sp", c_int32),
+        ("Pi", c_void_p), ("Pj", c_void_p), ("ldp", c_int64),
+        ("Ws", c_void_p), ("W2f", c_void_p), ("b2", c_void_p),
+        ("gate_w", c_void_p), ("gate_b", c_void_p),
+        ("W3", c_void_p), ("b3", c_void_p), ("W4", c_void_p), ("b4", c_void_p),
+        ("coors_scale", c_void_p),
+        ("coors", c_void_p), ("edges", c_void_p), ("mask", c_void_p), ("idx", c_void_p), ("rank", c_void_p),
+        ("valid_radius", c_float), ("clamp", c_float), ("pool_mean", c_int32),
+        ("m_i", c_void_p), ("coors_out", c_void_p),
+    ]
+
+
+class EGNNHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return os.environ.get("EGNN_HIP_LIB", os.path.join(_PKG_DIR, _LIB_NAME))
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises EGNNHipError if the library is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise EGNNHipError(
+            f"{path} not found: the HIP extension is not built. Build it with "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (or egnn_pytorch_amd/csrc/build.sh). "
+            f"egnn_pytorch_amd has no CPU / PyTorch fallback.")
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as exc:  # pragma: no cover
+        raise EGNNHipError(f"cannot load {path}: {exc}") from exc
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise EGNNHipError(f"{path} does not export {missing}; rebuild it")
+
+    lib.egnn_abi_version.restype = c_int
+    lib.egnn_abi_version.argtypes = []
+    lib.egnn_error_string.restype = c_char_p
+    lib.egnn_error_string.argtypes = [c_int]
+    lib.egnn_padded_hidden.restype = c_int
+    lib.egnn_padded_hidden.argtypes = [c_int]
+    lib.egnn_knn_select_f32.restype = c_int
+    lib.egnn_knn_select_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p]
+    lib.egnn_adj_max_degree_u8.restype = c_int
+    lib.egnn_adj_max_degree_u8.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_void_p]
+    lib.egnn_linear_f32.restype = c_int
+    lib.egnn_linear_f32.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                    c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]
+    lib.egnn_node_prep_f32.restype = c_int
+    lib.egnn_node_prep_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
+                                       c_int, c_int, c_void_p]
+    lib.egnn_edge_fused_f32.restype = c_int
+    lib.egnn_edge_fused_f32.argtypes = [POINTER(EdgeArgs), c_void_p]
+
+    if lib.egnn_abi_version() != ABI_VERSION:
+        raise EGNNHipError(f"{path}: ABI version {lib.egnn_abi_version()} != {ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    """Map a C-ABI return code to an exception (0 = ok, <0 = EGNN_E_*, >0 = hipError_t)."""
+    if code == 0:
+        return
+    msg = load().egnn_error_string(code).decode()
+    if code == -5:   # EGNN_E_K_GT_N -- same text torch.topk raises in the reference (egnn_pytorch.py:258)
+        raise RuntimeError(f"{what}: {msg}")
+    raise EGNNHipError(f"{what} failed with code {code}: {msg}")

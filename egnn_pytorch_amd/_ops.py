@@ -1,0 +1,139 @@
+"""Thin wrappers: torch tensors (device memory + stream plumbing) -> C-ABI calls of libegnn_hip.so.
+
+Nothing here computes: each function validates, allocates outputs with torch (caching allocator) and
+enqueues one HIP kernel on torch's current stream.
+"""
+from __future__ import annotations
+
+import contextlib
+from ctypes import byref
+
+import torch
+
+from . import _abi
+
+
+class PhaseTimer:
+    """Optional per-kernel timing with events on the launch stream (used by bench.py / profiling).
+
+    with phase_timer() as t: layer(...)   ->  t.summary() = {kernel: [ms, ...]}
+    """
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1 in self.records:
+            out.setdefault(name, []).append(e0.elapsed_time(e1))
+        return out
+
+
+_timer = None
+
+
+@contextlib.contextmanager
+def phase_timer():
+    global _timer
+    prev, _timer = _timer, PhaseTimer()
+    try:
+        yield _timer
+    finally:
+        _timer = prev
+
+
+@contextlib.contextmanager
+def _timed(name):
+    if _timer is None:
+        yield
+        return
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    yield
+    e1.record()
+    _timer.records.append((name, e0, e1))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _u8(t):
+    """bool tensor -> same storage viewed as bytes."""
+    if t is None:
+        return None
+    if t.dtype != torch.bool:
+        raise TypeError(f"mask / adj_mat must be torch.bool (got {t.dtype})")
+    return t.contiguous().view(torch.uint8)
+
+
+def knn_select(coors, mask, adj_mat, k):
+    """(idx int32 (B,N,K), rank fp32 (B,N,K)) -- egnn_knn_select_f32."""
+    b, n, _ = coors.shape
+    idx = torch.empty(b, n, k, dtype=torch.int32, device=coors.device)
+    rank = torch.empty(b, n, k, dtype=torch.float32, device=coors.device)
+    m8 = _u8(mask)
+    a8 = _u8(adj_mat)
+    stride = 0
+    if a8 is not None:
+        if a8.dim() == 3:
+            if a8.shape != (b, n, n):
+                raise ValueError(f"adj_mat shape {tuple(a8.shape)} != {(b, n, n)}")
+            stride = n * n
+        elif a8.shape != (n, n):
+            raise ValueError(f"adj_mat shape {tuple(a8.shape)} != {(n, n)}")
+    with _timed("knn_select"):
+        rc = _abi.load().egnn_knn_select_f32(_ptr(coors), _ptr(m8), _ptr(a8), stride, b, n, k,
+                                             _ptr(idx), _ptr(rank), _stream())
+    _abi.check(rc, "egnn_knn_select_f32")
+    return idx, rank
+
+
+def adj_max_degree(adj_mat):
+    """int(adj_mat.float().sum(-1).max()) -- one device->host read, like the reference's .item() (:249)."""
+    a8 = _u8(adj_mat)
+    n = a8.shape[-1]
+    rows = a8.numel() // n
+    out = torch.empty(1, dtype=torch.int32, device=a8.device)
+    rc = _abi.load().egnn_adj_max_degree_u8(_ptr(a8), rows, n, _ptr(out), _stream())
+    _abi.check(rc, "egnn_adj_max_degree_u8")
+    return int(out.item())
+
+
+def linear(a, w, bias=None, residual=None, act=0, name="linear"):
+    """act(a @ w.T + bias) (+ residual) -- egnn_linear_f32.  a: (M,K) fp32 contiguous; w: (N,K)."""
+    m, k = a.shape
+    n = w.shape[0]
+    assert w.shape[1] == k and a.is_contiguous() and w.is_contiguous()
+    c = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    ldr = 0
+    if residual is not None:
+        assert residual.shape == (m, n) and residual.is_contiguous()
+        ldr = n
+    with _timed(name):
+        rc = _abi.load().egnn_linear_f32(_ptr(a), k, _ptr(w), k, _ptr(bias), _ptr(residual), ldr,
+                                         _ptr(c), n, m, n, k, act, _stream())
+    _abi.check(rc, "egnn_linear_f32")
+    return c
+
+
+def node_prep(feats2d, m_i, gamma, beta, eps, m_dim):
+    rows, dim = feats2d.shape
+    out = torch.empty(rows, dim + m_dim, dtype=torch.float32, device=feats2d.device)
+    with _timed("node_prep"):
+        rc = _abi.load().egnn_node_prep_f32(_ptr(feats2d), _ptr(m_i), _ptr(gamma), _ptr(beta), float(eps),
+                                            _ptr(out), rows, dim, m_dim, _stream())
+    _abi.check(rc, "egnn_node_prep_f32")
+    return out
+
+
+def edge_fused(args: _abi.EdgeArgs):
+    with _timed("edge_fused"):
+        rc = _abi.load().egnn_edge_fused_f32(byref(args), _stream())
+    _abi.check(rc, "egnn_edge_fused_f32")

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libegnn_hip.so (gfx950 only) in-tree.  Usage: csrc/build.sh [outdir]
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="${1:-$HERE/..}"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed"
+mkdir -p "$HERE/obj"
+pids=()
+for f in knn_select linear_f32 edge_fused node_ops; do
+  EXTRA=""
+  # the ranking kernel must reproduce the reference's un-fused ((dx*dx+dy*dy)+dz*dz) bit for bit
+  [ "$f" = knn_select ] && EXTRA="-ffp-contract=off"
+  ( "$HIPCC" $FLAGS $EXTRA -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" ) &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libegnn_hip.so" "$HERE"/obj/*.o
+echo "built $OUT/libegnn_hip.so"

@@ -1,0 +1,370 @@
+// The fused edge pass of EGNN.forward on gfx950 (reference: egnn_pytorch/egnn_pytorch.py:262-333).
+//
+// Per edge (b, i, k) with neighbour j = idx[b,i,k] (or j = k on the dense all-pairs path):
+//     x[h]   = Pi[i,h] + Pj[j,h] + sum_s scal[s] * Ws[s,h]        (first Linear of edge_mlp, factorised:
+//                                                                    Pi/Pj are node-level projections)
+//     m_ij   = SiLU(W2 * SiLU(x) + b2)                             (second Linear, H -> m_dim)
+//     m_ij  *= sigmoid(gate_w . m_ij + gate_b)                     (soft_edges)
+//     w_ij   = W4 . SiLU(W3 * m_ij + b3) + b4                      (coors_mlp)
+//     mask, clamp, CoorsNorm;  x_i' = x_i + sum_k w_ij * rel_ij;  m_i = sum_k m_ij  (or mean)
+//
+// Mapping to the machine
+//   * one 256-thread workgroup owns G consecutive nodes of one graph = up to 256 edge slots per round;
+//     each wave owns 64 slots = 4 MFMA tiles of 16 edges.
+//   * the H -> 16 contraction runs on v_mfma_f32_16x16x4_f32 in the "swapped" orientation
+//     D[channel][edge] = sum_h W2[channel][h] * hidden[edge][h]:  lane l (e = l & 15, g = l >> 4) owns edge e
+//     of its tile and the 4 hidden units h0+4g .. h0+4g+3 of every 16-wide step, so
+//        - the gather of Pj (the only HBM/L2-heavy stream) is one 16-byte load per lane per step,
+//        - W2 is read from LDS in pre-built fragment order (lane-linear, conflict free),
+//        - the result lands as D[4g + r][e]: every lane keeps "its" edge for the whole epilogue and holds
+//          exactly the B-operand fragments the coors_mlp MFMAs (16 -> 64) need -- no transposes, no LDS.
+//   * hidden activations (E x H) never leave registers; per-edge results go through a 20 KB LDS buffer and
+//     are summed per node in k order (deterministic, no float atomics).
+//   * W2 / Ws are staged through LDS in chunks of HC hidden columns, shared by the 4 waves.
+//   * blocks are remapped so that each XCD works on a contiguous range of graphs (Pj rows of a graph stay
+//     in that XCD's L2).
+#include "egnn_common.h"
+
+namespace {
+
+constexpr int EDGE_THREADS = 256;
+constexpr int TILES = 4;                 // MFMA tiles (16 edges) per wave
+constexpr int SLOTS_PER_ROUND = 256;     // 4 waves x 4 tiles x 16 edges
+constexpr int HC = 256;                  // hidden columns per LDS chunk
+constexpr int NCH = 20;                  // per-edge channels reduced per node: 16 m | 3 coords | 1 count
+constexpr int GMAX = 64;                 // nodes per workgroup
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+    return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+}
+
+// SP: padded number of per-edge scalar inputs; TPI: consecutive tiles of a wave that share one node i
+// (K % 64 == 0 -> 4, K % 32 == 0 -> 2, else 1 = per-lane Pi rows).
+template <int SP, int TPI>
+__global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* w2s = reinterpret_cast<float*>(smem);            // [HC/16][64][4]
+    float* wss = w2s + HC * 16;                              // [SP][HC]
+    float* ebuf = wss + SP * HC;                             // [256][NCH]
+    float* nodeacc = ebuf + SLOTS_PER_ROUND * NCH;           // [GMAX][NCH]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int e = lane & 15;
+    const int g = lane >> 4;
+
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = v / gpg;
+    const int node0 = (v % gpg) * G;
+    const int N = p.N, K = p.K;
+    const int slots_total = G * K;                           // per node group (may exceed 256 only if G == 1)
+    const int rounds = (slots_total + SLOTS_PER_ROUND - 1) / SLOTS_PER_ROUND;
+    const bool has_mask = p.mask != nullptr;
+    const bool has_rank = p.rank != nullptr && p.idx != nullptr;
+    const size_t bN = (size_t)b * N;
+
+    for (int o = tid; o < GMAX * NCH; o += EDGE_THREADS) nodeacc[o] = 0.f;
+
+    for (int round = 0; round < rounds; ++round) {
+        // ------------------------------------------------------------------ per-slot setup
+        const float* pjp[TILES];
+        const float* pip[TILES];
+        float sc[TILES][SP];
+        float relx[TILES], rely[TILES], relz[TILES];
+        bool fm[TILES];                                      // edge contributes (valid slot and unmasked)
+
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const int q = round * SLOTS_PER_ROUND + wave * 64 + t * 16 + e;
+            int nl = q / K;
+            int k = q - nl * K;
+            int i = node0 + nl;
+            bool valid = (q < slots_total) && (i < N);
+            if (!valid) { i = node0 < N ? node0 : 0; k = 0; }
+            const int j = p.idx ? p.idx[(bN + i) * K + k] : k;
+            const float* ci = p.coors + (bN + i) * 3;
+            const float* cj = p.coors + (bN + j) * 3;
+            float dx, dy, dz;
+            const float d = egnn_sqdist(ci[0], ci[1], ci[2], cj[0], cj[1], cj[2], dx, dy, dz);
+            relx[t] = dx; rely[t] = dy; relz[t] = dz;
+#pragma unroll
+            for (int s = 0; s < SP; ++s) sc[t][s] = 0.f;
+            {
+                const int F = p.fourier;
+                // [sin(d/2^f)..., cos(d/2^f)..., d, edges...]   (egnn_pytorch.py:34-41, 282-285)
+#pragma unroll
+                for (int s = 0; s < SP; ++s) {
+                    float val = 0.f;
+                    if (s < F) val = sinf(d * exp2f(-(float)s));
+                    else if (s < 2 * F) val = cosf(d * exp2f(-(float)(s - F)));
+                    else if (s == 2 * F) val = d;
+                    else if (s < p.S) val = p.edges[((bN + i) * N + j) * p.edge_dim + (s - 2 * F - 1)];
+                    sc[t][s] = val;
+                }
+            }
+            bool em = valid;
+            if (has_mask) {
+                em = em && p.mask[bN + i] && p.mask[bN + j];
+                if (has_rank) em = em && (p.rank[(bN + i) * K + k] <= p.valid_radius);
+            }
+            fm[t] = em;
+            pjp[t] = p.Pj + (bN + j) * p.ldp + 4 * g;
+            pip[t] = p.Pi + (bN + i) * p.ldp + 4 * g;
+        }
+
+        f32x4 acc[TILES];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ------------------------------------------------------------------ main loop over hidden units
+        // Software pipeline: the Pi/Pj rows of step st+1 are requested before step st is computed, so the
+        // gather latency (L2 / Infinity Cache) hides under 16 MFMAs + 64 SiLUs per wave.
+        constexpr int NPI = TILES / TPI;
+        f32x4 pjn[TILES], pin[NPI];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) pjn[t] = *reinterpret_cast<const f32x4*>(pjp[t]);
+#pragma unroll
+        for (int u = 0; u < NPI; ++u) pin[u] = *reinterpret_cast<const f32x4*>(pip[u * TPI]);
+
+        for (int c0 = 0; c0 < p.Hp; c0 += HC) {
+            const int hc = (p.Hp - c0) < HC ? (p.Hp - c0) : HC;
+            __syncthreads();
+            {
+                const float4* src = reinterpret_cast<const float4*>(p.W2f + (size_t)c0 * 16);
+                float4* dst = reinterpret_cast<float4*>(w2s);
+                for (int x = tid; x < hc * 4; x += EDGE_THREADS) dst[x] = src[x];
+#pragma unroll
+                for (int s = 0; s < SP; ++s) {
+                    const float4* ssrc = reinterpret_cast<const float4*>(p.Ws + (size_t)s * p.Hp + c0);
+                    float4* sdst = reinterpret_cast<float4*>(wss + s * HC);
+                    for (int x = tid; x < hc / 4; x += EDGE_THREADS) sdst[x] = ssrc[x];
+                }
+            }
+            __syncthreads();
+
+            const int nst = hc >> 4;
+            for (int st = 0; st < nst; ++st) {
+                const int hoff = c0 + st * 16;
+                f32x4 pjc[TILES], pic[NPI];
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) pjc[t] = pjn[t];
+#pragma unroll
+                for (int u = 0; u < NPI; ++u) pic[u] = pin[u];
+                int hnext = hoff + 16;
+                if (hnext >= p.Hp) hnext = hoff;                 // last step: harmless re-read
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) pjn[t] = *reinterpret_cast<const f32x4*>(pjp[t] + hnext);
+#pragma unroll
+                for (int u = 0; u < NPI; ++u) pin[u] = *reinterpret_cast<const f32x4*>(pip[u * TPI] + hnext);
+
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(w2s + (st * 64 + lane) * 4);
+                f32x4 ws[SP];
+#pragma unroll
+                for (int s = 0; s < SP; ++s) ws[s] = *reinterpret_cast<const f32x4*>(wss + s * HC + st * 16 + 4 * g);
+
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    f32x4 x = pic[t / TPI] + pjc[t];
+#pragma unroll
+                    for (int s = 0; s < SP; ++s) x += sc[t][s] * ws[s];
+                    f32x4 hv;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) hv[u] = egnn_silu(x[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[u], hv[u], acc[t], 0, 0, 0);
+                }
+            }
+        }
+
+        // ------------------------------------------------------------------ per-edge epilogue (registers)
+        f32x4 b2r;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b2r[u] = p.b2[4 * g + u];
+        f32x4 gwr = f32x4{0.f, 0.f, 0.f, 0.f};
+        float gb = 0.f;
+        if (p.gate_w) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gwr[u] = p.gate_w[4 * g + u];
+            gb = p.gate_b[0];
+        }
+        float cscale = 0.f;
+        if (p.coors_scale) cscale = p.coors_scale[0];
+
+        float cw[TILES];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            f32x4 m;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m[u] = egnn_silu(acc[t][u] + b2r[u]);
+            if (p.gate_w) {
+                float part = gwr[0] * m[0] + gwr[1] * m[1] + gwr[2] * m[2] + gwr[3] * m[3];
+                part += __shfl_xor(part, 16);
+                part += __shfl_xor(part, 32);
+                const float gt = egnn_sigmoid(part + gb);
+                m *= gt;
+            }
+            acc[t] = m;
+            cw[t] = 0.f;
+        }
+
+        if (p.W3) {
+            float part[TILES];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) part[t] = 0.f;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                const f32x4 w3 = *reinterpret_cast<const f32x4*>(p.W3 + (16 * blk + e) * 16 + 4 * g);
+                const f32x4 b3 = *reinterpret_cast<const f32x4*>(p.b3 + 16 * blk + 4 * g);
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.W4 + 16 * blk + 4 * g);
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[u], acc[t][u], a2, 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) part[t] += w4[u] * egnn_silu(a2[u] + b3[u]);
+                }
+            }
+            const float b4 = p.b4[0];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                float s = part[t];
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                s += b4;
+                if (has_mask && !fm[t]) s = 0.f;                         // :308-309
+                if (p.clamp >= 0.f) s = fminf(fmaxf(s, -p.clamp), p.clamp);   // :311-313
+                if (!fm[t] && !has_mask) s = 0.f;                        // padding slot (not a real edge)
+                cw[t] = s;
+            }
+        }
+
+        __syncthreads();                                     // previous round's reduction has read ebuf
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const int slot = wave * 64 + t * 16 + e;
+            const float keep = fm[t] ? 1.f : 0.f;
+            float* row = ebuf + slot * NCH;
+            *reinterpret_cast<f32x4*>(row + 4 * g) = acc[t] * keep;
+            if (g == 0) {
+                float rx = relx[t], ry = rely[t], rz = relz[t];
+                if (p.coors_scale) {                                    // CoorsNorm, egnn_pytorch.py:67-77
+                    const float nrm = sqrtf(rx * rx + ry * ry + rz * rz);
+                    const float inv = cscale / fmaxf(nrm, 1e-8f);
+                    rx *= inv; ry *= inv; rz *= inv;
+                }
+                row[16] = cw[t] * rx;
+                row[17] = cw[t] * ry;
+                row[18] = cw[t] * rz;
+                row[19] = keep;
+            }
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------------ per-node reduction, k order
+        const int qbase = round * SLOTS_PER_ROUND;
+        for (int o = tid; o < G * NCH; o += EDGE_THREADS) {
+            const int nl = o / NCH, ch = o - nl * NCH;
+            int q0 = nl * K, q1 = q0 + K;
+            if (q0 < qbase) q0 = qbase;
+            if (q1 > qbase + SLOTS_PER_ROUND) q1 = qbase + SLOTS_PER_ROUND;
+            float s = 0.f;
+            for (int q = q0; q < q1; ++q) s += ebuf[(q - qbase) * NCH + ch];
+            if (q1 > q0) nodeacc[o] += s;
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------------- node outputs
+    for (int o = tid; o < G * NCH; o += EDGE_THREADS) {
+        const int nl = o / NCH, ch = o - nl * NCH;
+        const int i = node0 + nl;
+        if (i >= N) continue;
+        float val = nodeacc[o];
+        if (ch < 16) {
+            if (p.m_i && ch < p.m_dim) {
+                if (p.pool_mean) {
+                    if (has_mask) {                                     // safe_div, egnn_pytorch.py:13-16
+                        const float cnt = nodeacc[nl * NCH + 19];
+                        val = (cnt == 0.f) ? 0.f : val / fmaxf(cnt, 1e-8f);
+                    } else {
+                        val = val / (float)K;                           // :330
+                    }
+                }
+                p.m_i[(bN + i) * p.m_dim + ch] = val;
+            }
+        } else if (ch < 19) {
+            if (p.coors_out) p.coors_out[(bN + i) * 3 + (ch - 16)] = p.coors[(bN + i) * 3 + (ch - 16)] + val;
+        }
+    }
+}
+
+template <int SP, int TPI>
+int launch_edge(const egnn_edge_args& a, hipStream_t s)
+{
+    int G = SLOTS_PER_ROUND / a.K;
+    if (G < 1) G = 1;
+    if (G > GMAX) G = GMAX;
+    if (G > a.N) G = a.N;
+    const int gpg = (a.N + G - 1) / G;
+    const int64_t nblk = (int64_t)a.B * gpg;
+    if (nblk > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
+    const size_t lds = sizeof(float) * ((size_t)HC * 16 + (size_t)SP * HC + SLOTS_PER_ROUND * NCH + GMAX * NCH);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_kernel<SP, TPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((edge_kernel<SP, TPI>), dim3((unsigned)nblk), dim3(EDGE_THREADS), lds, s, a, G, gpg);
+    return egnn_launch_status();
+}
+
+template <int SP>
+int dispatch_tpi(const egnn_edge_args& a, hipStream_t s)
+{
+    // tiles of 16 consecutive slots share node i only when K is a multiple of 16 and the group is full
+    if (a.K % 64 == 0) return launch_edge<SP, 4>(a, s);
+    if (a.K % 32 == 0) return launch_edge<SP, 2>(a, s);
+    return launch_edge<SP, 1>(a, s);
+}
+
+}  // namespace
+
+extern "C" int egnn_padded_hidden(int H) { return (H + 31) / 32 * 32; }
+
+extern "C" int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream)
+{
+    if (!args) return EGNN_E_NULLPTR;
+    const egnn_edge_args& a = *args;
+    if (!a.Pi || !a.Pj || !a.Ws || !a.W2f || !a.b2 || !a.coors) return EGNN_E_NULLPTR;
+    if (!a.m_i && !a.coors_out) return EGNN_E_NULLPTR;
+    if (a.coors_out && (!a.W3 || !a.b3 || !a.W4 || !a.b4)) return EGNN_E_NULLPTR;
+    if (a.gate_w && !a.gate_b) return EGNN_E_NULLPTR;
+    if (a.B <= 0 || a.N <= 0 || a.K <= 0 || a.H <= 0) return EGNN_E_SHAPE;
+    if (a.Hp != egnn_padded_hidden(a.H) || a.ldp < a.Hp || (a.ldp % 4) != 0) return EGNN_E_SHAPE;
+    if (a.m_dim < 1 || a.m_dim > 16) return EGNN_E_UNSUPPORTED;
+    if (a.S != 2 * a.fourier + 1 + a.edge_dim || a.Sp < a.S) return EGNN_E_SHAPE;
+    if (a.edge_dim > 0 && !a.edges) return EGNN_E_NULLPTR;
+    if (a.idx == nullptr && a.K != a.N) return EGNN_E_SHAPE;          // dense path: K == N
+    if ((reinterpret_cast<uintptr_t>(a.Pi) & 15) || (reinterpret_cast<uintptr_t>(a.Pj) & 15) ||
+        (reinterpret_cast<uintptr_t>(a.Ws) & 15) || (reinterpret_cast<uintptr_t>(a.W2f) & 15))
+        return EGNN_E_ALIGN;
+    if (a.W3 && ((reinterpret_cast<uintptr_t>(a.W3) & 15) || (reinterpret_cast<uintptr_t>(a.b3) & 15) ||
+                 (reinterpret_cast<uintptr_t>(a.W4) & 15)))
+        return EGNN_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (a.Sp) {
+        case 1: return dispatch_tpi<1>(a, s);
+        case 2: return dispatch_tpi<2>(a, s);
+        case 3: return dispatch_tpi<3>(a, s);
+        case 5: return dispatch_tpi<5>(a, s);
+        case 8: return dispatch_tpi<8>(a, s);
+        case 16: return dispatch_tpi<16>(a, s);
+        default: return EGNN_E_UNSUPPORTED;
+    }
+}

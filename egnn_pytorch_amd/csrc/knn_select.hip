@@ -1,0 +1,217 @@
+// Fused pairwise squared distance + ranking overrides + per-row top-K selection (gfx950).
+//
+// Replaces egnn_pytorch/egnn_pytorch.py:232-233, 237-256, 258 of the reference without ever
+// materialising an (N x N) tensor: one wavefront owns one query row i at a time; the graph's
+// coordinates live in LDS as SoA (conflict-free: lane l reads x[c*64+l]); every lane keeps
+// CPL = ceil(N/64) candidate keys in registers.
+//
+// Selection is an exact radix descent on the order-preserving uint32 image of the fp32 ranking
+// value (32 wave-uniform steps of ballot+popcount), followed by an index-ordered pick among the
+// candidates that tie with the K-th value, a ballot-prefix compaction into LDS and a rank-by-counting
+// sort of the K survivors on the composite key (value, index).  The result is deterministic:
+// ascending value, ties by ascending index -- the tie policy of SURVEY.md §8c(5).
+//
+// Bound: VALU (N compares x 32 bits per row); HBM traffic is only coors in + (idx, rank) out.
+#include "egnn_common.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t f2key(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ void wave_lds_sync() {
+    // same-wave LDS hand-off: DS operations of one wave execute in issue order; this only pins the
+    // compiler's ordering.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int KNN_THREADS = 256;
+constexpr int KNN_WAVES = KNN_THREADS / 64;
+
+template <int CPL>
+__global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
+    const float* __restrict__ coors, const uint8_t* __restrict__ mask, const uint8_t* __restrict__ adj,
+    int64_t adj_bstride, int N, int K, int Npad, int Kpad, int rows_per_wg,
+    int32_t* __restrict__ idx_out, float* __restrict__ rank_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);
+    float* ys = xs + Npad;
+    float* zs = ys + Npad;
+    uint8_t* ms = reinterpret_cast<uint8_t*>(zs + Npad);
+    uint64_t* selall = reinterpret_cast<uint64_t*>(smem + (size_t)Npad * 13 + 8 - ((size_t)Npad * 13) % 8);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int row0 = blockIdx.x * rows_per_wg;
+    uint64_t* selbuf = selall + (size_t)wave * Kpad;
+
+    const float* cb = coors + (size_t)b * N * 3;
+    for (int j = tid; j < Npad; j += KNN_THREADS) {
+        if (j < N) {
+            xs[j] = cb[j * 3 + 0];
+            ys[j] = cb[j * 3 + 1];
+            zs[j] = cb[j * 3 + 2];
+            ms[j] = mask ? mask[(size_t)b * N + j] : (uint8_t)1;
+        } else {
+            xs[j] = 0.f; ys[j] = 0.f; zs[j] = 0.f; ms[j] = 0;
+        }
+    }
+    __syncthreads();
+
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+    for (int r = wave; r < rows_per_wg; r += KNN_WAVES) {
+        const int i = row0 + r;
+        if (i >= N) break;                       // wave-uniform
+        const float xi = xs[i], yi = ys[i], zi = zs[i];
+        const bool mi = ms[i] != 0;
+        const uint8_t* adjrow = adj ? adj + (size_t)b * adj_bstride + (size_t)i * N : nullptr;
+
+        uint32_t key[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = c * 64 + lane;
+            uint32_t k = 0xFFFFFFFFu;            // padding candidates sort last
+            if (j < N) {
+                float dx, dy, dz;
+                float rk = egnn_sqdist(xi, yi, zi, xs[j], ys[j], zs[j], dx, dy, dz);
+                if (!(mi && ms[j] != 0)) rk = 1e5f;                 // :240-242
+                if (adjrow) {
+                    if (j == i) rk = -1.0f;                         // :255
+                    else if (adjrow[j]) rk = 0.0f;                  // :256
+                }
+                k = f2key(rk);
+            }
+            key[c] = k;
+        }
+
+        // ---- exact K-th smallest key: bitwise radix descent, all control flow wave-uniform
+        uint32_t T = 0;
+        int below = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t want = T >> bit;
+            int cnt = 0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                cnt += __popcll(__ballot((key[c] >> bit) == want));
+            if (below + cnt < K) {
+                below += cnt;
+                T |= (1u << bit);
+            }
+        }
+
+        // ---- pick: everything below T, then the lowest-index `need` candidates equal to T
+        int need = K - below;
+        int base = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const bool less = key[c] < T;
+            const bool eq = key[c] == T;
+            const uint64_t beq = __ballot(eq);
+            const int ceq = __popcll(beq);
+            const bool take_eq = eq && (__popcll(beq & lt_mask) < need);
+            need -= (need < ceq ? need : ceq);
+            const bool sel = less || take_eq;
+            const uint64_t bs = __ballot(sel);
+            if (sel)
+                selbuf[base + __popcll(bs & lt_mask)] =
+                    ((uint64_t)key[c] << 32) | (uint32_t)(c * 64 + lane);
+            base += __popcll(bs);
+        }
+        wave_lds_sync();
+
+        // ---- sort the K survivors by (value, index): rank by counting
+        const size_t obase = ((size_t)b * N + i) * K;
+        for (int t = lane; t < K; t += 64) {
+            const uint64_t mine = selbuf[t];
+            int rnk = 0;
+            for (int u = 0; u < K; ++u) rnk += (selbuf[u] < mine) ? 1 : 0;
+            idx_out[obase + rnk] = (int32_t)(uint32_t)(mine & 0xFFFFFFFFull);
+            rank_out[obase + rnk] = key2f((uint32_t)(mine >> 32));
+        }
+        wave_lds_sync();
+    }
+}
+
+__global__ __launch_bounds__(256) void adj_max_degree_kernel(const uint8_t* __restrict__ adj, int64_t rows,
+                                                              int N, int32_t* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    int best = 0;
+    for (int64_t r = wave_global; r < rows; r += nwaves) {
+        const uint8_t* row = adj + r * N;
+        int cnt = 0;
+        for (int j = lane; j < N; j += 64) cnt += row[j] ? 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        best = cnt > best ? cnt : best;
+    }
+    if (lane == 0 && best > 0) atomicMax(out, best);
+}
+
+template <int CPL>
+int launch_knn(const float* coors, const uint8_t* mask, const uint8_t* adj, int64_t adj_bstride, int B, int N,
+               int K, int32_t* idx_out, float* rank_out, hipStream_t s)
+{
+    const int Npad = (N + 63) / 64 * 64;
+    const int Kpad = (K + 1) / 2 * 2;
+    int rows_per_wg = 32;
+    if (N < rows_per_wg) rows_per_wg = (N + 3) / 4 * 4;
+    const size_t coord_bytes = (size_t)Npad * 13 + 8 - ((size_t)Npad * 13) % 8;
+    const size_t lds = coord_bytes + (size_t)KNN_WAVES * Kpad * 8;
+    if (lds > 160 * 1024) return EGNN_E_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_select_kernel<CPL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid((N + rows_per_wg - 1) / rows_per_wg, B);
+    hipLaunchKernelGGL(knn_select_kernel<CPL>, grid, dim3(KNN_THREADS), lds, s, coors, mask, adj, adj_bstride, N, K,
+                       Npad, Kpad, rows_per_wg, idx_out, rank_out);
+    return egnn_launch_status();
+}
+
+}  // namespace
+
+extern "C" int egnn_knn_select_f32(const float* coors, const uint8_t* mask, const uint8_t* adj,
+                                   int64_t adj_batch_stride, int B, int N, int K, int32_t* idx_out,
+                                   float* rank_out, void* stream)
+{
+    if (!coors || !idx_out || !rank_out) return EGNN_E_NULLPTR;
+    if (B <= 0 || N <= 0 || K <= 0) return EGNN_E_SHAPE;
+    if (K > N) return EGNN_E_K_GT_N;
+    if (N > 4096 || K > 1024) return EGNN_E_UNSUPPORTED;
+    if (B > 65535) return EGNN_E_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (N <= 64) return launch_knn<1>(coors, mask, adj, adj_batch_stride, B, N, K, idx_out, rank_out, s);
+    if (N <= 128) return launch_knn<2>(coors, mask, adj, adj_batch_stride, B, N, K, idx_out, rank_out, s);
+    if (N <= 256) return launch_knn<4>(coors, mask, adj, adj_batch_stride, B, N, K, idx_out, rank_out, s);
+    if (N <= 512) return launch_knn<8>(coors, mask, adj, adj_batch_stride, B, N, K, idx_out, rank_out, s);
+    if (N <= 1024) return launch_knn<16>(coors, mask, adj, adj_batch_stride, B, N, K, idx_out, rank_out, s);
+    if (N <= 2048) return launch_knn<32>(coors, mask, adj, adj_batch_stride, B, N, K, idx_out, rank_out, s);
+    return launch_knn<64>(coors, mask, adj, adj_batch_stride, B, N, K, idx_out, rank_out, s);
+}
+
+extern "C" int egnn_adj_max_degree_u8(const uint8_t* adj, int64_t rows, int N, int32_t* out_dev, void* stream)
+{
+    if (!adj || !out_dev) return EGNN_E_NULLPTR;
+    if (rows <= 0 || N <= 0) return EGNN_E_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(out_dev, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return (int)e;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adj_max_degree_kernel, dim3((unsigned)blocks), dim3(256), 0, s, adj, rows, N, out_dev);
+    return egnn_launch_status();
+}

@@ -1,0 +1,269 @@
+"""Drop-in `EGNN` / `EGNN_Network` modules whose forward runs on the gfx950 HIP kernels.
+
+Boundary mirrored: constructor keywords, `forward` signatures (note the different
+positional order of the two entry points), parameter names / shapes of the reference's
+`state_dict`, error behaviour (asserts at construction, `topk` out-of-range when K > N).
+Reference: egnn_pytorch/egnn_pytorch.py:148-341 (EGNN), :343-454 (EGNN_Network).
+
+The forward pass is inference-only (no autograd graph is recorded; backward is a SURVEY.md §8f
+item) and runs ONLY on a CUDA(HIP) device in fp32 with 3-D coordinates.  There is no CPU or
+PyTorch-eager fallback: anything the kernels do not cover raises.
+"""
+from __future__ import annotations
+
+import warnings
+
+import torch
+from torch import nn
+
+from . import _abi, _ops, _weights
+
+
+def _mlp(d_in, d_hidden, d_out, dropout, final_act):
+    """Linear -> dropout|Identity -> SiLU -> Linear [-> SiLU]; indices 0 and 3 hold the Linears, which is
+    what gives the reference's state_dict keys (`edge_mlp.0.*`, `edge_mlp.3.*`, ...)."""
+    mods = [nn.Linear(d_in, d_hidden), dropout, nn.SiLU(), nn.Linear(d_hidden, d_out)]
+    if final_act:
+        mods.append(nn.SiLU())
+    return nn.Sequential(*mods)
+
+
+class CoorsNorm(nn.Module):
+    """Holder of the learned `scale` of the reference's CoorsNorm (egnn_pytorch.py:67-77); the
+    normalisation itself (x / max(|x|, eps) * scale) happens inside the fused edge kernel."""
+
+    def __init__(self, eps=1e-8, scale_init=1.0):
+        super().__init__()
+        self.eps = eps
+        self.scale = nn.Parameter(torch.full((1,), float(scale_init)))
+
+
+class EGNN(nn.Module):
+    def __init__(self, dim, edge_dim=0, m_dim=16, fourier_features=0, num_nearest_neighbors=0,
+                 dropout=0.0, init_eps=1e-3, norm_feats=False, norm_coors=False,
+                 norm_coors_scale_init=1e-2, update_feats=True, update_coors=True,
+                 only_sparse_neighbors=False, valid_radius=float("inf"), m_pool_method="sum",
+                 soft_edges=False, coor_weights_clamp_value=None):
+        super().__init__()
+        assert m_pool_method in {"sum", "mean"}, "pool method must be either sum or mean"
+        assert update_feats or update_coors, "you must update either features, coordinates, or both"
+
+        self.dim = dim
+        self.edge_dim = edge_dim
+        self.m_dim = m_dim
+        self.fourier_features = fourier_features
+        self.num_nearest_neighbors = num_nearest_neighbors
+        self.only_sparse_neighbors = only_sparse_neighbors
+        self.valid_radius = valid_radius
+        self.m_pool_method = m_pool_method
+        self.coor_weights_clamp_value = coor_weights_clamp_value
+        self.norm_feats = norm_feats
+        self.norm_coors = norm_coors
+        self.dropout_p = dropout
+        self.init_eps = init_eps
+
+        edge_input_dim = 2 * fourier_features + 2 * dim + edge_dim + 1
+        drop = nn.Dropout(dropout) if dropout > 0 else nn.Identity()     # one shared instance, as upstream
+
+        self.edge_mlp = _mlp(edge_input_dim, 2 * edge_input_dim, m_dim, drop, final_act=True)
+        self.edge_gate = nn.Sequential(nn.Linear(m_dim, 1), nn.Sigmoid()) if soft_edges else None
+        self.node_norm = nn.LayerNorm(dim) if norm_feats else nn.Identity()
+        self.coors_norm = CoorsNorm(scale_init=norm_coors_scale_init) if norm_coors else nn.Identity()
+        self.node_mlp = _mlp(dim + m_dim, 2 * dim, dim, drop, final_act=False) if update_feats else None
+        self.coors_mlp = _mlp(m_dim, 4 * m_dim, 1, drop, final_act=False) if update_coors else None
+
+        for mod in self.modules():                                       # upstream init_: N(0, init_eps)
+            if type(mod) is nn.Linear:
+                nn.init.normal_(mod.weight, std=init_eps)
+
+        self._packed = None
+        self._packed_key = None
+        self._warned_grad = False
+
+    # ------------------------------------------------------------------ kernel-side weights
+    def packed_weights(self):
+        key = _weights.version_key(self)
+        if self._packed is None or key != self._packed_key:
+            self._packed = _weights.pack(self)
+            self._packed_key = key
+        return self._packed
+
+    # ------------------------------------------------------------------ forward
+    def _check_inputs(self, feats, coors, edges, mask, adj_mat):
+        if not feats.is_cuda:
+            raise RuntimeError("egnn_pytorch_amd.EGNN runs only on an MI355X (cuda/HIP) device; "
+                               "there is no CPU fallback (move the module and inputs with .cuda())")
+        if feats.dtype != torch.float32 or coors.dtype != torch.float32:
+            raise NotImplementedError("the gfx950 path is fp32 only (got "
+                                      f"{feats.dtype}/{coors.dtype})")
+        if feats.dim() != 3 or coors.dim() != 3 or feats.shape[:2] != coors.shape[:2]:
+            raise ValueError(f"feats {tuple(feats.shape)} / coors {tuple(coors.shape)}: expected (B,N,dim) and (B,N,3)")
+        if coors.shape[-1] != 3:
+            raise NotImplementedError("the gfx950 path supports 3-D coordinates only")
+        if feats.shape[-1] != self.dim:
+            raise ValueError(f"feats last dim {feats.shape[-1]} != dim {self.dim}")
+        if self.training and self.dropout_p > 0:
+            raise NotImplementedError("dropout in training mode is not supported (inference path); call .eval()")
+        if (edges is not None) != (self.edge_dim > 0):
+            raise ValueError("`edges` must be passed if and only if edge_dim > 0")
+        b, n = feats.shape[:2]
+        if edges is not None and tuple(edges.shape) != (b, n, n, self.edge_dim):
+            raise ValueError(f"edges shape {tuple(edges.shape)} != {(b, n, n, self.edge_dim)}")
+        if mask is not None and tuple(mask.shape) != (b, n):
+            raise ValueError(f"mask shape {tuple(mask.shape)} != {(b, n)}")
+        if torch.is_grad_enabled() and not self._warned_grad and any(p.requires_grad for p in self.parameters()):
+            warnings.warn("egnn_pytorch_amd.EGNN.forward is inference-only: outputs carry no autograd graph",
+                          stacklevel=3)
+            self._warned_grad = True
+
+    @torch.no_grad()
+    def forward(self, feats, coors, edges=None, mask=None, adj_mat=None):
+        self._check_inputs(feats, coors, edges, mask, adj_mat)
+        _abi.load()
+        with torch.cuda.device(feats.device):
+            return self._forward_hip(feats, coors, edges, mask, adj_mat)
+
+    def _forward_hip(self, feats, coors, edges, mask, adj_mat):
+        b, n, dim = feats.shape
+        w = self.packed_weights()
+        feats = feats.contiguous()
+        coors = coors.contiguous()
+        feats2d = feats.view(b * n, dim)
+        if edges is not None:
+            edges = edges.contiguous().float()
+        mask8 = _ops._u8(mask)
+
+        # ---- neighbour selection (egnn_pytorch.py:230-260)
+        num_nearest = self.num_nearest_neighbors
+        valid_radius = self.valid_radius
+        use_nearest = num_nearest > 0 or self.only_sparse_neighbors
+        idx = rank = None
+        if use_nearest:
+            if adj_mat is not None and self.only_sparse_neighbors:
+                num_nearest = _ops.adj_max_degree(adj_mat)                # host sync, as upstream (:249)
+                valid_radius = 0.0
+            k = num_nearest
+            if k > n:
+                raise RuntimeError("selected index k out of range")      # torch.topk's error upstream
+            if k > 0:
+                idx, rank = _ops.knn_select(coors, mask, adj_mat, k)
+        else:
+            k = n
+
+        node_out, coors_out = feats, coors
+        m_i = None
+        if k > 0:
+            # ---- node-level projections P = feats [W_i ; W_j]^T + [b1 ; 0]
+            proj = _ops.linear(feats2d, w["Wcat"], w["bcat"], name="node_proj")
+            hp = w["Hp"]
+            a = _abi.EdgeArgs()
+            a.B, a.N, a.K, a.dim, a.m_dim = b, n, k, dim, self.m_dim
+            a.H, a.Hp = w["H"], hp
+            a.fourier, a.edge_dim, a.S, a.Sp = self.fourier_features, self.edge_dim, w["S"], w["Sp"]
+            a.Pi = proj.data_ptr()
+            a.Pj = proj.data_ptr() + 4 * hp
+            a.ldp = 2 * hp
+            a.Ws, a.W2f, a.b2 = w["Ws"].data_ptr(), w["W2f"].data_ptr(), w["b2"].data_ptr()
+            if self.edge_gate is not None:
+                a.gate_w, a.gate_b = w["gate_w"].data_ptr(), w["gate_b"].data_ptr()
+            if self.coors_mlp is not None:
+                a.W3, a.b3, a.W4, a.b4 = (w[x].data_ptr() for x in ("W3", "b3", "W4", "b4"))
+                coors_out = torch.empty_like(coors)
+                a.coors_out = coors_out.data_ptr()
+            if self.norm_coors:
+                a.coors_scale = w["coors_scale"].data_ptr()
+            a.coors = coors.data_ptr()
+            a.edges = _ops._ptr(edges)
+            a.mask = _ops._ptr(mask8)
+            a.idx, a.rank = _ops._ptr(idx), _ops._ptr(rank)
+            a.valid_radius = float(min(valid_radius, 3.0e38))
+            cv = self.coor_weights_clamp_value
+            a.clamp = -1.0 if cv is None else float(cv)
+            a.pool_mean = int(self.m_pool_method == "mean")
+            if self.node_mlp is not None:
+                m_i = torch.empty(b * n, self.m_dim, dtype=torch.float32, device=feats.device)
+                a.m_i = m_i.data_ptr()
+            _ops.edge_fused(a)
+            del proj
+        elif self.node_mlp is not None:
+            m_i = torch.zeros(b * n, self.m_dim, dtype=torch.float32, device=feats.device)
+
+        # ---- node update (egnn_pytorch.py:335-337)
+        if self.node_mlp is not None:
+            node_in = _ops.node_prep(feats2d, m_i, w.get("gamma"), w.get("beta"), w.get("ln_eps", 1e-5), self.m_dim)
+            hid = _ops.linear(node_in, w["W5"], w["b5"], act=1, name="node_mlp0")
+            node_out = _ops.linear(hid, w["W6"], w["b6"], residual=feats2d, name="node_mlp1").view(b, n, dim)
+        return node_out, coors_out
+
+
+class EGNN_Network(nn.Module):
+    """Stack of EGNN layers (egnn_pytorch.py:343-454).  The layer loop -- the part BASELINE.json's
+    configs exercise -- runs on the HIP kernels; the token / position / edge / adjacency-degree
+    front-end is ordinary tensor plumbing on the device.  Global linear attention
+    (`global_linear_attn_every > 0`) is outside the hot path and not provided."""
+
+    def __init__(self, *, depth, dim, num_tokens=None, num_edge_tokens=None, num_positions=None,
+                 edge_dim=0, num_adj_degrees=None, adj_dim=0, global_linear_attn_every=0,
+                 global_linear_attn_heads=8, global_linear_attn_dim_head=64, num_global_tokens=4,
+                 **kwargs):
+        super().__init__()
+        assert not (num_adj_degrees is not None and num_adj_degrees < 1), \
+            "make sure adjacent degrees is greater than 1"
+        if global_linear_attn_every > 0:
+            raise NotImplementedError("global linear attention is outside the MI355X hot path "
+                                      "(SURVEY.md §8f) and is not provided")
+        self.num_positions = num_positions
+        self.token_emb = nn.Embedding(num_tokens, dim) if num_tokens is not None else None
+        self.pos_emb = nn.Embedding(num_positions, dim) if num_positions is not None else None
+        self.edge_emb = nn.Embedding(num_edge_tokens, edge_dim) if num_edge_tokens is not None else None
+        self.has_edges = edge_dim > 0
+        self.num_adj_degrees = num_adj_degrees
+        self.adj_emb = nn.Embedding(num_adj_degrees + 1, adj_dim) \
+            if (num_adj_degrees is not None and adj_dim > 0) else None
+        edge_dim = edge_dim if self.has_edges else 0
+        adj_dim = adj_dim if num_adj_degrees is not None else 0
+        self.global_tokens = None
+
+        self.layers = nn.ModuleList()
+        for _ in range(depth):
+            # index 0 of each pair is the (absent) attention block: keeps keys `layers.{l}.1.*`
+            self.layers.append(nn.ModuleList([None, EGNN(dim=dim, edge_dim=edge_dim + adj_dim,
+                                                          norm_feats=True, **kwargs)]))
+
+    @torch.no_grad()
+    def forward(self, feats, coors, adj_mat=None, edges=None, mask=None, return_coor_changes=False):
+        b = feats.shape[0]
+        if self.token_emb is not None:
+            feats = self.token_emb(feats)
+        if self.pos_emb is not None:
+            n = feats.shape[1]
+            assert n <= self.num_positions, \
+                f"given sequence length {n} must be less than the number of positions {self.num_positions} set at init"
+            feats = feats + self.pos_emb(torch.arange(n, device=feats.device))[None]
+        if edges is not None and self.edge_emb is not None:
+            edges = self.edge_emb(edges)
+
+        if self.num_adj_degrees is not None:
+            assert adj_mat is not None, "adjacency matrix must be passed in (keyword argument adj_mat)"
+            if adj_mat.dim() == 2:
+                adj_mat = adj_mat[None].expand(b, -1, -1)
+            adj_mat = adj_mat.clone()
+            adj_indices = adj_mat.long()
+            for ind in range(self.num_adj_degrees - 1):
+                degree = ind + 2
+                af = adj_mat.float()
+                next_adj = (af @ af) > 0
+                next_mask = (next_adj.float() - af).bool()
+                adj_indices.masked_fill_(next_mask, degree)
+                adj_mat = next_adj
+            if self.adj_emb is not None:
+                adj_emb = self.adj_emb(adj_indices)
+                edges = torch.cat((edges, adj_emb), dim=-1) if edges is not None else adj_emb
+
+        coor_changes = [coors]
+        for _, egnn in self.layers:
+            feats, coors = egnn(feats, coors, adj_mat=adj_mat, edges=edges, mask=mask)
+            coor_changes.append(coors)
+        if return_coor_changes:
+            return feats, coors, coor_changes
+        return feats, coors

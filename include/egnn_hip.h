@@ -1,0 +1,138 @@
+/* egnn_hip.h -- C ABI of libegnn_hip.so: the MI355X (gfx950) EGNN.forward hot path.
+ *
+ * The reference (lucidrains/egnn-pytorch v0.2.8) has no FFI layer: its boundary is the Python
+ * nn.Module API `EGNN.forward(feats, coors, edges, mask, adj_mat)` (egnn_pytorch/egnn_pytorch.py:224).
+ * The entry points below are what a binding for that path calls (the shipped binding is
+ * egnn_pytorch_amd/_abi.py, ctypes; INTEGRATION.md shows the stub a reference maintainer would add).
+ * Each entry point names the reference lines it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) owned by the caller; the library allocates nothing,
+ *     keeps no global state and never synchronises (egnn_adj_max_degree_u8 excepted: see below);
+ *   - all tensors are contiguous row-major fp32 unless a leading dimension (ld*) is given;
+ *     masks / adjacency are 1 byte per element (torch.bool);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); work is enqueued
+ *     asynchronously on it;
+ *   - return value: 0 = ok, <0 = EGNN_E_* (bad argument / unsupported shape), >0 = hipError_t of
+ *     the failed launch.  egnn_error_string() maps the negative codes to text.
+ *   - re-entrant and thread-safe (no shared mutable state); one process per GPU in multi-GPU runs.
+ */
+#ifndef EGNN_HIP_H
+#define EGNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGNN_ABI_VERSION 1
+
+enum {
+    EGNN_OK = 0,
+    EGNN_E_NULLPTR = -1,      /* a required pointer is NULL */
+    EGNN_E_SHAPE = -2,        /* non-positive or inconsistent sizes */
+    EGNN_E_UNSUPPORTED = -3,  /* shape outside what the kernels are built for (see each entry) */
+    EGNN_E_ALIGN = -4,        /* pointer / leading dimension not aligned as required */
+    EGNN_E_K_GT_N = -5        /* K > N: the reference's topk raises here too (egnn_pytorch.py:258) */
+};
+
+int egnn_abi_version(void);
+const char* egnn_error_string(int code);
+
+/* Padded hidden width the projection / edge kernels use for H = 2*edge_input_dim:
+ * H rounded up to a multiple of 32 floats (128-byte rows). */
+int egnn_padded_hidden(int H);
+
+/* ---------------------------------------------------------------------------------------------
+ * Neighbour selection: replaces egnn_pytorch.py:232-233 (pairwise rel_coors / rel_dist), :237-256
+ * (ranking: masked pairs -> 1e5, with adj_mat: self -> -1, adjacent -> 0) and :258 (topk smallest K,
+ * ascending).  Nothing of size N*N is materialised.
+ *   coors  (B,N,3) fp32.  rel_dist is computed as ((dx*dx + dy*dy) + dz*dz) with every multiply and
+ *          add rounded separately (no FMA) -- bit-identical to the reference's CPU result.
+ *   mask   (B,N) bytes or NULL.
+ *   adj    (N,N) bytes (adj_batch_stride = 0) or (B,N,N) bytes (adj_batch_stride = N*N), or NULL.
+ *          The diagonal is ignored (the reference clears it, :254).
+ *   idx_out  (B,N,K) int32   neighbour indices, ascending rank; ties broken by ascending index
+ *   rank_out (B,N,K) fp32    the ranking values of the selected neighbours (reference `nbhd_ranking`)
+ * Limits: 1 <= K <= min(N, 1024), N <= 4096.
+ */
+int egnn_knn_select_f32(const float* coors, const uint8_t* mask, const uint8_t* adj,
+                        int64_t adj_batch_stride, int B, int N, int K,
+                        int32_t* idx_out, float* rank_out, void* stream);
+
+/* Replaces `int(adj_mat.float().sum(dim=-1).max().item())` (egnn_pytorch.py:249; the diagonal is
+ * counted when set).  adj: (rows, N) bytes.  *out_dev (device int32) receives the maximum row sum;
+ * the call zeroes it first on `stream`.  The caller reads it back (that read is the host sync the
+ * reference also has at :249). */
+int egnn_adj_max_degree_u8(const uint8_t* adj, int64_t rows, int N, int32_t* out_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense layer on the fp32 matrix cores: C = act(A * W^T + bias) (+ residual).
+ * Used for (a) the node-level projections P = feats * [W_i ; W_j]^T + [b1 ; 0] that replace the
+ * per-edge first Linear of edge_mlp (egnn_pytorch.py:178-179, 279-287: Linear(cat(h_i,h_j,d,e)) =
+ * W_i h_i + W_j h_j + w_d d + W_e e + b), and (b) node_mlp (egnn_pytorch.py:196-201, 336-337).
+ *   A (M,K) lda;  W (N,K) ldw (nn.Linear weight layout);  bias (N) or NULL;
+ *   residual (M,N) ldr or NULL;  C (M,N) ldc;  act: 0 = identity, 1 = SiLU.
+ * v_mfma_f32_32x32x2_f32: exact fp32 products/accumulation.
+ */
+int egnn_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                    const float* residual, int64_t ldr, float* C, int64_t ldc,
+                    int64_t M, int N, int K, int act, void* stream);
+
+/* node_norm + concat (egnn_pytorch.py:335-336): out[r] = [ LayerNorm(feats[r]) | m_i[r] ].
+ * gamma/beta NULL -> Identity (norm_feats=False).  out: (rows, dim + m_dim). */
+int egnn_node_prep_f32(const float* feats, const float* m_i, const float* gamma, const float* beta,
+                       float eps, float* out, int64_t rows, int dim, int m_dim, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The fused edge pass: replaces egnn_pytorch.py:262-266, 270-285 (gathers, fourier, concat), :287
+ * (edge_mlp), :289-290 (edge_gate), :292-300 (mask combine), :302-317 (coors_mlp, CoorsNorm, clamp,
+ * coordinate reduction) and :319-333 (message pooling).  Nothing of size E x H reaches HBM.
+ */
+typedef struct egnn_edge_args {
+    /* shapes */
+    int32_t B, N, K;            /* K = neighbours per node (= N on the dense all-pairs path) */
+    int32_t dim;                /* unused by the kernel, kept for validation */
+    int32_t m_dim;              /* <= 16 */
+    int32_t H, Hp;              /* hidden width 2*Din and its padding (egnn_padded_hidden) */
+    int32_t fourier;            /* F = fourier_features */
+    int32_t edge_dim;           /* width of `edges` (0 if none) */
+    int32_t S;                  /* per-edge scalar inputs: 2F + 1 + edge_dim */
+    int32_t Sp;                 /* rows of Ws (>= S, zero padded; one of 1,2,3,4,5,6,8,12,16) */
+    /* node-level projections, produced by egnn_linear_f32 */
+    const float* Pi;            /* (B*N, ldp): W_i h_i + b1      (pad columns must be 0) */
+    const float* Pj;            /* (B*N, ldp): W_j h_j */
+    int64_t ldp;
+    /* re-laid-out weights (egnn_pytorch_amd/_weights.py) */
+    const float* Ws;            /* (Sp, Hp): columns [2dim .. 2dim+S) of edge_mlp.0.weight, transposed */
+    const float* W2f;           /* (Hp/16, 64, 4): edge_mlp.3.weight in MFMA-fragment order */
+    const float* b2;            /* (16) edge_mlp.3.bias, zero padded */
+    const float* gate_w;        /* (16) edge_gate.0.weight or NULL (soft_edges=False) */
+    const float* gate_b;        /* (1) */
+    const float* W3;            /* (64,16) coors_mlp.0.weight zero padded, or NULL (update_coors=False) */
+    const float* b3;            /* (64) */
+    const float* W4;            /* (64) coors_mlp.3.weight */
+    const float* b4;            /* (1) */
+    const float* coors_scale;   /* (1) CoorsNorm.scale or NULL (norm_coors=False) */
+    /* inputs */
+    const float* coors;         /* (B,N,3) */
+    const float* edges;         /* (B,N,N,edge_dim) or NULL */
+    const uint8_t* mask;        /* (B,N) or NULL */
+    const int32_t* idx;         /* (B,N,K) from egnn_knn_select_f32, or NULL = dense (j = k) */
+    const float* rank;          /* (B,N,K) or NULL */
+    float valid_radius;         /* nbhd_mask = rank <= valid_radius, applied only when mask != NULL (:292) */
+    float clamp;                /* coor_weights_clamp_value; < 0 = no clamp */
+    int32_t pool_mean;          /* m_pool_method == 'mean' */
+    /* outputs */
+    float* m_i;                 /* (B*N, m_dim) or NULL (update_feats=False) */
+    float* coors_out;           /* (B,N,3) or NULL (update_coors=False) */
+} egnn_edge_args;
+
+int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGNN_HIP_H */

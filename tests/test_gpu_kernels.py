@@ -1,0 +1,114 @@
+"""Per-kernel parity on the MI355X, through the C ABI (egnn_pytorch_amd._ops -> libegnn_hip.so)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import egnn_oracle as O
+from tests._util import check_neighbors, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(x):
+    return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+# ------------------------------------------------------------------ neighbour selection: bit-exact
+@pytest.mark.parametrize("n,k,use_mask,adj_kind", [
+    (16, 4, False, None), (64, 8, True, None), (100, 7, True, None), (256, 32, True, None),
+    (1024, 32, True, None), (2048, 16, False, None), (300, 40, True, "random"), (64, 8, True, "chain"),
+    (4096, 8, False, None), (33, 33, True, None), (1024, 100, True, None),
+])
+def test_knn_select_bit_exact(n, k, use_mask, adj_kind):
+    from egnn_pytorch_amd import _ops
+    rng = np.random.default_rng(n * 131 + k)
+    b = 3
+    coors = rng.standard_normal((b, n, 3)).astype(np.float32)
+    mask = None
+    if use_mask:
+        lens = rng.integers(max(k, n // 2), n + 1, size=b)
+        mask = np.arange(n)[None, :] < lens[:, None]
+    adj = None
+    if adj_kind == "chain":
+        i = np.arange(n)
+        adj = np.abs(i[:, None] - i[None, :]) <= 1
+    elif adj_kind == "random":
+        adj = np.zeros((b, n, n), bool)
+        for bb in range(b):
+            for i in range(n):
+                js = rng.choice(n, size=rng.integers(0, 4), replace=False)
+                adj[bb, i, js] = True
+                adj[bb, js, i] = True
+            adj[bb][np.arange(n), np.arange(n)] = True
+    _, dist = O.pairwise(coors)
+    ranking, _ = O.build_ranking(dist, mask, adj)
+    ref_val, ref_idx = O.topk_smallest(ranking, k)
+    idx, rank = _ops.knn_select(_dev(coors), _dev(mask), _dev(adj), k)
+    idx, rank = idx.cpu().numpy(), rank.cpu().numpy()
+    # oracle and kernel share the tie policy (ascending index): everything must be identical
+    np.testing.assert_array_equal(ref_val.view(np.uint32), rank.view(np.uint32))
+    np.testing.assert_array_equal(ref_idx.astype(np.int32), idx)
+
+
+@pytest.mark.parametrize("name", [g for g in golden_names()])
+def test_knn_select_matches_reference_topk(name):
+    """Against the indices the reference's own topk returned (golden), under the §8c tie policy."""
+    from egnn_pytorch_amd import _ops
+    meta, _, d = load_golden(name)
+    if meta["kind"] != "layer" or not meta["n_topk"]:
+        pytest.skip("dense path / network case")
+    k = d["topk_values.0"].shape[-1]
+    idx, rank = _ops.knn_select(_dev(d["coors"]), _dev(d.get("mask")), _dev(d.get("adj_mat")), k)
+    check_neighbors(d["topk_values.0"], d["topk_indices.0"], rank.cpu().numpy(), idx.cpu().numpy())
+
+
+def test_knn_k_gt_n_raises():
+    from egnn_pytorch_amd import _ops
+    with pytest.raises(RuntimeError):
+        _ops.knn_select(torch.zeros(1, 4, 3, device="cuda"), None, None, 5)
+
+
+def test_adj_max_degree():
+    from egnn_pytorch_amd import _ops
+    rng = np.random.default_rng(1)
+    adj = rng.random((3, 70, 70)) < 0.1
+    assert _ops.adj_max_degree(_dev(adj)) == O.sparse_num_nearest(adj)
+    adj2 = np.eye(37, dtype=bool)
+    assert _ops.adj_max_degree(_dev(adj2)) == 1
+
+
+# ------------------------------------------------------------------ fp32 MFMA linear
+@pytest.mark.parametrize("m,n,k,act,res", [
+    (16, 130, 32, 0, False), (300, 257, 65, 1, False), (1024, 4160, 512, 0, False),
+    (2048, 1024, 528, 1, False), (2048, 512, 1024, 0, True), (77, 40, 36, 0, True), (5, 3, 7, 1, True),
+])
+def test_linear_f32(m, n, k, act, res):
+    from egnn_pytorch_amd import _ops
+    rng = np.random.default_rng(m + n + k)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    r = rng.standard_normal((m, n)).astype(np.float32) if res else None
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    if act:
+        ref = ref / (1.0 + np.exp(-ref))
+    if res:
+        ref = ref + r
+    out = _ops.linear(_dev(a), _dev(w), _dev(bias), _dev(r), act=act).cpu().numpy()
+    assert out.shape == (m, n)
+    # asymmetric operands: a transposed / mis-mapped C tile cannot pass
+    np.testing.assert_allclose(out, ref, atol=2e-5, rtol=0)
+
+
+def test_node_prep():
+    from egnn_pytorch_amd import _ops
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((300, 100)).astype(np.float32) * 3 + 1
+    mi = rng.standard_normal((300, 16)).astype(np.float32)
+    g = rng.standard_normal(100).astype(np.float32)
+    bt = rng.standard_normal(100).astype(np.float32)
+    out = _ops.node_prep(_dev(x), _dev(mi), _dev(g), _dev(bt), 1e-5, 16).cpu().numpy()
+    ref = np.concatenate([O.layer_norm(x, g, bt), mi], axis=-1)
+    np.testing.assert_allclose(out, ref, atol=1e-5, rtol=0)
+    out2 = _ops.node_prep(_dev(x), _dev(mi), None, None, 1e-5, 16).cpu().numpy()
+    np.testing.assert_array_equal(out2, np.concatenate([x, mi], axis=-1))
