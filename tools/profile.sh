@@ -1,0 +1,23 @@
+#!/bin/bash
+# rocprofv3 passes over the default bench (north-star workload). Run on the GPU box from the repo root:
+#   bash tools/profile.sh <tag>
+# kernel-trace/stats and every PMC group are separate runs (FETCH_SIZE and WRITE_SIZE cannot share a pass;
+# gpurun refuses --pmc combined with sys/hip/hsa traces).
+TAG="${1:-r01}"
+REPO="$(pwd)"
+OUT="$REPO/gpurun_out/prof_$TAG"
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+cd /tmp
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- $BENCH > "$OUT/trace.log" 2>&1
+echo "trace rc=$?"
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE" "MfmaUtil" "VALUBusy"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $grp -d "$OUT/pmc$i" -o pmc --output-format csv -- $BENCH > "$OUT/pmc$i.log" 2>&1
+  echo "pmc$i [$grp] rc=$?"
+done
+cd "$REPO"
+python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+tail -60 "$OUT/summary.txt"
