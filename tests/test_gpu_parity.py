@@ -57,9 +57,9 @@ CONFIGS = [
     ("k_eq_n", dict(dim=32, num_nearest_neighbors=24), 1, 24, dict()),
     # hundreds of neighbours per node: damp the message scale so outputs stay O(1..10); at |out| ~ 600 the fp32
     # ORACLE itself sits 3e-4 from an fp64 run, i.e. the 1e-4 bar would measure summation order, not parity
-    ("dense_n600_multi_round", dict(dim=32), 1, 600, dict(mask=True, scale={"edge_mlp.3.weight": 0.1})),
+    ("dense_n600_multi_round", dict(dim=32), 1, 600, dict(mask=True, scale={"edge_mlp.3.weight": 0.1, "coors_mlp.3.weight": 0.05})),
     ("knn_k300_multi_round", dict(dim=32, num_nearest_neighbors=300), 1, 400,
-     dict(scale={"edge_mlp.3.weight": 0.1})),
+     dict(scale={"edge_mlp.3.weight": 0.1, "coors_mlp.3.weight": 0.05})),
 ]
 
 

@@ -8,13 +8,23 @@ from collections import defaultdict
 out = sys.argv[1]
 
 
+import json
+import re
+
+ROLE = {"linear_kernel<0, false": "node_proj", "linear_kernel<1, false": "node_mlp0",
+        "linear_kernel<0, true": "node_mlp1", "edge_kernel": "edge_fused", "knn_select_kernel": "knn_select",
+        "node_prep_kernel": "node_prep"}
+
+
 def short(name):
-    for key in ("knn_select", "linear_kernel", "edge_kernel", "node_prep", "adj_max"):
-        if key in name:
-            if key == "linear_kernel":
-                return "linear_kernel<" + name.split("linear_kernelILi")[1][:12] + ">" if "ILi" in name else key
-            return key
-    return name[:60]
+    m = re.search(r"(\w+_kernel)<([^>]*)>", name) or re.search(r"(\w+_kernel)", name)
+    if not m:
+        return name[:60]
+    full = m.group(0)
+    for key, role in ROLE.items():
+        if full.startswith(key):
+            return f"{role} [{full}]"
+    return full
 
 
 print("== kernel stats (rocprofv3 --kernel-trace --stats)")
@@ -45,3 +55,26 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
         for k, cs in agg.items():
             for cname, vals in cs.items():
                 print(f"{os.path.basename(d):6s} {k:44s} {cname:28s} n={len(vals):4d} avg={sum(vals)/len(vals):16.1f}")
+
+# ---- HBM traffic per launch for bench.py's roofline.traffic (MI355X_MICROARCH.md, HBM section):
+# FETCH_SIZE / WRITE_SIZE are in KiB and come from separate passes; on gfx950 FETCH_SIZE reports one half of the
+# bytes of a wide (16 B/lane) coalesced read, so it is doubled; WRITE_SIZE is taken as is (uncalibrated).
+traffic = {}
+vals = defaultdict(dict)
+for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        agg = defaultdict(lambda: defaultdict(list))
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    agg[short(row["Kernel_Name"]).split(" [")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for k, cs in agg.items():
+            for c, v in cs.items():
+                vals[k][c] = sum(v) / len(v)
+for k, cs in vals.items():
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs and k in ROLE.values():
+        traffic[k] = int((2.0 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024)
+        print(f"traffic {k:12s} fetch_KiB={cs['FETCH_SIZE']:.0f} (x2 gfx950 correction) write_KiB={cs['WRITE_SIZE']:.0f} "
+              f"-> {traffic[k]/1e9:.3f} GB per launch")
+with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
+    json.dump(traffic, fh, indent=1)
