@@ -1,0 +1,147 @@
+"""CPU-side checks of the shipped host code: the C-ABI library loads and exports every symbol the header
+declares, the drop-in modules keep the reference's constructor / state_dict contract, the weight re-layout
+is algebraically exact, and the product path refuses to run without a GPU (no fallback)."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import egnn_oracle as O
+from tests._util import golden_names, layer_kwargs, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_library_loads_and_exports_header_symbols():
+    from egnn_pytorch_amd import _abi
+    lib = _abi.load()                                   # no compute call: loading needs no GPU
+    header = open(os.path.join(ROOT, "include", "egnn_hip.h")).read()
+    declared = set(re.findall(r"\b(egnn_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.egnn_abi_version() == _abi.ABI_VERSION
+    assert lib.egnn_padded_hidden(2050) == 2080 and lib.egnn_padded_hidden(64) == 64
+    assert b"out of range" in lib.egnn_error_string(-5)
+
+
+def test_edge_args_struct_matches_header():
+    """Field order / count of the ctypes mirror against `struct egnn_edge_args` in the header."""
+    from egnn_pytorch_amd import _abi
+    header = open(os.path.join(ROOT, "include", "egnn_hip.h")).read()
+    body = header[header.index("typedef struct egnn_edge_args {"):header.index("} egnn_edge_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            names.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", part)[-1])
+    assert names == [f[0] for f in _abi.EdgeArgs._fields_]
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from egnn_pytorch_amd import _abi
+    monkeypatch.setattr(_abi, "_lib", None)
+    monkeypatch.setenv("EGNN_HIP_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(_abi.EGNNHipError):
+        _abi.load()
+
+
+def test_no_cpu_fallback():
+    from egnn_pytorch_amd import EGNN
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        EGNN(dim=8)(torch.randn(1, 4, 8), torch.randn(1, 4, 3))
+
+
+def test_product_code_never_imports_oracle():
+    pkg = os.path.join(ROOT, "egnn_pytorch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("checks it against the CPU oracle", ""), f
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_state_dict_roundtrip_with_reference_keys(name):
+    """The reference's state_dict (stored in the golden file) loads strictly into the drop-in module."""
+    from egnn_pytorch_amd import EGNN, EGNN_Network
+    meta, params, _ = load_golden(name)
+    net = EGNN(**meta["kwargs"]) if meta["kind"] == "layer" else EGNN_Network(**meta["kwargs"])
+    sd = {k: torch.from_numpy(v) for k, v in params.items()}
+    res = net.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert list(net.state_dict().keys()) == list(sd.keys())            # same registration order too
+    for k, v in net.state_dict().items():
+        assert v.shape == sd[k].shape
+
+
+def test_constructor_contract():
+    from egnn_pytorch_amd import EGNN, EGNN_Network
+    with pytest.raises(AssertionError):
+        EGNN(dim=8, m_pool_method="max")
+    with pytest.raises(AssertionError):
+        EGNN(dim=8, update_feats=False, update_coors=False)
+    with pytest.raises(AssertionError):
+        EGNN_Network(depth=1, dim=8, num_adj_degrees=0)
+    layer = EGNN(dim=16)
+    w = layer.edge_mlp[0].weight
+    assert abs(float(w.std()) - 1e-3) < 3e-4                        # init_: N(0, init_eps)
+    net = EGNN_Network(depth=2, dim=8, num_nearest_neighbors=3, norm_coors=True)
+    assert all(l[1].norm_feats for l in net.layers)                 # forced on, egnn_pytorch.py:387
+
+
+@pytest.mark.parametrize("kw", [dict(dim=20, m_dim=8, edge_dim=3, fourier_features=2, soft_edges=True),
+                                dict(dim=64), dict(dim=33, edge_dim=1)])
+def test_weight_relayout_is_exact(kw):
+    """Evaluate the factorised / padded / fragment-ordered weights with plain numpy on random edges and
+    compare with the oracle's unfactorised Linear(cat(h_i, h_j, scal)): same numbers to fp32 round-off."""
+    from egnn_pytorch_amd import EGNN, _weights
+    torch.manual_seed(0)
+    layer = EGNN(**kw)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(torch.randn_like(p) * 0.2)
+    w = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in _weights.pack(layer).items()}
+    dim, m = kw["dim"], kw.get("m_dim", 16)
+    s = w["S"]
+    rng = np.random.default_rng(0)
+    hi = rng.standard_normal((7, dim)).astype(np.float32)
+    hj = rng.standard_normal((7, dim)).astype(np.float32)
+    sc = rng.standard_normal((7, s)).astype(np.float32)
+    sd = {k: v.detach().numpy() for k, v in layer.state_dict().items()}
+    x_ref = np.concatenate([hi, hj, sc], -1) @ sd["edge_mlp.0.weight"].T + sd["edge_mlp.0.bias"]
+    hp, h = w["Hp"], w["H"]
+    assert hp % 32 == 0 and hp >= h and w["Sp"] >= s
+    pi = hi @ w["Wcat"][:hp].T + w["bcat"][:hp]
+    pj = hj @ w["Wcat"][hp:].T + w["bcat"][hp:]
+    x = pi + pj + sc @ w["Ws"][:s]
+    np.testing.assert_allclose(x[:, :h], x_ref, atol=2e-5)
+    assert np.all(x[:, h:] == 0) and np.all(w["Ws"][s:] == 0)
+    # fragment order back to (16, Hp)
+    w2 = w["W2f"].reshape(hp // 16, 4, 16, 4).transpose(2, 0, 1, 3).reshape(16, hp)
+    np.testing.assert_array_equal(w2[:m, :h], sd["edge_mlp.3.weight"])
+    assert np.all(w2[m:] == 0) and np.all(w2[:, h:] == 0)
+    m_ref = O.silu(O.silu(x_ref) @ sd["edge_mlp.3.weight"].T + sd["edge_mlp.3.bias"])
+    m_new = O.silu(O.silu(x) @ w2.T + w["b2"])
+    np.testing.assert_allclose(m_new[:, :m], m_ref, atol=2e-5)
+    assert np.all(m_new[:, m:] == 0)
+    np.testing.assert_array_equal(w["W3"][:4 * m, :m], sd["coors_mlp.0.weight"])
+    assert w["W3"].shape == (64, 16) and np.all(w["W3"][4 * m:] == 0)
+
+
+def test_packed_weights_cache_tracks_parameter_updates():
+    from egnn_pytorch_amd import EGNN
+    layer = EGNN(dim=8)
+    a = layer.packed_weights()
+    assert layer.packed_weights() is a
+    with torch.no_grad():
+        layer.edge_mlp[0].weight.add_(1.0)
+    b = layer.packed_weights()
+    assert b is not a and not torch.equal(a["Wcat"], b["Wcat"])

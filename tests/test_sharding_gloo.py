@@ -1,0 +1,99 @@
+"""The multi-GPU path (independent graphs sharded over ranks, no data-path collective) exercised with
+world_size-2 `gloo` processes on CPU: shard bounds, parameter broadcast, bench.py's timed region
+(barrier + max over ranks) and the optional output all-gather.  The per-rank compute is a stand-in
+(the CPU oracle -- test infrastructure) because the HIP path needs a GPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, batch, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from egnn_pytorch_amd import EGNN, sharding
+    from oracle import egnn_oracle as O
+    import bench
+
+    kw = dict(dim=16, num_nearest_neighbors=4)
+    torch.manual_seed(100 + rank)                       # ranks start with DIFFERENT weights ...
+    layer = EGNN(**kw)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.mul_(50.0)
+    sharding.broadcast_parameters(layer)                # ... and must end with rank 0's
+    params = {k: v.numpy() for k, v in layer.state_dict().items()}
+
+    g = torch.Generator().manual_seed(0)                # the same global batch on every rank
+    n = 12
+    feats = torch.randn(batch, n, 16, generator=g)
+    coors = torch.randn(batch, n, 3, generator=g)
+    mask = torch.rand(batch, n, generator=g) > 0.2
+    adj = torch.eye(n, dtype=torch.bool)
+    f, c, m, a = sharding.shard_batch(rank, world, feats, coors, mask, adj)
+    lo, hi = sharding.shard_bounds(batch, rank, world)
+    assert f.shape[0] == hi - lo and a is adj
+
+    cfg = O.EGNNConfig(**kw)
+    calls = []
+
+    def step():
+        calls.append(1)
+        return O.egnn_forward(cfg, params, f.numpy(), c.numpy(), mask=m.numpy())
+
+    elapsed = bench.timed_region(step, steps=3, warmup=1, sync=lambda: None, barrier=dist.barrier,
+                                 reduce_max=lambda x: _max(x))
+    assert len(calls) == 4 and elapsed > 0
+    node, co = step()
+    full = sharding.gather_batch(torch.from_numpy(node), batch)
+    ref, _ = O.egnn_forward(cfg, params, feats.numpy(), coors.numpy(), mask=mask.numpy())
+    np.testing.assert_allclose(full.numpy(), ref, atol=1e-5)
+    np.save(os.path.join(out_dir, f"w{rank}.npy"), params["edge_mlp.0.weight"])
+    np.save(os.path.join(out_dir, f"t{rank}.npy"), np.array([elapsed]))
+    dist.destroy_process_group()
+
+
+def _max(x):
+    t = torch.tensor([x], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+@pytest.mark.parametrize("batch", [5, 8])
+def test_two_rank_batch_shard(tmp_path, batch):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, batch, str(tmp_path)), nprocs=2, join=True)
+    w0, w1 = np.load(tmp_path / "w0.npy"), np.load(tmp_path / "w1.npy")
+    np.testing.assert_array_equal(w0, w1)                       # parameters replicated
+    t0, t1 = np.load(tmp_path / "t0.npy"), np.load(tmp_path / "t1.npy")
+    assert t0 == t1                                             # both ranks report the max over ranks
+
+
+def test_shard_bounds_cover_batch():
+    from egnn_pytorch_amd import sharding
+    for batch in (1, 7, 64, 512):
+        for world in (1, 2, 4, 8):
+            spans = [sharding.shard_bounds(batch, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == batch
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_bounds(4, 2, 2)
