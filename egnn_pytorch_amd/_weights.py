@@ -7,14 +7,23 @@ derived, padded copies built here and cached per parameter version:
       -> Wcat (2*Hp, dim): rows [0,H) = W_i, rows [Hp, Hp+H) = W_j   (node-level projection weights)
       -> bcat (2*Hp):      [0,H) = edge_mlp.0.bias                   (folded into P_i)
       -> Ws   (Sp, Hp):    the per-edge scalar columns, transposed
-  edge_mlp.3.weight (m, H) -> W2f (Hp/16, 64, 4): MFMA-fragment order, lane = 16*g + channel,
-                                                   element t = W2[channel, 16*step + 4*g + t]
+     all three multiplied by -log2(e): the edge kernel evaluates SiLU(x) = -ln2 * y / (1 + 2^y), y = -log2(e) x,
+     with v_exp_f32 (= 2^y) and no extra multiply.
+  edge_mlp.3.weight (m, H) -> W2h (Hp/32, 2, 64, 8) fp16: (-ln2 * w2_scale * W2) split into hi + lo halves
+     (hi = fp16(w), lo = fp16(w - hi): 22 significant bits), in v_mfma_f32_16x16x32_f16 fragment order:
+     [step][hi|lo][lane = 16*g + channel][t] = W2[channel, 32*step + 8*g + t].  w2_scale is the power of two that
+     brings max|W2| into [1, 2) so hi and lo stay in fp16's normal range; the kernel multiplies by 1/w2_scale.
   coors_mlp.* / edge_gate.* -> zero padded to 16 channels / 64 hidden units
-Zero padding is exact: padded hidden units see x = 0 -> SiLU(0) = 0 and meet zero W2 columns.
+Zero padding is exact: padded hidden units see y = 0 -> 0 / (1 + 1) = 0 and meet zero W2 columns.
 """
 from __future__ import annotations
 
+import math
+
 import torch
+
+NEG_LOG2E = -1.4426950408889634
+NEG_LN2 = -0.6931471805599453
 
 SP_SUPPORTED = (1, 2, 3, 5, 8, 16)     # template instantiations of the edge kernel
 M_PAD = 16                              # channels of one 16x16 MFMA tile
@@ -52,21 +61,27 @@ def pack(layer) -> dict:
     z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
 
     wcat = z(2 * hp, dim)
-    wcat[:h] = w1[:, :dim]
-    wcat[hp:hp + h] = w1[:, dim:2 * dim]
+    wcat[:h] = w1[:, :dim] * NEG_LOG2E
+    wcat[hp:hp + h] = w1[:, dim:2 * dim] * NEG_LOG2E
     bcat = z(2 * hp)
-    bcat[:h] = b1
+    bcat[:h] = b1 * NEG_LOG2E
     ws = z(sp, hp)
-    ws[:s, :h] = w1[:, 2 * dim:].t()
+    ws[:s, :h] = w1[:, 2 * dim:].t() * NEG_LOG2E
 
     w2p = z(M_PAD, hp)
-    w2p[:m, :h] = w2
+    w2p[:m, :h] = w2 * NEG_LN2
+    amax = float(w2p.abs().max())
+    w2_scale = 2.0 ** (-math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
+    w2s = w2p * w2_scale                                   # max |.| in [1, 2)
+    w2_hi = w2s.half()
+    w2_lo = (w2s - w2_hi.float()).half()
     # (channel, step, g, t) -> (step, g, channel, t) -> (step, lane = 16 g + channel, t)
-    w2f = w2p.view(M_PAD, hp // 16, 4, 4).permute(1, 2, 0, 3).contiguous().view(hp // 16, 64, 4)
+    frag = lambda t: t.view(M_PAD, hp // 32, 4, 8).permute(1, 2, 0, 3).contiguous().view(hp // 32, 64, 8)
+    w2h = torch.stack([frag(w2_hi), frag(w2_lo)], dim=1).contiguous()      # (Hp/32, 2, 64, 8) fp16
     b2p = z(M_PAD)
     b2p[:m] = b2
 
-    out = dict(H=h, Hp=hp, S=s, Sp=sp, Wcat=wcat, bcat=bcat, Ws=ws, W2f=w2f, b2=b2p)
+    out = dict(H=h, Hp=hp, S=s, Sp=sp, Wcat=wcat, bcat=bcat, Ws=ws, W2h=w2h, w2_inv_scale=1.0 / w2_scale, b2=b2p)
 
     if layer.edge_gate is not None:
         gw = z(M_PAD)

@@ -8,29 +8,45 @@
 //     w_ij   = W4 . SiLU(W3 * m_ij + b3) + b4                      (coors_mlp)
 //     mask, clamp, CoorsNorm;  x_i' = x_i + sum_k w_ij * rel_ij;  m_i = sum_k m_ij  (or mean)
 //
+// What bounds it on MI355X (tools/ubench/overlap_asm.hip, measured): the E x H SiLU evaluations.  The f32-input
+// MFMA (v_mfma_f32_16x16x4_f32) executes on the SAME datapath as the f32 VALU -- MFMA time and VALU time add --
+// while f16/bf16 MFMAs run on the matrix cores and hide completely behind VALU work.  So the H -> 16 contraction
+// is done as a 3-term split-f16 product on v_mfma_f32_16x16x32_f16 (hid = hi + lo, W2 = hi + lo in f16;
+// hi*hi + lo*hi + hi*lo, f32 accumulation: per-product error ~2^-22, i.e. f32 class) and the VALU is left with
+// exactly: 2 ops for x, 4 for SiLU (v_exp_f32, v_rcp_f32 are quarter rate), 2 for the split.
+//   * Pi/Pj/Ws arrive pre-scaled by -log2(e) (folded into the projection weights) so that SiLU(x) is
+//     -ln2 * y * rcp(1 + exp2(y)) with y the loaded value; the -ln2 and a power-of-two range scale are folded
+//     into the f16 W2 fragments and undone once per tile (w2_inv_scale).
+//
 // Mapping to the machine
-//   * one 256-thread workgroup owns G consecutive nodes of one graph = up to 256 edge slots per round;
-//     each wave owns 64 slots = 4 MFMA tiles of 16 edges.
-//   * the H -> 16 contraction runs on v_mfma_f32_16x16x4_f32 in the "swapped" orientation
-//     D[channel][edge] = sum_h W2[channel][h] * hidden[edge][h]:  lane l (e = l & 15, g = l >> 4) owns edge e
-//     of its tile and the 4 hidden units h0+4g .. h0+4g+3 of every 16-wide step, so
-//        - the gather of Pj (the only HBM/L2-heavy stream) is one 16-byte load per lane per step,
+//   * one 512-thread workgroup owns G consecutive nodes of one graph = up to 256 edge slots per round;
+//     each wave owns 32 slots = 2 MFMA tiles of 16 edges.
+//   * swapped orientation D[channel][edge] = sum_h W2[channel][h] * hidden[edge][h]:  lane l (e = l & 15, g = l >> 4)
+//     owns edge e of its tile and the 8 hidden units h0+8g .. h0+8g+7 of every 32-wide step, so
+//        - the gather of Pj is 32 contiguous bytes per lane per step (4 lanes cover one 128-byte line),
 //        - W2 is read from LDS in pre-built fragment order (lane-linear, conflict free),
 //        - the result lands as D[4g + r][e]: every lane keeps "its" edge for the whole epilogue and holds
 //          exactly the B-operand fragments the coors_mlp MFMAs (16 -> 64) need -- no transposes, no LDS.
 //   * hidden activations (E x H) never leave registers; per-edge results go through a 20 KB LDS buffer and
 //     are summed per node in k order (deterministic, no float atomics).
-//   * W2 / Ws are staged through LDS in chunks of HC hidden columns, shared by the 4 waves.
+//   * W2 / Ws are staged through LDS in chunks of HC hidden columns, shared by the 8 waves; the Pi/Pj rows of
+//     step s+1 are requested before step s is computed.
 //   * blocks are remapped so that each XCD works on a contiguous range of graphs (Pj rows of a graph stay
-//     in that XCD's L2).
+//     in that XCD's L2; measured hit rate 92 %).
 #include "egnn_common.h"
 
 namespace {
 
-constexpr int EDGE_THREADS = 256;
-constexpr int TILES = 4;                 // MFMA tiles (16 edges) per wave
-constexpr int SLOTS_PER_ROUND = 256;     // 4 waves x 4 tiles x 16 edges
-constexpr int HC = 256;                  // hidden columns per LDS chunk
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int EDGE_THREADS = 512;
+constexpr int EDGE_WAVES = EDGE_THREADS / 64;
+constexpr int TILES = 2;                 // MFMA tiles (16 edges) per wave
+constexpr int SLOTS_PER_WAVE = TILES * 16;
+constexpr int SLOTS_PER_ROUND = EDGE_WAVES * SLOTS_PER_WAVE;     // 256
+constexpr int HC = 256;                  // hidden columns per LDS chunk (8 steps of 32)
+constexpr int KSTEP = 32;                // hidden units per v_mfma_f32_16x16x32_f16
 constexpr int NCH = 20;                  // per-edge channels reduced per node: 16 m | 3 coords | 1 count
 constexpr int GMAX = 64;                 // nodes per workgroup
 
@@ -40,13 +56,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 // SP: padded number of per-edge scalar inputs; TPI: consecutive tiles of a wave that share one node i
-// (K % 64 == 0 -> 4, K % 32 == 0 -> 2, else 1 = per-lane Pi rows).
+// (K % 32 == 0 -> 2 = both tiles of a wave, else 1 = per-lane Pi rows).
 template <int SP, int TPI>
 __global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* w2s = reinterpret_cast<float*>(smem);            // [HC/16][64][4]
-    float* wss = w2s + HC * 16;                              // [SP][HC]
+    _Float16* w2s = reinterpret_cast<_Float16*>(smem);      // [HC/32][hi|lo][64][8] halves = HC * 64 bytes
+    float* wss = reinterpret_cast<float*>(smem + HC * 64);   // [SP][HC]
     float* ebuf = wss + SP * HC;                             // [256][NCH]
     float* nodeacc = ebuf + SLOTS_PER_ROUND * NCH;           // [GMAX][NCH]
 
@@ -78,7 +94,7 @@ __global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_a
 
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
-            const int q = round * SLOTS_PER_ROUND + wave * 64 + t * 16 + e;
+            const int q = round * SLOTS_PER_ROUND + wave * SLOTS_PER_WAVE + t * 16 + e;
             int nl = q / K;
             int k = q - nl * K;
             int i = node0 + nl;
@@ -111,8 +127,8 @@ __global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_a
                 if (has_rank) em = em && (p.rank[(bN + i) * K + k] <= p.valid_radius);
             }
             fm[t] = em;
-            pjp[t] = p.Pj + (bN + j) * p.ldp + 4 * g;
-            pip[t] = p.Pi + (bN + i) * p.ldp + 4 * g;
+            pjp[t] = p.Pj + (bN + j) * p.ldp + 8 * g;
+            pip[t] = p.Pi + (bN + i) * p.ldp + 8 * g;
         }
 
         f32x4 acc[TILES];
@@ -121,19 +137,26 @@ __global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_a
 
         // ------------------------------------------------------------------ main loop over hidden units
         // Software pipeline: the Pi/Pj rows of step st+1 are requested before step st is computed, so the
-        // gather latency (L2 / Infinity Cache) hides under 16 MFMAs + 64 SiLUs per wave.
+        // gather latency (L2 / Infinity Cache) hides under the SiLU work of the current step.
         constexpr int NPI = TILES / TPI;
-        f32x4 pjn[TILES], pin[NPI];
+        f32x4 pjn[TILES][2], pin[NPI][2];
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) pjn[t] = *reinterpret_cast<const f32x4*>(pjp[t]);
+        for (int t = 0; t < TILES; ++t) {
+            pjn[t][0] = *reinterpret_cast<const f32x4*>(pjp[t]);
+            pjn[t][1] = *reinterpret_cast<const f32x4*>(pjp[t] + 4);
+        }
 #pragma unroll
-        for (int u = 0; u < NPI; ++u) pin[u] = *reinterpret_cast<const f32x4*>(pip[u * TPI]);
+        for (int u = 0; u < NPI; ++u) {
+            pin[u][0] = *reinterpret_cast<const f32x4*>(pip[u * TPI]);
+            pin[u][1] = *reinterpret_cast<const f32x4*>(pip[u * TPI] + 4);
+        }
 
         for (int c0 = 0; c0 < p.Hp; c0 += HC) {
             const int hc = (p.Hp - c0) < HC ? (p.Hp - c0) : HC;
             __syncthreads();
             {
-                const float4* src = reinterpret_cast<const float4*>(p.W2f + (size_t)c0 * 16);
+                // W2 fragments: (Hp/32, 2, 64, 8) halves = 2048 bytes per step, contiguous
+                const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.W2h) + (size_t)c0 * 64);
                 float4* dst = reinterpret_cast<float4*>(w2s);
                 for (int x = tid; x < hc * 4; x += EDGE_THREADS) dst[x] = src[x];
 #pragma unroll
@@ -145,37 +168,65 @@ __global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_a
             }
             __syncthreads();
 
-            const int nst = hc >> 4;
+            const int nst = hc / KSTEP;
             for (int st = 0; st < nst; ++st) {
-                const int hoff = c0 + st * 16;
-                f32x4 pjc[TILES], pic[NPI];
-#pragma unroll
-                for (int t = 0; t < TILES; ++t) pjc[t] = pjn[t];
-#pragma unroll
-                for (int u = 0; u < NPI; ++u) pic[u] = pin[u];
-                int hnext = hoff + 16;
-                if (hnext >= p.Hp) hnext = hoff;                 // last step: harmless re-read
-#pragma unroll
-                for (int t = 0; t < TILES; ++t) pjn[t] = *reinterpret_cast<const f32x4*>(pjp[t] + hnext);
-#pragma unroll
-                for (int u = 0; u < NPI; ++u) pin[u] = *reinterpret_cast<const f32x4*>(pip[u * TPI] + hnext);
-
-                const f32x4 w2 = *reinterpret_cast<const f32x4*>(w2s + (st * 64 + lane) * 4);
-                f32x4 ws[SP];
-#pragma unroll
-                for (int s = 0; s < SP; ++s) ws[s] = *reinterpret_cast<const f32x4*>(wss + s * HC + st * 16 + 4 * g);
-
+                const int hoff = c0 + st * KSTEP;
+                float x[TILES][8];
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
-                    f32x4 x = pic[t / TPI] + pjc[t];
 #pragma unroll
-                    for (int s = 0; s < SP; ++s) x += sc[t][s] * ws[s];
-                    f32x4 hv;
+                    for (int u = 0; u < 4; ++u) {
+                        x[t][u] = pin[t / TPI][0][u] + pjn[t][0][u];
+                        x[t][4 + u] = pin[t / TPI][1][u] + pjn[t][1][u];
+                    }
+                }
+                int hnext = hoff + KSTEP;
+                if (hnext >= p.Hp) hnext = hoff;                 // last step: harmless re-read
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) hv[u] = egnn_silu(x[u]);
+                for (int t = 0; t < TILES; ++t) {
+                    pjn[t][0] = *reinterpret_cast<const f32x4*>(pjp[t] + hnext);
+                    pjn[t][1] = *reinterpret_cast<const f32x4*>(pjp[t] + hnext + 4);
+                }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[u], hv[u], acc[t], 0, 0, 0);
+                for (int u = 0; u < NPI; ++u) {
+                    pin[u][0] = *reinterpret_cast<const f32x4*>(pip[u * TPI] + hnext);
+                    pin[u][1] = *reinterpret_cast<const f32x4*>(pip[u * TPI] + hnext + 4);
+                }
+
+                const f16x8 whi = *reinterpret_cast<const f16x8*>(w2s + ((st * 2 + 0) * 64 + lane) * 8);
+                const f16x8 wlo = *reinterpret_cast<const f16x8*>(w2s + ((st * 2 + 1) * 64 + lane) * 8);
+#pragma unroll
+                for (int s = 0; s < SP; ++s) {
+                    const f32x4 wa = *reinterpret_cast<const f32x4*>(wss + s * HC + st * KSTEP + 8 * g);
+                    const f32x4 wb = *reinterpret_cast<const f32x4*>(wss + s * HC + st * KSTEP + 8 * g + 4);
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            x[t][u] = __builtin_fmaf(sc[t][s], wa[u], x[t][u]);
+                            x[t][4 + u] = __builtin_fmaf(sc[t][s], wb[u], x[t][4 + u]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    // x holds y = -log2(e) * (pre-activation); hv = y / (1 + 2^y) = SiLU(pre) / (-ln 2)
+                    f16x8 bhi, blo;
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) {
+                        const float y0 = x[t][u], y1 = x[t][u + 1];
+                        const float h0 = y0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y0));
+                        const float h1 = y1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y1));
+                        const f16x2 hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+                        const float l0 = h0 - (float)hi[0];
+                        const float l1 = h1 - (float)hi[1];
+                        const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+                        bhi[u] = hi[0]; bhi[u + 1] = hi[1];
+                        blo[u] = lo[0]; blo[u + 1] = lo[1];
+                    }
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bhi, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, bhi, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, blo, acc[t], 0, 0, 0);
                 }
             }
         }
@@ -199,7 +250,7 @@ __global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_a
         for (int t = 0; t < TILES; ++t) {
             f32x4 m;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) m[u] = egnn_silu(acc[t][u] + b2r[u]);
+            for (int u = 0; u < 4; ++u) m[u] = egnn_silu(acc[t][u] * p.w2_inv_scale + b2r[u]);
             if (p.gate_w) {
                 float part = gwr[0] * m[0] + gwr[1] * m[1] + gwr[2] * m[2] + gwr[3] * m[3];
                 part += __shfl_xor(part, 16);
@@ -247,7 +298,7 @@ __global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_a
         __syncthreads();                                     // previous round's reduction has read ebuf
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
-            const int slot = wave * 64 + t * 16 + e;
+            const int slot = wave * SLOTS_PER_WAVE + t * 16 + e;
             const float keep = fm[t] ? 1.f : 0.f;
             float* row = ebuf + slot * NCH;
             *reinterpret_cast<f32x4*>(row + 4 * g) = acc[t] * keep;
@@ -314,7 +365,7 @@ int launch_edge(const egnn_edge_args& a, hipStream_t s)
     const int gpg = (a.N + G - 1) / G;
     const int64_t nblk = (int64_t)a.B * gpg;
     if (nblk > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
-    const size_t lds = sizeof(float) * ((size_t)HC * 16 + (size_t)SP * HC + SLOTS_PER_ROUND * NCH + GMAX * NCH);
+    const size_t lds = (size_t)HC * 64 + sizeof(float) * ((size_t)SP * HC + SLOTS_PER_ROUND * NCH + GMAX * NCH);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_kernel<SP, TPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -328,7 +379,6 @@ template <int SP>
 int dispatch_tpi(const egnn_edge_args& a, hipStream_t s)
 {
     // tiles of 16 consecutive slots share node i only when K is a multiple of 16 and the group is full
-    if (a.K % 64 == 0) return launch_edge<SP, 4>(a, s);
     if (a.K % 32 == 0) return launch_edge<SP, 2>(a, s);
     return launch_edge<SP, 1>(a, s);
 }
@@ -341,18 +391,18 @@ extern "C" int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream)
 {
     if (!args) return EGNN_E_NULLPTR;
     const egnn_edge_args& a = *args;
-    if (!a.Pi || !a.Pj || !a.Ws || !a.W2f || !a.b2 || !a.coors) return EGNN_E_NULLPTR;
+    if (!a.Pi || !a.Pj || !a.Ws || !a.W2h || !a.b2 || !a.coors) return EGNN_E_NULLPTR;
     if (!a.m_i && !a.coors_out) return EGNN_E_NULLPTR;
     if (a.coors_out && (!a.W3 || !a.b3 || !a.W4 || !a.b4)) return EGNN_E_NULLPTR;
     if (a.gate_w && !a.gate_b) return EGNN_E_NULLPTR;
     if (a.B <= 0 || a.N <= 0 || a.K <= 0 || a.H <= 0) return EGNN_E_SHAPE;
-    if (a.Hp != egnn_padded_hidden(a.H) || a.ldp < a.Hp || (a.ldp % 4) != 0) return EGNN_E_SHAPE;
+    if (a.Hp != egnn_padded_hidden(a.H) || a.ldp < a.Hp || (a.ldp % 4) != 0 || !(a.w2_inv_scale > 0.f)) return EGNN_E_SHAPE;
     if (a.m_dim < 1 || a.m_dim > 16) return EGNN_E_UNSUPPORTED;
     if (a.S != 2 * a.fourier + 1 + a.edge_dim || a.Sp < a.S) return EGNN_E_SHAPE;
     if (a.edge_dim > 0 && !a.edges) return EGNN_E_NULLPTR;
     if (a.idx == nullptr && a.K != a.N) return EGNN_E_SHAPE;          // dense path: K == N
     if ((reinterpret_cast<uintptr_t>(a.Pi) & 15) || (reinterpret_cast<uintptr_t>(a.Pj) & 15) ||
-        (reinterpret_cast<uintptr_t>(a.Ws) & 15) || (reinterpret_cast<uintptr_t>(a.W2f) & 15))
+        (reinterpret_cast<uintptr_t>(a.Ws) & 15) || (reinterpret_cast<uintptr_t>(a.W2h) & 15))
         return EGNN_E_ALIGN;
     if (a.W3 && ((reinterpret_cast<uintptr_t>(a.W3) & 15) || (reinterpret_cast<uintptr_t>(a.b3) & 15) ||
                  (reinterpret_cast<uintptr_t>(a.W4) & 15)))

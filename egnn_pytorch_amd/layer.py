@@ -163,7 +163,8 @@ class EGNN(nn.Module):
             a.Pi = proj.data_ptr()
             a.Pj = proj.data_ptr() + 4 * hp
             a.ldp = 2 * hp
-            a.Ws, a.W2f, a.b2 = w["Ws"].data_ptr(), w["W2f"].data_ptr(), w["b2"].data_ptr()
+            a.Ws, a.W2h, a.b2 = w["Ws"].data_ptr(), w["W2h"].data_ptr(), w["b2"].data_ptr()
+            a.w2_inv_scale = w["w2_inv_scale"]
             if self.edge_gate is not None:
                 a.gate_w, a.gate_b = w["gate_w"].data_ptr(), w["gate_b"].data_ptr()
             if self.coors_mlp is not None:

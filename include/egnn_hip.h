@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 1
+#define EGNN_ABI_VERSION 2
 
 enum {
     EGNN_OK = 0,
@@ -102,12 +102,15 @@ typedef struct egnn_edge_args {
     int32_t S;                  /* per-edge scalar inputs: 2F + 1 + edge_dim */
     int32_t Sp;                 /* rows of Ws (>= S, zero padded; one of 1,2,3,4,5,6,8,12,16) */
     /* node-level projections, produced by egnn_linear_f32 */
-    const float* Pi;            /* (B*N, ldp): W_i h_i + b1      (pad columns must be 0) */
-    const float* Pj;            /* (B*N, ldp): W_j h_j */
+    const float* Pi;            /* (B*N, ldp): -log2(e) * (W_i h_i + b1)      (pad columns must be 0) */
+    const float* Pj;            /* (B*N, ldp): -log2(e) * W_j h_j */
     int64_t ldp;
     /* re-laid-out weights (egnn_pytorch_amd/_weights.py) */
-    const float* Ws;            /* (Sp, Hp): columns [2dim .. 2dim+S) of edge_mlp.0.weight, transposed */
-    const float* W2f;           /* (Hp/16, 64, 4): edge_mlp.3.weight in MFMA-fragment order */
+    const float* Ws;            /* (Sp, Hp): columns [2dim .. 2dim+S) of edge_mlp.0.weight, transposed, x -log2(e) */
+    const void* W2h;            /* (Hp/32, 2, 64, 8) fp16: -ln2 * w2_scale * edge_mlp.3.weight split into hi | lo halves,
+                                   in v_mfma_f32_16x16x32_f16 fragment order: [step][hi|lo][lane = 16 g + channel][t] =
+                                   W2[channel][32 step + 8 g + t] */
+    float w2_inv_scale;         /* 1 / w2_scale (a power of two), applied to the accumulated H -> m_dim product */
     const float* b2;            /* (16) edge_mlp.3.bias, zero padded */
     const float* gate_w;        /* (16) edge_gate.0.weight or NULL (soft_edges=False) */
     const float* gate_b;        /* (1) */

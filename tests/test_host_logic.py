@@ -119,17 +119,27 @@ def test_weight_relayout_is_exact(kw):
     x_ref = np.concatenate([hi, hj, sc], -1) @ sd["edge_mlp.0.weight"].T + sd["edge_mlp.0.bias"]
     hp, h = w["Hp"], w["H"]
     assert hp % 32 == 0 and hp >= h and w["Sp"] >= s
+    # the kernel's variable is y = -log2(e) * x ...
     pi = hi @ w["Wcat"][:hp].T + w["bcat"][:hp]
     pj = hj @ w["Wcat"][hp:].T + w["bcat"][hp:]
-    x = pi + pj + sc @ w["Ws"][:s]
-    np.testing.assert_allclose(x[:, :h], x_ref, atol=2e-5)
-    assert np.all(x[:, h:] == 0) and np.all(w["Ws"][s:] == 0)
-    # fragment order back to (16, Hp)
-    w2 = w["W2f"].reshape(hp // 16, 4, 16, 4).transpose(2, 0, 1, 3).reshape(16, hp)
-    np.testing.assert_array_equal(w2[:m, :h], sd["edge_mlp.3.weight"])
+    y = pi + pj + sc @ w["Ws"][:s]
+    np.testing.assert_allclose(y[:, :h] / -np.log2(np.e), x_ref, atol=3e-5)
+    assert np.all(y[:, h:] == 0) and np.all(w["Ws"][s:] == 0)
+    # ... hidden = y / (1 + 2^y) = SiLU(x) / (-ln 2), contracted with hi + lo fp16 fragments of -ln2 * scale * W2
+    w2h = w["W2h"].astype(np.float64)                                 # (Hp/32, 2, 64, 8)
+    assert w["W2h"].dtype == np.float16 and w2h.shape == (hp // 32, 2, 64, 8)
+    unfrag = lambda f: f.reshape(hp // 32, 4, 16, 8).transpose(2, 0, 1, 3).reshape(16, hp)
+    w2 = (unfrag(w2h[:, 0]) + unfrag(w2h[:, 1])) * w["w2_inv_scale"]
+    # 22 significant bits for elements near the tensor's max; lo of much smaller elements falls into fp16
+    # subnormals (spacing 2^-24 of the scaled max), i.e. the absolute error stays at fp32 level of the max
+    w2_true = -np.log(2.0) * sd["edge_mlp.3.weight"].astype(np.float64)
+    np.testing.assert_allclose(w2[:m, :h], w2_true, rtol=4e-7, atol=2.0 ** -24 * np.abs(w2_true).max())
     assert np.all(w2[m:] == 0) and np.all(w2[:, h:] == 0)
+    lg = np.log2(w["w2_inv_scale"])
+    assert lg == np.round(lg) and 1.0 <= np.abs(unfrag(w2h[:, 0])).max() < 2.0      # power-of-two range scale
+    hid = y.astype(np.float64) / (1.0 + np.exp2(y.astype(np.float64)))
     m_ref = O.silu(O.silu(x_ref) @ sd["edge_mlp.3.weight"].T + sd["edge_mlp.3.bias"])
-    m_new = O.silu(O.silu(x) @ w2.T + w["b2"])
+    m_new = O.silu((hid @ w2.T + w["b2"]).astype(np.float32))
     np.testing.assert_allclose(m_new[:, :m], m_ref, atol=2e-5)
     assert np.all(m_new[:, m:] == 0)
     np.testing.assert_array_equal(w["W3"][:4 * m, :m], sd["coors_mlp.0.weight"])
