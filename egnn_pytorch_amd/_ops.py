@@ -123,6 +123,24 @@ def linear(a, w, bias=None, residual=None, act=0, name="linear"):
     return c
 
 
+def linear_split(a, wsplit, n, bias=None, residual=None, act=0, name="linear"):
+    """act(a @ W.T + bias) (+ residual) on the matrix cores -- egnn_linear_split_f32.
+    `wsplit` = (W_hi, W_lo, inv_scale) from _weights.split_f16; n = true number of output columns."""
+    whi, wlo, inv = wsplit
+    m, k = a.shape
+    assert a.is_contiguous() and whi.shape == wlo.shape and whi.shape[0] >= n and whi.shape[1] >= k
+    c = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    ldr = 0
+    if residual is not None:
+        assert residual.shape == (m, n) and residual.is_contiguous()
+        ldr = n
+    with _timed(name):
+        rc = _abi.load().egnn_linear_split_f32(_ptr(a), k, _ptr(whi), _ptr(wlo), whi.shape[1], float(inv), _ptr(bias),
+                                               _ptr(residual), ldr, _ptr(c), n, m, n, k, act, _stream())
+    _abi.check(rc, "egnn_linear_split_f32")
+    return c
+
+
 def node_prep(feats2d, m_i, gamma, beta, eps, m_dim):
     rows, dim = feats2d.shape
     out = torch.empty(rows, dim + m_dim, dtype=torch.float32, device=feats2d.device)

@@ -43,6 +43,21 @@ def padded_scalars(s: int) -> int:
         f"the gfx950 edge kernel is built for")
 
 
+def split_f16(w: torch.Tensor):
+    """(N, K) fp32 weight -> (W_hi, W_lo, inv_scale) for egnn_linear_split_f32: fp16 images of scale * W with
+    scale the power of two that brings max|W| into [1, 2) (hi and lo then sit in fp16's normal range),
+    hi = fp16(w), lo = fp16(w - hi), zero padded to (ceil(N/128)*128, ceil(K/32)*32)."""
+    n, k = w.shape
+    npad, kpad = (n + 127) // 128 * 128, (k + 31) // 32 * 32
+    amax = float(w.abs().max()) if w.numel() else 0.0
+    scale = 2.0 ** (-math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
+    ws = torch.zeros(npad, kpad, dtype=torch.float32, device=w.device)
+    ws[:n, :k] = w.float() * scale
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    return hi.contiguous(), lo.contiguous(), 1.0 / scale
+
+
 def pack(layer) -> dict:
     """Build the kernel-side weight set of one EGNN layer.  All outputs are fp32, contiguous, on the
     parameters' device."""
@@ -81,7 +96,8 @@ def pack(layer) -> dict:
     b2p = z(M_PAD)
     b2p[:m] = b2
 
-    out = dict(H=h, Hp=hp, S=s, Sp=sp, Wcat=wcat, bcat=bcat, Ws=ws, W2h=w2h, w2_inv_scale=1.0 / w2_scale, b2=b2p)
+    out = dict(H=h, Hp=hp, S=s, Sp=sp, Wcat=wcat, Wcat_split=split_f16(wcat), bcat=bcat, Ws=ws, W2h=w2h,
+               w2_inv_scale=1.0 / w2_scale, b2=b2p)
 
     if layer.edge_gate is not None:
         gw = z(M_PAD)
@@ -104,6 +120,8 @@ def pack(layer) -> dict:
                    b5=layer.node_mlp[0].bias.detach().float().contiguous(),
                    W6=layer.node_mlp[3].weight.detach().float().contiguous(),
                    b6=layer.node_mlp[3].bias.detach().float().contiguous())
+        out["W5_split"] = split_f16(out["W5"])
+        out["W6_split"] = split_f16(out["W6"])
         if layer.norm_feats:
             out.update(gamma=layer.node_norm.weight.detach().float().contiguous(),
                        beta=layer.node_norm.bias.detach().float().contiguous(),

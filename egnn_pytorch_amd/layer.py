@@ -154,7 +154,7 @@ class EGNN(nn.Module):
         m_i = None
         if k > 0:
             # ---- node-level projections P = feats [W_i ; W_j]^T + [b1 ; 0]
-            proj = _ops.linear(feats2d, w["Wcat"], w["bcat"], name="node_proj")
+            proj = _ops.linear_split(feats2d, w["Wcat_split"], 2 * w["Hp"], w["bcat"], name="node_proj")
             hp = w["Hp"]
             a = _abi.EdgeArgs()
             a.B, a.N, a.K, a.dim, a.m_dim = b, n, k, dim, self.m_dim
@@ -192,8 +192,9 @@ class EGNN(nn.Module):
         # ---- node update (egnn_pytorch.py:335-337)
         if self.node_mlp is not None:
             node_in = _ops.node_prep(feats2d, m_i, w.get("gamma"), w.get("beta"), w.get("ln_eps", 1e-5), self.m_dim)
-            hid = _ops.linear(node_in, w["W5"], w["b5"], act=1, name="node_mlp0")
-            node_out = _ops.linear(hid, w["W6"], w["b6"], residual=feats2d, name="node_mlp1").view(b, n, dim)
+            hid = _ops.linear_split(node_in, w["W5_split"], 2 * dim, w["b5"], act=1, name="node_mlp0")
+            node_out = _ops.linear_split(hid, w["W6_split"], dim, w["b6"], residual=feats2d,
+                                         name="node_mlp1").view(b, n, dim)
         return node_out, coors_out
 
 

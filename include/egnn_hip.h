@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 2
+#define EGNN_ABI_VERSION 3
 
 enum {
     EGNN_OK = 0,
@@ -69,7 +69,8 @@ int egnn_knn_select_f32(const float* coors, const uint8_t* mask, const uint8_t* 
 int egnn_adj_max_degree_u8(const uint8_t* adj, int64_t rows, int N, int32_t* out_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Dense layer on the fp32 matrix cores: C = act(A * W^T + bias) (+ residual).
+ * Dense layer, exact-fp32 variant (v_mfma_f32_32x32x2_f32): C = act(A * W^T + bias) (+ residual).
+ * Kept as the numerically exact reference implementation of egnn_linear_split_f32 (A/B tests, odd shapes).
  * Used for (a) the node-level projections P = feats * [W_i ; W_j]^T + [b1 ; 0] that replace the
  * per-edge first Linear of edge_mlp (egnn_pytorch.py:178-179, 279-287: Linear(cat(h_i,h_j,d,e)) =
  * W_i h_i + W_j h_j + w_d d + W_e e + b), and (b) node_mlp (egnn_pytorch.py:196-201, 336-337).
@@ -80,6 +81,19 @@ int egnn_adj_max_degree_u8(const uint8_t* adj, int64_t rows, int N, int32_t* out
 int egnn_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                     const float* residual, int64_t ldr, float* C, int64_t ldc,
                     int64_t M, int N, int K, int act, void* stream);
+
+/* The same operation on the matrix cores (the production path): fp32 in / fp32 out, every product evaluated as
+ * a 3-term split-f16 product with fp32 accumulation on v_mfma_f32_32x32x16_f16
+ * (a = a_hi + a_lo, w = w_hi + w_lo;  a_hi w_hi + a_lo w_hi + a_hi w_lo;  dropped term <= 2^-22 |a w|: fp32-class
+ * accuracy at 3/16 of the f32-MFMA cost -- on gfx950 the f32-input MFMA runs at vector rate on the vector datapath).
+ *   W_hi, W_lo: (Np, ldw) fp16 images of w_scale * W, split on the host (egnn_pytorch_amd/_weights.py::split_f16):
+ *               Np = N rounded up to 128, ldw = K rounded up to 32, zero padded; w_inv_scale = 1 / w_scale
+ *               (a power of two that brings max|W| into [1,2)).
+ *   A is split on the fly; requires |A| < 65504.  Other arguments as egnn_linear_f32.
+ */
+int egnn_linear_split_f32(const float* A, int64_t lda, const void* W_hi, const void* W_lo, int64_t ldw,
+                          float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
+                          float* C, int64_t ldc, int64_t M, int N, int K, int act, void* stream);
 
 /* node_norm + concat (egnn_pytorch.py:335-336): out[r] = [ LayerNorm(feats[r]) | m_i[r] ].
  * gamma/beta NULL -> Identity (norm_feats=False).  out: (rows, dim + m_dim). */

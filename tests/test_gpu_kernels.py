@@ -100,6 +100,37 @@ def test_linear_f32(m, n, k, act, res):
     np.testing.assert_allclose(out, ref, atol=2e-5, rtol=0)
 
 
+@pytest.mark.parametrize("m,n,k,act,res", [
+    (16, 130, 32, 0, False), (300, 257, 65, 1, False), (1024, 4160, 512, 0, False),
+    (2048, 1024, 528, 1, False), (2048, 512, 1024, 0, True), (77, 40, 36, 0, True), (5, 3, 7, 1, True),
+    (128, 128, 8, 0, False), (129, 129, 100, 0, False),
+])
+def test_linear_split_f16x3(m, n, k, act, res):
+    """fp32-in/fp32-out GEMM on the matrix cores (3-term split-f16): fp32-class accuracy against an fp64
+    reference, same tolerance as the exact-fp32 kernel; weights at very different scales exercise the
+    power-of-two range scaling."""
+    from egnn_pytorch_amd import _ops, _weights
+    rng = np.random.default_rng(m + n + k)
+    for wscale in (1.0, 1e-3, 37.0):
+        a = (rng.standard_normal((m, k)) * 3).astype(np.float32)
+        w = (rng.standard_normal((n, k)) / np.sqrt(k) * wscale).astype(np.float32)
+        bias = rng.standard_normal(n).astype(np.float32)
+        r = rng.standard_normal((m, n)).astype(np.float32) if res else None
+        ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
+        if act:
+            ref = ref / (1.0 + np.exp(-ref))
+        if res:
+            ref = ref + r
+        ws = _weights.split_f16(_dev(w))
+        out = _ops.linear_split(_dev(a), ws, n, _dev(bias), _dev(r), act=act).cpu().numpy()
+        assert out.shape == (m, n)
+        tol = 2e-5 * max(1.0, 3 * wscale)
+        np.testing.assert_allclose(out, ref, atol=tol, rtol=0)
+        # and it must agree with the exact-fp32 MFMA kernel at fp32 round-off level
+        exact = _ops.linear(_dev(a), _dev(w), _dev(bias), _dev(r), act=act).cpu().numpy()
+        np.testing.assert_allclose(out, exact, atol=tol, rtol=0)
+
+
 def test_node_prep():
     from egnn_pytorch_amd import _ops
     rng = np.random.default_rng(0)

@@ -43,7 +43,7 @@ def test_golden(name):
 CONFIGS = [
     # BASELINE.json configs at sizes the oracle finishes in seconds (full widths, reduced B / N)
     ("c2_dense_dim512", dict(dim=512), 2, 64, dict()),
-    ("c2_dense_dim512_n256", dict(dim=512), 1, 256, dict()),
+    ("c2_dense_dim512_n256", dict(dim=512), 1, 256, dict(scale={"coors_mlp.3.weight": 0.1})),   # 256 neighbours: keep |x'| O(10)
     ("ns_dim512_k32", dict(dim=512, num_nearest_neighbors=32), 2, 256, dict(mask=True)),
     ("c3_layer_dim128_k32", dict(dim=128, num_nearest_neighbors=32, norm_feats=True), 3, 320, dict(mask=True)),
     ("c4_sparse_dim512_edges", dict(dim=512, edge_dim=4, only_sparse_neighbors=True), 2, 128,
