@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -24,7 +24,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SYMBOLS = (
     "egnn_abi_version", "egnn_error_string", "egnn_padded_hidden", "egnn_knn_select_f32",
     "egnn_adj_max_degree_u8", "egnn_linear_f32", "egnn_linear_split_f32", "egnn_node_prep_f32",
-    "egnn_edge_fused_f32",
+    "egnn_edge_fused_f32", "egnn_spatial_order_f32",
 )
 
 
@@ -40,6 +40,7 @@ class EdgeArgs(Structure):
         ("W3", c_void_p), ("b3", c_void_p), ("W4", c_void_p), ("b4", c_void_p),
         ("coors_scale", c_void_p),
         ("coors", c_void_p), ("edges", c_void_p), ("mask", c_void_p), ("idx", c_void_p), ("rank", c_void_p),
+        ("order", c_void_p),
         ("valid_radius", c_float), ("clamp", c_float), ("pool_mean", c_int32),
         ("m_i", c_void_p), ("coors_out", c_void_p),
     ]
@@ -95,6 +96,8 @@ def load():
     lib.egnn_node_prep_f32.restype = c_int
     lib.egnn_node_prep_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
                                        c_int, c_int, c_void_p]
+    lib.egnn_spatial_order_f32.restype = c_int
+    lib.egnn_spatial_order_f32.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.egnn_edge_fused_f32.restype = c_int
     lib.egnn_edge_fused_f32.argtypes = [POINTER(EdgeArgs), c_void_p]
 

@@ -95,6 +95,16 @@ def knn_select(coors, mask, adj_mat, k):
     return idx, rank
 
 
+def spatial_order(coors):
+    """(B,N) int32 Morton permutation -- egnn_spatial_order_f32 (scheduling aid for the edge pass)."""
+    b, n, _ = coors.shape
+    order = torch.empty(b, n, dtype=torch.int32, device=coors.device)
+    with _timed("spatial_order"):
+        rc = _abi.load().egnn_spatial_order_f32(_ptr(coors), b, n, _ptr(order), _stream())
+    _abi.check(rc, "egnn_spatial_order_f32")
+    return order
+
+
 def adj_max_degree(adj_mat):
     """int(adj_mat.float().sum(-1).max()) -- one device->host read, like the reference's .item() (:249)."""
     a8 = _u8(adj_mat)

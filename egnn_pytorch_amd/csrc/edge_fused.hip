@@ -19,17 +19,19 @@
 //     into the f16 W2 fragments and undone once per tile (w2_inv_scale).
 //
 // Mapping to the machine
-//   * one 512-thread workgroup owns G consecutive nodes of one graph = up to 256 edge slots per round;
-//     each wave owns 32 slots = 2 MFMA tiles of 16 edges.
+//   * one 256-thread workgroup owns G consecutive nodes (in Morton order) of one graph = up to 128 edge slots
+//     per round; each wave owns 32 slots = 2 MFMA tiles of 16 edges; 128 VGPRs -> 4 waves per SIMD.
 //   * swapped orientation D[channel][edge] = sum_h W2[channel][h] * hidden[edge][h]:  lane l (e = l & 15, g = l >> 4)
 //     owns edge e of its tile and the 8 hidden units h0+8g .. h0+8g+7 of every 32-wide step, so
-//        - the gather of Pj is 32 contiguous bytes per lane per step (4 lanes cover one 128-byte line),
+//        - the gather of Pj fetches WHOLE 128-byte lines (lane l: chunk l&7 of the row of slot 8q + (l>>3)); a
+//          wave-level load is processed line by line (tools/ubench/gather.hip: 16 half-used lines per instruction
+//          9.7 TB/s, 8 full lines 20.9 TB/s), the fragments are then re-dealt through a wave-private LDS buffer,
 //        - W2 is read from LDS in pre-built fragment order (lane-linear, conflict free),
 //        - the result lands as D[4g + r][e]: every lane keeps "its" edge for the whole epilogue and holds
 //          exactly the B-operand fragments the coors_mlp MFMAs (16 -> 64) need -- no transposes, no LDS.
 //   * hidden activations (E x H) never leave registers; per-edge results go through a 20 KB LDS buffer and
 //     are summed per node in k order (deterministic, no float atomics).
-//   * W2 / Ws are staged through LDS in chunks of HC hidden columns, shared by the 8 waves; the Pi/Pj rows of
+//   * W2 / Ws are staged through LDS in chunks of HC hidden columns, shared by the 4 waves; the Pi/Pj rows of
 //     step s+1 are requested before step s is computed.
 //   * blocks are remapped so that each XCD works on a contiguous range of graphs (Pj rows of a graph stay
 //     in that XCD's L2; measured hit rate 92 %).
@@ -40,15 +42,25 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int EDGE_THREADS = 512;
+#ifndef EGNN_EDGE_THREADS
+#define EGNN_EDGE_THREADS 256
+#endif
+#ifndef EGNN_EDGE_HC
+#define EGNN_EDGE_HC 256
+#endif
+#ifndef EGNN_EDGE_MINW
+#define EGNN_EDGE_MINW 4
+#endif
+constexpr int EDGE_THREADS = EGNN_EDGE_THREADS;
 constexpr int EDGE_WAVES = EDGE_THREADS / 64;
 constexpr int TILES = 2;                 // MFMA tiles (16 edges) per wave
 constexpr int SLOTS_PER_WAVE = TILES * 16;
 constexpr int SLOTS_PER_ROUND = EDGE_WAVES * SLOTS_PER_WAVE;     // 256
-constexpr int HC = 256;                  // hidden columns per LDS chunk (8 steps of 32)
+constexpr int HC = EGNN_EDGE_HC;          // hidden columns per LDS chunk (steps of 32)
 constexpr int KSTEP = 32;                // hidden units per v_mfma_f32_16x16x32_f16
 constexpr int NCH = 20;                  // per-edge channels reduced per node: 16 m | 3 coords | 1 count
 constexpr int GMAX = 64;                 // nodes per workgroup
+constexpr int XLD = 36;                  // floats per row of the gather exchange buffer (128 B line + 16 B pad)
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
@@ -58,13 +70,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // SP: padded number of per-edge scalar inputs; TPI: consecutive tiles of a wave that share one node i
 // (K % 32 == 0 -> 2 = both tiles of a wave, else 1 = per-lane Pi rows).
 template <int SP, int TPI>
-__global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
+__global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* w2s = reinterpret_cast<_Float16*>(smem);      // [HC/32][hi|lo][64][8] halves = HC * 64 bytes
     float* wss = reinterpret_cast<float*>(smem + HC * 64);   // [SP][HC]
-    float* ebuf = wss + SP * HC;                             // [256][NCH]
-    float* nodeacc = ebuf + SLOTS_PER_ROUND * NCH;           // [GMAX][NCH]
+    float* nodeacc = wss + SP * HC;                          // [GMAX][NCH]
+    float* xchall = nodeacc + GMAX * NCH;                    // [EDGE_WAVES][32 slots][XLD]: per-wave gather exchange
+    float* ebuf = xchall;                                    // [256][NCH] aliases it (epilogue only; 20 <= XLD)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -86,7 +99,6 @@ __global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_a
 
     for (int round = 0; round < rounds; ++round) {
         // ------------------------------------------------------------------ per-slot setup
-        const float* pjp[TILES];
         const float* pip[TILES];
         float sc[TILES][SP];
         float relx[TILES], rely[TILES], relz[TILES];
@@ -97,9 +109,10 @@ __global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_a
             const int q = round * SLOTS_PER_ROUND + wave * SLOTS_PER_WAVE + t * 16 + e;
             int nl = q / K;
             int k = q - nl * K;
-            int i = node0 + nl;
-            bool valid = (q < slots_total) && (i < N);
-            if (!valid) { i = node0 < N ? node0 : 0; k = 0; }
+            int pos = node0 + nl;                                    // position in the (optionally permuted) node order
+            bool valid = (q < slots_total) && (pos < N);
+            if (!valid) { pos = node0 < N ? node0 : 0; k = 0; }
+            const int i = p.order ? p.order[bN + pos] : pos;
             const int j = p.idx ? p.idx[(bN + i) * K + k] : k;
             const float* ci = p.coors + (bN + i) * 3;
             const float* cj = p.coors + (bN + j) * 3;
@@ -127,9 +140,32 @@ __global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_a
                 if (has_rank) em = em && (p.rank[(bN + i) * K + k] <= p.valid_radius);
             }
             fm[t] = em;
-            pjp[t] = p.Pj + (bN + j) * p.ldp + 8 * g;
             pip[t] = p.Pi + (bN + i) * p.ldp + 8 * g;
         }
+
+        // Gather addressing.  A wave-level load instruction is processed line by line (measured,
+        // tools/ubench/gather.hip: 16 half-used 128-B lines per instruction run at 9.7 TB/s, 8 fully used lines at
+        // 20.9 TB/s), so P_j is fetched as whole lines -- lane l reads 16-byte chunk (l & 7) of the row of slot
+        // 8*q + (l >> 3) -- and redistributed to the MFMA fragment layout through a wave-private LDS buffer.
+        const float* gptr[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int q = round * SLOTS_PER_ROUND + wave * SLOTS_PER_WAVE + qq * 8 + (lane >> 3);
+            int nl = q / K;
+            int k = q - nl * K;
+            int pos = node0 + nl;
+            if (!((q < slots_total) && (pos < N))) { pos = node0 < N ? node0 : 0; k = 0; }
+            const int i2 = p.order ? p.order[bN + pos] : pos;
+            const int j2 = p.idx ? p.idx[(bN + i2) * K + k] : k;
+#if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 1)
+            gptr[qq] = p.Pj + (bN + (size_t)(i2 & ~7)) * p.ldp + 4 * (lane & 7);
+#else
+            gptr[qq] = p.Pj + (bN + j2) * p.ldp + 4 * (lane & 7);
+#endif
+        }
+        float* xch = xchall + wave * (SLOTS_PER_WAVE * XLD);
+        float* xw = xch + (lane >> 3) * XLD + 4 * (lane & 7);          // where this lane parks its chunk (+ 8*qq rows)
+        const float* xr = xch + e * XLD + 8 * g;                        // where it picks its fragment up (+ 16*t rows)
 
         f32x4 acc[TILES];
 #pragma unroll
@@ -139,12 +175,9 @@ __global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_a
         // Software pipeline: the Pi/Pj rows of step st+1 are requested before step st is computed, so the
         // gather latency (L2 / Infinity Cache) hides under the SiLU work of the current step.
         constexpr int NPI = TILES / TPI;
-        f32x4 pjn[TILES][2], pin[NPI][2];
+        f32x4 gl[4], pin[NPI][2];
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-            pjn[t][0] = *reinterpret_cast<const f32x4*>(pjp[t]);
-            pjn[t][1] = *reinterpret_cast<const f32x4*>(pjp[t] + 4);
-        }
+        for (int qq = 0; qq < 4; ++qq) gl[qq] = *reinterpret_cast<const f32x4*>(gptr[qq]);
 #pragma unroll
         for (int u = 0; u < NPI; ++u) {
             pin[u][0] = *reinterpret_cast<const f32x4*>(pip[u * TPI]);
@@ -171,22 +204,32 @@ __global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_a
             const int nst = hc / KSTEP;
             for (int st = 0; st < nst; ++st) {
                 const int hoff = c0 + st * KSTEP;
-                float x[TILES][8];
+#if defined(EGNN_EDGE_STEPSYNC) && EGNN_EDGE_STEPSYNC
+                __builtin_amdgcn_s_barrier();      // keep the workgroup's waves on the same step: gathered rows shared via L1
+#endif
+                // park the lines fetched for this step, then (same wave, DS ops execute in order) pick the fragments up
 #pragma unroll
-                for (int t = 0; t < TILES; ++t) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        x[t][u] = pin[t / TPI][0][u] + pjn[t][0][u];
-                        x[t][4 + u] = pin[t / TPI][1][u] + pjn[t][1][u];
-                    }
-                }
+                for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f32x4*>(xw + qq * 8 * XLD) = gl[qq];
                 int hnext = hoff + KSTEP;
                 if (hnext >= p.Hp) hnext = hoff;                 // last step: harmless re-read
 #pragma unroll
+                for (int qq = 0; qq < 4; ++qq) gl[qq] = *reinterpret_cast<const f32x4*>(gptr[qq] + hnext);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                float x[TILES][8];
+#pragma unroll
                 for (int t = 0; t < TILES; ++t) {
-                    pjn[t][0] = *reinterpret_cast<const f32x4*>(pjp[t] + hnext);
-                    pjn[t][1] = *reinterpret_cast<const f32x4*>(pjp[t] + hnext + 4);
+                    const f32x4 f0 = *reinterpret_cast<const f32x4*>(xr + t * 16 * XLD);
+                    const f32x4 f1 = *reinterpret_cast<const f32x4*>(xr + t * 16 * XLD + 4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        x[t][u] = pin[t / TPI][0][u] + f0[u];
+                        x[t][4 + u] = pin[t / TPI][1][u] + f1[u];
+                    }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int u = 0; u < NPI; ++u) {
                     pin[u][0] = *reinterpret_cast<const f32x4*>(pip[u * TPI] + hnext);
@@ -215,8 +258,13 @@ __global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_a
 #pragma unroll
                     for (int u = 0; u < 8; u += 2) {
                         const float y0 = x[t][u], y1 = x[t][u + 1];
+#if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 2)
+                        const float h0 = y0 * (1.0f + y0);                  // ablation: no transcendentals
+                        const float h1 = y1 * (1.0f + y1);
+#else
                         const float h0 = y0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y0));
                         const float h1 = y1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y1));
+#endif
                         const f16x2 hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(h0, h1));
                         const float l0 = h0 - (float)hi[0];
                         const float l1 = h1 - (float)hi[1];
@@ -224,9 +272,14 @@ __global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_a
                         bhi[u] = hi[0]; bhi[u + 1] = hi[1];
                         blo[u] = lo[0]; blo[u + 1] = lo[1];
                     }
+#if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 4)
+                    acc[t][0] += (float)bhi[0] + (float)blo[1] + (float)bhi[2] + (float)blo[3] + (float)bhi[4] +
+                                 (float)blo[5] + (float)bhi[6] + (float)blo[7];   // ablation: no MFMA
+#else
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bhi, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, bhi, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, blo, acc[t], 0, 0, 0);
+#endif
                 }
             }
         }
@@ -334,8 +387,8 @@ __global__ __launch_bounds__(EDGE_THREADS, 2) void edge_kernel(const egnn_edge_a
     // ---------------------------------------------------------------------- node outputs
     for (int o = tid; o < G * NCH; o += EDGE_THREADS) {
         const int nl = o / NCH, ch = o - nl * NCH;
-        const int i = node0 + nl;
-        if (i >= N) continue;
+        if (node0 + nl >= N) continue;
+        const int i = p.order ? p.order[bN + node0 + nl] : node0 + nl;
         float val = nodeacc[o];
         if (ch < 16) {
             if (p.m_i && ch < p.m_dim) {
@@ -365,7 +418,7 @@ int launch_edge(const egnn_edge_args& a, hipStream_t s)
     const int gpg = (a.N + G - 1) / G;
     const int64_t nblk = (int64_t)a.B * gpg;
     if (nblk > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
-    const size_t lds = (size_t)HC * 64 + sizeof(float) * ((size_t)SP * HC + SLOTS_PER_ROUND * NCH + GMAX * NCH);
+    const size_t lds = (size_t)HC * 64 + sizeof(float) * ((size_t)SP * HC + GMAX * NCH + (size_t)SLOTS_PER_ROUND * XLD);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_kernel<SP, TPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -410,11 +463,13 @@ extern "C" int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (a.Sp) {
         case 1: return dispatch_tpi<1>(a, s);
+#ifndef EGNN_EDGE_TUNING_BUILD
         case 2: return dispatch_tpi<2>(a, s);
         case 3: return dispatch_tpi<3>(a, s);
         case 5: return dispatch_tpi<5>(a, s);
         case 8: return dispatch_tpi<8>(a, s);
         case 16: return dispatch_tpi<16>(a, s);
+#endif
         default: return EGNN_E_UNSUPPORTED;
     }
 }

@@ -11,12 +11,15 @@ PyTorch-eager fallback: anything the kernels do not cover raises.
 """
 from __future__ import annotations
 
+import os
 import warnings
 
 import torch
 from torch import nn
 
 from . import _abi, _ops, _weights
+
+_SPATIAL_ORDER = os.environ.get("EGNN_SPATIAL_ORDER", "1") != "0"     # scheduling knob only; results do not depend on it
 
 
 def _mlp(d_in, d_hidden, d_out, dropout, final_act):
@@ -177,6 +180,10 @@ class EGNN(nn.Module):
             a.edges = _ops._ptr(edges)
             a.mask = _ops._ptr(mask8)
             a.idx, a.rank = _ops._ptr(idx), _ops._ptr(rank)
+            order = None
+            if idx is not None and adj_mat is None and 64 <= n <= 4096 and _SPATIAL_ORDER:
+                order = _ops.spatial_order(coors)       # k-NN path: neighbours are spatial -> share gathered rows in L1
+                a.order = order.data_ptr()
             a.valid_radius = float(min(valid_radius, 3.0e38))
             cv = self.coor_weights_clamp_value
             a.clamp = -1.0 if cv is None else float(cv)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 3
+#define EGNN_ABI_VERSION 4
 
 enum {
     EGNN_OK = 0,
@@ -67,6 +67,10 @@ int egnn_knn_select_f32(const float* coors, const uint8_t* mask, const uint8_t* 
  * the call zeroes it first on `stream`.  The caller reads it back (that read is the host sync the
  * reference also has at :249). */
 int egnn_adj_max_degree_u8(const uint8_t* adj, int64_t rows, int N, int32_t* out_dev, void* stream);
+
+/* Scheduling aid for egnn_edge_fused_f32 (no reference counterpart): per-graph Morton (Z-order) permutation of
+ * the nodes, order_out (B,N) int32.  N <= 4096. */
+int egnn_spatial_order_f32(const float* coors, int B, int N, int32_t* order_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense layer, exact-fp32 variant (v_mfma_f32_32x32x2_f32): C = act(A * W^T + bias) (+ residual).
@@ -139,6 +143,8 @@ typedef struct egnn_edge_args {
     const uint8_t* mask;        /* (B,N) or NULL */
     const int32_t* idx;         /* (B,N,K) from egnn_knn_select_f32, or NULL = dense (j = k) */
     const float* rank;          /* (B,N,K) or NULL */
+    const int32_t* order;       /* (B,N) permutation from egnn_spatial_order_f32 or NULL: workgroups own nodes that are
+                                   consecutive in this order (L1 sharing of gathered rows); results do not depend on it */
     float valid_radius;         /* nbhd_mask = rank <= valid_radius, applied only when mask != NULL (:292) */
     float clamp;                /* coor_weights_clamp_value; < 0 = no clamp */
     int32_t pool_mean;          /* m_pool_method == 'mean' */

@@ -143,3 +143,35 @@ def test_node_prep():
     np.testing.assert_allclose(out, ref, atol=1e-5, rtol=0)
     out2 = _ops.node_prep(_dev(x), _dev(mi), None, None, 1e-5, 16).cpu().numpy()
     np.testing.assert_array_equal(out2, np.concatenate([x, mi], axis=-1))
+
+
+def test_spatial_order_is_a_permutation_and_results_do_not_depend_on_it(monkeypatch):
+    """egnn_spatial_order_f32 is a scheduling aid: a valid per-graph permutation, and the layer's outputs are
+    bit-identical with and without it."""
+    from egnn_pytorch_amd import EGNN, _ops, layer as L
+    rng = np.random.default_rng(4)
+    for n in (64, 100, 1024, 3000):
+        coors = rng.standard_normal((3, n, 3)).astype(np.float32)
+        order = _ops.spatial_order(_dev(coors)).cpu().numpy()
+        assert order.shape == (3, n)
+        for b in range(3):
+            assert np.array_equal(np.sort(order[b]), np.arange(n))
+    # locality: consecutive nodes in the order are much closer than consecutive nodes in index order
+    c = coors[0]
+    d_idx = np.linalg.norm(c[1:] - c[:-1], axis=1).mean()
+    d_ord = np.linalg.norm(c[order[0][1:]] - c[order[0][:-1]], axis=1).mean()
+    assert d_ord < 0.5 * d_idx
+    kw = dict(dim=64, num_nearest_neighbors=16)
+    cfg = O.EGNNConfig(**kw)
+    params = O.random_params(cfg, seed=2)
+    net = EGNN(**kw)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    net = net.cuda().eval()
+    feats = _dev(rng.standard_normal((2, 300, 64)).astype(np.float32))
+    co = _dev(rng.standard_normal((2, 300, 3)).astype(np.float32))
+    mask = _dev(np.arange(300)[None, :] < np.array([[300], [211]]))
+    monkeypatch.setattr(L, "_SPATIAL_ORDER", True)
+    n1, c1 = net(feats, co, mask=mask)
+    monkeypatch.setattr(L, "_SPATIAL_ORDER", False)
+    n0, c0 = net(feats, co, mask=mask)
+    assert torch.equal(n0, n1) and torch.equal(c0, c1)
