@@ -77,7 +77,7 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
     float* wss = reinterpret_cast<float*>(smem + HC * 64);   // [SP][HC]
     float* nodeacc = wss + SP * HC;                          // [GMAX][NCH]
     float* xchall = nodeacc + GMAX * NCH;                    // [EDGE_WAVES][32 slots][XLD]: per-wave gather exchange
-    float* ebuf = xchall;                                    // [256][NCH] aliases it (epilogue only; 20 <= XLD)
+    float* ebuf = xchall;                                    // [slots][NCH] aliases it (epilogue only; NCH <= XLD)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -214,9 +214,10 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
                 if (hnext >= p.Hp) hnext = hoff;                 // last step: harmless re-read
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) gl[qq] = *reinterpret_cast<const f32x4*>(gptr[qq] + hnext);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                // Same-wave hand-off through LDS: DS operations of one wave execute in issue order; the explicit
+                // lgkmcnt(0) makes the store -> other-lane load dependency independent of that (4 stores, negligible).
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 float x[TILES][8];
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
@@ -327,9 +328,21 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
                     f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    // HAZARD (observed on gfx950 / ROCm 7.2, reproduced by tests/test_gpu_parity.py::
+                    // test_multi_round_stress...): when hipcc interleaves VALU / transcendental instructions that
+                    // overwrite the A/B source VGPRs of an in-flight v_mfma_f32_16x16x4_f32 (it executes on the vector
+                    // datapath over 8 passes), the MFMA can consume the new values: 1-2 wrong coordinate weights per
+                    // ~1e5 edges, run-to-run different.  The chain is therefore fenced: nothing is scheduled into it
+                    // and 32 wait states separate it from the code that reuses its operand registers.
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_nop 3");
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[u], acc[t][u], a2, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_nop 15");
+                    asm volatile("s_nop 15");
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) part[t] += w4[u] * egnn_silu(a2[u] + b3[u]);
                 }
@@ -381,6 +394,7 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
             for (int q = q0; q < q1; ++q) s += ebuf[(q - qbase) * NCH + ch];
             if (q1 > q0) nodeacc[o] += s;
         }
+        __syncthreads();          // multi-round groups: ebuf (aliasing the exchange buffers) is free again
     }
     __syncthreads();
 

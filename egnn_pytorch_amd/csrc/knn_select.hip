@@ -25,11 +25,10 @@ __device__ __forceinline__ float key2f(uint32_t k) {
     return __uint_as_float(u);
 }
 __device__ __forceinline__ void wave_lds_sync() {
-    // same-wave LDS hand-off: DS operations of one wave execute in issue order; this only pins the
-    // compiler's ordering.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // same-wave LDS hand-off: DS operations of one wave execute in issue order; the explicit wait makes the
+    // store -> other-lane load dependency independent of that, the wave barrier pins the compiler's ordering.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 constexpr int KNN_THREADS = 256;

@@ -186,6 +186,34 @@ def test_north_star_full_size_properties():
     assert torch.allclose(cr, co @ R + T, atol=2e-3)
 
 
+def test_multi_round_stress_is_deterministic_and_correct():
+    """Regression for a gfx950 hazard: VALU / transcendental instructions scheduled into a v_mfma_f32_16x16x4_f32
+    chain and overwriting its source VGPRs corrupted 1-2 coordinate weights per ~1e5 edges, differently on every
+    run (edge_fused.hip fences the chain).  6 graphs x 600 nodes dense (5 rounds per node group, every CU busy),
+    20 repeats: bit-identical, and on parity."""
+    kwargs = dict(dim=32)
+    cfg = O.EGNNConfig(**kwargs)
+    params = O.random_params(cfg, seed=17)
+    params["edge_mlp.3.weight"] = params["edge_mlp.3.weight"] * np.float32(0.1)
+    params["coors_mlp.3.weight"] = params["coors_mlp.3.weight"] * np.float32(0.05)
+    rng = np.random.default_rng(12345)
+    b, n = 6, 600
+    feats = rng.standard_normal((b, n, 32)).astype(np.float32)
+    coors = rng.standard_normal((b, n, 3)).astype(np.float32)
+    mask = np.arange(n)[None, :] < rng.integers(n // 2, n + 1, size=b)[:, None]
+    rn, rc = O.egnn_forward(cfg, params, feats, coors, None, mask, None)
+    net = _module("layer", kwargs, params)
+    fd, cd, md = _dev(feats), _dev(coors), _dev(mask)
+    first = None
+    for _ in range(20):
+        node, co = net(fd, cd, mask=md)
+        if first is None:
+            first = (node.clone(), co.clone())
+        assert torch.equal(node, first[0]) and torch.equal(co, first[1])
+    np.testing.assert_allclose(first[0].cpu().numpy(), rn, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(first[1].cpu().numpy(), rc, atol=ATOL, rtol=0)
+
+
 def test_cpu_input_raises():
     from egnn_pytorch_amd import EGNN
     layer = EGNN(dim=8)
