@@ -151,6 +151,65 @@ def linear_split(a, wsplit, n, bias=None, residual=None, act=0, name="linear"):
     return c
 
 
+def _kpad(k):
+    return (k + 31) // 32 * 32
+
+
+def split_f16(x2d):
+    """fp32 (rows, cols) -> (hi, lo) fp16 (rows, Kp) for egnn_linear_hl_f32 -- egnn_split_f16."""
+    rows, cols = x2d.shape
+    kp = _kpad(cols)
+    hi = torch.empty(rows, kp, dtype=torch.float16, device=x2d.device)
+    lo = torch.empty(rows, kp, dtype=torch.float16, device=x2d.device)
+    with _timed("split_f16"):
+        rc = _abi.load().egnn_split_f16(_ptr(x2d), cols, rows, cols, _ptr(hi), _ptr(lo), kp, _stream())
+    _abi.check(rc, "egnn_split_f16")
+    return hi, lo
+
+
+def linear_hl(a_hl, wsplit, n, bias=None, residual=None, act=0, out_f32=True, out_hl=False, name="linear"):
+    """act(A @ W.T + bias) (+ residual) with pre-split fp16 (hi, lo) operands -- egnn_linear_hl_f32.
+    Returns fp32 C, or (C_hi, C_lo) when out_hl (padded to 32 columns for the next GEMM), or both."""
+    ahi, alo = a_hl
+    whi, wlo, inv = wsplit
+    m, kp = ahi.shape
+    assert ahi.shape == alo.shape and whi.shape == wlo.shape and whi.shape[1] == kp and whi.shape[0] >= n
+    dev = ahi.device
+    c = torch.empty(m, n, dtype=torch.float32, device=dev) if out_f32 else None
+    chi = clo = None
+    ldch = 0
+    if out_hl:
+        ldch = _kpad(n)
+        alloc = torch.zeros if ldch != n else torch.empty
+        chi = alloc(m, ldch, dtype=torch.float16, device=dev)
+        clo = alloc(m, ldch, dtype=torch.float16, device=dev)
+    ldr = 0
+    if residual is not None:
+        assert residual.shape == (m, n) and residual.is_contiguous()
+        ldr = n
+    with _timed(name):
+        rc = _abi.load().egnn_linear_hl_f32(_ptr(ahi), _ptr(alo), kp, _ptr(whi), _ptr(wlo), kp, float(inv), _ptr(bias),
+                                            _ptr(residual), ldr, _ptr(c), n, _ptr(chi), _ptr(clo), ldch, m, n, kp, act,
+                                            _stream())
+    _abi.check(rc, "egnn_linear_hl_f32")
+    if out_f32 and out_hl:
+        return c, (chi, clo)
+    return (chi, clo) if out_hl else c
+
+
+def node_prep_hl(feats2d, m_i, gamma, beta, eps, m_dim):
+    """[LayerNorm(feats) | m_i] as the (hi, lo) fp16 pair -- egnn_node_prep_hl."""
+    rows, dim = feats2d.shape
+    kp = _kpad(dim + m_dim)
+    hi = torch.empty(rows, kp, dtype=torch.float16, device=feats2d.device)
+    lo = torch.empty(rows, kp, dtype=torch.float16, device=feats2d.device)
+    with _timed("node_prep"):
+        rc = _abi.load().egnn_node_prep_hl(_ptr(feats2d), _ptr(m_i), _ptr(gamma), _ptr(beta), float(eps), _ptr(hi), _ptr(lo),
+                                           kp, rows, dim, m_dim, _stream())
+    _abi.check(rc, "egnn_node_prep_hl")
+    return hi, lo
+
+
 def node_prep(feats2d, m_i, gamma, beta, eps, m_dim):
     rows, dim = feats2d.shape
     out = torch.empty(rows, dim + m_dim, dtype=torch.float32, device=feats2d.device)

@@ -156,24 +156,38 @@ __global__ __launch_bounds__(LS_THREADS, 2) void linear_split_kernel(
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload(kt + 1);
 
-#pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            f16x8 ah[2], al[2], bh[2], bl[2];
+        // fragments of k16-step s+1 are fetched while the 12 MFMAs of step s run; consecutive MFMAs hit different
+        // accumulators (the three terms of one product are issued 4 MFMAs apart).
+        f16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+        auto ldfrag = [&](int s, int slot) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8*>(Ah + aoff + i * 32 * LDH + s * 16);
-                al[i] = *reinterpret_cast<const f16x8*>(Al + aoff + i * 32 * LDH + s * 16);
-                bh[i] = *reinterpret_cast<const f16x8*>(Bh + boff + i * 32 * LDH + s * 16);
-                bl[i] = *reinterpret_cast<const f16x8*>(Bl + boff + i * 32 * LDH + s * 16);
+                ah[slot][i] = *reinterpret_cast<const f16x8*>(Ah + aoff + i * 32 * LDH + s * 16);
+                al[slot][i] = *reinterpret_cast<const f16x8*>(Al + aoff + i * 32 * LDH + s * 16);
+                bh[slot][i] = *reinterpret_cast<const f16x8*>(Bh + boff + i * 32 * LDH + s * 16);
+                bl[slot][i] = *reinterpret_cast<const f16x8*>(Bl + boff + i * 32 * LDH + s * 16);
             }
+        };
+        ldfrag(0, 0);
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < BK / 16) ldfrag(s + 1, cur ^ 1);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bh[cur][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][i], bh[cur][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bl[cur][j], acc[i][j], 0, 0, 0);
         }
 
         __syncthreads();                      // every wave is done reading this K-tile

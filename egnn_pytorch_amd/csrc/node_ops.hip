@@ -44,7 +44,52 @@ __global__ __launch_bounds__(256) void node_prep_kernel(const float* __restrict_
     }
 }
 
+// same, but the row is written as the (hi, lo) f16 pair the matrix-core GEMM consumes, zero padded to ldh columns
+__global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restrict__ feats, const float* __restrict__ m_i,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float eps, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                           int64_t ldh, int64_t rows, int dim, int m_dim)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        const float* x = feats + r * dim;
+        float mean = 0.f, rstd = 1.f;
+        if (gamma) {
+            float s = 0.f;
+            for (int c = lane; c < dim; c += 64) s += x[c];
+            mean = wave_sum(s) / (float)dim;
+            float v = 0.f;
+            for (int c = lane; c < dim; c += 64) { const float d = x[c] - mean; v += d * d; }
+            rstd = 1.0f / sqrtf(wave_sum(v) / (float)dim + eps);
+        }
+        for (int c = lane; c < ldh; c += 64) {
+            float y = 0.f;
+            if (c < dim) y = gamma ? (x[c] - mean) * rstd * gamma[c] + beta[c] : x[c];
+            else if (c < dim + m_dim) y = m_i ? m_i[r * m_dim + (c - dim)] : 0.f;
+            const _Float16 h = (_Float16)y;
+            hi[r * ldh + c] = h;
+            lo[r * ldh + c] = (_Float16)(y - (float)h);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int egnn_node_prep_hl(const float* feats, const float* m_i, const float* gamma, const float* beta, float eps,
+                                 void* out_hi, void* out_lo, int64_t ldh, int64_t rows, int dim, int m_dim, void* stream)
+{
+    if (!feats || !out_hi || !out_lo) return EGNN_E_NULLPTR;
+    if ((gamma == nullptr) != (beta == nullptr)) return EGNN_E_NULLPTR;
+    if (rows <= 0 || dim <= 0 || m_dim < 0 || ldh < dim + m_dim || (ldh % 32) != 0) return EGNN_E_SHAPE;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(node_prep_hl_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), feats,
+                       m_i, gamma, beta, eps, static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), ldh, rows, dim,
+                       m_dim);
+    return egnn_launch_status();
+}
 
 extern "C" int egnn_node_prep_f32(const float* feats, const float* m_i, const float* gamma, const float* beta, float eps,
                                   float* out, int64_t rows, int dim, int m_dim, void* stream)

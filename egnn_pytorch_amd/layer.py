@@ -157,7 +157,7 @@ class EGNN(nn.Module):
         m_i = None
         if k > 0:
             # ---- node-level projections P = feats [W_i ; W_j]^T + [b1 ; 0]
-            proj = _ops.linear_split(feats2d, w["Wcat_split"], 2 * w["Hp"], w["bcat"], name="node_proj")
+            proj = _ops.linear_hl(_ops.split_f16(feats2d), w["Wcat_split"], 2 * w["Hp"], w["bcat"], name="node_proj")
             hp = w["Hp"]
             a = _abi.EdgeArgs()
             a.B, a.N, a.K, a.dim, a.m_dim = b, n, k, dim, self.m_dim
@@ -198,10 +198,10 @@ class EGNN(nn.Module):
 
         # ---- node update (egnn_pytorch.py:335-337)
         if self.node_mlp is not None:
-            node_in = _ops.node_prep(feats2d, m_i, w.get("gamma"), w.get("beta"), w.get("ln_eps", 1e-5), self.m_dim)
-            hid = _ops.linear_split(node_in, w["W5_split"], 2 * dim, w["b5"], act=1, name="node_mlp0")
-            node_out = _ops.linear_split(hid, w["W6_split"], dim, w["b6"], residual=feats2d,
-                                         name="node_mlp1").view(b, n, dim)
+            node_in = _ops.node_prep_hl(feats2d, m_i, w.get("gamma"), w.get("beta"), w.get("ln_eps", 1e-5), self.m_dim)
+            hid = _ops.linear_hl(node_in, w["W5_split"], 2 * dim, w["b5"], act=1, out_f32=False, out_hl=True,
+                                 name="node_mlp0")
+            node_out = _ops.linear_hl(hid, w["W6_split"], dim, w["b6"], residual=feats2d, name="node_mlp1").view(b, n, dim)
         return node_out, coors_out
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 4
+#define EGNN_ABI_VERSION 5
 
 enum {
     EGNN_OK = 0,
@@ -98,6 +98,24 @@ int egnn_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, co
 int egnn_linear_split_f32(const float* A, int64_t lda, const void* W_hi, const void* W_lo, int64_t ldw,
                           float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
                           float* C, int64_t ldc, int64_t M, int N, int K, int act, void* stream);
+
+/* The production GEMM: both operands pre-split into fp16 (hi, lo) pairs (A by egnn_split_f16 / egnn_node_prep_hl /
+ * a previous call's C_hi, C_lo; W by egnn_pytorch_amd/_weights.py::split_f16), staged by LDS-DMA
+ * (global_load_lds_dwordx4, double-buffered) and multiplied with three v_mfma_f32_32x32x16_f16 per product term.
+ *   A_hi, A_lo (M, lda) fp16, W_hi, W_lo (>= ceil(N/128)*128, ldw) fp16, all zero padded to Kp columns (Kp % 32 == 0);
+ *   C (M,N) fp32 and/or C_hi, C_lo (M, ldch) fp16 (the result re-split for the next GEMM); other arguments as above. */
+int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, int64_t lda, const void* W_hi, const void* W_lo,
+                       int64_t ldw, float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
+                       float* C, int64_t ldc, void* C_hi, void* C_lo, int64_t ldch, int64_t M, int N, int Kp,
+                       int act, void* stream);
+
+/* X (rows, cols) fp32 -> hi = fp16(x), lo = fp16(x - hi), (rows, ldh) each, columns [cols, ldh) zeroed; ldh % 32 == 0.
+ * Requires |X| < 65504. */
+int egnn_split_f16(const float* X, int64_t ldx, int64_t rows, int cols, void* hi, void* lo, int64_t ldh, void* stream);
+
+/* egnn_node_prep_f32 writing the (hi, lo) pair directly: out_hi, out_lo (rows, ldh), ldh >= dim + m_dim, ldh % 32 == 0. */
+int egnn_node_prep_hl(const float* feats, const float* m_i, const float* gamma, const float* beta, float eps,
+                      void* out_hi, void* out_lo, int64_t ldh, int64_t rows, int dim, int m_dim, void* stream);
 
 /* node_norm + concat (egnn_pytorch.py:335-336): out[r] = [ LayerNorm(feats[r]) | m_i[r] ].
  * gamma/beta NULL -> Identity (norm_feats=False).  out: (rows, dim + m_dim). */

@@ -131,6 +131,57 @@ def test_linear_split_f16x3(m, n, k, act, res):
         np.testing.assert_allclose(out, exact, atol=tol, rtol=0)
 
 
+@pytest.mark.parametrize("m,n,k,act,res", [
+    (16, 130, 32, 0, False), (300, 257, 65, 1, False), (1024, 4160, 512, 0, False),
+    (2048, 1024, 528, 1, False), (2048, 512, 1024, 0, True), (77, 40, 36, 0, True), (5, 3, 7, 1, True),
+    (129, 129, 100, 0, False), (4096, 256, 2048, 0, False),
+])
+def test_linear_hl_lds_dma(m, n, k, act, res):
+    """The production GEMM (pre-split fp16 hi/lo operands, LDS-DMA staging, swizzled LDS image): fp32-class accuracy
+    against an fp64 reference, fp32 and re-split outputs, operands that are neither symmetric nor tile aligned."""
+    from egnn_pytorch_amd import _ops, _weights
+    rng = np.random.default_rng(m * 7 + n + k)
+    a = (rng.standard_normal((m, k)) * 2).astype(np.float32)
+    a[:, ::7] *= 1e-3                                               # mixed magnitudes inside a row
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    r = rng.standard_normal((m, n)).astype(np.float32) if res else None
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    if act:
+        ref = ref / (1.0 + np.exp(-ref))
+    if res:
+        ref = ref + r
+    ahl = _ops.split_f16(_dev(a))
+    assert ahl[0].shape[1] % 32 == 0
+    back = ahl[0].float() + ahl[1].float()
+    np.testing.assert_allclose(back[:, :k].cpu().numpy(), a, rtol=3e-7, atol=1e-9)      # 22-bit split
+    assert float(back[:, k:].abs().max()) == 0.0 if back.shape[1] > k else True
+    ws = _weights.split_f16(_dev(w))
+    out, (chi, clo) = _ops.linear_hl(ahl, ws, n, _dev(bias), _dev(r), act=act, out_f32=True, out_hl=True)
+    out = out.cpu().numpy()
+    np.testing.assert_allclose(out, ref, atol=3e-5, rtol=0)
+    resplit = (chi.float() + clo.float()).cpu().numpy()
+    np.testing.assert_allclose(resplit[:, :n], out, rtol=3e-7, atol=1e-7)
+    assert np.all(resplit[:, n:] == 0)
+    exact = _ops.linear(_dev(a), _dev(w), _dev(bias), _dev(r), act=act).cpu().numpy()      # exact-fp32 MFMA kernel
+    np.testing.assert_allclose(out, exact, atol=3e-5, rtol=0)
+
+
+def test_node_prep_hl():
+    from egnn_pytorch_amd import _ops
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((300, 100)).astype(np.float32) * 3 + 1
+    mi = rng.standard_normal((300, 16)).astype(np.float32)
+    g = rng.standard_normal(100).astype(np.float32)
+    bt = rng.standard_normal(100).astype(np.float32)
+    hi, lo = _ops.node_prep_hl(_dev(x), _dev(mi), _dev(g), _dev(bt), 1e-5, 16)
+    assert hi.shape == (300, 128)
+    out = (hi.float() + lo.float()).cpu().numpy()
+    ref = np.concatenate([O.layer_norm(x, g, bt), mi], axis=-1)
+    np.testing.assert_allclose(out[:, :116], ref, atol=1e-5, rtol=0)
+    assert np.all(out[:, 116:] == 0)
+
+
 def test_node_prep():
     from egnn_pytorch_amd import _ops
     rng = np.random.default_rng(0)
