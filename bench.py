@@ -31,7 +31,8 @@ sys.path.insert(0, ROOT)
 
 # chip peaks: /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 HBM_PEAK_GBS = 8000.0          # HBM3E spec
-MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_* (f32 in / f32 acc), dense
+MFMA_F16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_*_f16 dense (the GEMMs issue 3 f16 MFMAs per fp32 product: split-f16x3)
+SPLIT_TERMS = 3
 
 WORKLOADS = {
     # name: (layer kwargs, graphs per GPU, nodes)
@@ -55,11 +56,14 @@ def model_counts(kwargs, b, n):
         # every edge reads its neighbour's feature row once, every node row read + written once
         "edge_fused": dict(bound="hbm", bytes=4 * dim * (e + 2 * bn) + 4 * e + 24 * bn + bn + 4 * edge_dim * e + weights,
                            flops=2.0 * e * hp * 16 + 2.0 * e * (16 * 64 + 64)),
+        # GEMMs: algorithmic (fp32-equivalent) flops; the kernels issue SPLIT_TERMS x that on the f16 matrix cores
         "node_proj": dict(bound="mfma", flops=2.0 * bn * dim * 2 * hp, bytes=4 * (bn * dim + 2 * hp * dim + bn * 2 * hp)),
         "node_mlp0": dict(bound="mfma", flops=2.0 * bn * (dim + m) * 2 * dim,
                           bytes=4 * (bn * (dim + m) + 2 * dim * (dim + m) + bn * 2 * dim)),
         "node_mlp1": dict(bound="mfma", flops=2.0 * bn * 2 * dim * dim, bytes=4 * (bn * 2 * dim + 2 * dim * dim + 2 * bn * dim)),
         "node_prep": dict(bound="hbm", bytes=4 * 2 * bn * (dim + m), flops=8.0 * bn * dim),
+        "split_f16": dict(bound="hbm", bytes=4 * 2 * bn * dim, flops=2.0 * bn * dim),
+        "spatial_order": dict(bound="hbm", bytes=16 * bn, flops=0.0),
         # fused select: compulsory traffic is tiny; the comparable figure is one fp32 rank per ordered pair
         "knn_select": dict(bound="hbm", bytes=4 * b * n * n, flops=8.0 * b * n * n),
     }, dict(E=e, K=k, H=h, Hp=hp)
@@ -72,9 +76,10 @@ def roofline_entry(name, counts, ms):
         ach = c["bytes"] / sec / 1e9
         return dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 4), avg_ms=round(ms, 4), algorithmic_bytes=int(c["bytes"]))
-    ach = c["flops"] / sec / 1e12
-    return dict(kernel=name, bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), avg_ms=round(ms, 4), flops=c["flops"])
+    ach = SPLIT_TERMS * c["flops"] / sec / 1e12          # MFMA-issued flops (3 f16 MFMAs per fp32 product)
+    return dict(kernel=name, bound="mfma", achieved=round(ach, 2), peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=round(ach / MFMA_F16_PEAK_TFLOPS, 4), avg_ms=round(ms, 4), mfma_issued_flops=SPLIT_TERMS * c["flops"],
+                algorithmic_tflops=round(c["flops"] / sec / 1e12, 2), mfma_dtype="f16 (split x3, fp32 accumulate)")
 
 
 def make_inputs(kwargs, b, n, device, seed):

@@ -96,7 +96,7 @@ def load():
     lib.egnn_linear_hl_f32.restype = c_int
     lib.egnn_linear_hl_f32.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p,
                                        c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
-                                       c_void_p]
+                                       c_int, c_void_p]
     lib.egnn_split_f16.restype = c_int
     lib.egnn_split_f16.argtypes = [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p]
     lib.egnn_node_prep_hl.restype = c_int

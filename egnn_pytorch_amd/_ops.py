@@ -189,8 +189,8 @@ def linear_hl(a_hl, wsplit, n, bias=None, residual=None, act=0, out_f32=True, ou
         ldr = n
     with _timed(name):
         rc = _abi.load().egnn_linear_hl_f32(_ptr(ahi), _ptr(alo), kp, _ptr(whi), _ptr(wlo), kp, float(inv), _ptr(bias),
-                                            _ptr(residual), ldr, _ptr(c), n, _ptr(chi), _ptr(clo), ldch, m, n, kp, act,
-                                            _stream())
+                                            _ptr(residual), ldr, _ptr(c), n, _ptr(chi), _ptr(clo), ldch, m, n, kp,
+                                            whi.shape[0], act, _stream())
     _abi.check(rc, "egnn_linear_hl_f32")
     if out_f32 and out_hl:
         return c, (chi, clo)

@@ -46,9 +46,10 @@ def padded_scalars(s: int) -> int:
 def split_f16(w: torch.Tensor):
     """(N, K) fp32 weight -> (W_hi, W_lo, inv_scale) for egnn_linear_split_f32: fp16 images of scale * W with
     scale the power of two that brings max|W| into [1, 2) (hi and lo then sit in fp16's normal range),
-    hi = fp16(w), lo = fp16(w - hi), zero padded to (ceil(N/128)*128, ceil(K/32)*32)."""
+    hi = fp16(w), lo = fp16(w - hi), zero padded to (ceil(N/256)*256, ceil(K/32)*32) so that both the 128- and the
+    256-wide output tiles of egnn_linear_hl_f32 can read whole tiles."""
     n, k = w.shape
-    npad, kpad = (n + 127) // 128 * 128, (k + 31) // 32 * 32
+    npad, kpad = (n + 255) // 256 * 256, (k + 31) // 32 * 32
     amax = float(w.abs().max()) if w.numel() else 0.0
     scale = 2.0 ** (-math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
     ws = torch.zeros(npad, kpad, dtype=torch.float32, device=w.device)

@@ -64,13 +64,22 @@ __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restri
             for (int c = lane; c < dim; c += 64) { const float d = x[c] - mean; v += d * d; }
             rstd = 1.0f / sqrtf(wave_sum(v) / (float)dim + eps);
         }
-        for (int c = lane; c < ldh; c += 64) {
-            float y = 0.f;
-            if (c < dim) y = gamma ? (x[c] - mean) * rstd * gamma[c] + beta[c] : x[c];
-            else if (c < dim + m_dim) y = m_i ? m_i[r * m_dim + (c - dim)] : 0.f;
-            const _Float16 h = (_Float16)y;
-            hi[r * ldh + c] = h;
-            lo[r * ldh + c] = (_Float16)(y - (float)h);
+        // 4 consecutive columns per lane: 8-byte stores of the hi and lo images (ldh % 32 == 0)
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        for (int c0 = lane * 4; c0 < ldh; c0 += 256) {
+            f16x4 h4, l4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u;
+                float y = 0.f;
+                if (c < dim) y = gamma ? (x[c] - mean) * rstd * gamma[c] + beta[c] : x[c];
+                else if (c < dim + m_dim) y = m_i ? m_i[r * m_dim + (c - dim)] : 0.f;
+                const _Float16 h = (_Float16)y;
+                h4[u] = h;
+                l4[u] = (_Float16)(y - (float)h);
+            }
+            *reinterpret_cast<f16x4*>(hi + r * ldh + c0) = h4;
+            *reinterpret_cast<f16x4*>(lo + r * ldh + c0) = l4;
         }
     }
 }

@@ -102,12 +102,13 @@ int egnn_linear_split_f32(const float* A, int64_t lda, const void* W_hi, const v
 /* The production GEMM: both operands pre-split into fp16 (hi, lo) pairs (A by egnn_split_f16 / egnn_node_prep_hl /
  * a previous call's C_hi, C_lo; W by egnn_pytorch_amd/_weights.py::split_f16), staged by LDS-DMA
  * (global_load_lds_dwordx4, double-buffered) and multiplied with three v_mfma_f32_32x32x16_f16 per product term.
- *   A_hi, A_lo (M, lda) fp16, W_hi, W_lo (>= ceil(N/128)*128, ldw) fp16, all zero padded to Kp columns (Kp % 32 == 0);
+ *   A_hi, A_lo (M, lda) fp16, W_hi, W_lo (w_rows, ldw) fp16 with w_rows >= ceil(N/128)*128 (256 x 256 tiles are used
+ *   when w_rows also covers ceil(N/256)*256), all zero padded to Kp columns (Kp % 32 == 0);
  *   C (M,N) fp32 and/or C_hi, C_lo (M, ldch) fp16 (the result re-split for the next GEMM); other arguments as above. */
 int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, int64_t lda, const void* W_hi, const void* W_lo,
                        int64_t ldw, float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
                        float* C, int64_t ldc, void* C_hi, void* C_lo, int64_t ldch, int64_t M, int N, int Kp,
-                       int act, void* stream);
+                       int w_rows, int act, void* stream);
 
 /* X (rows, cols) fp32 -> hi = fp16(x), lo = fp16(x - hi), (rows, ldh) each, columns [cols, ldh) zeroed; ldh % 32 == 0.
  * Requires |X| < 65504. */

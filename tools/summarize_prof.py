@@ -11,9 +11,9 @@ out = sys.argv[1]
 import json
 import re
 
-ROLE = {"linear_kernel<0, false": "node_proj", "linear_kernel<1, false": "node_mlp0",
-        "linear_kernel<0, true": "node_mlp1", "edge_kernel": "edge_fused", "knn_select_kernel": "knn_select",
-        "node_prep_kernel": "node_prep"}
+ROLE = {r"linear_hl_kernel<\d+, 0, false": "node_proj", r"linear_hl_kernel<\d+, 1, false": "node_mlp0",
+        r"linear_hl_kernel<\d+, 0, true": "node_mlp1", r"edge_kernel": "edge_fused", r"knn_select_kernel": "knn_select",
+        r"node_prep_hl_kernel": "node_prep", r"split_f16_kernel": "split_f16", r"spatial_order_kernel": "spatial_order"}
 
 
 def short(name):
@@ -22,7 +22,7 @@ def short(name):
         return name[:60]
     full = m.group(0)
     for key, role in ROLE.items():
-        if full.startswith(key):
+        if re.match(key, full):
             return f"{role} [{full}]"
     return full
 
