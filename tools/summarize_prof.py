@@ -17,6 +17,15 @@ ROLE = {r"linear_hl_kernel<\d+, 0, false": "node_proj", r"linear_hl_kernel<\d+, 
 
 
 def short(name):
+    # rocprofv3 leaves kernels with _Float16 parameters mangled: rebuild "kernel<args>" from the Itanium name
+    mm = re.search(r"_GLOBAL__N_1\d+([a-z][a-z_0-9]*?_kernel)I((?:L[ib]\d+E)+)E", name)
+    if mm:
+        args = re.findall(r"L([ib])(\d+)E", mm.group(2))
+        name = mm.group(1) + "<" + ", ".join(("true" if v == "1" else "false") if t == "b" else v for t, v in args) + ">"
+    else:
+        mm = re.search(r"_GLOBAL__N_1\d+([a-z][a-z_0-9]*?_kernel)E", name)
+        if mm:
+            name = mm.group(1)
     m = re.search(r"(\w+_kernel)<([^>]*)>", name) or re.search(r"(\w+_kernel)", name)
     if not m:
         return name[:60]
