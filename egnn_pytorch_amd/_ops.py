@@ -135,7 +135,7 @@ def linear(a, w, bias=None, residual=None, act=0, name="linear"):
 
 def linear_split(a, wsplit, n, bias=None, residual=None, act=0, name="linear"):
     """act(a @ W.T + bias) (+ residual) on the matrix cores -- egnn_linear_split_f32.
-    `wsplit` = (W_hi, W_lo, inv_scale) from _weights.split_f16; n = true number of output columns."""
+    `wsplit` = (W_hi, W_lo, inv_scale) from _weights.split_f16_rowmajor; n = true number of output columns."""
     whi, wlo, inv = wsplit
     m, k = a.shape
     assert a.is_contiguous() and whi.shape == wlo.shape and whi.shape[0] >= n and whi.shape[1] >= k
@@ -155,59 +155,76 @@ def _kpad(k):
     return (k + 31) // 32 * 32
 
 
+def _packed_empty(rows, kp, device, zero=False):
+    n = (rows + 31) // 32 * 32 * kp
+    alloc = torch.zeros if zero else torch.empty
+    return alloc(n, dtype=torch.float16, device=device)
+
+
+class PackedHL:
+    """A (rows, kp) matrix as fp16 (hi, lo) images in the packed tile-major layout (include/egnn_hip.h)."""
+    __slots__ = ("hi", "lo", "rows", "kp")
+
+    def __init__(self, hi, lo, rows, kp):
+        self.hi, self.lo, self.rows, self.kp = hi, lo, rows, kp
+
+    def dense(self):
+        """Row-major fp32 reconstruction hi + lo (tests / debugging)."""
+        from ._weights import unpack_tiles
+        return (unpack_tiles(self.hi, self.rows, self.kp).float() + unpack_tiles(self.lo, self.rows, self.kp).float())[: self.rows]
+
+
 def split_f16(x2d):
-    """fp32 (rows, cols) -> (hi, lo) fp16 (rows, Kp) for egnn_linear_hl_f32 -- egnn_split_f16."""
+    """fp32 (rows, cols) -> packed fp16 (hi, lo) pair for egnn_linear_hl_f32 -- egnn_split_f16."""
     rows, cols = x2d.shape
     kp = _kpad(cols)
-    hi = torch.empty(rows, kp, dtype=torch.float16, device=x2d.device)
-    lo = torch.empty(rows, kp, dtype=torch.float16, device=x2d.device)
+    hi = _packed_empty(rows, kp, x2d.device)
+    lo = _packed_empty(rows, kp, x2d.device)
     with _timed("split_f16"):
         rc = _abi.load().egnn_split_f16(_ptr(x2d), cols, rows, cols, _ptr(hi), _ptr(lo), kp, _stream())
     _abi.check(rc, "egnn_split_f16")
-    return hi, lo
+    return PackedHL(hi, lo, rows, kp)
 
 
-def linear_hl(a_hl, wsplit, n, bias=None, residual=None, act=0, out_f32=True, out_hl=False, name="linear"):
-    """act(A @ W.T + bias) (+ residual) with pre-split fp16 (hi, lo) operands -- egnn_linear_hl_f32.
-    Returns fp32 C, or (C_hi, C_lo) when out_hl (padded to 32 columns for the next GEMM), or both."""
-    ahi, alo = a_hl
-    whi, wlo, inv = wsplit
-    m, kp = ahi.shape
-    assert ahi.shape == alo.shape and whi.shape == wlo.shape and whi.shape[1] == kp and whi.shape[0] >= n
-    dev = ahi.device
+def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32=True, out_hl=False, name="linear"):
+    """act(A @ W.T + bias) (+ residual) with pre-split packed fp16 (hi, lo) operands -- egnn_linear_hl_f32.
+    Returns fp32 C, or a PackedHL (padded to 32 columns for the next GEMM) when out_hl, or both."""
+    whi, wlo, inv, w_rows = wsplit
+    m, kp = a.rows, a.kp
+    assert whi.numel() == w_rows * kp and w_rows >= n
+    dev = a.hi.device
     c = torch.empty(m, n, dtype=torch.float32, device=dev) if out_f32 else None
-    chi = clo = None
-    ldch = 0
+    out = None
+    kp_out = 0
     if out_hl:
-        ldch = _kpad(n)
-        alloc = torch.zeros if ldch != n else torch.empty
-        chi = alloc(m, ldch, dtype=torch.float16, device=dev)
-        clo = alloc(m, ldch, dtype=torch.float16, device=dev)
+        kp_out = _kpad(n)
+        zero = kp_out != n                                   # pad columns must read as zero in the next GEMM
+        out = PackedHL(_packed_empty(m, kp_out, dev, zero), _packed_empty(m, kp_out, dev, zero), m, kp_out)
     ldr = 0
     if residual is not None:
         assert residual.shape == (m, n) and residual.is_contiguous()
         ldr = n
     with _timed(name):
-        rc = _abi.load().egnn_linear_hl_f32(_ptr(ahi), _ptr(alo), kp, _ptr(whi), _ptr(wlo), kp, float(inv), _ptr(bias),
-                                            _ptr(residual), ldr, _ptr(c), n, _ptr(chi), _ptr(clo), ldch, m, n, kp,
-                                            whi.shape[0], act, _stream())
+        rc = _abi.load().egnn_linear_hl_f32(_ptr(a.hi), _ptr(a.lo), _ptr(whi), _ptr(wlo), float(inv), _ptr(bias),
+                                            _ptr(residual), ldr, _ptr(c), n, _ptr(out.hi) if out else None,
+                                            _ptr(out.lo) if out else None, kp_out, m, n, kp, w_rows, act, _stream())
     _abi.check(rc, "egnn_linear_hl_f32")
     if out_f32 and out_hl:
-        return c, (chi, clo)
-    return (chi, clo) if out_hl else c
+        return c, out
+    return out if out_hl else c
 
 
 def node_prep_hl(feats2d, m_i, gamma, beta, eps, m_dim):
-    """[LayerNorm(feats) | m_i] as the (hi, lo) fp16 pair -- egnn_node_prep_hl."""
+    """[LayerNorm(feats) | m_i] as a packed fp16 (hi, lo) pair -- egnn_node_prep_hl."""
     rows, dim = feats2d.shape
     kp = _kpad(dim + m_dim)
-    hi = torch.empty(rows, kp, dtype=torch.float16, device=feats2d.device)
-    lo = torch.empty(rows, kp, dtype=torch.float16, device=feats2d.device)
+    hi = _packed_empty(rows, kp, feats2d.device)
+    lo = _packed_empty(rows, kp, feats2d.device)
     with _timed("node_prep"):
         rc = _abi.load().egnn_node_prep_hl(_ptr(feats2d), _ptr(m_i), _ptr(gamma), _ptr(beta), float(eps), _ptr(hi), _ptr(lo),
                                            kp, rows, dim, m_dim, _stream())
     _abi.check(rc, "egnn_node_prep_hl")
-    return hi, lo
+    return PackedHL(hi, lo, rows, kp)
 
 
 def node_prep(feats2d, m_i, gamma, beta, eps, m_dim):

@@ -43,13 +43,47 @@ def padded_scalars(s: int) -> int:
         f"the gfx950 edge kernel is built for")
 
 
+def pack_tiles(x: torch.Tensor) -> torch.Tensor:
+    """Row-major (R, Kp) -> the packed tile-major layout of include/egnn_hip.h (R % 32 == 0, Kp % 32 == 0):
+    [R/32][Kp/16][32][2][8] with the 16-byte chunk index XOR-swizzled by ((row >> 3) & 1).  Returns a flat tensor."""
+    r, kp = x.shape
+    assert r % 32 == 0 and kp % 32 == 0
+    t = x.reshape(r // 32, 32, kp // 16, 2, 8).permute(0, 2, 1, 3, 4).contiguous()      # (rb, kt, r, ck, e)
+    sw = (torch.arange(32, device=x.device) >> 3) & 1
+    swapped = t.flip(3)
+    out = torch.where(sw.view(1, 1, 32, 1, 1).bool(), swapped, t)
+    return out.reshape(-1)
+
+
+def unpack_tiles(flat: torch.Tensor, rows: int, kp: int) -> torch.Tensor:
+    """Inverse of pack_tiles (tests / debugging): flat packed buffer -> row-major (ceil(rows/32)*32, kp)."""
+    rp = (rows + 31) // 32 * 32
+    t = flat[: rp * kp].reshape(rp // 32, kp // 16, 32, 2, 8)
+    sw = (torch.arange(32, device=flat.device) >> 3) & 1
+    t = torch.where(sw.view(1, 1, 32, 1, 1).bool(), t.flip(3), t)
+    return t.permute(0, 2, 1, 3, 4).reshape(rp, kp)
+
+
 def split_f16(w: torch.Tensor):
-    """(N, K) fp32 weight -> (W_hi, W_lo, inv_scale) for egnn_linear_split_f32: fp16 images of scale * W with
-    scale the power of two that brings max|W| into [1, 2) (hi and lo then sit in fp16's normal range),
+    """(N, K) fp32 weight -> (W_hi, W_lo, inv_scale, w_rows) for egnn_linear_hl_f32: packed fp16 images of scale * W,
+    scale = the power of two that brings max|W| into [1, 2) (hi and lo then sit in fp16's normal range),
     hi = fp16(w), lo = fp16(w - hi), zero padded to (ceil(N/256)*256, ceil(K/32)*32) so that both the 128- and the
-    256-wide output tiles of egnn_linear_hl_f32 can read whole tiles."""
+    256-wide output tiles can read whole tiles."""
     n, k = w.shape
     npad, kpad = (n + 255) // 256 * 256, (k + 31) // 32 * 32
+    amax = float(w.abs().max()) if w.numel() else 0.0
+    scale = 2.0 ** (-math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
+    ws = torch.zeros(npad, kpad, dtype=torch.float32, device=w.device)
+    ws[:n, :k] = w.float() * scale
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    return pack_tiles(hi), pack_tiles(lo), 1.0 / scale, npad
+
+
+def split_f16_rowmajor(w: torch.Tensor):
+    """Row-major variant for the reference kernel egnn_linear_split_f32 (A split on the fly)."""
+    n, k = w.shape
+    npad, kpad = (n + 127) // 128 * 128, (k + 31) // 32 * 32
     amax = float(w.abs().max()) if w.numel() else 0.0
     scale = 2.0 ** (-math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
     ws = torch.zeros(npad, kpad, dtype=torch.float32, device=w.device)

@@ -35,6 +35,16 @@ __device__ __forceinline__ float egnn_sqdist(float xi, float yi, float zi, float
     return sxy + sz;
 }
 
+// Packed ("tile-major") layout of the fp16 GEMM operands: an (R x Kp) matrix, R padded to 32 rows, Kp % 32 == 0, is
+// stored as [R/32][Kp/16][32 rows][2 chunks][8 halves]; the chunk index is XOR-swizzled by ((row >> 3) & 1) so that the
+// 1 KB (row block, K-tile) piece is exactly the bank-conflict-free LDS image the GEMM wants.  nkt = Kp / 16.
+__host__ __device__ __forceinline__ size_t egnn_pk_off(int64_t row, int k, int nkt) {
+    const int r = (int)(row & 31);
+    const int64_t rb = row >> 5;
+    const int kt = k >> 4, ck = (k >> 3) & 1, e = k & 7;
+    return (size_t)((((rb * nkt + kt) * 32 + r) * 2 + (ck ^ ((r >> 3) & 1))) * 8 + e);
+}
+
 static inline int egnn_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? EGNN_OK : (int)e;

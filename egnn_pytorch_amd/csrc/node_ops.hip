@@ -48,11 +48,12 @@ __global__ __launch_bounds__(256) void node_prep_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restrict__ feats, const float* __restrict__ m_i,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float eps, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                                           int64_t ldh, int64_t rows, int dim, int m_dim)
+                                                           int Kp, int64_t rows, int dim, int m_dim)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int nkt = Kp / 16;
     for (int64_t r = wave0; r < rows; r += nwaves) {
         const float* x = feats + r * dim;
         float mean = 0.f, rstd = 1.f;
@@ -64,22 +65,23 @@ __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restri
             for (int c = lane; c < dim; c += 64) { const float d = x[c] - mean; v += d * d; }
             rstd = 1.0f / sqrtf(wave_sum(v) / (float)dim + eps);
         }
-        // 4 consecutive columns per lane: 8-byte stores of the hi and lo images (ldh % 32 == 0)
-        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-        for (int c0 = lane * 4; c0 < ldh; c0 += 256) {
-            f16x4 h4, l4;
+        // 8 consecutive columns (one 16-byte chunk of the packed layout) per lane
+        typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+        for (int c0 = lane * 8; c0 < Kp; c0 += 512) {
+            f16x8v h8, l8;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int c = c0 + u;
                 float y = 0.f;
                 if (c < dim) y = gamma ? (x[c] - mean) * rstd * gamma[c] + beta[c] : x[c];
                 else if (c < dim + m_dim) y = m_i ? m_i[r * m_dim + (c - dim)] : 0.f;
                 const _Float16 h = (_Float16)y;
-                h4[u] = h;
-                l4[u] = (_Float16)(y - (float)h);
+                h8[u] = h;
+                l8[u] = (_Float16)(y - (float)h);
             }
-            *reinterpret_cast<f16x4*>(hi + r * ldh + c0) = h4;
-            *reinterpret_cast<f16x4*>(lo + r * ldh + c0) = l4;
+            const size_t o = egnn_pk_off(r, c0, nkt);
+            *reinterpret_cast<f16x8v*>(hi + o) = h8;
+            *reinterpret_cast<f16x8v*>(lo + o) = l8;
         }
     }
 }
@@ -87,15 +89,15 @@ __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restri
 }  // namespace
 
 extern "C" int egnn_node_prep_hl(const float* feats, const float* m_i, const float* gamma, const float* beta, float eps,
-                                 void* out_hi, void* out_lo, int64_t ldh, int64_t rows, int dim, int m_dim, void* stream)
+                                 void* out_hi, void* out_lo, int Kp, int64_t rows, int dim, int m_dim, void* stream)
 {
     if (!feats || !out_hi || !out_lo) return EGNN_E_NULLPTR;
     if ((gamma == nullptr) != (beta == nullptr)) return EGNN_E_NULLPTR;
-    if (rows <= 0 || dim <= 0 || m_dim < 0 || ldh < dim + m_dim || (ldh % 32) != 0) return EGNN_E_SHAPE;
+    if (rows <= 0 || dim <= 0 || m_dim < 0 || Kp < dim + m_dim || (Kp % 32) != 0) return EGNN_E_SHAPE;
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(node_prep_hl_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), feats,
-                       m_i, gamma, beta, eps, static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), ldh, rows, dim,
+                       m_i, gamma, beta, eps, static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), Kp, rows, dim,
                        m_dim);
     return egnn_launch_status();
 }

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 5
+#define EGNN_ABI_VERSION 6
 
 enum {
     EGNN_OK = 0,
@@ -99,24 +99,36 @@ int egnn_linear_split_f32(const float* A, int64_t lda, const void* W_hi, const v
                           float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
                           float* C, int64_t ldc, int64_t M, int N, int K, int act, void* stream);
 
-/* The production GEMM: both operands pre-split into fp16 (hi, lo) pairs (A by egnn_split_f16 / egnn_node_prep_hl /
- * a previous call's C_hi, C_lo; W by egnn_pytorch_amd/_weights.py::split_f16), staged by LDS-DMA
- * (global_load_lds_dwordx4, double-buffered) and multiplied with three v_mfma_f32_32x32x16_f16 per product term.
- *   A_hi, A_lo (M, lda) fp16, W_hi, W_lo (w_rows, ldw) fp16 with w_rows >= ceil(N/128)*128 (256 x 256 tiles are used
- *   when w_rows also covers ceil(N/256)*256), all zero padded to Kp columns (Kp % 32 == 0);
- *   C (M,N) fp32 and/or C_hi, C_lo (M, ldch) fp16 (the result re-split for the next GEMM); other arguments as above. */
-int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, int64_t lda, const void* W_hi, const void* W_lo,
-                       int64_t ldw, float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
-                       float* C, int64_t ldc, void* C_hi, void* C_lo, int64_t ldch, int64_t M, int N, int Kp,
+/* Packed ("tile-major") layout of the fp16 GEMM operands.  An (R x Kp) fp16 matrix -- R padded up to a multiple of 32
+ * rows, Kp % 32 == 0, both pads zero -- is stored as [R/32][Kp/16][32 rows][2 chunks][8 halves] with the 16-byte chunk
+ * index XOR-swizzled by ((row >> 3) & 1):
+ *     offset(row, k) = ((((row>>5) * (Kp/16) + (k>>4)) * 32 + (row&31)) * 2 + (((k>>3)&1) ^ (((row&31)>>3)&1))) * 8 + (k&7)
+ * so one K-tile of one 32-row block is 1 KB of contiguous memory that is already the bank-conflict-free LDS image.
+ * (Why: a wave-level load is processed line by line; row-major operands made every staging instruction touch 32 partly
+ * used 128-B lines and capped the stream at ~10 TB/s out of L2.)  egnn_packed_halves = number of fp16 elements. */
+int64_t egnn_packed_halves(int64_t rows, int Kp);
+
+/* The production GEMM: C = act(A * W^T + bias) (+ residual), fp32 semantics on the f16 matrix cores.
+ * Both operands arrive pre-split into fp16 (hi, lo) pairs in the packed layout (A from egnn_split_f16 /
+ * egnn_node_prep_hl / a previous call's C_hi, C_lo; W from egnn_pytorch_amd/_weights.py::split_f16), are staged by
+ * LDS-DMA (global_load_lds_dwordx4, 4-deep ring, one barrier per K-tile) and multiplied with three
+ * v_mfma_f32_32x32x16_f16 per fragment pair (a_hi w_hi + a_lo w_hi + a_hi w_lo; fp32 accumulation: fp32-class accuracy).
+ *   A_hi, A_lo: packed (M, Kp);  W_hi, W_lo: packed (w_rows, Kp), w_rows >= ceil(N/128)*128 (256 x 256 output tiles are
+ *   used when w_rows also covers ceil(N/256)*256), holding w_scale * W with w_inv_scale = 1 / w_scale (a power of two);
+ *   C (M,N) fp32 row-major and/or C_hi, C_lo packed (M, Kp_out) (the result re-split for the next GEMM; their pad
+ *   columns [N, Kp_out) must be zero on entry);  |A| must stay below 65504.  Other arguments as egnn_linear_f32. */
+int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo,
+                       float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
+                       float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
                        int w_rows, int act, void* stream);
 
-/* X (rows, cols) fp32 -> hi = fp16(x), lo = fp16(x - hi), (rows, ldh) each, columns [cols, ldh) zeroed; ldh % 32 == 0.
- * Requires |X| < 65504. */
-int egnn_split_f16(const float* X, int64_t ldx, int64_t rows, int cols, void* hi, void* lo, int64_t ldh, void* stream);
+/* X (rows, cols) fp32 row-major -> packed (rows, Kp) images hi = fp16(x), lo = fp16(x - hi); pads zero; Kp % 32 == 0,
+ * Kp >= cols.  Requires |X| < 65504. */
+int egnn_split_f16(const float* X, int64_t ldx, int64_t rows, int cols, void* hi, void* lo, int Kp, void* stream);
 
-/* egnn_node_prep_f32 writing the (hi, lo) pair directly: out_hi, out_lo (rows, ldh), ldh >= dim + m_dim, ldh % 32 == 0. */
+/* egnn_node_prep_f32 writing the packed (hi, lo) pair directly: (rows, Kp), Kp >= dim + m_dim, Kp % 32 == 0. */
 int egnn_node_prep_hl(const float* feats, const float* m_i, const float* gamma, const float* beta, float eps,
-                      void* out_hi, void* out_lo, int64_t ldh, int64_t rows, int dim, int m_dim, void* stream);
+                      void* out_hi, void* out_lo, int Kp, int64_t rows, int dim, int m_dim, void* stream);
 
 /* node_norm + concat (egnn_pytorch.py:335-336): out[r] = [ LayerNorm(feats[r]) | m_i[r] ].
  * gamma/beta NULL -> Identity (norm_feats=False).  out: (rows, dim + m_dim). */

@@ -121,7 +121,7 @@ def test_linear_split_f16x3(m, n, k, act, res):
             ref = ref / (1.0 + np.exp(-ref))
         if res:
             ref = ref + r
-        ws = _weights.split_f16(_dev(w))
+        ws = _weights.split_f16_rowmajor(_dev(w))
         out = _ops.linear_split(_dev(a), ws, n, _dev(bias), _dev(r), act=act).cpu().numpy()
         assert out.shape == (m, n)
         tol = 2e-5 * max(1.0, 3 * wscale)
@@ -152,16 +152,16 @@ def test_linear_hl_lds_dma(m, n, k, act, res):
     if res:
         ref = ref + r
     ahl = _ops.split_f16(_dev(a))
-    assert ahl[0].shape[1] % 32 == 0
-    back = ahl[0].float() + ahl[1].float()
+    assert ahl.kp % 32 == 0 and ahl.hi.numel() == (m + 31) // 32 * 32 * ahl.kp
+    back = ahl.dense()
     # 22-bit split; lo of elements below ~1e-3 is an fp16 subnormal: absolute error up to 2^-25
     np.testing.assert_allclose(back[:, :k].cpu().numpy(), a, rtol=3e-7, atol=3.1e-8)
     assert float(back[:, k:].abs().max()) == 0.0 if back.shape[1] > k else True
     ws = _weights.split_f16(_dev(w))
-    out, (chi, clo) = _ops.linear_hl(ahl, ws, n, _dev(bias), _dev(r), act=act, out_f32=True, out_hl=True)
+    out, chl = _ops.linear_hl(ahl, ws, n, _dev(bias), _dev(r), act=act, out_f32=True, out_hl=True)
     out = out.cpu().numpy()
     np.testing.assert_allclose(out, ref, atol=3e-5, rtol=0)
-    resplit = (chi.float() + clo.float()).cpu().numpy()
+    resplit = chl.dense().cpu().numpy()
     np.testing.assert_allclose(resplit[:, :n], out, rtol=3e-7, atol=3.1e-8)
     assert np.all(resplit[:, n:] == 0)
     exact = _ops.linear(_dev(a), _dev(w), _dev(bias), _dev(r), act=act).cpu().numpy()      # exact-fp32 MFMA kernel
@@ -175,9 +175,9 @@ def test_node_prep_hl():
     mi = rng.standard_normal((300, 16)).astype(np.float32)
     g = rng.standard_normal(100).astype(np.float32)
     bt = rng.standard_normal(100).astype(np.float32)
-    hi, lo = _ops.node_prep_hl(_dev(x), _dev(mi), _dev(g), _dev(bt), 1e-5, 16)
-    assert hi.shape == (300, 128)
-    out = (hi.float() + lo.float()).cpu().numpy()
+    phl = _ops.node_prep_hl(_dev(x), _dev(mi), _dev(g), _dev(bt), 1e-5, 16)
+    assert phl.kp == 128 and phl.rows == 300
+    out = phl.dense().cpu().numpy()
     ref = np.concatenate([O.layer_norm(x, g, bt), mi], axis=-1)
     np.testing.assert_allclose(out[:, :116], ref, atol=1e-5, rtol=0)
     assert np.all(out[:, 116:] == 0)

@@ -155,3 +155,22 @@ def test_packed_weights_cache_tracks_parameter_updates():
         layer.edge_mlp[0].weight.add_(1.0)
     b = layer.packed_weights()
     assert b is not a and not torch.equal(a["Wcat"], b["Wcat"])
+
+
+def test_packed_tile_layout_matches_header_formula():
+    """_weights.pack_tiles / unpack_tiles against the offset formula documented in include/egnn_hip.h."""
+    from egnn_pytorch_amd import _weights
+    r, kp = 96, 64
+    x = torch.arange(r * kp, dtype=torch.float32).reshape(r, kp)
+    flat = _weights.pack_tiles(x)
+    assert flat.numel() == r * kp
+    rng = np.random.default_rng(0)
+    for _ in range(500):
+        row, k = int(rng.integers(r)), int(rng.integers(kp))
+        off = ((((row >> 5) * (kp // 16) + (k >> 4)) * 32 + (row & 31)) * 2 + (((k >> 3) & 1) ^ (((row & 31) >> 3) & 1))) * 8 + (k & 7)
+        assert float(flat[off]) == float(x[row, k])
+    assert torch.equal(_weights.unpack_tiles(flat, r, kp), x)
+    hi, lo, inv, w_rows = _weights.split_f16(torch.randn(130, 70))
+    assert w_rows == 256 and hi.numel() == 256 * 96 and hi.dtype == torch.float16
+    back = (_weights.unpack_tiles(hi, 256, 96).float() + _weights.unpack_tiles(lo, 256, 96).float()) * inv
+    assert float(back[130:].abs().max()) == 0 and float(back[:, 70:].abs().max()) == 0
