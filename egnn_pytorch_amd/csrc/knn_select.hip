@@ -5,11 +5,12 @@
 // coordinates live in LDS as SoA (conflict-free: lane l reads x[c*64+l]); every lane keeps
 // CPL = ceil(N/64) candidate keys in registers.
 //
-// Selection is an exact radix descent on the order-preserving uint32 image of the fp32 ranking
-// value (32 wave-uniform steps of ballot+popcount), followed by an index-ordered pick among the
-// candidates that tie with the K-th value, a ballot-prefix compaction into LDS and a rank-by-counting
-// sort of the K survivors on the composite key (value, index).  The result is deterministic:
-// ascending value, ties by ascending index -- the tie policy of SURVEY.md §8c(5).
+// Selection works on the order-preserving uint32 image of the fp32 ranking value.  Fast path (K <= 64): the K-th
+// smallest of the 64 per-lane minima bounds the K-th smallest candidate, which prunes the row to ~1.3 K survivors;
+// they are compacted into LDS (ballot prefix) and ranked by counting on the composite key (value, index).  General
+// path (K > 64, or heavily tied rows such as fully masked ones): exact radix descent over all candidates (32
+// wave-uniform steps of ballot+popcount), index-ordered pick among the ties with the K-th value, same compaction and
+// ranking.  Both are deterministic: ascending value, ties by ascending index -- the tie policy of SURVEY.md §8c(5).
 //
 // Bound: VALU (N compares x 32 bits per row); HBM traffic is only coors in + (idx, rank) out.
 #include "egnn_common.h"
@@ -94,7 +95,53 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
             key[c] = k;
         }
 
-        // ---- exact K-th smallest key: bitwise radix descent, all control flow wave-uniform
+        const size_t obase = ((size_t)b * N + i) * K;
+
+        // ---- fast path (K <= 64): prune with the lane minima.  Let M be the K-th smallest of the 64 per-lane minima:
+        // at least K candidates are <= M, so the K smallest candidates all are.  Typically only ~1.3 K candidates
+        // survive (N = 1024, K = 32: ~43); if they fit one per lane they are ranked by counting directly.
+        bool done = false;
+        if (K <= 64) {
+            uint32_t lmin = key[0];
+#pragma unroll
+            for (int c = 1; c < CPL; ++c) lmin = key[c] < lmin ? key[c] : lmin;
+            uint32_t M = 0;
+            int belowm = 0;
+            for (int bit = 31; bit >= 0; --bit) {
+                const int cnt = __popcll(__ballot((lmin >> bit) == (M >> bit)));
+                if (belowm + cnt < K) {
+                    belowm += cnt;
+                    M |= (1u << bit);
+                }
+            }
+            int S = 0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) S += __popcll(__ballot(key[c] <= M));
+            if (S <= 64) {                                   // wave-uniform
+                int base = 0;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const bool sel = key[c] <= M;
+                    const uint64_t bs = __ballot(sel);
+                    if (sel)
+                        selbuf[base + __popcll(bs & lt_mask)] = ((uint64_t)key[c] << 32) | (uint32_t)(c * 64 + lane);
+                    base += __popcll(bs);
+                }
+                wave_lds_sync();
+                const uint64_t mine = lane < S ? selbuf[lane] : ~0ull;
+                int rnk = 0;
+                for (int u = 0; u < S; ++u) rnk += (selbuf[u] < mine) ? 1 : 0;
+                if (lane < S && rnk < K) {
+                    idx_out[obase + rnk] = (int32_t)(uint32_t)(mine & 0xFFFFFFFFull);
+                    rank_out[obase + rnk] = key2f((uint32_t)(mine >> 32));
+                }
+                wave_lds_sync();
+                done = true;
+            }
+        }
+        if (done) continue;
+
+        // ---- general path: exact K-th smallest key by bitwise radix descent, all control flow wave-uniform
         uint32_t T = 0;
         int below = 0;
         for (int bit = 31; bit >= 0; --bit) {
@@ -130,7 +177,6 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
         wave_lds_sync();
 
         // ---- sort the K survivors by (value, index): rank by counting
-        const size_t obase = ((size_t)b * N + i) * K;
         for (int t = lane; t < K; t += 64) {
             const uint64_t mine = selbuf[t];
             int rnk = 0;
@@ -164,7 +210,7 @@ int launch_knn(const float* coors, const uint8_t* mask, const uint8_t* adj, int6
                int K, int32_t* idx_out, float* rank_out, hipStream_t s)
 {
     const int Npad = (N + 63) / 64 * 64;
-    const int Kpad = (K + 1) / 2 * 2;
+    const int Kpad = K > 64 ? (K + 1) / 2 * 2 : 64;        // the fast path parks up to 64 survivors
     int rows_per_wg = 32;
     if (N < rows_per_wg) rows_per_wg = (N + 3) / 4 * 4;
     const size_t coord_bytes = (size_t)Npad * 13 + 8 - ((size_t)Npad * 13) % 8;
