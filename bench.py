@@ -35,9 +35,13 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_*_f16 dense (the GEMMs issue 3 f16 M
 SPLIT_TERMS = 3
 
 WORKLOADS = {
-    # name: (layer kwargs, graphs per GPU, nodes)
+    # name: (layer kwargs, graphs per GPU, nodes)  -- the default is the configuration BASELINE.json's metric is quoted on
     "north_star": (dict(dim=512, num_nearest_neighbors=32), 64, 1024),
+    # the other BASELINE.json configs (parity-test cases; timed on request with --workload, not part of the default line)
     "c2_dense": (dict(dim=512), 8, 256),
+    "c3_network": (dict(depth=3, dim=128, num_nearest_neighbors=32), 64, 1024),
+    "c4_sparse": (dict(dim=512, edge_dim=4, only_sparse_neighbors=True), 32, 2048),
+    "c5_shard": (dict(depth=6, dim=256, num_nearest_neighbors=32, norm_coors=True), 64, 1024),   # 1/8 of B=512
 }
 
 
@@ -164,18 +168,28 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
 
-    from egnn_pytorch_amd import EGNN, phase_timer
+    from egnn_pytorch_amd import EGNN, EGNN_Network, phase_timer
 
     kwargs, b, n = WORKLOADS[args.workload]
     torch.manual_seed(0)
-    layer = EGNN(**kwargs).to(device).eval()
+    is_net = "depth" in kwargs
+    layer = (EGNN_Network(**kwargs) if is_net else EGNN(**kwargs)).to(device).eval()
     if dist is not None:
         from egnn_pytorch_amd.sharding import broadcast_parameters
         broadcast_parameters(layer)                       # the only collective: one-off weight replication
     feats, coors, mask = make_inputs(kwargs, b, n, device, seed=1000 + rank)   # this rank's shard of the batch
+    edges = adj = None
+    if kwargs.get("edge_dim", 0) > 0:
+        edges = torch.randn(b, n, n, kwargs["edge_dim"], device=device)
+    if kwargs.get("only_sparse_neighbors"):
+        i = torch.arange(n, device=device)
+        adj = (i[:, None] - i[None, :]).abs() <= 1                              # README chain adjacency incl. diagonal
 
     def step():
-        layer(feats, coors, mask=mask)
+        if is_net:
+            layer(feats, coors, adj_mat=adj, edges=edges, mask=mask)
+        else:
+            layer(feats, coors, edges, mask, adj)
 
     def barrier():
         if dist is not None:
@@ -196,7 +210,18 @@ def main():
             step()
     per_kernel = {k: sum(v) / len(v) for k, v in pt.summary().items()}
 
-    if rank == 0:
+    if rank == 0 and args.workload != "north_star":
+        # secondary configs: throughput + per-kernel times only (the roofline bookkeeping is defined for the metric's config)
+        graphs = world * b * args.steps
+        depth = kwargs.get("depth", 1)
+        print(json.dumps({"metric": "EGNN.forward graphs/sec", "value": round(graphs / elapsed, 2), "unit": "graphs/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": args.workload, "kwargs": kwargs, "graphs_per_gpu": b, "nodes": n},
+                          "kernel_ms_per_step": {k: round(v * (len(pt.summary()[k]) / 5), 4) for k, v in per_kernel.items()},
+                          "layers": depth}), flush=True)
+    elif rank == 0:
         counts, shp = model_counts(kwargs, b, n)
         kernels = [roofline_entry(k, counts, ms) for k, ms in sorted(per_kernel.items(), key=lambda kv: -kv[1])
                    if k in counts]

@@ -222,32 +222,6 @@ __global__ __launch_bounds__(Cfg<BT>::THREADS, 2) void linear_hl_kernel(
     }
 }
 
-// fp32 row-major (rows, cols) -> packed (hi, lo) images; one thread per 16-byte output chunk (writes fully coalesced)
-__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int cols,
-                                                        _Float16* __restrict__ hi, _Float16* __restrict__ lo, int nkt,
-                                                        int64_t nchunks)
-{
-    typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
-    for (int64_t oc = (int64_t)blockIdx.x * 256 + threadIdx.x; oc < nchunks; oc += (int64_t)gridDim.x * 256) {
-        const int pc = (int)(oc & 1);
-        const int r = (int)((oc >> 1) & 31);
-        const int64_t t = oc >> 6;                                     // (rb * nkt + kt)
-        const int kt = (int)(t % nkt);
-        const int64_t row = (t / nkt) * 32 + r;
-        const int k = kt * 16 + ((pc ^ ((r >> 3) & 1)) * 8);
-        f16x8v h, l;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float v = (row < rows && k + e < cols) ? X[row * ldx + k + e] : 0.f;
-            const _Float16 hh = (_Float16)v;
-            h[e] = hh;
-            l[e] = (_Float16)(v - (float)hh);
-        }
-        *reinterpret_cast<f16x8v*>(hi + oc * 8) = h;
-        *reinterpret_cast<f16x8v*>(lo + oc * 8) = l;
-    }
-}
-
 template <int BT, int ACT, bool HAS_RES>
 int launch_hl_bt(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, const _Float16* Wlo,
               const float* bias, const float* R, int64_t ldr, float* C, int64_t ldc, _Float16* Chi, _Float16* Clo,
@@ -321,10 +295,5 @@ extern "C" int egnn_split_f16(const float* X, int64_t ldx, int64_t rows, int col
 {
     if (!X || !hi || !lo) return EGNN_E_NULLPTR;
     if (rows <= 0 || cols <= 0 || ldx < cols || Kp < cols || (Kp % 32) != 0) return EGNN_E_SHAPE;
-    const int64_t nchunks = egnn_packed_halves(rows, Kp) / 8;
-    int64_t blocks = (nchunks + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), X, ldx, rows,
-                       cols, static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), Kp / 16, nchunks);
-    return egnn_launch_status();
+    return egnn_pack_rows_launch(X, ldx, nullptr, nullptr, nullptr, 0.f, hi, lo, Kp, rows, cols, 0, stream);
 }

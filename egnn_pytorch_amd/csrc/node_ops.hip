@@ -44,37 +44,51 @@ __global__ __launch_bounds__(256) void node_prep_kernel(const float* __restrict_
     }
 }
 
-// same, but the row is written as the (hi, lo) f16 pair the matrix-core GEMM consumes, zero padded to ldh columns
-__global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restrict__ feats, const float* __restrict__ m_i,
+// Packed-layout producer: the row [LayerNorm(x) | m_i] (or just x) as the (hi, lo) f16 pair the matrix-core GEMM consumes.
+// 16 lanes per row, 4 consecutive rows per wave: a lane converts 8 consecutive columns (one 16-byte chunk) at a time, so a
+// wave load covers 4 x 512 contiguous bytes and a wave store fills whole 128-byte lines of the packed layout (rows r..r+3
+// of one K-tile are adjacent).  Row statistics: two-pass (mean, centred variance) with 16-lane xor shuffles.
+__device__ __forceinline__ float sum16(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restrict__ feats, int64_t ldx, const float* __restrict__ m_i,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float eps, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                                            int Kp, int64_t rows, int dim, int m_dim)
 {
+    typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
     const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int sub = lane & 15;
+    const int64_t quad0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));         // one wave = 4 rows
+    const int64_t nquads = (int64_t)gridDim.x * 4;
     const int nkt = Kp / 16;
-    for (int64_t r = wave0; r < rows; r += nwaves) {
-        const float* x = feats + r * dim;
+    const int64_t rows_p = (rows + 31) / 32 * 32;                                  // pad rows are written as zeros
+    for (int64_t qd = quad0; qd * 4 < rows_p; qd += nquads) {
+        const int64_t r = qd * 4 + (lane >> 4);
+        const bool live = r < rows;
+        const float* x = feats + (live ? r : 0) * ldx;
         float mean = 0.f, rstd = 1.f;
         if (gamma) {
             float s = 0.f;
-            for (int c = lane; c < dim; c += 64) s += x[c];
-            mean = wave_sum(s) / (float)dim;
+            for (int c = sub; c < dim; c += 16) s += x[c];
+            mean = sum16(s) / (float)dim;
             float v = 0.f;
-            for (int c = lane; c < dim; c += 64) { const float d = x[c] - mean; v += d * d; }
-            rstd = 1.0f / sqrtf(wave_sum(v) / (float)dim + eps);
+            for (int c = sub; c < dim; c += 16) { const float d = x[c] - mean; v += d * d; }
+            rstd = 1.0f / sqrtf(sum16(v) / (float)dim + eps);
         }
-        // 8 consecutive columns (one 16-byte chunk of the packed layout) per lane
-        typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
-        for (int c0 = lane * 8; c0 < Kp; c0 += 512) {
+        for (int c0 = sub * 8; c0 < Kp; c0 += 128) {
             f16x8v h8, l8;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = c0 + u;
                 float y = 0.f;
-                if (c < dim) y = gamma ? (x[c] - mean) * rstd * gamma[c] + beta[c] : x[c];
-                else if (c < dim + m_dim) y = m_i ? m_i[r * m_dim + (c - dim)] : 0.f;
+                if (live) {
+                    if (c < dim) y = gamma ? (x[c] - mean) * rstd * gamma[c] + beta[c] : x[c];
+                    else if (c < dim + m_dim) y = m_i ? m_i[r * m_dim + (c - dim)] : 0.f;
+                }
                 const _Float16 h = (_Float16)y;
                 h8[u] = h;
                 l8[u] = (_Float16)(y - (float)h);
@@ -88,18 +102,26 @@ __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restri
 
 }  // namespace
 
+// internal: shared by egnn_node_prep_hl and egnn_split_f16
+int egnn_pack_rows_launch(const float* X, int64_t ldx, const float* m_i, const float* gamma, const float* beta, float eps,
+                          void* hi, void* lo, int Kp, int64_t rows, int dim, int m_dim, void* stream)
+{
+    const int64_t quads = ((rows + 31) / 32 * 32) / 4;
+    int64_t blocks = (quads + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(node_prep_hl_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), X, ldx, m_i,
+                       gamma, beta, eps, static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), Kp, rows, dim, m_dim);
+    return egnn_launch_status();
+}
+
+
 extern "C" int egnn_node_prep_hl(const float* feats, const float* m_i, const float* gamma, const float* beta, float eps,
                                  void* out_hi, void* out_lo, int Kp, int64_t rows, int dim, int m_dim, void* stream)
 {
     if (!feats || !out_hi || !out_lo) return EGNN_E_NULLPTR;
     if ((gamma == nullptr) != (beta == nullptr)) return EGNN_E_NULLPTR;
     if (rows <= 0 || dim <= 0 || m_dim < 0 || Kp < dim + m_dim || (Kp % 32) != 0) return EGNN_E_SHAPE;
-    int64_t blocks = (rows + 3) / 4;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(node_prep_hl_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), feats,
-                       m_i, gamma, beta, eps, static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), Kp, rows, dim,
-                       m_dim);
-    return egnn_launch_status();
+    return egnn_pack_rows_launch(feats, dim, m_i, gamma, beta, eps, out_hi, out_lo, Kp, rows, dim, m_dim, stream);
 }
 
 extern "C" int egnn_node_prep_f32(const float* feats, const float* m_i, const float* gamma, const float* beta, float eps,
