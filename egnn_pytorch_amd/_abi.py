@@ -12,11 +12,11 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -25,7 +25,7 @@ SYMBOLS = (
     "egnn_abi_version", "egnn_error_string", "egnn_padded_hidden", "egnn_knn_select_f32",
     "egnn_adj_max_degree_u8", "egnn_linear_f32", "egnn_linear_split_f32", "egnn_node_prep_f32",
     "egnn_edge_fused_f32", "egnn_spatial_order_f32", "egnn_linear_hl_f32", "egnn_split_f16", "egnn_node_prep_hl",
-    "egnn_packed_halves",
+    "egnn_packed_halves", "egnn_adj_expand_u8", "egnn_adj_expand_workspace_bytes",
 )
 
 
@@ -94,6 +94,10 @@ def load():
     lib.egnn_linear_split_f32.restype = c_int
     lib.egnn_linear_split_f32.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p,
                                           c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]
+    lib.egnn_adj_expand_workspace_bytes.restype = c_size_t
+    lib.egnn_adj_expand_workspace_bytes.argtypes = [c_int, c_int]
+    lib.egnn_adj_expand_u8.restype = c_int
+    lib.egnn_adj_expand_u8.argtypes = [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.egnn_packed_halves.restype = c_int64
     lib.egnn_packed_halves.argtypes = [c_int64, c_int]
     lib.egnn_linear_hl_f32.restype = c_int

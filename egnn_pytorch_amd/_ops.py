@@ -105,6 +105,25 @@ def spatial_order(coors):
     return order
 
 
+def adj_expand(adj_mat, b, num_adj_degrees):
+    """N-degree adjacency expansion (egnn_pytorch.py:414-427) -- egnn_adj_expand_u8.
+    Returns (expanded adjacency (B,N,N) bool, adj_indices (B,N,N) uint8)."""
+    a8 = _u8(adj_mat)
+    n = a8.shape[-1]
+    stride = n * n if a8.dim() == 3 else 0
+    if a8.dim() == 3 and a8.shape[0] != b:
+        raise ValueError(f"adj_mat batch {a8.shape[0]} != {b}")
+    dev = a8.device
+    adj_out = torch.empty(b, n, n, dtype=torch.uint8, device=dev)
+    deg = torch.empty(b, n, n, dtype=torch.uint8, device=dev)
+    ws = torch.empty(_abi.load().egnn_adj_expand_workspace_bytes(b, n), dtype=torch.uint8, device=dev)
+    with _timed("adj_expand"):
+        rc = _abi.load().egnn_adj_expand_u8(_ptr(a8), stride, b, n, num_adj_degrees, _ptr(adj_out), _ptr(deg), _ptr(ws),
+                                            _stream())
+    _abi.check(rc, "egnn_adj_expand_u8")
+    return adj_out.view(torch.bool), deg
+
+
 def adj_max_degree(adj_mat):
     """int(adj_mat.float().sum(-1).max()) -- one device->host read, like the reference's .item() (:249)."""
     a8 = _u8(adj_mat)

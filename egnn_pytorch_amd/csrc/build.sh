@@ -7,7 +7,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed"
 mkdir -p "$HERE/obj"
 pids=()
-for f in knn_select spatial_order linear_f32 linear_split linear_hl edge_fused node_ops; do
+for f in knn_select spatial_order adj_expand linear_f32 linear_split linear_hl edge_fused node_ops; do
   EXTRA=""
   # the ranking kernel must reproduce the reference's un-fused ((dx*dx+dy*dy)+dz*dz) bit for bit
   [ "$f" = knn_select ] && EXTRA="-ffp-contract=off"

@@ -254,19 +254,12 @@ class EGNN_Network(nn.Module):
 
         if self.num_adj_degrees is not None:
             assert adj_mat is not None, "adjacency matrix must be passed in (keyword argument adj_mat)"
-            if adj_mat.dim() == 2:
-                adj_mat = adj_mat[None].expand(b, -1, -1)
-            adj_mat = adj_mat.clone()
-            adj_indices = adj_mat.long()
-            for ind in range(self.num_adj_degrees - 1):
-                degree = ind + 2
-                af = adj_mat.float()
-                next_adj = (af @ af) > 0
-                next_mask = (next_adj.float() - af).bool()
-                adj_indices.masked_fill_(next_mask, degree)
-                adj_mat = next_adj
+            if not adj_mat.is_cuda:
+                raise RuntimeError("egnn_pytorch_amd.EGNN_Network runs only on an MI355X (cuda/HIP) device")
+            # N-degree expansion (egnn_pytorch.py:414-427) as bit-set algebra on the device instead of float matmuls
+            adj_mat, adj_indices = _ops.adj_expand(adj_mat, b, self.num_adj_degrees)
             if self.adj_emb is not None:
-                adj_emb = self.adj_emb(adj_indices)
+                adj_emb = self.adj_emb(adj_indices.long())
                 edges = torch.cat((edges, adj_emb), dim=-1) if edges is not None else adj_emb
 
         coor_changes = [coors]

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 6
+#define EGNN_ABI_VERSION 7
 
 enum {
     EGNN_OK = 0,
@@ -71,6 +71,18 @@ int egnn_adj_max_degree_u8(const uint8_t* adj, int64_t rows, int N, int32_t* out
 /* Scheduling aid for egnn_edge_fused_f32 (no reference counterpart): per-graph Morton (Z-order) permutation of
  * the nodes, order_out (B,N) int32.  N <= 4096. */
 int egnn_spatial_order_f32(const float* coors, int B, int N, int32_t* order_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * EGNN_Network front-end: N-degree adjacency expansion, egnn_pytorch.py:414-427.
+ * Replaces the float matmuls `(adj.float() @ adj.float()) > 0` and the XOR labelling by bit-set algebra (bit-exact).
+ *   adj         (N,N) bytes (adj_batch_stride = 0) or (B,N,N) bytes (adj_batch_stride = N*N)
+ *   adj_out     (B,N,N) bytes: the expanded adjacency the layers receive (:425)
+ *   degree_out  (B,N,N) bytes: adj_indices (:419-424): 0 = not connected, 1 = adjacent, d = first reached at degree d
+ *   workspace   egnn_adj_expand_workspace_bytes(B, N) bytes
+ * Limits: N <= 4096, 1 <= num_adj_degrees <= 255. */
+size_t egnn_adj_expand_workspace_bytes(int B, int N);
+int egnn_adj_expand_u8(const uint8_t* adj, int64_t adj_batch_stride, int B, int N, int num_adj_degrees,
+                       uint8_t* adj_out, uint8_t* degree_out, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense layer, exact-fp32 variant (v_mfma_f32_32x32x2_f32): C = act(A * W^T + bias) (+ residual).

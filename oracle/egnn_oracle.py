@@ -256,13 +256,56 @@ def egnn_forward(cfg, params, feats, coors, edges=None, mask=None, adj_mat=None,
     return node_out, coors_out
 
 
+def adjacency_degrees(adj_mat, num_adj_degrees):
+    """N-degree adjacency expansion (egnn_pytorch/egnn_pytorch.py:414-427).  adj_mat (B,N,N) bool.
+    Returns (adj_indices int64 (B,N,N), expanded adj_mat bool): degree d >= 2 labels the entries where
+    (adj @ adj > 0) differs from adj (the reference's `(next.float() - adj.float()).bool()` is an XOR), and the
+    adjacency handed to the layers is the expanded one."""
+    adj = adj_mat.copy()
+    adj_indices = adj.astype(np.int64)
+    for ind in range(num_adj_degrees - 1):
+        degree = ind + 2
+        a = adj.astype(np.float32)
+        nxt = (a @ a) > 0
+        mask = nxt != adj
+        adj_indices[mask] = degree
+        adj = nxt
+    return adj_indices, adj
+
+
+def network_frontend(params, feats, coors, adj_mat=None, edges=None, num_adj_degrees=None):
+    """EGNN_Network.forward up to the layer loop (egnn_pytorch/egnn_pytorch.py:401-432): token / position / edge-token
+    embeddings, adjacency-degree expansion and its embedding concatenated onto the edge features.
+    Embedding tables are taken from `params` when present (token_emb / pos_emb / edge_emb / adj_emb .weight)."""
+    b = feats.shape[0]
+    if "token_emb.weight" in params:
+        feats = params["token_emb.weight"][feats]                                    # :401-402
+    if "pos_emb.weight" in params:
+        n = feats.shape[1]
+        feats = feats + params["pos_emb.weight"][np.arange(n)][None]                 # :404-408
+    if edges is not None and "edge_emb.weight" in params:
+        edges = params["edge_emb.weight"][edges]                                     # :410-411
+    if num_adj_degrees is not None:
+        assert adj_mat is not None
+        n = adj_mat.shape[-1]
+        adj = np.broadcast_to(adj_mat, (b, n, n)).copy() if adj_mat.ndim == 2 else adj_mat.copy()
+        adj_indices, adj_mat = adjacency_degrees(adj, num_adj_degrees)               # :414-427
+        if "adj_emb.weight" in params:
+            adj_emb = params["adj_emb.weight"][adj_indices]                          # :429-431
+            edges = np.concatenate([edges, adj_emb], axis=-1) if edges is not None else adj_emb
+    return feats, coors, adj_mat, edges
+
+
 def egnn_network_forward(depth, cfg, params, feats, coors, adj_mat=None, edges=None, mask=None,
-                         return_coor_changes=False):
-    """The EGNN_Network layer loop (egnn_pytorch/egnn_pytorch.py:442-454) for float `feats`
-    (no token / position / edge embeddings, no adjacency-degree expansion, no global attention:
-    those front-end pieces are outside the hot path).
-    `cfg` must have norm_feats=True (forced at :387).  State-dict prefix: layers.{l}.1."""
+                         return_coor_changes=False, num_adj_degrees=None):
+    """EGNN_Network.forward (egnn_pytorch/egnn_pytorch.py:390-454) without global attention: the front-end
+    (network_frontend) and the layer loop (:442-454).  `cfg` is the per-layer EGNN configuration (edge_dim already
+    includes adj_dim) and must have norm_feats=True (forced at :387).  State-dict prefix: layers.{l}.1."""
     assert cfg.norm_feats
+    feats, coors, adj_mat, edges = network_frontend(params, feats, coors, adj_mat, edges, num_adj_degrees)
+    feats = feats.astype(coors.dtype, copy=False)
+    if edges is not None:
+        edges = edges.astype(coors.dtype, copy=False)
     coor_changes = [coors]
     for layer in range(depth):
         feats, coors = egnn_forward(cfg, params, feats, coors, edges=edges, mask=mask,

@@ -23,10 +23,19 @@ def load_golden(name):
     return meta, params, data
 
 
+NETWORK_ONLY = ("depth", "num_tokens", "num_edge_tokens", "num_positions", "num_adj_degrees", "adj_dim",
+                "global_linear_attn_every", "global_linear_attn_heads", "global_linear_attn_dim_head", "num_global_tokens")
+
+
 def layer_kwargs(meta):
+    """Per-layer EGNN kwargs of a golden case (for networks: what EGNN_Network passes to each EGNN, :387)."""
     kw = dict(meta["kwargs"])
     if meta["kind"] == "network":
-        kw.pop("depth")
+        edge_dim = kw.get("edge_dim", 0) if kw.get("edge_dim", 0) > 0 else 0
+        adj_dim = kw.get("adj_dim", 0) if kw.get("num_adj_degrees") is not None else 0
+        for k in NETWORK_ONLY:
+            kw.pop(k, None)
+        kw["edge_dim"] = edge_dim + adj_dim
         kw["norm_feats"] = True          # forced by EGNN_Network (egnn_pytorch/egnn_pytorch.py:387)
     return kw
 

@@ -123,6 +123,16 @@ CASES = [
     ("net3_dim32_k8_mask", "network", dict(depth=3, dim=32, num_nearest_neighbors=8), 2, 48, dict(mask=True)),
     ("net2_normcoors_clamp", "network", dict(depth=2, dim=32, num_nearest_neighbors=8, norm_coors=True,
                                              coor_weights_clamp_value=2.0), 2, 32, dict(mask=True)),
+    # EGNN_Network front-end: token / position / edge-token embeddings, N-degree adjacency
+    # expansion + adjacency embedding (README.md:95-120)
+    ("net_tokens_pos", "network", dict(depth=2, dim=32, num_tokens=21, num_positions=64, num_nearest_neighbors=8,
+                                       coor_weights_clamp_value=2.0), 2, 40, dict(mask=True, tokens=21)),
+    ("net_adj_degrees_sparse", "network", dict(depth=2, dim=32, num_tokens=21, num_adj_degrees=3, adj_dim=8,
+                                               only_sparse_neighbors=True), 2, 32, dict(mask=True, tokens=21, adj="chain_nodiag")),
+    # (sparse-only neighbours: with an expanded adjacency the rank-0 tie group would straddle any fixed K)
+    ("net_edge_tokens_adj2", "network", dict(depth=2, dim=32, num_edge_tokens=4, edge_dim=4, num_adj_degrees=2, adj_dim=4,
+                                             only_sparse_neighbors=True), 2, 24,
+     dict(mask=True, edge_tokens=4, adj="random")),
 ]
 
 
@@ -131,12 +141,19 @@ def run_case(idx, name, kind, kwargs, b, n, flags):
     dim = kwargs["dim"]
     edge_dim = kwargs.get("edge_dim", 0)
     feats = torch.randn(b, n, dim, generator=g)
+    if flags.get("tokens"):
+        feats = torch.randint(0, flags["tokens"], (b, n), generator=g)
     coors = torch.randn(b, n, 3, generator=g)
     edges = torch.randn(b, n, n, edge_dim, generator=g) if flags.get("edges") else None
+    if flags.get("edge_tokens"):
+        edges = torch.randint(0, flags["edge_tokens"], (b, n, n), generator=g)
     mask = ragged_mask(b, n, g) if flags.get("mask") else None
     adj = None
     if flags.get("adj") == "chain":
         adj = chain_adj(n)
+    elif flags.get("adj") == "chain_nodiag":
+        i = torch.arange(n)
+        adj = (i[:, None] - i[None, :]).abs() == 1          # README.md:110 style: neighbours only, no diagonal
     elif flags.get("adj") == "random":
         adj = random_adj(n, g)
     elif flags.get("adj") == "random_batched":

@@ -227,3 +227,32 @@ def test_spatial_order_is_a_permutation_and_results_do_not_depend_on_it(monkeypa
     monkeypatch.setattr(L, "_SPATIAL_ORDER", False)
     n0, c0 = net(feats, co, mask=mask)
     assert torch.equal(n0, n1) and torch.equal(c0, c1)
+
+
+@pytest.mark.parametrize("n,degrees,kind", [(16, 2, "chain"), (100, 3, "random"), (256, 4, "chain_nodiag"), (1024, 3, "random"),
+                                            (70, 1, "random"), (130, 5, "sparse_random")])
+def test_adj_expand_bit_exact(n, degrees, kind):
+    """N-degree adjacency expansion (bit sets on the device) against the oracle's float-matmul restatement of
+    egnn_pytorch.py:414-427: labels and expanded adjacency identical, 2-D and batched inputs."""
+    from egnn_pytorch_amd import _ops
+    rng = np.random.default_rng(n + degrees)
+    b = 3
+    i = np.arange(n)
+    if kind == "chain":
+        adj = np.broadcast_to(np.abs(i[:, None] - i[None, :]) <= 1, (b, n, n)).copy()
+    elif kind == "chain_nodiag":
+        adj = np.broadcast_to(np.abs(i[:, None] - i[None, :]) == 1, (b, n, n)).copy()
+    elif kind == "sparse_random":
+        adj = rng.random((b, n, n)) < 0.01                       # asymmetric, some empty rows, no forced diagonal
+    else:
+        adj = rng.random((b, n, n)) < 0.03
+        adj = adj | adj.transpose(0, 2, 1) | np.eye(n, dtype=bool)[None]
+    ref_idx, ref_adj = O.adjacency_degrees(adj, degrees)
+    out_adj, out_idx = _ops.adj_expand(_dev(adj), b, degrees)
+    np.testing.assert_array_equal(out_idx.cpu().numpy().astype(np.int64), ref_idx)
+    np.testing.assert_array_equal(out_adj.cpu().numpy(), ref_adj)
+    # shared (N,N) adjacency broadcast over the batch
+    out_adj2, out_idx2 = _ops.adj_expand(_dev(adj[0]), b, degrees)
+    for bb in range(b):
+        np.testing.assert_array_equal(out_idx2[bb].cpu().numpy().astype(np.int64), ref_idx[0])
+        np.testing.assert_array_equal(out_adj2[bb].cpu().numpy(), ref_adj[0])

@@ -18,7 +18,8 @@ def test_oracle_matches_reference_golden(name):
             check_neighbors(d["topk_values.0"], d["topk_indices.0"], nr.astype(np.float32), ni.astype(np.int32))
     else:
         node, coors, changes = O.egnn_network_forward(meta["kwargs"]["depth"], cfg, params, d["feats"], d["coors"],
-                                                      return_coor_changes=True, **kw)
+                                                      return_coor_changes=True,
+                                                      num_adj_degrees=meta["kwargs"].get("num_adj_degrees"), **kw)
         for i, c in enumerate(changes):
             np.testing.assert_allclose(c, d[f"coor_change.{i}"], atol=ATOL, rtol=0)
     # the oracle follows the reference's op order, so it sits far inside the 1e-4 north-star tolerance
