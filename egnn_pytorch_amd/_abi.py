@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -38,7 +38,7 @@ class EdgeArgs(Structure):
         ("Pi", c_void_p), ("Pj", c_void_p), ("ldp", c_int64),
         ("Ws", c_void_p), ("W2h", c_void_p), ("w2_inv_scale", c_float), ("b2", c_void_p),
         ("gate_w", c_void_p), ("gate_b", c_void_p),
-        ("W3", c_void_p), ("b3", c_void_p), ("W4", c_void_p), ("b4", c_void_p),
+        ("W3h", c_void_p), ("w3_inv_scale", c_float), ("b3", c_void_p), ("W4", c_void_p), ("b4", c_void_p),
         ("coors_scale", c_void_p),
         ("coors", c_void_p), ("edges", c_void_p), ("mask", c_void_p), ("idx", c_void_p), ("rank", c_void_p),
         ("order", c_void_p),

@@ -143,11 +143,17 @@ def pack(layer) -> dict:
         w3 = layer.coors_mlp[0].weight.detach().float()          # (4m, m)
         w3p = z(C_PAD, M_PAD)
         w3p[:4 * m, :m] = w3
+        a3 = float(w3p.abs().max())
+        w3_scale = 2.0 ** (-math.floor(math.log2(a3))) if a3 > 0 and math.isfinite(a3) else 1.0
+        w3s = w3p * w3_scale
+        w3_hi = w3s.half()
+        w3h = torch.stack([w3_hi, (w3s - w3_hi.float()).half()]).contiguous()        # (2, 64, 16) fp16: hi | lo
         b3p = z(C_PAD)
         b3p[:4 * m] = layer.coors_mlp[0].bias.detach().float()
         w4p = z(C_PAD)
         w4p[:4 * m] = layer.coors_mlp[3].weight.detach().float()[0]
-        out.update(W3=w3p, b3=b3p, W4=w4p, b4=layer.coors_mlp[3].bias.detach().float().contiguous())
+        out.update(W3=w3p, W3h=w3h, w3_inv_scale=1.0 / w3_scale, b3=b3p, W4=w4p,
+                   b4=layer.coors_mlp[3].bias.detach().float().contiguous())
     if layer.norm_coors:
         out["coors_scale"] = layer.coors_norm.scale.detach().float().contiguous()
     if layer.node_mlp is not None:

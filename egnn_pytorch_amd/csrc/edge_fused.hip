@@ -316,35 +316,42 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
             cw[t] = 0.f;
         }
 
-        if (p.W3) {
+        if (p.W3h) {
             float part[TILES];
 #pragma unroll
             for (int t = 0; t < TILES; ++t) part[t] = 0.f;
+            // coors_mlp first Linear (16 -> 64) on the matrix cores, same split-f16 scheme: lane (e, g) already holds
+            // channels 4g..4g+3 of its edge = the B fragment of v_mfma_f32_16x16x16_f16; A = rows 16 blk + e of W3.
+            // (An earlier version used v_mfma_f32_16x16x4_f32 here and hit a gfx950 source-operand hazard: VALU /
+            // transcendental instructions scheduled into the chain and overwriting its A/B VGPRs corrupted 1-2
+            // coordinate weights per ~1e5 edges, differently on every run; regression:
+            // tests/test_gpu_parity.py::test_multi_round_stress_is_deterministic_and_correct.)
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            f16x4 mhi[TILES], mlo[TILES];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const _Float16 h = (_Float16)acc[t][u];
+                    mhi[t][u] = h;
+                    mlo[t][u] = (_Float16)(acc[t][u] - (float)h);
+                }
+            }
+            const _Float16* w3h = static_cast<const _Float16*>(p.W3h);
 #pragma unroll
             for (int blk = 0; blk < 4; ++blk) {
-                const f32x4 w3 = *reinterpret_cast<const f32x4*>(p.W3 + (16 * blk + e) * 16 + 4 * g);
+                const f16x4 w3hi = *reinterpret_cast<const f16x4*>(w3h + (16 * blk + e) * 16 + 4 * g);
+                const f16x4 w3lo = *reinterpret_cast<const f16x4*>(w3h + 64 * 16 + (16 * blk + e) * 16 + 4 * g);
                 const f32x4 b3 = *reinterpret_cast<const f32x4*>(p.b3 + 16 * blk + 4 * g);
                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.W4 + 16 * blk + 4 * g);
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
                     f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    // HAZARD (observed on gfx950 / ROCm 7.2, reproduced by tests/test_gpu_parity.py::
-                    // test_multi_round_stress...): when hipcc interleaves VALU / transcendental instructions that
-                    // overwrite the A/B source VGPRs of an in-flight v_mfma_f32_16x16x4_f32 (it executes on the vector
-                    // datapath over 8 passes), the MFMA can consume the new values: 1-2 wrong coordinate weights per
-                    // ~1e5 edges, run-to-run different.  The chain is therefore fenced: nothing is scheduled into it
-                    // and 32 wait states separate it from the code that reuses its operand registers.
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_nop 3");
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x16f16(w3hi, mhi[t], a2, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x16f16(w3lo, mhi[t], a2, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x16f16(w3hi, mlo[t], a2, 0, 0, 0);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[u], acc[t][u], a2, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_nop 15");
-                    asm volatile("s_nop 15");
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) part[t] += w4[u] * egnn_silu(a2[u] + b3[u]);
+                    for (int u = 0; u < 4; ++u) part[t] += w4[u] * egnn_silu(a2[u] * p.w3_inv_scale + b3[u]);
                 }
             }
             const float b4 = p.b4[0];
@@ -460,7 +467,7 @@ extern "C" int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream)
     const egnn_edge_args& a = *args;
     if (!a.Pi || !a.Pj || !a.Ws || !a.W2h || !a.b2 || !a.coors) return EGNN_E_NULLPTR;
     if (!a.m_i && !a.coors_out) return EGNN_E_NULLPTR;
-    if (a.coors_out && (!a.W3 || !a.b3 || !a.W4 || !a.b4)) return EGNN_E_NULLPTR;
+    if (a.coors_out && (!a.W3h || !a.b3 || !a.W4 || !a.b4 || !(a.w3_inv_scale > 0.f))) return EGNN_E_NULLPTR;
     if (a.gate_w && !a.gate_b) return EGNN_E_NULLPTR;
     if (a.B <= 0 || a.N <= 0 || a.K <= 0 || a.H <= 0) return EGNN_E_SHAPE;
     if (a.Hp != egnn_padded_hidden(a.H) || a.ldp < a.Hp || (a.ldp % 4) != 0 || !(a.w2_inv_scale > 0.f)) return EGNN_E_SHAPE;
@@ -471,8 +478,8 @@ extern "C" int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream)
     if ((reinterpret_cast<uintptr_t>(a.Pi) & 15) || (reinterpret_cast<uintptr_t>(a.Pj) & 15) ||
         (reinterpret_cast<uintptr_t>(a.Ws) & 15) || (reinterpret_cast<uintptr_t>(a.W2h) & 15))
         return EGNN_E_ALIGN;
-    if (a.W3 && ((reinterpret_cast<uintptr_t>(a.W3) & 15) || (reinterpret_cast<uintptr_t>(a.b3) & 15) ||
-                 (reinterpret_cast<uintptr_t>(a.W4) & 15)))
+    if (a.W3h && ((reinterpret_cast<uintptr_t>(a.W3h) & 15) || (reinterpret_cast<uintptr_t>(a.b3) & 15) ||
+                  (reinterpret_cast<uintptr_t>(a.W4) & 15)))
         return EGNN_E_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (a.Sp) {

@@ -171,7 +171,8 @@ class EGNN(nn.Module):
             if self.edge_gate is not None:
                 a.gate_w, a.gate_b = w["gate_w"].data_ptr(), w["gate_b"].data_ptr()
             if self.coors_mlp is not None:
-                a.W3, a.b3, a.W4, a.b4 = (w[x].data_ptr() for x in ("W3", "b3", "W4", "b4"))
+                a.W3h, a.b3, a.W4, a.b4 = (w[x].data_ptr() for x in ("W3h", "b3", "W4", "b4"))
+                a.w3_inv_scale = w["w3_inv_scale"]
                 coors_out = torch.empty_like(coors)
                 a.coors_out = coors_out.data_ptr()
             if self.norm_coors:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 7
+#define EGNN_ABI_VERSION 8
 
 enum {
     EGNN_OK = 0,
@@ -175,7 +175,9 @@ typedef struct egnn_edge_args {
     const float* b2;            /* (16) edge_mlp.3.bias, zero padded */
     const float* gate_w;        /* (16) edge_gate.0.weight or NULL (soft_edges=False) */
     const float* gate_b;        /* (1) */
-    const float* W3;            /* (64,16) coors_mlp.0.weight zero padded, or NULL (update_coors=False) */
+    const void* W3h;            /* (2,64,16) fp16: w3_scale * coors_mlp.0.weight zero padded, hi image then lo image,
+                                   or NULL (update_coors=False) */
+    float w3_inv_scale;         /* 1 / w3_scale (a power of two) */
     const float* b3;            /* (64) */
     const float* W4;            /* (64) coors_mlp.3.weight */
     const float* b4;            /* (1) */
