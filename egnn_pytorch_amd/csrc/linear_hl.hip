@@ -27,30 +27,26 @@ typedef const __attribute__((address_space(1))) void glb_void;
 
 constexpr int BK = 16;                       // one v_mfma_f32_32x32x16_f16 step per K-tile
 constexpr int ROWB = BK * 2;                 // bytes per LDS row (32)
-constexpr int STAGES = 4;                    // LDS ring: tiles kt .. kt+3 resident / in flight
 constexpr int GROUP_M = 8;
 
-// Tile configurations: BT x BT output tile (BT = 128: 4 waves as 2 x 2; BT = 256: 8 waves as 2 x 4), K-tile 16.
-// The 256 tile halves the L2 -> LDS traffic per flop; the 128 tile keeps small problems from idling most of the chip.
-template <int BT> struct Cfg {
-    static constexpr int BM = BT, BN = BT;
-    static constexpr int WAVES = BT / 32;                  // one 32-row block of every operand image per wave
-    static constexpr int THREADS = WAVES * 64;
-    static constexpr int WN = BT == 256 ? 4 : 2;          // waves along N
-    static constexpr int TI = BM / 2 / 32;                 // MFMA tiles per wave along M (2 waves along M)
-    static constexpr int TJ = BN / WN / 32;                // ... along N
-    static constexpr int ARR = BT * ROWB;                  // bytes per operand image (hi or lo of A or W)
-    static constexpr int BUF = 4 * ARR;                    // Ah | Al | Bh | Bl
-};
+// Tile configurations (BM x BN output tile, K-tile 16, every wave owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles):
+//   0: 128 x 128, 4 waves (2 x 2), 4-deep ring of 16 KB  -> 64 KB LDS, two workgroups per CU
+//   1: 256 x 128, 8 waves (4 x 2), 3-deep ring of 24 KB  -> 72 KB LDS, two workgroups per CU; 1.37x the flops per byte
+//      streamed out of L2 (the 128 x 128 tile draws ~11 TB/s from L2 on the north-star projection, which is what
+//      holds its MFMA utilisation near 45 %)
+//   2: 256 x 256, 8 waves (2 x 4, 128 x 64 per wave), 4-deep ring of 32 KB -> 128 KB LDS, one workgroup per CU
+template <int CFG> struct Cfg;
+template <> struct Cfg<0> { static constexpr int BM = 128, BN = 128, WM = 2, WN = 2, TI = 2, TJ = 2, STAGES = 4; };
+template <> struct Cfg<1> { static constexpr int BM = 256, BN = 128, WM = 4, WN = 2, TI = 2, TJ = 2, STAGES = 3; };
+template <> struct Cfg<2> { static constexpr int BM = 256, BN = 256, WM = 2, WN = 4, TI = 4, TJ = 2, STAGES = 4; };
 
-// Pipeline (per K-tile of 16, ONE barrier):
-//     s_waitcnt vmcnt(4)     this wave's DMAs of tiles <= kt+1 have landed (tile kt+2 stays in flight)
-//     s_barrier              ... and everyone else's; also: every wave has fetched its fragments of tile kt
-//     issue DMA of tile kt+3 into the ring slot tile kt-1 occupied
-//     fetch the fragments of tile kt+1 into the other register slot | 3 x TI x TJ MFMAs on the fragments of tile kt
-// so a tile's L2 latency is covered by the MFMAs of two tiles and its LDS-read latency by those of one.
-template <int BT, int ACT, bool HAS_RES>
-__global__ __launch_bounds__(Cfg<BT>::THREADS, 2) void linear_hl_kernel(
+// Pipeline (per K-tile of 16, ONE barrier), S = STAGES:
+//     s_waitcnt vmcnt((S-2) * DPW)   this wave's DMAs of tile kt have landed (tiles kt+1 .. kt+S-2 stay in flight)
+//     s_barrier                      ... and everyone else's; also: every wave is done reading the ring slot of tile kt-1
+//     issue the DMAs of tile kt+S-1 into that slot
+//     fragments of tile kt -> 3 x TI x TJ MFMAs
+template <int CFG, int ACT, bool HAS_RES>
+__global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl_kernel(
     const _Float16* __restrict__ Ahi, const _Float16* __restrict__ Alo,
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
     const float* __restrict__ bias, const float* __restrict__ R, int64_t ldr,
@@ -58,8 +54,15 @@ __global__ __launch_bounds__(Cfg<BT>::THREADS, 2) void linear_hl_kernel(
     int64_t M, int N, int Kp, int ntm, int ntn, float out_scale)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // STAGES x BUF
-    using C_ = Cfg<BT>;
-    constexpr int BM = C_::BM, BN = C_::BN, ARR = C_::ARR, BUF = C_::BUF, TI = C_::TI, TJ = C_::TJ;
+    using C_ = Cfg<CFG>;
+    constexpr int BM = C_::BM, BN = C_::BN, TI = C_::TI, TJ = C_::TJ, STAGES = C_::STAGES;
+    constexpr int WAVES = C_::WM * C_::WN;
+    constexpr int ARB = BM / 32, WRB = BN / 32;                       // 32-row blocks per image
+    constexpr int AARR = BM * ROWB, WARR = BN * ROWB;                 // bytes per A / W image
+    constexpr int BUF = 2 * AARR + 2 * WARR;                          // Ah | Al | Wh | Wl
+    constexpr int NDMA = 2 * ARB + 2 * WRB;                           // 1 KB pieces per K-tile
+    constexpr int DPW = NDMA / WAVES;                                 // ... per wave
+    static_assert(NDMA % WAVES == 0, "DMA pieces must divide evenly over the waves");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -81,30 +84,42 @@ __global__ __launch_bounds__(Cfg<BT>::THREADS, 2) void linear_hl_kernel(
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
 
-    // ---- LDS-DMA sources: wave w stages the 32-row block w of each of the 4 operand images, one instruction each.
-    // In the packed layout the (row block, K-tile) piece is 1 KB of contiguous memory that is ALREADY in LDS image
-    // order (chunk swizzle included): lane l copies bytes [16 l, 16 l + 16).
+    // ---- LDS-DMA pieces: piece d = wave + WAVES * j (j < DPW) of the list [Ah blocks | Al blocks | Wh blocks | Wl blocks].
+    // In the packed layout a (row block, K-tile) piece is 1 KB of contiguous memory that is ALREADY the LDS image
+    // (chunk swizzle included): lane l copies bytes [16 l, 16 l + 16).
     const int nkt = Kp / BK;
-    const _Float16 *srcAh, *srcAl, *srcWh, *srcWl;
+    const _Float16* src[DPW];
+    int dst[DPW];
     {
-        int64_t rbA = (m0 >> 5) + wave;
         const int64_t rbA_max = (M - 1) >> 5;
-        if (rbA > rbA_max) rbA = rbA_max;                              // clamp: valid memory, result rows discarded
-        const int64_t rbW = (int64_t)(n0 >> 5) + wave;                 // W images are padded to whole tiles
-        srcAh = Ahi + rbA * nkt * 512 + lane * 8;
-        srcAl = Alo + rbA * nkt * 512 + lane * 8;
-        srcWh = Whi + rbW * nkt * 512 + lane * 8;
-        srcWl = Wlo + rbW * nkt * 512 + lane * 8;
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int d = wave + WAVES * j;
+            const _Float16* base;
+            int64_t rb;
+            int off;
+            if (d < 2 * ARB) {
+                const int blk = d % ARB;
+                rb = (m0 >> 5) + blk;
+                if (rb > rbA_max) rb = rbA_max;                        // clamp: valid memory, result rows discarded
+                base = d < ARB ? Ahi : Alo;
+                off = (d < ARB ? 0 : AARR) + blk * 32 * ROWB;
+            } else {
+                const int e = d - 2 * ARB;
+                const int blk = e % WRB;
+                rb = (int64_t)(n0 >> 5) + blk;                         // W images are padded to whole tiles
+                base = e < WRB ? Whi : Wlo;
+                off = 2 * AARR + (e < WRB ? 0 : WARR) + blk * 32 * ROWB;
+            }
+            src[j] = base + rb * nkt * 512 + lane * 8;
+            dst[j] = off;
+        }
     }
-    const int dst_off = wave * 32 * ROWB;
-
-    auto stage = [&](int kt) {
-        const int k0 = kt * 512;                                       // halves per packed (row block, K-tile) piece
-        char* base = smem + (kt % STAGES) * BUF + dst_off;
-        __builtin_amdgcn_global_load_lds((glb_void*)(srcAh + k0), (lds_void*)(base + 0 * ARR), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void*)(srcAl + k0), (lds_void*)(base + 1 * ARR), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void*)(srcWh + k0), (lds_void*)(base + 2 * ARR), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void*)(srcWl + k0), (lds_void*)(base + 3 * ARR), 16, 0, 0);
+    auto stage = [&](int kt_src, int slot) {
+        char* base = smem + slot * BUF;
+#pragma unroll
+        for (int j = 0; j < DPW; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void*)(src[j] + kt_src * 512), (lds_void*)(base + dst[j]), 16, 0, 0);
     };
 
     f32x16 acc[TI][TJ];
@@ -119,75 +134,55 @@ __global__ __launch_bounds__(Cfg<BT>::THREADS, 2) void linear_hl_kernel(
     const int fi = lane & 31, kk = lane >> 5;
     const int foff = fi * ROWB + ((kk ^ ((fi >> 3) & 1)) * 16);        // tile rows are 32-aligned
     const int a_base = (wm * TI * 32) * ROWB + foff;
-    const int b_base = 2 * ARR + (wn * TJ * 32) * ROWB + foff;
+    const int b_base = 2 * AARR + (wn * TJ * 32) * ROWB + foff;
 
     const int nk = nkt;
-    // prologue: tiles 0, 1, 2 in flight (issue dummies past the end so that the vmcnt bookkeeping stays uniform)
+    // prologue: tiles 0 .. S-2 in flight (dummies past the end keep the vmcnt bookkeeping uniform)
 #pragma unroll
-    for (int t = 0; t < STAGES - 1; ++t) stage(t < nk ? t : nk - 1);
+    for (int t = 0; t < STAGES - 1; ++t) stage(t < nk ? t : nk - 1, t);
 
-    f16x8 ah[2][TI], al[2][TI], bh[2][TJ], bl[2][TJ];
-    auto ldfrag = [&](int kt, int slot) {
-        const char* tb = smem + (kt % STAGES) * BUF;
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            ah[slot][i] = *reinterpret_cast<const f16x8*>(tb + a_base + 0 * ARR + i * 32 * ROWB);
-            al[slot][i] = *reinterpret_cast<const f16x8*>(tb + a_base + 1 * ARR + i * 32 * ROWB);
-        }
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            bh[slot][j] = *reinterpret_cast<const f16x8*>(tb + b_base + 0 * ARR + j * 32 * ROWB);
-            bl[slot][j] = *reinterpret_cast<const f16x8*>(tb + b_base + 1 * ARR + j * 32 * ROWB);
-        }
-    };
-    auto mfmas = [&](int slot) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[slot][i], bh[slot][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[slot][i], bh[slot][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[slot][i], bl[slot][j], acc[i][j], 0, 0, 0);
-    };
-    // one pipeline step: tile kt+1 is published by the barrier, tile kt+3 is requested, the fragments of tile kt+1 are
-    // fetched into the other register slot while the MFMAs of tile kt (fragments fetched one step earlier) run.
-    auto step = [&](int kt, int slot) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");              // own DMAs of tiles <= kt+1 landed (kt+2 in flight)
+    int slot = 0;                                                      // ring slot of tile kt
+    for (int kt = 0; kt < nk; ++kt) {
+        if (STAGES == 4 && DPW == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (STAGES == 3 && DPW == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         {
             const int nt = kt + STAGES - 1;
-            const int src_t = nt < nk ? nt : nk - 1;                   // past the end: harmless re-fetch of the last tile
-            const int k0 = src_t * 512;
-            char* base = smem + (nt % STAGES) * BUF + dst_off;
-            __builtin_amdgcn_global_load_lds((glb_void*)(srcAh + k0), (lds_void*)(base + 0 * ARR), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)(srcAl + k0), (lds_void*)(base + 1 * ARR), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)(srcWh + k0), (lds_void*)(base + 2 * ARR), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)(srcWl + k0), (lds_void*)(base + 3 * ARR), 16, 0, 0);
+            int nslot = slot - 1;
+            if (nslot < 0) nslot += STAGES;                            // (kt + S - 1) % S
+            stage(nt < nk ? nt : nk - 1, nslot);                       // past the end: harmless re-fetch of the last tile
         }
-        ldfrag(kt + 1 < nk ? kt + 1 : kt, slot ^ 1);
-        mfmas(slot);
-    };
-
-    // tile 0's fragments: wait for tile 0 only, publish, fetch
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    ldfrag(0, 0);
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {                                     // register slots alternate statically
-        step(kt, 0);
-        step(kt + 1, 1);
+        const char* tb = smem + slot * BUF;
+        f16x8 ah[TI], al[TI], bh[TJ], bl[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8*>(tb + a_base + i * 32 * ROWB);
+            al[i] = *reinterpret_cast<const f16x8*>(tb + a_base + AARR + i * 32 * ROWB);
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            bh[j] = *reinterpret_cast<const f16x8*>(tb + b_base + j * 32 * ROWB);
+            bl[j] = *reinterpret_cast<const f16x8*>(tb + b_base + WARR + j * 32 * ROWB);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
-    if (kt < nk) step(kt, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the dummy DMAs before the LDS is released
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -222,38 +217,39 @@ __global__ __launch_bounds__(Cfg<BT>::THREADS, 2) void linear_hl_kernel(
     }
 }
 
-template <int BT, int ACT, bool HAS_RES>
-int launch_hl_bt(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, const _Float16* Wlo,
-              const float* bias, const float* R, int64_t ldr, float* C, int64_t ldc, _Float16* Chi, _Float16* Clo,
-              int nkt_out, int64_t M, int N, int Kp, float out_scale, hipStream_t s)
+template <int CFG, int ACT, bool HAS_RES>
+int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, const _Float16* Wlo,
+                  const float* bias, const float* R, int64_t ldr, float* C, int64_t ldc, _Float16* Chi, _Float16* Clo,
+                  int nkt_out, int64_t M, int N, int Kp, float out_scale, hipStream_t s)
 {
-    const int64_t ntm = (M + BT - 1) / BT;
-    const int64_t ntn = (N + BT - 1) / BT;
+    using C_ = Cfg<CFG>;
+    const int64_t ntm = (M + C_::BM - 1) / C_::BM;
+    const int64_t ntn = (N + C_::BN - 1) / C_::BN;
     if (ntm * ntn > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
-    const size_t lds = (size_t)STAGES * Cfg<BT>::BUF;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_hl_kernel<BT, ACT, HAS_RES>),
+    const size_t lds = (size_t)C_::STAGES * (2 * C_::BM + 2 * C_::BN) * ROWB;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_hl_kernel<CFG, ACT, HAS_RES>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((linear_hl_kernel<BT, ACT, HAS_RES>), dim3((unsigned)(ntm * ntn)), dim3(Cfg<BT>::THREADS), lds, s, Ahi,
-                       Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale);
+    hipLaunchKernelGGL((linear_hl_kernel<CFG, ACT, HAS_RES>), dim3((unsigned)(ntm * ntn)), dim3(C_::WM * C_::WN * 64), lds, s,
+                       Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale);
     return egnn_launch_status();
 }
+
+#ifndef EGNN_HL_CFG
+#define EGNN_HL_CFG 1
+#endif
 
 template <int ACT, bool HAS_RES>
 int launch_hl(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, const _Float16* Wlo,
               const float* bias, const float* R, int64_t ldr, float* C, int64_t ldc, _Float16* Chi, _Float16* Clo,
               int nkt_out, int64_t M, int N, int Kp, float out_scale, int w_rows, hipStream_t s)
 {
-    // Tile choice (measured on the north-star projection, M = 65536, N = 4160, K = 512): 128 x 128 tiles with two
-    // workgroups per CU (0.88 ms) beat 256 x 256 with one (0.95 ms) -- the second workgroup's main loop covers the
-    // other's prologue / output stores.  The 256 variant stays selectable at build time for experiments.
-    const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-#ifndef EGNN_HL_MIN256
-#define EGNN_HL_MIN256 (1LL << 60)
-#endif
-    if (t256 >= EGNN_HL_MIN256 && w_rows >= (N + 255) / 256 * 256)
-        return launch_hl_bt<256, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, s);
-    return launch_hl_bt<128, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, s);
+    // Large problems (enough 256 x 128 tiles to fill the chip twice) use the larger tile; small ones the 128 x 128 tile.
+    constexpr int BIG = EGNN_HL_CFG;
+    const int64_t tbig = ((M + Cfg<BIG>::BM - 1) / Cfg<BIG>::BM) * ((N + Cfg<BIG>::BN - 1) / Cfg<BIG>::BN);
+    if (BIG != 0 && tbig >= 512 && w_rows >= (N + Cfg<BIG>::BN - 1) / Cfg<BIG>::BN * Cfg<BIG>::BN)
+        return launch_hl_cfg<BIG, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, s);
+    return launch_hl_cfg<0, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, s);
 }
 
 }  // namespace
