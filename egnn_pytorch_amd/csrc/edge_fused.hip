@@ -67,6 +67,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
 }
 
+// Sum over the 16 lanes of a DPP row (= the 16 edges of an MFMA tile); every lane ends with the same bits.
+__device__ __forceinline__ float row16_sum(float v)
+{
+#define EGNN_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+    EGNN_DPP_ADD(0xB1);      // quad_perm [1,0,3,2]
+    EGNN_DPP_ADD(0x4E);      // quad_perm [2,3,0,1]
+    EGNN_DPP_ADD(0x141);     // row_half_mirror
+    EGNN_DPP_ADD(0x140);     // row_mirror
+#undef EGNN_DPP_ADD
+    return v;
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
 // SP: padded number of per-edge scalar inputs; TPI: consecutive tiles of a wave that share one node i
 // (K % 32 == 0 -> 2 = both tiles of a wave, else 1 = per-lane Pi rows).
 template <int SP, int TPI>
@@ -81,7 +96,7 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int e = lane & 15;
     const int g = lane >> 4;
 
@@ -104,11 +119,16 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
         float relx[TILES], rely[TILES], relz[TILES];
         bool fm[TILES];                                      // edge contributes (valid slot and unmasked)
 
+        // TPI == 2 (K % 32 == 0): the 32 slots of a wave belong to ONE node -> node index and first k are wave-uniform
+        const int qwave = round * SLOTS_PER_ROUND + wave * SLOTS_PER_WAVE;
+        const int nl_w = (TPI == 2) ? qwave / K : 0;
+        const int k_w = qwave - nl_w * K;
+
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
-            const int q = round * SLOTS_PER_ROUND + wave * SLOTS_PER_WAVE + t * 16 + e;
-            int nl = q / K;
-            int k = q - nl * K;
+            const int q = qwave + t * 16 + e;
+            int nl = (TPI == 2) ? nl_w : q / K;
+            int k = (TPI == 2) ? k_w + t * 16 + e : q - nl * K;
             int pos = node0 + nl;                                    // position in the (optionally permuted) node order
             bool valid = (q < slots_total) && (pos < N);
             if (!valid) { pos = node0 < N ? node0 : 0; k = 0; }
@@ -150,9 +170,9 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
         const float* gptr[4];
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            const int q = round * SLOTS_PER_ROUND + wave * SLOTS_PER_WAVE + qq * 8 + (lane >> 3);
-            int nl = q / K;
-            int k = q - nl * K;
+            const int q = qwave + qq * 8 + (lane >> 3);
+            int nl = (TPI == 2) ? nl_w : q / K;
+            int k = (TPI == 2) ? k_w + qq * 8 + (lane >> 3) : q - nl * K;
             int pos = node0 + nl;
             if (!((q < slots_total) && (pos < N))) { pos = node0 < N ? node0 : 0; k = 0; }
             const int i2 = p.order ? p.order[bN + pos] : pos;
@@ -189,15 +209,19 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
             __syncthreads();
             {
                 // W2 fragments: (Hp/32, 2, 64, 8) halves = 2048 bytes per step, contiguous
-                const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.W2h) + (size_t)c0 * 64);
-                float4* dst = reinterpret_cast<float4*>(w2s);
-                for (int x = tid; x < hc * 4; x += EDGE_THREADS) dst[x] = src[x];
+                // LDS-DMA, 1 KB (64 lanes x 16 B) per instruction: no VGPR round trip, no VALU address loop
+                const char* src = reinterpret_cast<const char*>(p.W2h) + (size_t)c0 * 64 + lane * 16;
+                for (int pc = wave; pc < hc / 16; pc += EDGE_WAVES)
+                    __builtin_amdgcn_global_load_lds((glb_void*)(src + pc * 1024),
+                                                     (lds_void*)(reinterpret_cast<char*>(w2s) + pc * 1024), 16, 0, 0);
+                static_assert(HC <= 256, "one DMA instruction per Ws row");
 #pragma unroll
                 for (int s = 0; s < SP; ++s) {
-                    const float4* ssrc = reinterpret_cast<const float4*>(p.Ws + (size_t)s * p.Hp + c0);
-                    float4* sdst = reinterpret_cast<float4*>(wss + s * HC);
-                    for (int x = tid; x < hc / 4; x += EDGE_THREADS) sdst[x] = ssrc[x];
+                    if ((s % EDGE_WAVES) == wave && lane < hc / 4)
+                        __builtin_amdgcn_global_load_lds((glb_void*)(p.Ws + (size_t)s * p.Hp + c0 + lane * 4),
+                                                         (lds_void*)(wss + s * HC), 16, 0, 0);
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
 
@@ -368,38 +392,74 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
             }
         }
 
-        __syncthreads();                                     // previous round's reduction has read ebuf
+        if (TPI == 2) {
+            // The wave's 32 edges belong to one node: sum them in registers (DPP butterfly over the 16 edges of a
+            // tile, fixed order -> deterministic) and hand 20 partials per wave to the cross-wave reduction.
+            float rx[TILES], ry[TILES], rz[TILES], keep[TILES];
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-            const int slot = wave * SLOTS_PER_WAVE + t * 16 + e;
-            const float keep = fm[t] ? 1.f : 0.f;
-            float* row = ebuf + slot * NCH;
-            *reinterpret_cast<f32x4*>(row + 4 * g) = acc[t] * keep;
-            if (g == 0) {
-                float rx = relx[t], ry = rely[t], rz = relz[t];
+            for (int t = 0; t < TILES; ++t) {
+                keep[t] = fm[t] ? 1.f : 0.f;
+                rx[t] = relx[t]; ry[t] = rely[t]; rz[t] = relz[t];
                 if (p.coors_scale) {                                    // CoorsNorm, egnn_pytorch.py:67-77
-                    const float nrm = sqrtf(rx * rx + ry * ry + rz * rz);
+                    const float nrm = sqrtf(rx[t] * rx[t] + ry[t] * ry[t] + rz[t] * rz[t]);
                     const float inv = cscale / fmaxf(nrm, 1e-8f);
-                    rx *= inv; ry *= inv; rz *= inv;
+                    rx[t] *= inv; ry[t] *= inv; rz[t] *= inv;
                 }
-                row[16] = cw[t] * rx;
-                row[17] = cw[t] * ry;
-                row[18] = cw[t] * rz;
-                row[19] = keep;
             }
-        }
-        __syncthreads();
+            f32x4 ms = acc[0] * keep[0] + acc[1] * keep[1];
+            float c4[4] = {cw[0] * rx[0] + cw[1] * rx[1], cw[0] * ry[0] + cw[1] * ry[1],
+                           cw[0] * rz[0] + cw[1] * rz[1], keep[0] + keep[1]};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ms[u] = row16_sum(ms[u]); c4[u] = row16_sum(c4[u]); }
+            // the wave's own exchange rows double as its partial-sum row (no other wave touches them)
+            if (e == 0) *reinterpret_cast<f32x4*>(xch + 4 * g) = ms;
+            if (lane == 0) *reinterpret_cast<f32x4*>(xch + 16) = f32x4{c4[0], c4[1], c4[2], c4[3]};
+            __syncthreads();
+            const int kw = K / SLOTS_PER_WAVE;                           // waves per node
+            const int wbase = round * EDGE_WAVES;
+            for (int o = tid; o < G * NCH; o += EDGE_THREADS) {
+                const int nl = o / NCH, ch = o - nl * NCH;
+                int w0 = nl * kw, w1 = w0 + kw;
+                if (w0 < wbase) w0 = wbase;
+                if (w1 > wbase + EDGE_WAVES) w1 = wbase + EDGE_WAVES;
+                float s = 0.f;
+                for (int w = w0; w < w1; ++w) s += xchall[(w - wbase) * (SLOTS_PER_WAVE * XLD) + ch];
+                if (w1 > w0) nodeacc[o] += s;
+            }
+        } else {
+            __syncthreads();                                     // previous round's reduction has read ebuf
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                const int slot = wave * SLOTS_PER_WAVE + t * 16 + e;
+                const float keep = fm[t] ? 1.f : 0.f;
+                float* row = ebuf + slot * NCH;
+                *reinterpret_cast<f32x4*>(row + 4 * g) = acc[t] * keep;
+                if (g == 0) {
+                    float rx = relx[t], ry = rely[t], rz = relz[t];
+                    if (p.coors_scale) {                                    // CoorsNorm, egnn_pytorch.py:67-77
+                        const float nrm = sqrtf(rx * rx + ry * ry + rz * rz);
+                        const float inv = cscale / fmaxf(nrm, 1e-8f);
+                        rx *= inv; ry *= inv; rz *= inv;
+                    }
+                    row[16] = cw[t] * rx;
+                    row[17] = cw[t] * ry;
+                    row[18] = cw[t] * rz;
+                    row[19] = keep;
+                }
+            }
+            __syncthreads();
 
-        // ------------------------------------------------------------------ per-node reduction, k order
-        const int qbase = round * SLOTS_PER_ROUND;
-        for (int o = tid; o < G * NCH; o += EDGE_THREADS) {
-            const int nl = o / NCH, ch = o - nl * NCH;
-            int q0 = nl * K, q1 = q0 + K;
-            if (q0 < qbase) q0 = qbase;
-            if (q1 > qbase + SLOTS_PER_ROUND) q1 = qbase + SLOTS_PER_ROUND;
-            float s = 0.f;
-            for (int q = q0; q < q1; ++q) s += ebuf[(q - qbase) * NCH + ch];
-            if (q1 > q0) nodeacc[o] += s;
+            // ------------------------------------------------------------------ per-node reduction, k order
+            const int qbase = round * SLOTS_PER_ROUND;
+            for (int o = tid; o < G * NCH; o += EDGE_THREADS) {
+                const int nl = o / NCH, ch = o - nl * NCH;
+                int q0 = nl * K, q1 = q0 + K;
+                if (q0 < qbase) q0 = qbase;
+                if (q1 > qbase + SLOTS_PER_ROUND) q1 = qbase + SLOTS_PER_ROUND;
+                float s = 0.f;
+                for (int q = q0; q < q1; ++q) s += ebuf[(q - qbase) * NCH + ch];
+                if (q1 > q0) nodeacc[o] += s;
+            }
         }
         __syncthreads();          // multi-round groups: ebuf (aliasing the exchange buffers) is free again
     }
