@@ -250,7 +250,7 @@ def main():
             "kernels": kernels,
             "sum_kernel_ms": round(sum(per_kernel.values()), 4),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(kwargs, n)
         print(json.dumps(out), flush=True)
 

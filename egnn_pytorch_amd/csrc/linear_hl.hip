@@ -39,6 +39,8 @@ template <int CFG> struct Cfg;
 template <> struct Cfg<0> { static constexpr int BM = 128, BN = 128, WM = 2, WN = 2, TI = 2, TJ = 2, STAGES = 4; };
 template <> struct Cfg<1> { static constexpr int BM = 256, BN = 128, WM = 4, WN = 2, TI = 2, TJ = 2, STAGES = 3; };
 template <> struct Cfg<2> { static constexpr int BM = 256, BN = 256, WM = 2, WN = 4, TI = 4, TJ = 2, STAGES = 4; };
+template <> struct Cfg<3> { static constexpr int BM = 256, BN = 128, WM = 2, WN = 2, TI = 4, TJ = 2, STAGES = 3; };
+template <> struct Cfg<4> { static constexpr int BM = 128, BN = 256, WM = 1, WN = 4, TI = 4, TJ = 2, STAGES = 3; };
 
 // Pipeline (per K-tile of 16, ONE barrier), S = STAGES:
 //     s_waitcnt vmcnt((S-2) * DPW)   this wave's DMAs of tile kt have landed (tiles kt+1 .. kt+S-2 stay in flight)
@@ -145,6 +147,8 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
     for (int kt = 0; kt < nk; ++kt) {
         if (STAGES == 4 && DPW == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else if (STAGES == 3 && DPW == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else if (STAGES == 3 && DPW == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else if (STAGES == 4 && DPW == 6) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -152,7 +156,13 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
             const int nt = kt + STAGES - 1;
             int nslot = slot - 1;
             if (nslot < 0) nslot += STAGES;                            // (kt + S - 1) % S
+#if defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 4)
+            stage(0, nslot);                                           // ablation: always the same (L1/L2-hot) tile
+#elif defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 8)
+            if (kt == 0) stage(0, nslot); else { asm volatile("" ::: "memory"); }   // ablation: (almost) no DMA -- vmcnt bookkeeping breaks, timing only
+#else
             stage(nt < nk ? nt : nk - 1, nslot);                       // past the end: harmless re-fetch of the last tile
+#endif
         }
         const char* tb = smem + slot * BUF;
         f16x8 ah[TI], al[TI], bh[TJ], bl[TJ];
@@ -166,6 +176,15 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
             bh[j] = *reinterpret_cast<const f16x8*>(tb + b_base + j * 32 * ROWB);
             bl[j] = *reinterpret_cast<const f16x8*>(tb + b_base + WARR + j * 32 * ROWB);
         }
+#if defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 2)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)                                // ablation: one MFMA per (i, j) instead of three
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i] + al[i], bh[j] + bl[j], acc[i][j], 0, 0, 0);
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+        continue;
+#endif
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
