@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -25,7 +25,7 @@ SYMBOLS = (
     "egnn_abi_version", "egnn_error_string", "egnn_padded_hidden", "egnn_knn_select_f32",
     "egnn_adj_max_degree_u8", "egnn_linear_f32", "egnn_linear_split_f32", "egnn_node_prep_f32",
     "egnn_edge_fused_f32", "egnn_spatial_order_f32", "egnn_linear_hl_f32", "egnn_split_f16", "egnn_node_prep_hl",
-    "egnn_packed_halves", "egnn_adj_expand_u8", "egnn_adj_expand_workspace_bytes",
+    "egnn_packed_halves", "egnn_adj_expand_u8", "egnn_adj_expand_workspace_bytes", "egnn_edge_mfmas",
 )
 
 
@@ -34,9 +34,9 @@ class EdgeArgs(Structure):
     _fields_ = [
         ("B", c_int32), ("N", c_int32), ("K", c_int32), ("dim", c_int32), ("m_dim", c_int32),
         ("H", c_int32), ("Hp", c_int32), ("fourier", c_int32), ("edge_dim", c_int32),
-        ("S", c_int32), ("Sp", c_int32),
+        ("S", c_int32), ("pi_split", c_int32),
         ("Pi", c_void_p), ("Pj", c_void_p), ("ldp", c_int64),
-        ("Ws", c_void_p), ("W2h", c_void_p), ("w2_inv_scale", c_float), ("b2", c_void_p),
+        ("Wst", c_void_p), ("wst_terms", c_int32), ("ws_inv_scale", c_float), ("W2h", c_void_p), ("w2_inv_scale", c_float), ("b2", c_void_p),
         ("gate_w", c_void_p), ("gate_b", c_void_p),
         ("W3h", c_void_p), ("w3_inv_scale", c_float), ("b3", c_void_p), ("W4", c_void_p), ("b4", c_void_p),
         ("coors_scale", c_void_p),
@@ -102,7 +102,7 @@ def load():
     lib.egnn_packed_halves.argtypes = [c_int64, c_int]
     lib.egnn_linear_hl_f32.restype = c_int
     lib.egnn_linear_hl_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p,
-                                       c_int64, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p]
+                                       c_int64, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.egnn_split_f16.restype = c_int
     lib.egnn_split_f16.argtypes = [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]
     lib.egnn_node_prep_hl.restype = c_int
@@ -113,6 +113,8 @@ def load():
                                        c_int, c_int, c_void_p]
     lib.egnn_spatial_order_f32.restype = c_int
     lib.egnn_spatial_order_f32.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.egnn_edge_mfmas.restype = c_int
+    lib.egnn_edge_mfmas.argtypes = [c_int]
     lib.egnn_edge_fused_f32.restype = c_int
     lib.egnn_edge_fused_f32.argtypes = [POINTER(EdgeArgs), c_void_p]
 

@@ -205,9 +205,11 @@ def split_f16(x2d):
     return PackedHL(hi, lo, rows, kp)
 
 
-def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32=True, out_hl=False, name="linear"):
+def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32=True, out_hl=False, name="linear",
+              split_cols=0):
     """act(A @ W.T + bias) (+ residual) with pre-split packed fp16 (hi, lo) operands -- egnn_linear_hl_f32.
-    Returns fp32 C, or a PackedHL (padded to 32 columns for the next GEMM) when out_hl, or both."""
+    Returns fp32 C, or a PackedHL (padded to 32 columns for the next GEMM) when out_hl, or both.
+    split_cols: columns [0, split_cols) of C hold (fp16 hi, fp16 lo) words instead of fp32 values."""
     whi, wlo, inv, w_rows = wsplit
     m, kp = a.rows, a.kp
     assert whi.numel() == w_rows * kp and w_rows >= n
@@ -226,7 +228,8 @@ def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32
     with _timed(name):
         rc = _abi.load().egnn_linear_hl_f32(_ptr(a.hi), _ptr(a.lo), _ptr(whi), _ptr(wlo), float(inv), _ptr(bias),
                                             _ptr(residual), ldr, _ptr(c), n, _ptr(out.hi) if out else None,
-                                            _ptr(out.lo) if out else None, kp_out, m, n, kp, w_rows, act, _stream())
+                                            _ptr(out.lo) if out else None, kp_out, m, n, kp, w_rows, act, int(split_cols),
+                                            _stream())
     _abi.check(rc, "egnn_linear_hl_f32")
     if out_f32 and out_hl:
         return c, out

@@ -6,13 +6,16 @@ derived, padded copies built here and cached per parameter version:
   edge_mlp.0.weight (H, Din), columns [h_i | h_j | fourier sin, cos | d | e]  (egnn_pytorch.py:282-285)
       -> Wcat (2*Hp, dim): rows [0,H) = W_i, rows [Hp, Hp+H) = W_j   (node-level projection weights)
       -> bcat (2*Hp):      [0,H) = edge_mlp.0.bias                   (folded into P_i)
-      -> Ws   (Sp, Hp):    the per-edge scalar columns, transposed
+      -> Wst  (Hp, 4 NM, 2) fp16: the per-edge scalar columns as A fragments of the first-layer MFMA (see
+                           `scalar_table`)
      all three multiplied by -log2(e): the edge kernel evaluates SiLU(x) = -ln2 * y / (1 + 2^y), y = -log2(e) x,
      with v_exp_f32 (= 2^y) and no extra multiply.
   edge_mlp.3.weight (m, H) -> W2h (Hp/32, 2, 64, 8) fp16: (-ln2 * w2_scale * W2) split into hi + lo halves
      (hi = fp16(w), lo = fp16(w - hi): 22 significant bits), in v_mfma_f32_16x16x32_f16 fragment order:
-     [step][hi|lo][lane = 16*g + channel][t] = W2[channel, 32*step + 8*g + t].  w2_scale is the power of two that
-     brings max|W2| into [1, 2) so hi and lo stay in fp16's normal range; the kernel multiplies by 1/w2_scale.
+     [step][hi|lo][lane = 16*g + channel][t] = W2[channel, 32*step + hidden_slot(g, t)], hidden_slot(g, t) =
+     4*g + t (t < 4), 16 + 4*g + (t - 4) (t >= 4) -- the order in which the first-layer MFMA leaves the hidden
+     units in a lane.  w2_scale is the power of two that brings max|W2| into [1, 2) so hi and lo stay in fp16's
+     normal range; the kernel multiplies by 1/w2_scale.
   coors_mlp.* / edge_gate.* -> zero padded to 16 channels / 64 hidden units
 Zero padding is exact: padded hidden units see y = 0 -> 0 / (1 + 1) = 0 and meet zero W2 columns.
 """
@@ -25,7 +28,8 @@ import torch
 NEG_LOG2E = -1.4426950408889634
 NEG_LN2 = -0.6931471805599453
 
-SP_SUPPORTED = (1, 2, 3, 5, 8, 16)     # template instantiations of the edge kernel
+S_MAX = 16                              # per-edge scalar inputs the edge kernel is instantiated for
+SCALAR_SHIFT = 1024.0                   # 2^10: the coarse part of a per-edge scalar is carried as fp16(s / 2^10)
 M_PAD = 16                              # channels of one 16x16 MFMA tile
 C_PAD = 64                              # coors_mlp hidden units (4 * 16)
 
@@ -34,13 +38,44 @@ def padded_hidden(h: int) -> int:
     return (h + 31) // 32 * 32
 
 
-def padded_scalars(s: int) -> int:
-    for sp in SP_SUPPORTED:
-        if sp >= s:
-            return sp
-    raise NotImplementedError(
-        f"{s} per-edge scalar inputs (2*fourier_features + 1 + edge_dim) exceed the {SP_SUPPORTED[-1]} "
-        f"the gfx950 edge kernel is built for")
+def check_scalars(s: int) -> int:
+    if s > S_MAX:
+        raise NotImplementedError(
+            f"{s} per-edge scalar inputs (2*fourier_features + 1 + edge_dim) exceed the {S_MAX} "
+            f"the gfx950 edge kernel is built for")
+    return s
+
+
+def pow2_scale(amax: float) -> float:
+    """The power of two that brings amax into [1, 2) (1 for 0 / non-finite)."""
+    return 2.0 ** (-math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
+
+
+def edge_mfmas(s: int) -> int:
+    """Mirror of egnn_edge_mfmas (include/egnn_hip.h): first-layer MFMAs the edge kernel chains for s scalars."""
+    return 1 if s <= 1 else (3 if s <= 4 else (6 if s <= 8 else 12))
+
+
+def scalar_table(ws: torch.Tensor):
+    """(S, Hp) fp32 scalar weights -> (Wst, ws_inv_scale).  Wst is (Hp, 4 * edge_mfmas(S), 2) fp16: per hidden unit h
+    the (fp16, fp16) words that sit in K-slots 4g+2, 4g+3 of lane group g of first-layer MFMA m
+    (v_mfma_f32_16x16x16_f16; K-slots 4g, 4g+1 belong to the (hi, lo) pair of P_i), term index 4 m + g = 3 s + kind:
+        kind 0: (hi, lo) of c * W * 2^10      x  B = (s1, s1),      s1 = fp16(s' / 2^10)
+        kind 1: (hi, lo) of c * W             x  B = (r_hi, r_hi),  r = s' - 2^10 s1
+        kind 2: (hi, 0)  of c * W             x  B = (r_lo, 0)
+    with s' = s / c the per-edge scalar and c = ws_scale the power of two that brings max|W| into [1, 2).  The five
+    products add up to W * s with ~2^-22 relative error for |s'| < 6e7 (dist^2: |rel| < ~7000 length units)."""
+    s_, hp = ws.shape
+    c = pow2_scale(float(ws.abs().max()) if ws.numel() else 0.0)
+    w = (ws * c).t().contiguous()                                    # (Hp, S)
+    wa = w * SCALAR_SHIFT
+    hi, ahi = w.half(), wa.half()
+    lo, alo = (w - hi.float()).half(), (wa - ahi.float()).half()
+    zero = torch.zeros_like(hi)
+    terms = torch.stack([torch.stack([ahi, alo], -1), torch.stack([hi, lo], -1), torch.stack([hi, zero], -1)], dim=2)
+    tab = torch.zeros(hp, 4 * edge_mfmas(s_), 2, dtype=torch.float16, device=ws.device)
+    tab[:, :3 * s_] = terms.reshape(hp, 3 * s_, 2)                   # (Hp, S, 3, 2) -> term index 3 s + kind
+    return tab.contiguous(), 1.0 / c
 
 
 def pack_tiles(x: torch.Tensor) -> torch.Tensor:
@@ -107,7 +142,7 @@ def pack(layer) -> dict:
     if m > M_PAD:
         raise NotImplementedError(f"m_dim={m} > {M_PAD} is not supported by the gfx950 edge kernel")
     hp = padded_hidden(h)
-    sp = padded_scalars(s)
+    check_scalars(s)
     z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
 
     wcat = z(2 * hp, dim)
@@ -115,8 +150,9 @@ def pack(layer) -> dict:
     wcat[hp:hp + h] = w1[:, dim:2 * dim] * NEG_LOG2E
     bcat = z(2 * hp)
     bcat[:h] = b1 * NEG_LOG2E
-    ws = z(sp, hp)
-    ws[:s, :h] = w1[:, 2 * dim:].t() * NEG_LOG2E
+    ws = z(s, hp)
+    ws[:, :h] = w1[:, 2 * dim:].t() * NEG_LOG2E
+    wst, ws_inv_scale = scalar_table(ws)
 
     w2p = z(M_PAD, hp)
     w2p[:m, :h] = w2 * NEG_LN2
@@ -125,14 +161,14 @@ def pack(layer) -> dict:
     w2s = w2p * w2_scale                                   # max |.| in [1, 2)
     w2_hi = w2s.half()
     w2_lo = (w2s - w2_hi.float()).half()
-    # (channel, step, g, t) -> (step, g, channel, t) -> (step, lane = 16 g + channel, t)
-    frag = lambda t: t.view(M_PAD, hp // 32, 4, 8).permute(1, 2, 0, 3).contiguous().view(hp // 32, 64, 8)
+    # h = 32 step + 16 hb + 4 g + r:  (channel, step, hb, g, r) -> (step, g, channel, hb, r) -> (step, lane = 16 g + channel, t = 4 hb + r)
+    frag = lambda t: t.view(M_PAD, hp // 32, 2, 4, 4).permute(1, 3, 0, 2, 4).contiguous().view(hp // 32, 64, 8)
     w2h = torch.stack([frag(w2_hi), frag(w2_lo)], dim=1).contiguous()      # (Hp/32, 2, 64, 8) fp16
     b2p = z(M_PAD)
     b2p[:m] = b2
 
-    out = dict(H=h, Hp=hp, S=s, Sp=sp, Wcat=wcat, Wcat_split=split_f16(wcat), bcat=bcat, Ws=ws, W2h=w2h,
-               w2_inv_scale=1.0 / w2_scale, b2=b2p)
+    out = dict(H=h, Hp=hp, S=s, Wcat=wcat, Wcat_split=split_f16(wcat), bcat=bcat, Ws=ws, Wst=wst,
+               ws_inv_scale=ws_inv_scale, W2h=w2h, w2_inv_scale=1.0 / w2_scale, b2=b2p)
 
     if layer.edge_gate is not None:
         gw = z(M_PAD)

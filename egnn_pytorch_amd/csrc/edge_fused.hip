@@ -60,7 +60,7 @@ constexpr int HC = EGNN_EDGE_HC;          // hidden columns per LDS chunk (steps
 constexpr int KSTEP = 32;                // hidden units per v_mfma_f32_16x16x32_f16
 constexpr int NCH = 20;                  // per-edge channels reduced per node: 16 m | 3 coords | 1 count
 constexpr int GMAX = 64;                 // nodes per workgroup
-constexpr int XLD = 36;                  // floats per row of the gather exchange buffer (128 B line + 16 B pad)
+constexpr int XLD = 32;                  // floats per row of the gather exchange buffer (one 128 B line, chunk-swizzled)
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
@@ -79,20 +79,32 @@ __device__ __forceinline__ float row16_sum(float v)
     return v;
 }
 
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pack_h2(_Float16 a, _Float16 b)
+{
+    const f16x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-// SP: padded number of per-edge scalar inputs; TPI: consecutive tiles of a wave that share one node i
-// (K % 32 == 0 -> 2 = both tiles of a wave, else 1 = per-lane Pi rows).
-template <int SP, int TPI>
-__global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
+// NM: chained first-layer MFMAs (4 split terms each, 3 terms per per-edge scalar); HCT: hidden columns per LDS chunk;
+// TPI: consecutive tiles of a wave that share one node i (K % 32 == 0 -> 2 = both tiles of a wave, P_i rides in the
+// MFMA; else 1 = per-lane P_i rows, added on the VALU).
+template <int NM, int HCT, int TPI>
+__global__ __launch_bounds__(EDGE_THREADS, NM == 1 ? EGNN_EDGE_MINW : 2) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* w2s = reinterpret_cast<_Float16*>(smem);      // [HC/32][hi|lo][64][8] halves = HC * 64 bytes
-    float* wss = reinterpret_cast<float*>(smem + HC * 64);   // [SP][HC]
-    float* nodeacc = wss + SP * HC;                          // [GMAX][NCH]
-    float* xchall = nodeacc + GMAX * NCH;                    // [EDGE_WAVES][32 slots][XLD]: per-wave gather exchange
-    float* ebuf = xchall;                                    // [slots][NCH] aliases it (epilogue only; NCH <= XLD)
+    constexpr int HC = HCT;
+    const int S = p.S;
+    _Float16* w2s = reinterpret_cast<_Float16*>(smem);                  // [HC/32][hi|lo][64][8] halves = HC * 64 bytes
+    float* xchall = reinterpret_cast<float*>(smem + HC * 64);           // [EDGE_WAVES][32 slots][XLD]: per-wave gather exchange
+    float* ebuf = xchall;                                                // [slots][NCH] aliases it (TPI == 1 epilogue only)
+    float* nodeacc = xchall + SLOTS_PER_ROUND * XLD;                    // [G][NCH]
+    char* wst = reinterpret_cast<char*>(nodeacc + G * NCH);             // [HC][4 NM] dwords: first-layer A fragments
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -104,18 +116,19 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
     const int b = v / gpg;
     const int node0 = (v % gpg) * G;
     const int N = p.N, K = p.K;
-    const int slots_total = G * K;                           // per node group (may exceed 256 only if G == 1)
+    const int slots_total = G * K;                           // per node group (exceeds one round only if G == 1)
     const int rounds = (slots_total + SLOTS_PER_ROUND - 1) / SLOTS_PER_ROUND;
     const bool has_mask = p.mask != nullptr;
     const bool has_rank = p.rank != nullptr && p.idx != nullptr;
     const size_t bN = (size_t)b * N;
 
-    for (int o = tid; o < GMAX * NCH; o += EDGE_THREADS) nodeacc[o] = 0.f;
+    for (int o = tid; o < G * NCH; o += EDGE_THREADS) nodeacc[o] = 0.f;
 
     for (int round = 0; round < rounds; ++round) {
         // ------------------------------------------------------------------ per-slot setup
-        const float* pip[TILES];
-        float sc[TILES][SP];
+        const float* pip[TILES];                             // TPI == 1: this lane's P_i row (+ 4 g)
+        const uint32_t* piw = nullptr;                       // TPI == 2: the wave's P_i row as (hi, lo) words (+ lane & 15)
+        u32x2 bq[TILES][NM];                                 // B fragments of the first-layer MFMAs (constant over the hidden loop)
         float relx[TILES], rely[TILES], relz[TILES];
         bool fm[TILES];                                      // edge contributes (valid slot and unmasked)
 
@@ -139,34 +152,49 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
             float dx, dy, dz;
             const float d = egnn_sqdist(ci[0], ci[1], ci[2], cj[0], cj[1], cj[2], dx, dy, dz);
             relx[t] = dx; rely[t] = dy; relz[t] = dz;
+
+            // Per-edge scalars [sin(d/2^f)..., cos(d/2^f)..., d, edges...] (egnn_pytorch.py:34-41, 282-285) as B
+            // fragments of v_mfma_f32_16x16x16_f16: lane group g of MFMA m carries split term tau = 4 m + g of scalar
+            // tau / 3 in K-slots 4g+2, 4g+3 (K-slots 4g, 4g+1 belong to P_i):
+            //     s' = s / ws_scale = 2^10 s1 + r_hi + r_lo      (s1 coarse; r the exact remainder, |s'| clamped to 6e7)
+            // meeting the (hi, lo) weight pairs of egnn_pytorch_amd/_weights.py::scalar_table.
+            const int F = p.fourier;
 #pragma unroll
-            for (int s = 0; s < SP; ++s) sc[t][s] = 0.f;
-            {
-                const int F = p.fourier;
-                // [sin(d/2^f)..., cos(d/2^f)..., d, edges...]   (egnn_pytorch.py:34-41, 282-285)
-#pragma unroll
-                for (int s = 0; s < SP; ++s) {
-                    float val = 0.f;
-                    if (s < F) val = sinf(d * exp2f(-(float)s));
-                    else if (s < 2 * F) val = cosf(d * exp2f(-(float)(s - F)));
-                    else if (s == 2 * F) val = d;
-                    else if (s < p.S) val = p.edges[((bN + i) * N + j) * p.edge_dim + (s - 2 * F - 1)];
-                    sc[t][s] = val;
+            for (int m = 0; m < NM; ++m) {
+                const int tau = 4 * m + g;
+                const int sidx = tau / 3, kind = tau - 3 * sidx;
+                u32x2 bw = u32x2{0u, 0u};
+                if (sidx < S) {
+                    float val;
+                    if (sidx < F) val = sinf(d * exp2f(-(float)sidx));
+                    else if (sidx < 2 * F) val = cosf(d * exp2f(-(float)(sidx - F)));
+                    else if (sidx == 2 * F) val = d;
+                    else val = p.edges[((bN + i) * N + j) * p.edge_dim + (sidx - 2 * F - 1)];
+                    val = fminf(fmaxf(val * p.ws_inv_scale, -6.0e7f), 6.0e7f);
+                    const _Float16 s1 = (_Float16)(val * (1.0f / 1024.0f));
+                    const float r = val - (float)s1 * 1024.0f;
+                    const _Float16 rh = (_Float16)r;
+                    const _Float16 rl = (_Float16)(r - (float)rh);
+                    bw[1] = kind == 0 ? pack_h2(s1, s1) : (kind == 1 ? pack_h2(rh, rh) : pack_h2(rl, (_Float16)0.f));
                 }
+                if (TPI == 2 && m == 0 && g == 0) bw[0] = pack_h2((_Float16)1.f, (_Float16)1.f);   // x (P_i hi, P_i lo)
+                bq[t][m] = bw;
             }
+
             bool em = valid;
             if (has_mask) {
                 em = em && p.mask[bN + i] && p.mask[bN + j];
                 if (has_rank) em = em && (p.rank[(bN + i) * K + k] <= p.valid_radius);
             }
             fm[t] = em;
-            pip[t] = p.Pi + (bN + i) * p.ldp + 8 * g;
+            pip[t] = p.Pi + (bN + i) * p.ldp + 4 * g;
+            if (TPI == 2 && t == 0) piw = reinterpret_cast<const uint32_t*>(p.Pi) + (bN + i) * p.ldp + e;
         }
 
         // Gather addressing.  A wave-level load instruction is processed line by line (measured,
         // tools/ubench/gather.hip: 16 half-used 128-B lines per instruction run at 9.7 TB/s, 8 fully used lines at
         // 20.9 TB/s), so P_j is fetched as whole lines -- lane l reads 16-byte chunk (l & 7) of the row of slot
-        // 8*q + (l >> 3) -- and redistributed to the MFMA fragment layout through a wave-private LDS buffer.
+        // 8*q + (l >> 3) -- and redistributed to the MFMA accumulator layout through a wave-private LDS buffer.
         const float* gptr[4];
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
@@ -183,9 +211,28 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
             gptr[qq] = p.Pj + (bN + j2) * p.ldp + 4 * (lane & 7);
 #endif
         }
+        // Exchange buffer: row = slot (128 B), 16-byte chunk c stored at position c ^ ((row >> 1) & 7): the parking
+        // stores (2 rows x 8 chunks per 16 lanes) and the pick-up loads (16 rows x 1 chunk per 16 lanes) are both
+        // bank-conflict free.
         float* xch = xchall + wave * (SLOTS_PER_WAVE * XLD);
-        float* xw = xch + (lane >> 3) * XLD + 4 * (lane & 7);          // where this lane parks its chunk (+ 8*qq rows)
-        const float* xr = xch + e * XLD + 8 * g;                        // where it picks its fragment up (+ 16*t rows)
+        float* xw[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int row = 8 * qq + (lane >> 3);
+            xw[qq] = xch + row * XLD + 4 * ((lane & 7) ^ ((row >> 1) & 7));
+        }
+        const float* xr[TILES][2];                                      // lane (e, g): hidden rows 16 hb + 4 g .. + 3 of slot 16 t + e
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const int row = 16 * t + e;
+                xr[t][hb] = xch + row * XLD + 4 * ((4 * hb + g) ^ ((row >> 1) & 7));
+            }
+
+        // first-layer A fragments: row (hidden unit) e of the 16-block, split term 4 m + g
+        const char* tl = wst + (e * (4 * NM) + g) * 4;
+        constexpr int tstep = 16 * 4 * NM * 4;                          // bytes per 16 hidden units
 
         f32x4 acc[TILES];
 #pragma unroll
@@ -194,33 +241,37 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
         // ------------------------------------------------------------------ main loop over hidden units
         // Software pipeline: the Pi/Pj rows of step st+1 are requested before step st is computed, so the
         // gather latency (L2 / Infinity Cache) hides under the SiLU work of the current step.
-        constexpr int NPI = TILES / TPI;
-        f32x4 gl[4], pin[NPI][2];
+        f32x4 gl[4];
+        f32x4 pin[TPI == 1 ? TILES : 1][2];
+        uint32_t piv[2] = {0u, 0u};
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) gl[qq] = *reinterpret_cast<const f32x4*>(gptr[qq]);
+        if (TPI == 1) {
 #pragma unroll
-        for (int u = 0; u < NPI; ++u) {
-            pin[u][0] = *reinterpret_cast<const f32x4*>(pip[u * TPI]);
-            pin[u][1] = *reinterpret_cast<const f32x4*>(pip[u * TPI] + 4);
+            for (int t = 0; t < TILES; ++t) {
+                pin[t][0] = *reinterpret_cast<const f32x4*>(pip[t]);
+                pin[t][1] = *reinterpret_cast<const f32x4*>(pip[t] + 16);
+            }
+        } else {
+            piv[0] = piw[0];
+            piv[1] = piw[16];
         }
 
         for (int c0 = 0; c0 < p.Hp; c0 += HC) {
             const int hc = (p.Hp - c0) < HC ? (p.Hp - c0) : HC;
             __syncthreads();
             {
-                // W2 fragments: (Hp/32, 2, 64, 8) halves = 2048 bytes per step, contiguous
-                // LDS-DMA, 1 KB (64 lanes x 16 B) per instruction: no VGPR round trip, no VALU address loop
+                // LDS-DMA, 1 KB (64 lanes x 16 B) per instruction: no VGPR round trip, no VALU address loop.
+                // W2 fragments: (Hp/32, 2, 64, 8) halves = 2048 bytes per step; scalar table: NM * 16 bytes per hidden unit.
                 const char* src = reinterpret_cast<const char*>(p.W2h) + (size_t)c0 * 64 + lane * 16;
                 for (int pc = wave; pc < hc / 16; pc += EDGE_WAVES)
                     __builtin_amdgcn_global_load_lds((glb_void*)(src + pc * 1024),
                                                      (lds_void*)(reinterpret_cast<char*>(w2s) + pc * 1024), 16, 0, 0);
-                static_assert(HC <= 256, "one DMA instruction per Ws row");
-#pragma unroll
-                for (int s = 0; s < SP; ++s) {
-                    if ((s % EDGE_WAVES) == wave && lane < hc / 4)
-                        __builtin_amdgcn_global_load_lds((glb_void*)(p.Ws + (size_t)s * p.Hp + c0 + lane * 4),
-                                                         (lds_void*)(wss + s * HC), 16, 0, 0);
-                }
+                const int tbytes = hc * NM * 16;
+                const char* tsrc = reinterpret_cast<const char*>(p.Wst) + (size_t)c0 * NM * 16 + lane * 16;
+                for (int pc = wave; pc * 1024 < tbytes; pc += EDGE_WAVES)
+                    if (pc * 1024 + lane * 16 < tbytes)
+                        __builtin_amdgcn_global_load_lds((glb_void*)(tsrc + pc * 1024), (lds_void*)(wst + pc * 1024), 16, 0, 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
@@ -231,9 +282,9 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
 #if defined(EGNN_EDGE_STEPSYNC) && EGNN_EDGE_STEPSYNC
                 __builtin_amdgcn_s_barrier();      // keep the workgroup's waves on the same step: gathered rows shared via L1
 #endif
-                // park the lines fetched for this step, then (same wave, DS ops execute in order) pick the fragments up
+                // park the lines fetched for this step, then (same wave, DS ops execute in order) pick the rows up
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f32x4*>(xw + qq * 8 * XLD) = gl[qq];
+                for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f32x4*>(xw[qq]) = gl[qq];
                 int hnext = hoff + KSTEP;
                 if (hnext >= p.Hp) hnext = hoff;                 // last step: harmless re-read
 #pragma unroll
@@ -242,47 +293,55 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
                 // lgkmcnt(0) makes the store -> other-lane load dependency independent of that (4 stores, negligible).
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                float x[TILES][8];
+                // x starts as the gathered P_j values, in the MFMA accumulator layout: lane (e, g) = edge e, hidden rows
+                // 16 hb + 4 g .. + 3 of this step
+                f32x4 x[TILES][2];
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
-                    const f32x4 f0 = *reinterpret_cast<const f32x4*>(xr + t * 16 * XLD);
-                    const f32x4 f1 = *reinterpret_cast<const f32x4*>(xr + t * 16 * XLD + 4);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        x[t][u] = pin[t / TPI][0][u] + f0[u];
-                        x[t][4 + u] = pin[t / TPI][1][u] + f1[u];
-                    }
+                    x[t][0] = *reinterpret_cast<const f32x4*>(xr[t][0]);
+                    x[t][1] = *reinterpret_cast<const f32x4*>(xr[t][1]);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int u = 0; u < NPI; ++u) {
-                    pin[u][0] = *reinterpret_cast<const f32x4*>(pip[u * TPI] + hnext);
-                    pin[u][1] = *reinterpret_cast<const f32x4*>(pip[u * TPI] + hnext + 4);
-                }
 
+                u32x2 av[NM][2];
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    av[m][0] = u32x2{0u, *reinterpret_cast<const uint32_t*>(tl + m * 16 + st * 2 * tstep)};
+                    av[m][1] = u32x2{0u, *reinterpret_cast<const uint32_t*>(tl + m * 16 + st * 2 * tstep + tstep)};
+                }
                 const f16x8 whi = *reinterpret_cast<const f16x8*>(w2s + ((st * 2 + 0) * 64 + lane) * 8);
                 const f16x8 wlo = *reinterpret_cast<const f16x8*>(w2s + ((st * 2 + 1) * 64 + lane) * 8);
-#pragma unroll
-                for (int s = 0; s < SP; ++s) {
-                    const f32x4 wa = *reinterpret_cast<const f32x4*>(wss + s * HC + st * KSTEP + 8 * g);
-                    const f32x4 wb = *reinterpret_cast<const f32x4*>(wss + s * HC + st * KSTEP + 8 * g + 4);
+                if (TPI == 2) {
+                    av[0][0][0] = piv[0];                          // K-slots 4g, 4g+1 (B is zero there for g > 0)
+                    av[0][1][0] = piv[1];
+                    piv[0] = piw[hnext];
+                    piv[1] = piw[hnext + 16];
+                } else {
 #pragma unroll
                     for (int t = 0; t < TILES; ++t) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            x[t][u] = __builtin_fmaf(sc[t][s], wa[u], x[t][u]);
-                            x[t][4 + u] = __builtin_fmaf(sc[t][s], wb[u], x[t][4 + u]);
-                        }
+                        x[t][0] += pin[t][0];
+                        x[t][1] += pin[t][1];
+                        pin[t][0] = *reinterpret_cast<const f32x4*>(pip[t] + hnext);
+                        pin[t][1] = *reinterpret_cast<const f32x4*>(pip[t] + hnext + 16);
                     }
                 }
+                // First Linear of edge_mlp on the matrix cores: x += [P_i | W_s] x [1 | scalars]  (split-f16 products)
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                        for (int m = 0; m < NM; ++m)
+                            x[t][hb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, av[m][hb]),
+                                                                            __builtin_bit_cast(f16x4, bq[t][m]), x[t][hb], 0, 0, 0);
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
                     // x holds y = -log2(e) * (pre-activation); hv = y / (1 + 2^y) = SiLU(pre) / (-ln 2)
                     f16x8 bhi, blo;
 #pragma unroll
                     for (int u = 0; u < 8; u += 2) {
-                        const float y0 = x[t][u], y1 = x[t][u + 1];
+                        const float y0 = x[t][u >> 2][u & 3], y1 = x[t][u >> 2][(u & 3) + 1];
 #if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 2)
                         const float h0 = y0 * (1.0f + y0);                  // ablation: no transcendentals
                         const float h1 = y1 * (1.0f + y1);
@@ -297,14 +356,9 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
                         bhi[u] = hi[0]; bhi[u + 1] = hi[1];
                         blo[u] = lo[0]; blo[u + 1] = lo[1];
                     }
-#if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 4)
-                    acc[t][0] += (float)bhi[0] + (float)blo[1] + (float)bhi[2] + (float)blo[3] + (float)bhi[4] +
-                                 (float)blo[5] + (float)bhi[6] + (float)blo[7];   // ablation: no MFMA
-#else
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bhi, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, bhi, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, blo, acc[t], 0, 0, 0);
-#endif
                 }
             }
         }
@@ -350,7 +404,6 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
             // transcendental instructions scheduled into the chain and overwriting its A/B VGPRs corrupted 1-2
             // coordinate weights per ~1e5 edges, differently on every run; regression:
             // tests/test_gpu_parity.py::test_multi_round_stress_is_deterministic_and_correct.)
-            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
             f16x4 mhi[TILES], mlo[TILES];
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
@@ -489,7 +542,7 @@ __global__ __launch_bounds__(EDGE_THREADS, EGNN_EDGE_MINW) void edge_kernel(cons
     }
 }
 
-template <int SP, int TPI>
+template <int NM, int HCT, int TPI>
 int launch_edge(const egnn_edge_args& a, hipStream_t s)
 {
     int G = SLOTS_PER_ROUND / a.K;
@@ -499,58 +552,64 @@ int launch_edge(const egnn_edge_args& a, hipStream_t s)
     const int gpg = (a.N + G - 1) / G;
     const int64_t nblk = (int64_t)a.B * gpg;
     if (nblk > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
-    const size_t lds = (size_t)HC * 64 + sizeof(float) * ((size_t)SP * HC + GMAX * NCH + (size_t)SLOTS_PER_ROUND * XLD);
+    // W2 fragments | gather exchange | node accumulators | first-layer A fragments (40 KB = 4 workgroups per CU at S = 1)
+    const size_t lds = (size_t)HCT * 64 + sizeof(float) * ((size_t)SLOTS_PER_ROUND * XLD + (size_t)G * NCH) + (size_t)HCT * NM * 16;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_kernel<SP, TPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_kernel<NM, HCT, TPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((edge_kernel<SP, TPI>), dim3((unsigned)nblk), dim3(EDGE_THREADS), lds, s, a, G, gpg);
+    hipLaunchKernelGGL((edge_kernel<NM, HCT, TPI>), dim3((unsigned)nblk), dim3(EDGE_THREADS), lds, s, a, G, gpg);
     return egnn_launch_status();
 }
 
-template <int SP>
+template <int NM, int HCT>
 int dispatch_tpi(const egnn_edge_args& a, hipStream_t s)
 {
-    // tiles of 16 consecutive slots share node i only when K is a multiple of 16 and the group is full
-    if (a.K % 32 == 0) return launch_edge<SP, 2>(a, s);
-    return launch_edge<SP, 1>(a, s);
+    // both tiles (32 consecutive slots) of a wave share node i when K is a multiple of 32: P_i then rides in the
+    // first-layer MFMA as (hi, lo) words (pi_split), otherwise it is added per lane from the fp32 projection
+    if (a.K % 32 == 0) return launch_edge<NM, HCT, 2>(a, s);
+    return launch_edge<NM, HCT, 1>(a, s);
 }
 
 }  // namespace
 
 extern "C" int egnn_padded_hidden(int H) { return (H + 31) / 32 * 32; }
 
+extern "C" int egnn_edge_mfmas(int S) { return S <= 1 ? 1 : (S <= 4 ? 3 : (S <= 8 ? 6 : 12)); }
+
 extern "C" int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream)
 {
     if (!args) return EGNN_E_NULLPTR;
     const egnn_edge_args& a = *args;
-    if (!a.Pi || !a.Pj || !a.Ws || !a.W2h || !a.b2 || !a.coors) return EGNN_E_NULLPTR;
+    if (!a.Pi || !a.Pj || !a.Wst || !a.W2h || !a.b2 || !a.coors) return EGNN_E_NULLPTR;
     if (!a.m_i && !a.coors_out) return EGNN_E_NULLPTR;
     if (a.coors_out && (!a.W3h || !a.b3 || !a.W4 || !a.b4 || !(a.w3_inv_scale > 0.f))) return EGNN_E_NULLPTR;
     if (a.gate_w && !a.gate_b) return EGNN_E_NULLPTR;
     if (a.B <= 0 || a.N <= 0 || a.K <= 0 || a.H <= 0) return EGNN_E_SHAPE;
     if (a.Hp != egnn_padded_hidden(a.H) || a.ldp < a.Hp || (a.ldp % 4) != 0 || !(a.w2_inv_scale > 0.f)) return EGNN_E_SHAPE;
     if (a.m_dim < 1 || a.m_dim > 16) return EGNN_E_UNSUPPORTED;
-    if (a.S != 2 * a.fourier + 1 + a.edge_dim || a.Sp < a.S) return EGNN_E_SHAPE;
+    if (a.S != 2 * a.fourier + 1 + a.edge_dim) return EGNN_E_SHAPE;
+    if (a.S > 16) return EGNN_E_UNSUPPORTED;
+    if (!(a.ws_inv_scale > 0.f)) return EGNN_E_SHAPE;
+    if ((a.pi_split != 0) != (a.K % 32 == 0)) return EGNN_E_SHAPE;     // P_i format must match the kernel variant
     if (a.edge_dim > 0 && !a.edges) return EGNN_E_NULLPTR;
     if (a.idx == nullptr && a.K != a.N) return EGNN_E_SHAPE;          // dense path: K == N
     if ((reinterpret_cast<uintptr_t>(a.Pi) & 15) || (reinterpret_cast<uintptr_t>(a.Pj) & 15) ||
-        (reinterpret_cast<uintptr_t>(a.Ws) & 15) || (reinterpret_cast<uintptr_t>(a.W2h) & 15))
+        (reinterpret_cast<uintptr_t>(a.Wst) & 15) || (reinterpret_cast<uintptr_t>(a.W2h) & 15))
         return EGNN_E_ALIGN;
     if (a.W3h && ((reinterpret_cast<uintptr_t>(a.W3h) & 15) || (reinterpret_cast<uintptr_t>(a.b3) & 15) ||
                   (reinterpret_cast<uintptr_t>(a.W4) & 15)))
         return EGNN_E_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    switch (a.Sp) {
-        case 1: return dispatch_tpi<1>(a, s);
+    // NM = ceil(3 S / 4) first-layer MFMAs, rounded up to an instantiated value; Wst must be laid out for that NM
+    if (a.wst_terms != 4 * egnn_edge_mfmas(a.S)) return EGNN_E_SHAPE;
+    if (a.S == 1) return dispatch_tpi<1, HC>(a, s);
 #ifndef EGNN_EDGE_TUNING_BUILD
-        case 2: return dispatch_tpi<2>(a, s);
-        case 3: return dispatch_tpi<3>(a, s);
-        case 5: return dispatch_tpi<5>(a, s);
-        case 8: return dispatch_tpi<8>(a, s);
-        case 16: return dispatch_tpi<16>(a, s);
+    if (a.S <= 4) return dispatch_tpi<3, 128>(a, s);
+    if (a.S <= 8) return dispatch_tpi<6, 64>(a, s);
+    return dispatch_tpi<12, 64>(a, s);
+#else
+    return EGNN_E_UNSUPPORTED;
 #endif
-        default: return EGNN_E_UNSUPPORTED;
-    }
 }

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
     const float* __restrict__ bias, const float* __restrict__ R, int64_t ldr,
     float* __restrict__ C, int64_t ldc, _Float16* __restrict__ Chi, _Float16* __restrict__ Clo, int nkt_out,
-    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale)
+    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // STAGES x BUF
     using C_ = Cfg<CFG>;
@@ -224,7 +224,16 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
 #if defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 1)
                 if (x == 123.456f)                                   // ablation: no output stores
 #endif
-                if (C) C[gm * ldc + gn] = x;
+                if (C) {
+                    if (gn < split_cols) {                            // this column as an (fp16 hi, fp16 lo) word
+                        const _Float16 h = (_Float16)x;
+                        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                        const f16x2 w = {h, (_Float16)(x - (float)h)};
+                        C[gm * ldc + gn] = __builtin_bit_cast(float, w);
+                    } else {
+                        C[gm * ldc + gn] = x;
+                    }
+                }
                 if (Chi) {
                     const _Float16 h = (_Float16)x;
                     const size_t o = egnn_pk_off(gm, gn, nkt_out);
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
 template <int CFG, int ACT, bool HAS_RES>
 int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, const _Float16* Wlo,
                   const float* bias, const float* R, int64_t ldr, float* C, int64_t ldc, _Float16* Chi, _Float16* Clo,
-                  int nkt_out, int64_t M, int N, int Kp, float out_scale, hipStream_t s)
+                  int nkt_out, int64_t M, int N, int Kp, float out_scale, int split_cols, hipStream_t s)
 {
     using C_ = Cfg<CFG>;
     const int64_t ntm = (M + C_::BM - 1) / C_::BM;
@@ -250,7 +259,7 @@ int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((linear_hl_kernel<CFG, ACT, HAS_RES>), dim3((unsigned)(ntm * ntn)), dim3(C_::WM * C_::WN * 64), lds, s,
-                       Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale);
+                       Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale, split_cols);
     return egnn_launch_status();
 }
 
@@ -261,14 +270,14 @@ int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi,
 template <int ACT, bool HAS_RES>
 int launch_hl(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, const _Float16* Wlo,
               const float* bias, const float* R, int64_t ldr, float* C, int64_t ldc, _Float16* Chi, _Float16* Clo,
-              int nkt_out, int64_t M, int N, int Kp, float out_scale, int w_rows, hipStream_t s)
+              int nkt_out, int64_t M, int N, int Kp, float out_scale, int w_rows, int split_cols, hipStream_t s)
 {
     // Large problems (enough 256 x 128 tiles to fill the chip twice) use the larger tile; small ones the 128 x 128 tile.
     constexpr int BIG = EGNN_HL_CFG;
     const int64_t tbig = ((M + Cfg<BIG>::BM - 1) / Cfg<BIG>::BM) * ((N + Cfg<BIG>::BN - 1) / Cfg<BIG>::BN);
     if (BIG != 0 && tbig >= 512 && w_rows >= (N + Cfg<BIG>::BN - 1) / Cfg<BIG>::BN * Cfg<BIG>::BN)
-        return launch_hl_cfg<BIG, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, s);
-    return launch_hl_cfg<0, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, s);
+        return launch_hl_cfg<BIG, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, split_cols, s);
+    return launch_hl_cfg<0, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, split_cols, s);
 }
 
 }  // namespace
@@ -276,7 +285,7 @@ int launch_hl(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, con
 extern "C" int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo,
                                   float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
                                   float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
-                                  int w_rows, int act, void* stream)
+                                  int w_rows, int act, int split_cols, void* stream)
 {
     if (!A_hi || !A_lo || !W_hi || !W_lo) return EGNN_E_NULLPTR;
     if (!C && !C_hi) return EGNN_E_NULLPTR;
@@ -288,6 +297,7 @@ extern "C" int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void
     if (residual && ldr < N) return EGNN_E_SHAPE;
     if (act != 0 && act != 1) return EGNN_E_UNSUPPORTED;
     if (!(w_inv_scale > 0.f)) return EGNN_E_SHAPE;
+    if (split_cols < 0 || split_cols > N || (split_cols % 32) != 0 || (split_cols && (!C || residual))) return EGNN_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(A_hi) & 15) || (reinterpret_cast<uintptr_t>(A_lo) & 15) ||
         (reinterpret_cast<uintptr_t>(W_hi) & 15) || (reinterpret_cast<uintptr_t>(W_lo) & 15))
         return EGNN_E_ALIGN;
@@ -297,11 +307,11 @@ extern "C" int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void
     _Float16 *ch = static_cast<_Float16*>(C_hi), *cl = static_cast<_Float16*>(C_lo);
     const int nkt_out = Kp_out / 16;
     if (act == 0) {
-        if (residual) return launch_hl<0, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, s);
-        return launch_hl<0, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, s);
+        if (residual) return launch_hl<0, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, s);
+        return launch_hl<0, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, s);
     }
-    if (residual) return launch_hl<1, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, s);
-    return launch_hl<1, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, s);
+    if (residual) return launch_hl<1, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, s);
+    return launch_hl<1, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, s);
 }
 
 extern "C" int64_t egnn_packed_halves(int64_t rows, int Kp) { return (rows + 31) / 32 * 32 * (int64_t)Kp; }

@@ -157,16 +157,20 @@ class EGNN(nn.Module):
         m_i = None
         if k > 0:
             # ---- node-level projections P = feats [W_i ; W_j]^T + [b1 ; 0]
-            proj = _ops.linear_hl(_ops.split_f16(feats2d), w["Wcat_split"], 2 * w["Hp"], w["bcat"], name="node_proj")
+            # (K % 32 == 0: the edge pass feeds P_i to its first-layer MFMA as (fp16 hi, fp16 lo) words)
             hp = w["Hp"]
+            pi_split = k % 32 == 0
+            proj = _ops.linear_hl(_ops.split_f16(feats2d), w["Wcat_split"], 2 * hp, w["bcat"], name="node_proj",
+                                  split_cols=hp if pi_split else 0)
             a = _abi.EdgeArgs()
             a.B, a.N, a.K, a.dim, a.m_dim = b, n, k, dim, self.m_dim
             a.H, a.Hp = w["H"], hp
-            a.fourier, a.edge_dim, a.S, a.Sp = self.fourier_features, self.edge_dim, w["S"], w["Sp"]
+            a.fourier, a.edge_dim, a.S, a.pi_split = self.fourier_features, self.edge_dim, w["S"], int(pi_split)
             a.Pi = proj.data_ptr()
             a.Pj = proj.data_ptr() + 4 * hp
             a.ldp = 2 * hp
-            a.Ws, a.W2h, a.b2 = w["Ws"].data_ptr(), w["W2h"].data_ptr(), w["b2"].data_ptr()
+            a.Wst, a.W2h, a.b2 = w["Wst"].data_ptr(), w["W2h"].data_ptr(), w["b2"].data_ptr()
+            a.ws_inv_scale, a.wst_terms = w["ws_inv_scale"], w["Wst"].shape[1]
             a.w2_inv_scale = w["w2_inv_scale"]
             if self.edge_gate is not None:
                 a.gate_w, a.gate_b = w["gate_w"].data_ptr(), w["gate_b"].data_ptr()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 8
+#define EGNN_ABI_VERSION 9
 
 enum {
     EGNN_OK = 0,
@@ -128,11 +128,14 @@ int64_t egnn_packed_halves(int64_t rows, int Kp);
  *   A_hi, A_lo: packed (M, Kp);  W_hi, W_lo: packed (w_rows, Kp), w_rows >= ceil(N/128)*128 (256 x 256 output tiles are
  *   used when w_rows also covers ceil(N/256)*256), holding w_scale * W with w_inv_scale = 1 / w_scale (a power of two);
  *   C (M,N) fp32 row-major and/or C_hi, C_lo packed (M, Kp_out) (the result re-split for the next GEMM; their pad
- *   columns [N, Kp_out) must be zero on entry);  |A| must stay below 65504.  Other arguments as egnn_linear_f32. */
+ *   columns [N, Kp_out) must be zero on entry);  |A| must stay below 65504.
+ *   split_cols (multiple of 32, <= N, needs C and no residual): columns [0, split_cols) of C are written as 32-bit words
+ *   holding (fp16 hi | fp16 lo << 16) of the value instead of the fp32 value -- the form in which the edge pass feeds
+ *   P_i to its first-layer MFMA (egnn_edge_args.pi_split).  Other arguments as egnn_linear_f32. */
 int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo,
                        float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
                        float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
-                       int w_rows, int act, void* stream);
+                       int w_rows, int act, int split_cols, void* stream);
 
 /* X (rows, cols) fp32 row-major -> packed (rows, Kp) images hi = fp16(x), lo = fp16(x - hi); pads zero; Kp % 32 == 0,
  * Kp >= cols.  Requires |X| < 65504. */
@@ -160,17 +163,23 @@ typedef struct egnn_edge_args {
     int32_t H, Hp;              /* hidden width 2*Din and its padding (egnn_padded_hidden) */
     int32_t fourier;            /* F = fourier_features */
     int32_t edge_dim;           /* width of `edges` (0 if none) */
-    int32_t S;                  /* per-edge scalar inputs: 2F + 1 + edge_dim */
-    int32_t Sp;                 /* rows of Ws (>= S, zero padded; one of 1,2,3,4,5,6,8,12,16) */
-    /* node-level projections, produced by egnn_linear_f32 */
+    int32_t S;                  /* per-edge scalar inputs: 2F + 1 + edge_dim  (<= 16) */
+    int32_t pi_split;           /* format of Pi: 0 = fp32, 1 = (fp16 hi, fp16 lo) words (egnn_linear_hl_f32 split_cols);
+                                   must be 1 exactly when K % 32 == 0 */
+    /* node-level projections, produced by egnn_linear_hl_f32 */
     const float* Pi;            /* (B*N, ldp): -log2(e) * (W_i h_i + b1)      (pad columns must be 0) */
-    const float* Pj;            /* (B*N, ldp): -log2(e) * W_j h_j */
+    const float* Pj;            /* (B*N, ldp): -log2(e) * W_j h_j, fp32 */
     int64_t ldp;
     /* re-laid-out weights (egnn_pytorch_amd/_weights.py) */
-    const float* Ws;            /* (Sp, Hp): columns [2dim .. 2dim+S) of edge_mlp.0.weight, transposed, x -log2(e) */
+    const void* Wst;            /* (Hp, wst_terms, 2) fp16: columns [2dim .. 2dim+S) of edge_mlp.0.weight x -log2(e) x ws_scale as
+                                   A fragments of the first-layer MFMA (v_mfma_f32_16x16x16_f16, K-slots 4g+2, 4g+3 of lane
+                                   group g of MFMA m hold term 4m+g); per hidden unit and scalar s three (fp16, fp16) words,
+                                   terms 3s .. 3s+2:  (hi, lo) of 2^10 w | (hi, lo) of w | (hi, 0) of w;  rest zero */
+    int32_t wst_terms;          /* = 4 * egnn_edge_mfmas(S) */
+    float ws_inv_scale;         /* 1 / ws_scale (a power of two): the kernel multiplies the per-edge scalars by it */
     const void* W2h;            /* (Hp/32, 2, 64, 8) fp16: -ln2 * w2_scale * edge_mlp.3.weight split into hi | lo halves,
                                    in v_mfma_f32_16x16x32_f16 fragment order: [step][hi|lo][lane = 16 g + channel][t] =
-                                   W2[channel][32 step + 8 g + t] */
+                                   W2[channel][32 step + (t < 4 ? 4 g + t : 16 + 4 g + t - 4)] */
     float w2_inv_scale;         /* 1 / w2_scale (a power of two), applied to the accumulated H -> m_dim product */
     const float* b2;            /* (16) edge_mlp.3.bias, zero padded */
     const float* gate_w;        /* (16) edge_gate.0.weight or NULL (soft_edges=False) */
@@ -199,6 +208,9 @@ typedef struct egnn_edge_args {
 } egnn_edge_args;
 
 int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream);
+
+/* Number of chained first-layer MFMAs the edge kernel is instantiated with for S per-edge scalars (>= ceil(3 S / 4)). */
+int egnn_edge_mfmas(int S);
 
 #ifdef __cplusplus
 }

@@ -168,6 +168,27 @@ def test_linear_hl_lds_dma(m, n, k, act, res):
     np.testing.assert_allclose(out, exact, atol=3e-5, rtol=0)
 
 
+def test_linear_hl_split_cols():
+    """split_cols: the leading columns of C come out as (fp16 hi | fp16 lo << 16) words of the same values -- the form
+    in which the edge pass takes P_i -- the rest stays fp32."""
+    from egnn_pytorch_amd import _ops, _weights
+    rng = np.random.default_rng(5)
+    m, n, k, sc = 300, 192, 96, 64
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    ahl = _ops.split_f16(_dev(a))
+    ws = _weights.split_f16(_dev(w))
+    plain = _ops.linear_hl(ahl, ws, n, _dev(bias)).cpu().numpy()
+    mixed = _ops.linear_hl(ahl, ws, n, _dev(bias), split_cols=sc).cpu().numpy()
+    np.testing.assert_array_equal(mixed[:, sc:], plain[:, sc:])
+    words = np.ascontiguousarray(mixed[:, :sc]).view(np.uint32)
+    hi = (words & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float32)
+    lo = (words >> 16).astype(np.uint16).view(np.float16).astype(np.float32)
+    np.testing.assert_array_equal(hi, plain[:, :sc].astype(np.float16).astype(np.float32))
+    np.testing.assert_allclose(hi + lo, plain[:, :sc], rtol=3e-7, atol=3.1e-8)
+
+
 def test_node_prep_hl():
     from egnn_pytorch_amd import _ops
     rng = np.random.default_rng(0)

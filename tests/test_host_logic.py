@@ -26,6 +26,9 @@ def test_abi_library_loads_and_exports_header_symbols():
         assert hasattr(lib, sym), sym
     assert lib.egnn_abi_version() == _abi.ABI_VERSION
     assert lib.egnn_padded_hidden(2050) == 2080 and lib.egnn_padded_hidden(64) == 64
+    from egnn_pytorch_amd import _weights
+    for s_ in range(1, 17):                             # host mirror of the kernel's instantiation table
+        assert lib.egnn_edge_mfmas(s_) == _weights.edge_mfmas(s_) and 4 * _weights.edge_mfmas(s_) >= 3 * s_
     assert b"out of range" in lib.egnn_error_string(-5)
 
 
@@ -118,17 +121,31 @@ def test_weight_relayout_is_exact(kw):
     sd = {k: v.detach().numpy() for k, v in layer.state_dict().items()}
     x_ref = np.concatenate([hi, hj, sc], -1) @ sd["edge_mlp.0.weight"].T + sd["edge_mlp.0.bias"]
     hp, h = w["Hp"], w["H"]
-    assert hp % 32 == 0 and hp >= h and w["Sp"] >= s
+    assert hp % 32 == 0 and hp >= h and w["Ws"].shape == (s, hp)
     # the kernel's variable is y = -log2(e) * x ...
     pi = hi @ w["Wcat"][:hp].T + w["bcat"][:hp]
     pj = hj @ w["Wcat"][hp:].T + w["bcat"][hp:]
-    y = pi + pj + sc @ w["Ws"][:s]
+    y = pi + pj + sc @ w["Ws"]
     np.testing.assert_allclose(y[:, :h] / -np.log2(np.e), x_ref, atol=3e-5)
-    assert np.all(y[:, h:] == 0) and np.all(w["Ws"][s:] == 0)
+    assert np.all(y[:, h:] == 0)
+    # the scalar columns as first-layer MFMA fragments: five fp16 products per (scalar, hidden unit) rebuild W * s
+    nt = 4 * _weights.edge_mfmas(s)
+    assert w["Wst"].dtype == np.float16 and w["Wst"].shape == (hp, nt, 2) and 3 * s <= nt
+    assert np.all(w["Wst"][:, 3 * s:] == 0)
+    tab = w["Wst"][:, :3 * s].astype(np.float64).reshape(hp, s, 3, 2)  # (hidden unit, scalar, kind, hi|lo)
+    sp = sc.astype(np.float64) * w["ws_inv_scale"]                    # what the kernel splits: s' = s / ws_scale
+    s1 = (sp / 1024).astype(np.float16).astype(np.float64)
+    r = sp - 1024 * s1
+    rh = r.astype(np.float16).astype(np.float64)
+    rl = (r - rh).astype(np.float16).astype(np.float64)
+    ys = np.einsum("es,hs->eh", s1, tab[:, :, 0].sum(-1)) + np.einsum("es,hs->eh", rh, tab[:, :, 1].sum(-1)) \
+        + np.einsum("es,hs->eh", rl, tab[:, :, 2, 0])
+    np.testing.assert_allclose(ys, sc.astype(np.float64) @ w["Ws"].astype(np.float64), atol=2e-6)
     # ... hidden = y / (1 + 2^y) = SiLU(x) / (-ln 2), contracted with hi + lo fp16 fragments of -ln2 * scale * W2
     w2h = w["W2h"].astype(np.float64)                                 # (Hp/32, 2, 64, 8)
     assert w["W2h"].dtype == np.float16 and w2h.shape == (hp // 32, 2, 64, 8)
-    unfrag = lambda f: f.reshape(hp // 32, 4, 16, 8).transpose(2, 0, 1, 3).reshape(16, hp)
+    # [step][lane = 16 g + channel][t = 4 hb + r] holds hidden unit 32 step + 16 hb + 4 g + r
+    unfrag = lambda f: f.reshape(hp // 32, 4, 16, 2, 4).transpose(2, 0, 3, 1, 4).reshape(16, hp)
     w2 = (unfrag(w2h[:, 0]) + unfrag(w2h[:, 1])) * w["w2_inv_scale"]
     # 22 significant bits for elements near the tensor's max; lo of much smaller elements falls into fp16
     # subnormals (spacing 2^-24 of the scaled max), i.e. the absolute error stays at fp32 level of the max
