@@ -18,6 +18,7 @@ import torch
 from torch import nn
 
 from . import _abi, _ops, _weights
+from .attention import GlobalLinearAttention
 
 _SPATIAL_ORDER = os.environ.get("EGNN_SPATIAL_ORDER", "1") != "0"     # scheduling knob only; results do not depend on it
 
@@ -213,8 +214,8 @@ class EGNN(nn.Module):
 class EGNN_Network(nn.Module):
     """Stack of EGNN layers (egnn_pytorch.py:343-454).  The layer loop -- the part BASELINE.json's
     configs exercise -- runs on the HIP kernels; the token / position / edge / adjacency-degree
-    front-end is ordinary tensor plumbing on the device.  Global linear attention
-    (`global_linear_attn_every > 0`) is outside the hot path and not provided."""
+    front-end is ordinary tensor plumbing on the device, and so is the optional induced-set attention between
+    layers (`global_linear_attn_every > 0`, egnn_pytorch_amd/attention.py: outside the per-edge hot path)."""
 
     def __init__(self, *, depth, dim, num_tokens=None, num_edge_tokens=None, num_positions=None,
                  edge_dim=0, num_adj_degrees=None, adj_dim=0, global_linear_attn_every=0,
@@ -223,9 +224,6 @@ class EGNN_Network(nn.Module):
         super().__init__()
         assert not (num_adj_degrees is not None and num_adj_degrees < 1), \
             "make sure adjacent degrees is greater than 1"
-        if global_linear_attn_every > 0:
-            raise NotImplementedError("global linear attention is outside the MI355X hot path "
-                                      "(SURVEY.md §8f) and is not provided")
         self.num_positions = num_positions
         self.token_emb = nn.Embedding(num_tokens, dim) if num_tokens is not None else None
         self.pos_emb = nn.Embedding(num_positions, dim) if num_positions is not None else None
@@ -236,13 +234,17 @@ class EGNN_Network(nn.Module):
             if (num_adj_degrees is not None and adj_dim > 0) else None
         edge_dim = edge_dim if self.has_edges else 0
         adj_dim = adj_dim if num_adj_degrees is not None else 0
-        self.global_tokens = None
+        has_global_attn = global_linear_attn_every > 0
+        self.global_tokens = nn.Parameter(torch.randn(num_global_tokens, dim)) if has_global_attn else None
 
         self.layers = nn.ModuleList()
-        for _ in range(depth):
-            # index 0 of each pair is the (absent) attention block: keeps keys `layers.{l}.1.*`
-            self.layers.append(nn.ModuleList([None, EGNN(dim=dim, edge_dim=edge_dim + adj_dim,
-                                                          norm_feats=True, **kwargs)]))
+        for ind in range(depth):
+            # index 0 of each pair is the optional attention block: keys `layers.{l}.0.*` / `layers.{l}.1.*` (:381-388)
+            is_global = has_global_attn and ind % global_linear_attn_every == 0
+            self.layers.append(nn.ModuleList([
+                GlobalLinearAttention(dim=dim, heads=global_linear_attn_heads,
+                                      dim_head=global_linear_attn_dim_head) if is_global else None,
+                EGNN(dim=dim, edge_dim=edge_dim + adj_dim, norm_feats=True, **kwargs)]))
 
     @torch.no_grad()
     def forward(self, feats, coors, adj_mat=None, edges=None, mask=None, return_coor_changes=False):
@@ -267,8 +269,13 @@ class EGNN_Network(nn.Module):
                 adj_emb = self.adj_emb(adj_indices.long())
                 edges = torch.cat((edges, adj_emb), dim=-1) if edges is not None else adj_emb
 
+        global_tokens = None
+        if self.global_tokens is not None:
+            global_tokens = self.global_tokens[None].expand(b, -1, -1)
         coor_changes = [coors]
-        for _, egnn in self.layers:
+        for global_attn, egnn in self.layers:
+            if global_attn is not None:
+                feats, global_tokens = global_attn(feats, global_tokens, mask=mask)           # :445-446
             feats, coors = egnn(feats, coors, adj_mat=adj_mat, edges=edges, mask=mask)
             coor_changes.append(coors)
         if return_coor_changes:

@@ -296,18 +296,70 @@ def network_frontend(params, feats, coors, adj_mat=None, edges=None, num_adj_deg
     return feats, coors, adj_mat, edges
 
 
+def gelu(x):
+    """nn.GELU() default (exact erf form), egnn_pytorch.py:129."""
+    import math
+    erf = np.vectorize(math.erf, otypes=[x.dtype])
+    return (0.5 * x * (1.0 + erf(x / np.sqrt(2.0).astype(x.dtype)))).astype(x.dtype)
+
+
+def attention(params, prefix, x, context, heads, mask=None):
+    """Attention.forward (egnn_pytorch/egnn_pytorch.py:93-113): multi-head softmax attention of x over context;
+    `mask` (B, n_context) removes context positions (filled with -finfo.max before the softmax, :104-107)."""
+    q = linear(x, params[prefix + "to_q.weight"])                                   # :96
+    kv = linear(context, params[prefix + "to_kv.weight"])                            # :97
+    inner = q.shape[-1]
+    k, v = kv[..., :inner], kv[..., inner:]
+    dh = inner // heads
+    split = lambda t: t.reshape(t.shape[0], t.shape[1], heads, dh).transpose(0, 2, 1, 3)      # b h n d, :99
+    q, k, v = split(q), split(k), split(v)
+    dots = np.einsum("bhid,bhjd->bhij", q, k) * np.asarray(dh ** -0.5, dtype=q.dtype)           # :100, scale :86
+    if mask is not None:
+        dots = np.where(mask[:, None, None, :], dots, -np.finfo(dots.dtype).max)                 # :102-105
+    dots = dots - dots.max(-1, keepdims=True)
+    attn = np.exp(dots)
+    attn = attn / attn.sum(-1, keepdims=True)                                        # :107
+    out = np.einsum("bhij,bhjd->bhid", attn, v).astype(q.dtype)                      # :108
+    out = out.transpose(0, 2, 1, 3).reshape(x.shape[0], x.shape[1], inner)           # :110
+    return linear(out, params[prefix + "to_out.weight"], params[prefix + "to_out.bias"])         # :111
+
+
+def global_linear_attention(params, prefix, x, queries, heads, mask=None):
+    """GlobalLinearAttention.forward (egnn_pytorch/egnn_pytorch.py:133-144): the global tokens attend over the
+    (masked) sequence, the sequence attends over the induced tokens; residuals; LayerNorm-Linear-GELU-Linear."""
+    res_x, res_q = x, queries
+    x = layer_norm(x, params[prefix + "norm_seq.weight"], params[prefix + "norm_seq.bias"])             # :135
+    queries = layer_norm(queries, params[prefix + "norm_queries.weight"], params[prefix + "norm_queries.bias"])
+    induced = attention(params, prefix + "attn1.", queries, x, heads, mask=mask)      # :137
+    out = attention(params, prefix + "attn2.", x, induced, heads)                      # :138
+    x = out + res_x                                                                    # :140
+    queries = induced + res_q                                                          # :141
+    h = layer_norm(x, params[prefix + "ff.0.weight"], params[prefix + "ff.0.bias"])
+    h = gelu(linear(h, params[prefix + "ff.1.weight"], params[prefix + "ff.1.bias"]))
+    x = linear(h, params[prefix + "ff.3.weight"], params[prefix + "ff.3.bias"]) + x   # :143
+    return x, queries
+
+
 def egnn_network_forward(depth, cfg, params, feats, coors, adj_mat=None, edges=None, mask=None,
-                         return_coor_changes=False, num_adj_degrees=None):
-    """EGNN_Network.forward (egnn_pytorch/egnn_pytorch.py:390-454) without global attention: the front-end
-    (network_frontend) and the layer loop (:442-454).  `cfg` is the per-layer EGNN configuration (edge_dim already
-    includes adj_dim) and must have norm_feats=True (forced at :387).  State-dict prefix: layers.{l}.1."""
+                         return_coor_changes=False, num_adj_degrees=None, global_linear_attn_every=0,
+                         global_linear_attn_heads=8):
+    """EGNN_Network.forward (egnn_pytorch/egnn_pytorch.py:390-454): the front-end (network_frontend), the optional
+    global attention blocks (:376-388, :434-446) and the layer loop (:442-454).  `cfg` is the per-layer EGNN
+    configuration (edge_dim already includes adj_dim) and must have norm_feats=True (forced at :387).
+    State-dict prefixes: layers.{l}.0. (attention, layers with l % every == 0), layers.{l}.1. (EGNN)."""
     assert cfg.norm_feats
     feats, coors, adj_mat, edges = network_frontend(params, feats, coors, adj_mat, edges, num_adj_degrees)
     feats = feats.astype(coors.dtype, copy=False)
     if edges is not None:
         edges = edges.astype(coors.dtype, copy=False)
+    global_tokens = None
+    if global_linear_attn_every > 0:
+        global_tokens = np.broadcast_to(params["global_tokens"][None], (feats.shape[0],) + params["global_tokens"].shape)
     coor_changes = [coors]
     for layer in range(depth):
+        if global_linear_attn_every > 0 and layer % global_linear_attn_every == 0:                    # :382
+            feats, global_tokens = global_linear_attention(params, f"layers.{layer}.0.", feats, global_tokens,
+                                                           global_linear_attn_heads, mask=mask)        # :445-446
         feats, coors = egnn_forward(cfg, params, feats, coors, edges=edges, mask=mask,
                                     adj_mat=adj_mat, prefix=f"layers.{layer}.1.")
         coor_changes.append(coors)

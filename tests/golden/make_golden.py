@@ -133,6 +133,10 @@ CASES = [
     ("net_edge_tokens_adj2", "network", dict(depth=2, dim=32, num_edge_tokens=4, edge_dim=4, num_adj_degrees=2, adj_dim=4,
                                              only_sparse_neighbors=True), 2, 24,
      dict(mask=True, edge_tokens=4, adj="random")),
+    # induced-set ("global linear") attention between the layers (egnn_pytorch.py:81-144, 376-388)
+    ("net_global_attn", "network", dict(depth=3, dim=32, num_nearest_neighbors=8, global_linear_attn_every=2,
+                                        global_linear_attn_heads=2, global_linear_attn_dim_head=8, num_global_tokens=4,
+                                        coor_weights_clamp_value=2.0), 2, 40, dict(mask=True)),
 ]
 
 
@@ -196,7 +200,10 @@ def run_case(idx, name, kind, kwargs, b, n, flags):
 if __name__ == "__main__":
     torch.set_num_threads(4)
     total = 0
+    only = set(sys.argv[1:])                    # optional: regenerate just the named cases
     for idx, case in enumerate(CASES):
+        if only and case[0] not in only:
+            continue
         path, size = run_case(idx, *case)
         total += size
         print(f"{os.path.basename(path):40s} {size/1024:8.1f} KiB")

@@ -19,7 +19,10 @@ def test_oracle_matches_reference_golden(name):
     else:
         node, coors, changes = O.egnn_network_forward(meta["kwargs"]["depth"], cfg, params, d["feats"], d["coors"],
                                                       return_coor_changes=True,
-                                                      num_adj_degrees=meta["kwargs"].get("num_adj_degrees"), **kw)
+                                                      num_adj_degrees=meta["kwargs"].get("num_adj_degrees"),
+                                                      global_linear_attn_every=meta["kwargs"].get("global_linear_attn_every", 0),
+                                                      global_linear_attn_heads=meta["kwargs"].get("global_linear_attn_heads", 8),
+                                                      **kw)
         for i, c in enumerate(changes):
             np.testing.assert_allclose(c, d[f"coor_change.{i}"], atol=ATOL, rtol=0)
     # the oracle follows the reference's op order, so it sits far inside the 1e-4 north-star tolerance
