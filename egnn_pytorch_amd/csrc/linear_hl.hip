@@ -39,8 +39,10 @@ template <int CFG> struct Cfg;
 template <> struct Cfg<0> { static constexpr int BM = 128, BN = 128, WM = 2, WN = 2, TI = 2, TJ = 2, STAGES = 4; };
 template <> struct Cfg<1> { static constexpr int BM = 256, BN = 128, WM = 4, WN = 2, TI = 2, TJ = 2, STAGES = 3; };
 template <> struct Cfg<2> { static constexpr int BM = 256, BN = 256, WM = 2, WN = 4, TI = 4, TJ = 2, STAGES = 4; };
-template <> struct Cfg<3> { static constexpr int BM = 256, BN = 128, WM = 2, WN = 2, TI = 4, TJ = 2, STAGES = 3; };
-template <> struct Cfg<4> { static constexpr int BM = 128, BN = 256, WM = 1, WN = 4, TI = 4, TJ = 2, STAGES = 3; };
+// Measured and dropped (north-star projection, 0.82 ms with configuration 1): 128 x 64 per wave with 4-wave workgroups
+// (256 x 128 or 128 x 256 tiles, 2 waves per SIMD) 0.89-0.90 ms; 128 x 128 per wave (256 x 256 tile, accumulators in
+// AGPRs, 1 wave per SIMD) 2.07 ms -- a wave that issues 8 LDS-DMA pieces per K-tile stalls its own MFMA stream and
+// nothing else is resident to cover it.
 
 // Pipeline (per K-tile of 16, ONE barrier), S = STAGES:
 //     s_waitcnt vmcnt((S-2) * DPW)   this wave's DMAs of tile kt have landed (tiles kt+1 .. kt+S-2 stay in flight)
@@ -147,8 +149,6 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
     for (int kt = 0; kt < nk; ++kt) {
         if (STAGES == 4 && DPW == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else if (STAGES == 3 && DPW == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-        else if (STAGES == 3 && DPW == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        else if (STAGES == 4 && DPW == 6) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
