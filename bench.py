@@ -65,7 +65,8 @@ def model_counts(kwargs, b, n):
         "node_mlp0": dict(bound="mfma", flops=2.0 * bn * (dim + m) * 2 * dim,
                           bytes=4 * (bn * (dim + m) + 2 * dim * (dim + m) + bn * 2 * dim)),
         "node_mlp1": dict(bound="mfma", flops=2.0 * bn * 2 * dim * dim, bytes=4 * (bn * 2 * dim + 2 * dim * dim + 2 * bn * dim)),
-        "node_prep": dict(bound="hbm", bytes=4 * 2 * bn * (dim + m), flops=8.0 * bn * dim),
+        # one pass over feats: read fp32 rows once, write the (hi, lo) split and [LayerNorm | 0] as a second (hi, lo) pair
+        "node_prep": dict(bound="hbm", bytes=4 * bn * dim + 4 * bn * dim + 4 * bn * (dim + m), flops=10.0 * bn * dim),
         "split_f16": dict(bound="hbm", bytes=4 * 2 * bn * dim, flops=2.0 * bn * dim),
         "spatial_order": dict(bound="hbm", bytes=16 * bn, flops=0.0),
         # fused select: compulsory traffic is tiny; the comparable figure is one fp32 rank per ordered pair

@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -44,6 +44,7 @@ class EdgeArgs(Structure):
         ("order", c_void_p),
         ("valid_radius", c_float), ("clamp", c_float), ("pool_mean", c_int32),
         ("m_i", c_void_p), ("coors_out", c_void_p),
+        ("node_hi", c_void_p), ("node_lo", c_void_p), ("node_kp", c_int32),
     ]
 
 
@@ -106,8 +107,8 @@ def load():
     lib.egnn_split_f16.restype = c_int
     lib.egnn_split_f16.argtypes = [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]
     lib.egnn_node_prep_hl.restype = c_int
-    lib.egnn_node_prep_hl.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int64,
-                                      c_int, c_int, c_void_p]
+    lib.egnn_node_prep_hl.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int,
+                                      c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]
     lib.egnn_node_prep_f32.restype = c_int
     lib.egnn_node_prep_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
                                        c_int, c_int, c_void_p]

@@ -236,17 +236,25 @@ def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32
     return out if out_hl else c
 
 
-def node_prep_hl(feats2d, m_i, gamma, beta, eps, m_dim):
-    """[LayerNorm(feats) | m_i] as a packed fp16 (hi, lo) pair -- egnn_node_prep_hl."""
+def node_prep_hl(feats2d, m_i, gamma, beta, eps, m_dim, with_raw=False):
+    """[LayerNorm(feats) | m_i] as a packed fp16 (hi, lo) pair -- egnn_node_prep_hl.  m_i None: those columns are
+    zero (the edge pass writes them in place).  with_raw: also return feats itself as a packed pair (the projection's
+    A operand), produced in the same pass."""
     rows, dim = feats2d.shape
     kp = _kpad(dim + m_dim)
     hi = _packed_empty(rows, kp, feats2d.device)
     lo = _packed_empty(rows, kp, feats2d.device)
+    raw = None
+    if with_raw:
+        rkp = _kpad(dim)
+        raw = PackedHL(_packed_empty(rows, rkp, feats2d.device), _packed_empty(rows, rkp, feats2d.device), rows, rkp)
     with _timed("node_prep"):
         rc = _abi.load().egnn_node_prep_hl(_ptr(feats2d), _ptr(m_i), _ptr(gamma), _ptr(beta), float(eps), _ptr(hi), _ptr(lo),
-                                           kp, rows, dim, m_dim, _stream())
+                                           kp, _ptr(raw.hi) if raw else None, _ptr(raw.lo) if raw else None,
+                                           raw.kp if raw else 0, rows, dim, m_dim, _stream())
     _abi.check(rc, "egnn_node_prep_hl")
-    return PackedHL(hi, lo, rows, kp)
+    out = PackedHL(hi, lo, rows, kp)
+    return (out, raw) if with_raw else out
 
 
 def node_prep(feats2d, m_i, gamma, beta, eps, m_dim):

@@ -525,7 +525,7 @@ __global__ __launch_bounds__(EDGE_THREADS, NM == 1 ? EGNN_EDGE_MINW : 2) void ed
         const int i = p.order ? p.order[bN + node0 + nl] : node0 + nl;
         float val = nodeacc[o];
         if (ch < 16) {
-            if (p.m_i && ch < p.m_dim) {
+            if (ch < p.m_dim && (p.m_i || p.node_hi)) {
                 if (p.pool_mean) {
                     if (has_mask) {                                     // safe_div, egnn_pytorch.py:13-16
                         const float cnt = nodeacc[nl * NCH + 19];
@@ -534,7 +534,13 @@ __global__ __launch_bounds__(EDGE_THREADS, NM == 1 ? EGNN_EDGE_MINW : 2) void ed
                         val = val / (float)K;                           // :330
                     }
                 }
-                p.m_i[(bN + i) * p.m_dim + ch] = val;
+                if (p.m_i) p.m_i[(bN + i) * p.m_dim + ch] = val;
+                if (p.node_hi) {                                        // straight into the node_mlp input, as a (hi, lo) pair
+                    const _Float16 h = (_Float16)val;
+                    const size_t off = egnn_pk_off((int64_t)(bN + i), p.dim + ch, p.node_kp / 16);
+                    static_cast<_Float16*>(p.node_hi)[off] = h;
+                    static_cast<_Float16*>(p.node_lo)[off] = (_Float16)(val - (float)h);
+                }
             }
         } else if (ch < 19) {
             if (p.coors_out) p.coors_out[(bN + i) * 3 + (ch - 16)] = p.coors[(bN + i) * 3 + (ch - 16)] + val;
@@ -583,7 +589,9 @@ extern "C" int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream)
     if (!args) return EGNN_E_NULLPTR;
     const egnn_edge_args& a = *args;
     if (!a.Pi || !a.Pj || !a.Wst || !a.W2h || !a.b2 || !a.coors) return EGNN_E_NULLPTR;
-    if (!a.m_i && !a.coors_out) return EGNN_E_NULLPTR;
+    if (!a.m_i && !a.coors_out && !a.node_hi) return EGNN_E_NULLPTR;
+    if ((a.node_hi == nullptr) != (a.node_lo == nullptr)) return EGNN_E_NULLPTR;
+    if (a.node_hi && (a.node_kp < a.dim + a.m_dim || (a.node_kp % 32) != 0 || a.dim <= 0)) return EGNN_E_SHAPE;
     if (a.coors_out && (!a.W3h || !a.b3 || !a.W4 || !a.b4 || !(a.w3_inv_scale > 0.f))) return EGNN_E_NULLPTR;
     if (a.gate_w && !a.gate_b) return EGNN_E_NULLPTR;
     if (a.B <= 0 || a.N <= 0 || a.K <= 0 || a.H <= 0) return EGNN_E_SHAPE;

@@ -47,7 +47,8 @@ __host__ __device__ __forceinline__ size_t egnn_pk_off(int64_t row, int k, int n
 
 // internal (node_ops.hip): producer of the packed (hi, lo) layout, shared by egnn_node_prep_hl and egnn_split_f16
 int egnn_pack_rows_launch(const float* X, int64_t ldx, const float* m_i, const float* gamma, const float* beta, float eps,
-                          void* hi, void* lo, int Kp, int64_t rows, int dim, int m_dim, void* stream);
+                          void* hi, void* lo, int Kp, void* raw_hi, void* raw_lo, int raw_Kp, int64_t rows, int dim, int m_dim,
+                          void* stream);
 
 static inline int egnn_launch_status() {
     hipError_t e = hipGetLastError();

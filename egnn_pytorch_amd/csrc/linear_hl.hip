@@ -320,5 +320,5 @@ extern "C" int egnn_split_f16(const float* X, int64_t ldx, int64_t rows, int col
 {
     if (!X || !hi || !lo) return EGNN_E_NULLPTR;
     if (rows <= 0 || cols <= 0 || ldx < cols || Kp < cols || (Kp % 32) != 0) return EGNN_E_SHAPE;
-    return egnn_pack_rows_launch(X, ldx, nullptr, nullptr, nullptr, 0.f, hi, lo, Kp, rows, cols, 0, stream);
+    return egnn_pack_rows_launch(X, ldx, nullptr, nullptr, nullptr, 0.f, hi, lo, Kp, nullptr, nullptr, 0, rows, cols, 0, stream);
 }

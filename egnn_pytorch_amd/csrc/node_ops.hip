@@ -57,7 +57,8 @@ __device__ __forceinline__ float sum16(float v) {
 __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restrict__ feats, int64_t ldx, const float* __restrict__ m_i,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float eps, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                                           int Kp, int64_t rows, int dim, int m_dim)
+                                                           int Kp, _Float16* __restrict__ raw_hi, _Float16* __restrict__ raw_lo,
+                                                           int raw_Kp, int64_t rows, int dim, int m_dim)
 {
     typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
     const int lane = threadIdx.x & 63;
@@ -65,6 +66,8 @@ __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restri
     const int64_t quad0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));         // one wave = 4 rows
     const int64_t nquads = (int64_t)gridDim.x * 4;
     const int nkt = Kp / 16;
+    const int raw_nkt = raw_Kp / 16;
+    const int Kmax = raw_hi && raw_Kp > Kp ? raw_Kp : Kp;
     const int64_t rows_p = (rows + 31) / 32 * 32;                                  // pad rows are written as zeros
     for (int64_t qd = quad0; qd * 4 < rows_p; qd += nquads) {
         const int64_t r = qd * 4 + (lane >> 4);
@@ -79,23 +82,37 @@ __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restri
             for (int c = sub; c < dim; c += 16) { const float d = x[c] - mean; v += d * d; }
             rstd = 1.0f / sqrtf(sum16(v) / (float)dim + eps);
         }
-        for (int c0 = sub * 8; c0 < Kp; c0 += 128) {
-            f16x8v h8, l8;
+        for (int c0 = sub * 8; c0 < Kmax; c0 += 128) {
+            f16x8v h8, l8, rh8, rl8;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = c0 + u;
-                float y = 0.f;
+                float y = 0.f, xr = 0.f;
                 if (live) {
-                    if (c < dim) y = gamma ? (x[c] - mean) * rstd * gamma[c] + beta[c] : x[c];
-                    else if (c < dim + m_dim) y = m_i ? m_i[r * m_dim + (c - dim)] : 0.f;
+                    if (c < dim) {
+                        xr = x[c];
+                        y = gamma ? (xr - mean) * rstd * gamma[c] + beta[c] : xr;
+                    } else if (c < dim + m_dim) {
+                        y = m_i ? m_i[r * m_dim + (c - dim)] : 0.f;
+                    }
                 }
                 const _Float16 h = (_Float16)y;
                 h8[u] = h;
                 l8[u] = (_Float16)(y - (float)h);
+                const _Float16 rh = (_Float16)xr;
+                rh8[u] = rh;
+                rl8[u] = (_Float16)(xr - (float)rh);
             }
-            const size_t o = egnn_pk_off(r, c0, nkt);
-            *reinterpret_cast<f16x8v*>(hi + o) = h8;
-            *reinterpret_cast<f16x8v*>(lo + o) = l8;
+            if (c0 < Kp) {
+                const size_t o = egnn_pk_off(r, c0, nkt);
+                *reinterpret_cast<f16x8v*>(hi + o) = h8;
+                *reinterpret_cast<f16x8v*>(lo + o) = l8;
+            }
+            if (raw_hi && c0 < raw_Kp) {                              // the un-normalised row as a second (hi, lo) pair
+                const size_t o = egnn_pk_off(r, c0, raw_nkt);
+                *reinterpret_cast<f16x8v*>(raw_hi + o) = rh8;
+                *reinterpret_cast<f16x8v*>(raw_lo + o) = rl8;
+            }
         }
     }
 }
@@ -104,24 +121,30 @@ __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restri
 
 // internal: shared by egnn_node_prep_hl and egnn_split_f16
 int egnn_pack_rows_launch(const float* X, int64_t ldx, const float* m_i, const float* gamma, const float* beta, float eps,
-                          void* hi, void* lo, int Kp, int64_t rows, int dim, int m_dim, void* stream)
+                          void* hi, void* lo, int Kp, void* raw_hi, void* raw_lo, int raw_Kp, int64_t rows, int dim, int m_dim,
+                          void* stream)
 {
     const int64_t quads = ((rows + 31) / 32 * 32) / 4;
     int64_t blocks = (quads + 3) / 4;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(node_prep_hl_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), X, ldx, m_i,
-                       gamma, beta, eps, static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), Kp, rows, dim, m_dim);
+                       gamma, beta, eps, static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), Kp,
+                       static_cast<_Float16*>(raw_hi), static_cast<_Float16*>(raw_lo), raw_Kp, rows, dim, m_dim);
     return egnn_launch_status();
 }
 
 
 extern "C" int egnn_node_prep_hl(const float* feats, const float* m_i, const float* gamma, const float* beta, float eps,
-                                 void* out_hi, void* out_lo, int Kp, int64_t rows, int dim, int m_dim, void* stream)
+                                 void* out_hi, void* out_lo, int Kp, void* raw_hi, void* raw_lo, int raw_Kp,
+                                 int64_t rows, int dim, int m_dim, void* stream)
 {
     if (!feats || !out_hi || !out_lo) return EGNN_E_NULLPTR;
     if ((gamma == nullptr) != (beta == nullptr)) return EGNN_E_NULLPTR;
+    if ((raw_hi == nullptr) != (raw_lo == nullptr)) return EGNN_E_NULLPTR;
     if (rows <= 0 || dim <= 0 || m_dim < 0 || Kp < dim + m_dim || (Kp % 32) != 0) return EGNN_E_SHAPE;
-    return egnn_pack_rows_launch(feats, dim, m_i, gamma, beta, eps, out_hi, out_lo, Kp, rows, dim, m_dim, stream);
+    if (raw_hi && (raw_Kp < dim || (raw_Kp % 32) != 0)) return EGNN_E_SHAPE;
+    return egnn_pack_rows_launch(feats, dim, m_i, gamma, beta, eps, out_hi, out_lo, Kp, raw_hi, raw_lo, raw_hi ? raw_Kp : 0,
+                                 rows, dim, m_dim, stream);
 }
 
 extern "C" int egnn_node_prep_f32(const float* feats, const float* m_i, const float* gamma, const float* beta, float eps,

@@ -155,14 +155,22 @@ class EGNN(nn.Module):
             k = n
 
         node_out, coors_out = feats, coors
-        m_i = None
+        node_in = None
         if k > 0:
             # ---- node-level projections P = feats [W_i ; W_j]^T + [b1 ; 0]
             # (K % 32 == 0: the edge pass feeds P_i to its first-layer MFMA as (fp16 hi, fp16 lo) words)
             hp = w["Hp"]
             pi_split = k % 32 == 0
-            proj = _ops.linear_hl(_ops.split_f16(feats2d), w["Wcat_split"], 2 * hp, w["bcat"], name="node_proj",
+            if self.node_mlp is not None:
+                # one pass over feats: its (hi, lo) split for the projection AND [LayerNorm(feats) | 0] for node_mlp
+                # (egnn_pytorch.py:335-336); the edge pass drops m_i into the zero columns
+                node_in, feats_hl = _ops.node_prep_hl(feats2d, None, w.get("gamma"), w.get("beta"), w.get("ln_eps", 1e-5),
+                                                      self.m_dim, with_raw=True)
+            else:
+                feats_hl = _ops.split_f16(feats2d)
+            proj = _ops.linear_hl(feats_hl, w["Wcat_split"], 2 * hp, w["bcat"], name="node_proj",
                                   split_cols=hp if pi_split else 0)
+            del feats_hl
             a = _abi.EdgeArgs()
             a.B, a.N, a.K, a.dim, a.m_dim = b, n, k, dim, self.m_dim
             a.H, a.Hp = w["H"], hp
@@ -195,16 +203,14 @@ class EGNN(nn.Module):
             a.clamp = -1.0 if cv is None else float(cv)
             a.pool_mean = int(self.m_pool_method == "mean")
             if self.node_mlp is not None:
-                m_i = torch.empty(b * n, self.m_dim, dtype=torch.float32, device=feats.device)
-                a.m_i = m_i.data_ptr()
+                a.node_hi, a.node_lo, a.node_kp = node_in.hi.data_ptr(), node_in.lo.data_ptr(), node_in.kp
             _ops.edge_fused(a)
             del proj
-        elif self.node_mlp is not None:
-            m_i = torch.zeros(b * n, self.m_dim, dtype=torch.float32, device=feats.device)
+        elif self.node_mlp is not None:                                   # K == 0: no messages, m_i = 0
+            node_in = _ops.node_prep_hl(feats2d, None, w.get("gamma"), w.get("beta"), w.get("ln_eps", 1e-5), self.m_dim)
 
         # ---- node update (egnn_pytorch.py:335-337)
         if self.node_mlp is not None:
-            node_in = _ops.node_prep_hl(feats2d, m_i, w.get("gamma"), w.get("beta"), w.get("ln_eps", 1e-5), self.m_dim)
             hid = _ops.linear_hl(node_in, w["W5_split"], 2 * dim, w["b5"], act=1, out_f32=False, out_hl=True,
                                  name="node_mlp0")
             node_out = _ops.linear_hl(hid, w["W6_split"], dim, w["b6"], residual=feats2d, name="node_mlp1").view(b, n, dim)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 9
+#define EGNN_ABI_VERSION 10
 
 enum {
     EGNN_OK = 0,
@@ -141,9 +141,13 @@ int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void* W_hi, con
  * Kp >= cols.  Requires |X| < 65504. */
 int egnn_split_f16(const float* X, int64_t ldx, int64_t rows, int cols, void* hi, void* lo, int Kp, void* stream);
 
-/* egnn_node_prep_f32 writing the packed (hi, lo) pair directly: (rows, Kp), Kp >= dim + m_dim, Kp % 32 == 0. */
+/* egnn_node_prep_f32 writing the packed (hi, lo) pair directly: (rows, Kp), Kp >= dim + m_dim, Kp % 32 == 0.
+ * m_i NULL: those columns are written as zeros (egnn_edge_fused_f32 fills them in place: egnn_edge_args.node_hi).
+ * raw_hi / raw_lo (optional, both or neither): additionally the un-normalised feats as a packed (rows, raw_Kp) pair --
+ * the A operand of the projection GEMM -- so that one pass over feats serves both consumers. */
 int egnn_node_prep_hl(const float* feats, const float* m_i, const float* gamma, const float* beta, float eps,
-                      void* out_hi, void* out_lo, int Kp, int64_t rows, int dim, int m_dim, void* stream);
+                      void* out_hi, void* out_lo, int Kp, void* raw_hi, void* raw_lo, int raw_Kp,
+                      int64_t rows, int dim, int m_dim, void* stream);
 
 /* node_norm + concat (egnn_pytorch.py:335-336): out[r] = [ LayerNorm(feats[r]) | m_i[r] ].
  * gamma/beta NULL -> Identity (norm_feats=False).  out: (rows, dim + m_dim). */
@@ -158,7 +162,7 @@ int egnn_node_prep_f32(const float* feats, const float* m_i, const float* gamma,
 typedef struct egnn_edge_args {
     /* shapes */
     int32_t B, N, K;            /* K = neighbours per node (= N on the dense all-pairs path) */
-    int32_t dim;                /* unused by the kernel, kept for validation */
+    int32_t dim;                /* feature width (first message column of node_hi / node_lo) */
     int32_t m_dim;              /* <= 16 */
     int32_t H, Hp;              /* hidden width 2*Din and its padding (egnn_padded_hidden) */
     int32_t fourier;            /* F = fourier_features */
@@ -203,8 +207,11 @@ typedef struct egnn_edge_args {
     float clamp;                /* coor_weights_clamp_value; < 0 = no clamp */
     int32_t pool_mean;          /* m_pool_method == 'mean' */
     /* outputs */
-    float* m_i;                 /* (B*N, m_dim) or NULL (update_feats=False) */
+    float* m_i;                 /* (B*N, m_dim) or NULL */
     float* coors_out;           /* (B,N,3) or NULL (update_coors=False) */
+    void* node_hi;              /* optional: packed (B*N, node_kp) fp16 (hi, lo) pair = the node_mlp input prepared by */
+    void* node_lo;              /*   egnn_node_prep_hl(m_i = NULL); the pooled messages are written into its columns  */
+    int32_t node_kp;            /*   [dim, dim + m_dim) (both or neither; node_kp % 32 == 0, >= dim + m_dim)          */
 } egnn_edge_args;
 
 int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream);

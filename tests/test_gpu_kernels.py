@@ -202,6 +202,15 @@ def test_node_prep_hl():
     ref = np.concatenate([O.layer_norm(x, g, bt), mi], axis=-1)
     np.testing.assert_allclose(out[:, :116], ref, atol=1e-5, rtol=0)
     assert np.all(out[:, 116:] == 0)
+    # one pass, two consumers: m_i columns left zero for the edge pass + the raw rows as a second (hi, lo) pair
+    phl2, raw = _ops.node_prep_hl(_dev(x), None, _dev(g), _dev(bt), 1e-5, 16, with_raw=True)
+    out2 = phl2.dense().cpu().numpy()
+    np.testing.assert_array_equal(out2[:, :100], out[:, :100])
+    assert np.all(out2[:, 100:] == 0)
+    assert raw.kp == 128 and raw.rows == 300
+    rawd = raw.dense().cpu().numpy()
+    np.testing.assert_allclose(rawd[:, :100], x, rtol=3e-7, atol=3.1e-8)
+    assert np.all(rawd[:, 100:] == 0)
 
 
 def test_node_prep():
