@@ -125,6 +125,14 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
         for (int j = 0; j < DPW; ++j)
             __builtin_amdgcn_global_load_lds((glb_void*)(src[j] + kt_src * 512), (lds_void*)(base + dst[j]), 16, 0, 0);
     };
+    // pieces j = part, part + 3, ... (the main loop spreads a K-tile's DMA issue over its three MFMA groups)
+    auto stage_part = [&](int kt_src, int slot, int part) {
+        char* base = smem + slot * BUF;
+#pragma unroll
+        for (int j = 0; j < DPW; ++j)
+            if (j % 3 == part)
+                __builtin_amdgcn_global_load_lds((glb_void*)(src[j] + kt_src * 512), (lds_void*)(base + dst[j]), 16, 0, 0);
+    };
 
     f32x16 acc[TI][TJ];
 #pragma unroll
@@ -152,18 +160,21 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        const int nt = kt + STAGES - 1;
+        int nslot = slot - 1;
+        if (nslot < 0) nslot += STAGES;                                // (kt + S - 1) % S
+        const int nsrc = nt < nk ? nt : nk - 1;                        // past the end: harmless re-fetch of the last tile
+#if !(defined(EGNN_HL_ILV) && EGNN_HL_ILV)
         {
-            const int nt = kt + STAGES - 1;
-            int nslot = slot - 1;
-            if (nslot < 0) nslot += STAGES;                            // (kt + S - 1) % S
 #if defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 4)
             stage(0, nslot);                                           // ablation: always the same (L1/L2-hot) tile
 #elif defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 8)
             if (kt == 0) stage(0, nslot); else { asm volatile("" ::: "memory"); }   // ablation: (almost) no DMA -- vmcnt bookkeeping breaks, timing only
 #else
-            stage(nt < nk ? nt : nk - 1, nslot);                       // past the end: harmless re-fetch of the last tile
+            stage(nsrc, nslot);
 #endif
         }
+#endif
         const char* tb = smem + slot * BUF;
         f16x8 ah[TI], al[TI], bh[TJ], bl[TJ];
 #pragma unroll
@@ -190,16 +201,31 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#if defined(EGNN_HL_ILV) && EGNN_HL_ILV
+        __builtin_amdgcn_sched_barrier(0);
+        stage_part(nsrc, nslot, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#if defined(EGNN_HL_ILV) && EGNN_HL_ILV
+        __builtin_amdgcn_sched_barrier(0);
+        stage_part(nsrc, nslot, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#if defined(EGNN_HL_ILV) && EGNN_HL_ILV
+        __builtin_amdgcn_sched_barrier(0);
+        stage_part(nsrc, nslot, 2);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the dummy DMAs before the LDS is released
@@ -263,6 +289,9 @@ int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi,
     return egnn_launch_status();
 }
 
+#ifndef EGNN_HL_ILV
+#define EGNN_HL_ILV 1
+#endif
 #ifndef EGNN_HL_CFG
 #define EGNN_HL_CFG 1
 #endif
