@@ -60,6 +60,20 @@ CONFIGS = [
     ("dense_n600_multi_round", dict(dim=32), 1, 600, dict(mask=True, scale={"edge_mlp.3.weight": 0.1, "coors_mlp.3.weight": 0.05})),
     ("knn_k300_multi_round", dict(dim=32, num_nearest_neighbors=300), 1, 400,
      dict(scale={"edge_mlp.3.weight": 0.1, "coors_mlp.3.weight": 0.05})),
+    # first-layer MFMA variants: K % 32 == 0 (P_i in the MFMA) with 3 / 6 / 12 chained MFMAs of split scalars, a node
+    # spanning two waves (k = 64), and the per-lane P_i variant with many scalars
+    ("k32_fourier1_s3", dict(dim=32, num_nearest_neighbors=32, fourier_features=1), 2, 64, dict(mask=True)),
+    ("k32_fourier2_edges3_s8", dict(dim=32, num_nearest_neighbors=32, fourier_features=2, edge_dim=3), 2, 64,
+     dict(mask=True, edges=True)),
+    ("k64_fourier4_edges7_s16", dict(dim=32, num_nearest_neighbors=64, fourier_features=4, edge_dim=7), 1, 96,
+     dict(mask=True, edges=True, scale={"edge_mlp.3.weight": 0.3, "coors_mlp.3.weight": 0.3})),
+    ("k20_fourier4_edges7_s16", dict(dim=32, num_nearest_neighbors=20, fourier_features=4, edge_dim=7), 2, 50,
+     dict(mask=True, edges=True)),
+    # wide dynamic range of the per-edge scalars (three-part fp16 split): coordinates x 60 -> dist^2 up to ~1e5 with a
+    # distance weight damped to keep the pre-activations O(1); edge features up to ~1e3
+    ("k32_large_distances", dict(dim=32, num_nearest_neighbors=32, edge_dim=2), 2, 64,
+     dict(mask=True, edges=True, coors_mul=60.0, edges_mul=300.0, scalar_cols=1e-4,
+          scale={"coors_mlp.3.weight": 0.01})),                      # |rel| ~ 100: keep the coordinate update O(1)
 ]
 
 
@@ -70,14 +84,18 @@ def test_layer_vs_oracle(name, kwargs, b, n, flags):
     params = O.random_params(cfg, seed=17)
     for key, sc in flags.get("scale", {}).items():
         params[key] = params[key] * np.float32(sc)
+    if "scalar_cols" in flags:                       # damp the [d | e] columns of edge_mlp.0.weight (egnn_pytorch.py:282-285)
+        w1 = params["edge_mlp.0.weight"].copy()
+        w1[:, 2 * kwargs["dim"]:] *= np.float32(flags["scalar_cols"])
+        params["edge_mlp.0.weight"] = w1
     feats = rng.standard_normal((b, n, kwargs["dim"])).astype(np.float32)
-    coors = rng.standard_normal((b, n, 3)).astype(np.float32)
+    coors = (rng.standard_normal((b, n, 3)) * flags.get("coors_mul", 1.0)).astype(np.float32)
     mask = edges = adj = None
     if flags.get("mask"):
         lens = rng.integers(n // 2, n + 1, size=b)
         mask = np.arange(n)[None, :] < lens[:, None]
     if flags.get("edges"):
-        edges = rng.standard_normal((b, n, n, kwargs["edge_dim"])).astype(np.float32)
+        edges = (rng.standard_normal((b, n, n, kwargs["edge_dim"])) * flags.get("edges_mul", 1.0)).astype(np.float32)
     if flags.get("adj") == "chain":
         i = np.arange(n)
         adj = np.abs(i[:, None] - i[None, :]) <= 1
