@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -40,7 +40,7 @@ class EdgeArgs(Structure):
         ("gate_w", c_void_p), ("gate_b", c_void_p),
         ("W3h", c_void_p), ("w3_inv_scale", c_float), ("b3", c_void_p), ("W4", c_void_p), ("b4", c_void_p),
         ("coors_scale", c_void_p),
-        ("coors", c_void_p), ("edges", c_void_p), ("mask", c_void_p), ("idx", c_void_p), ("rank", c_void_p),
+        ("coors", c_void_p), ("coor_dim", c_int32), ("edges", c_void_p), ("mask", c_void_p), ("idx", c_void_p), ("rank", c_void_p),
         ("order", c_void_p),
         ("valid_radius", c_float), ("clamp", c_float), ("pool_mean", c_int32),
         ("m_i", c_void_p), ("coors_out", c_void_p),
@@ -85,7 +85,7 @@ def load():
     lib.egnn_padded_hidden.restype = c_int
     lib.egnn_padded_hidden.argtypes = [c_int]
     lib.egnn_knn_select_f32.restype = c_int
-    lib.egnn_knn_select_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+    lib.egnn_knn_select_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p]
     lib.egnn_adj_max_degree_u8.restype = c_int
     lib.egnn_adj_max_degree_u8.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_void_p]

@@ -75,7 +75,7 @@ def _u8(t):
 
 def knn_select(coors, mask, adj_mat, k):
     """(idx int32 (B,N,K), rank fp32 (B,N,K)) -- egnn_knn_select_f32."""
-    b, n, _ = coors.shape
+    b, n, cdim = coors.shape
     idx = torch.empty(b, n, k, dtype=torch.int32, device=coors.device)
     rank = torch.empty(b, n, k, dtype=torch.float32, device=coors.device)
     m8 = _u8(mask)
@@ -89,7 +89,7 @@ def knn_select(coors, mask, adj_mat, k):
         elif a8.shape != (n, n):
             raise ValueError(f"adj_mat shape {tuple(a8.shape)} != {(n, n)}")
     with _timed("knn_select"):
-        rc = _abi.load().egnn_knn_select_f32(_ptr(coors), _ptr(m8), _ptr(a8), stride, b, n, k,
+        rc = _abi.load().egnn_knn_select_f32(_ptr(coors), _ptr(m8), _ptr(a8), stride, b, n, k, cdim,
                                              _ptr(idx), _ptr(rank), _stream())
     _abi.check(rc, "egnn_knn_select_f32")
     return idx, rank

@@ -14,6 +14,9 @@ for f in knn_select spatial_order adj_expand linear_f32 linear_split linear_hl e
   ( "$HIPCC" $FLAGS $EXTRA -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" ) &
   pids+=($!)
 done
+# the edge pass a second time for coordinate dimensions other than 3 (compile-time CDM = 8)
+( "$HIPCC" $FLAGS -DEGNN_EDGE_GENERIC_C -c "$HERE/edge_fused.hip" -o "$HERE/obj/edge_fused_c.o" ) &
+pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libegnn_hip.so" "$HERE"/obj/*.o
 echo "built $OUT/libegnn_hip.so"

@@ -58,7 +58,16 @@ constexpr int SLOTS_PER_WAVE = TILES * 16;
 constexpr int SLOTS_PER_ROUND = EDGE_WAVES * SLOTS_PER_WAVE;     // 256
 constexpr int HC = EGNN_EDGE_HC;          // hidden columns per LDS chunk (steps of 32)
 constexpr int KSTEP = 32;                // hidden units per v_mfma_f32_16x16x32_f16
-constexpr int NCH = 20;                  // per-edge channels reduced per node: 16 m | 3 coords | 1 count
+// Coordinate dimension: this translation unit is compiled twice -- CDM = 3 (the fast path, every BASELINE config) and,
+// with -DEGNN_EDGE_GENERIC_C, CDM = 8 for 1 <= C <= 8 at run time (egnn_pytorch.py works for any C; its tests use C = 5).
+#ifdef EGNN_EDGE_GENERIC_C
+constexpr int CDM = 8;
+#define EGNN_EDGE_ENTRY egnn_edge_fused_generic_c
+#else
+constexpr int CDM = 3;
+#define EGNN_EDGE_ENTRY egnn_edge_fused_c3
+#endif
+constexpr int NCH = 17 + CDM;            // per-edge channels reduced per node: 16 m | CDM coords | 1 count
 constexpr int GMAX = 64;                 // nodes per workgroup
 constexpr int XLD = 32;                  // floats per row of the gather exchange buffer (one 128 B line, chunk-swizzled)
 
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(EDGE_THREADS, NM == 1 ? EGNN_EDGE_MINW : 2) void ed
         const float* pip[TILES];                             // TPI == 1: this lane's P_i row (+ 4 g)
         const uint32_t* piw = nullptr;                       // TPI == 2: the wave's P_i row as (hi, lo) words (+ lane & 15)
         u32x2 bq[TILES][NM];                                 // B fragments of the first-layer MFMAs (constant over the hidden loop)
-        float relx[TILES], rely[TILES], relz[TILES];
+        float rel[TILES][CDM];                               // x_i - x_j (components >= C are 0)
         bool fm[TILES];                                      // edge contributes (valid slot and unmasked)
 
         // TPI == 2 (K % 32 == 0): the 32 slots of a wave belong to ONE node -> node index and first k are wave-uniform
@@ -147,11 +156,18 @@ __global__ __launch_bounds__(EDGE_THREADS, NM == 1 ? EGNN_EDGE_MINW : 2) void ed
             if (!valid) { pos = node0 < N ? node0 : 0; k = 0; }
             const int i = p.order ? p.order[bN + pos] : pos;
             const int j = p.idx ? p.idx[(bN + i) * K + k] : k;
-            const float* ci = p.coors + (bN + i) * 3;
-            const float* cj = p.coors + (bN + j) * 3;
-            float dx, dy, dz;
-            const float d = egnn_sqdist(ci[0], ci[1], ci[2], cj[0], cj[1], cj[2], dx, dy, dz);
-            relx[t] = dx; rely[t] = dy; relz[t] = dz;
+            const int C = (CDM == 3) ? 3 : p.coor_dim;
+            const float* ci = p.coors + (bN + i) * C;
+            const float* cj = p.coors + (bN + j) * C;
+            float d;
+            if (CDM == 3) {
+                d = egnn_sqdist(ci[0], ci[1], ci[2], cj[0], cj[1], cj[2], rel[t][0], rel[t][1], rel[t][2]);
+            } else {
+                float a[CDM], bb[CDM];
+#pragma unroll
+                for (int c = 0; c < CDM; ++c) { a[c] = c < C ? ci[c] : 0.f; bb[c] = c < C ? cj[c] : 0.f; }
+                d = egnn_sqdist_n<CDM>(a, bb, C, rel[t]);
+            }
 
             // Per-edge scalars [sin(d/2^f)..., cos(d/2^f)..., d, edges...] (egnn_pytorch.py:34-41, 282-285) as B
             // fragments of v_mfma_f32_16x16x16_f16: lane group g of MFMA m carries split term tau = 4 m + g of scalar
@@ -448,25 +464,35 @@ __global__ __launch_bounds__(EDGE_THREADS, NM == 1 ? EGNN_EDGE_MINW : 2) void ed
         if (TPI == 2) {
             // The wave's 32 edges belong to one node: sum them in registers (DPP butterfly over the 16 edges of a
             // tile, fixed order -> deterministic) and hand 20 partials per wave to the cross-wave reduction.
-            float rx[TILES], ry[TILES], rz[TILES], keep[TILES];
+            float rn[TILES][CDM], keep[TILES];
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
                 keep[t] = fm[t] ? 1.f : 0.f;
-                rx[t] = relx[t]; ry[t] = rely[t]; rz[t] = relz[t];
+                float inv = 1.f;
                 if (p.coors_scale) {                                    // CoorsNorm, egnn_pytorch.py:67-77
-                    const float nrm = sqrtf(rx[t] * rx[t] + ry[t] * ry[t] + rz[t] * rz[t]);
-                    const float inv = cscale / fmaxf(nrm, 1e-8f);
-                    rx[t] *= inv; ry[t] *= inv; rz[t] *= inv;
+                    float n2 = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CDM; ++c) n2 += rel[t][c] * rel[t][c];
+                    inv = cscale / fmaxf(sqrtf(n2), 1e-8f);
                 }
+#pragma unroll
+                for (int c = 0; c < CDM; ++c) rn[t][c] = rel[t][c] * inv;
             }
             f32x4 ms = acc[0] * keep[0] + acc[1] * keep[1];
-            float c4[4] = {cw[0] * rx[0] + cw[1] * rx[1], cw[0] * ry[0] + cw[1] * ry[1],
-                           cw[0] * rz[0] + cw[1] * rz[1], keep[0] + keep[1]};
+            float cs[CDM + 1];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { ms[u] = row16_sum(ms[u]); c4[u] = row16_sum(c4[u]); }
+            for (int c = 0; c < CDM; ++c) cs[c] = cw[0] * rn[0][c] + cw[1] * rn[1][c];
+            cs[CDM] = keep[0] + keep[1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ms[u] = row16_sum(ms[u]);
+#pragma unroll
+            for (int c = 0; c <= CDM; ++c) cs[c] = row16_sum(cs[c]);
             // the wave's own exchange rows double as its partial-sum row (no other wave touches them)
             if (e == 0) *reinterpret_cast<f32x4*>(xch + 4 * g) = ms;
-            if (lane == 0) *reinterpret_cast<f32x4*>(xch + 16) = f32x4{c4[0], c4[1], c4[2], c4[3]};
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c <= CDM; ++c) xch[16 + c] = cs[c];
+            }
             __syncthreads();
             const int kw = K / SLOTS_PER_WAVE;                           // waves per node
             const int wbase = round * EDGE_WAVES;
@@ -488,16 +514,16 @@ __global__ __launch_bounds__(EDGE_THREADS, NM == 1 ? EGNN_EDGE_MINW : 2) void ed
                 float* row = ebuf + slot * NCH;
                 *reinterpret_cast<f32x4*>(row + 4 * g) = acc[t] * keep;
                 if (g == 0) {
-                    float rx = relx[t], ry = rely[t], rz = relz[t];
+                    float inv = 1.f;
                     if (p.coors_scale) {                                    // CoorsNorm, egnn_pytorch.py:67-77
-                        const float nrm = sqrtf(rx * rx + ry * ry + rz * rz);
-                        const float inv = cscale / fmaxf(nrm, 1e-8f);
-                        rx *= inv; ry *= inv; rz *= inv;
+                        float n2 = 0.f;
+#pragma unroll
+                        for (int c = 0; c < CDM; ++c) n2 += rel[t][c] * rel[t][c];
+                        inv = cscale / fmaxf(sqrtf(n2), 1e-8f);
                     }
-                    row[16] = cw[t] * rx;
-                    row[17] = cw[t] * ry;
-                    row[18] = cw[t] * rz;
-                    row[19] = keep;
+#pragma unroll
+                    for (int c = 0; c < CDM; ++c) row[16 + c] = cw[t] * (rel[t][c] * inv);
+                    row[16 + CDM] = keep;
                 }
             }
             __syncthreads();
@@ -528,7 +554,7 @@ __global__ __launch_bounds__(EDGE_THREADS, NM == 1 ? EGNN_EDGE_MINW : 2) void ed
             if (ch < p.m_dim && (p.m_i || p.node_hi)) {
                 if (p.pool_mean) {
                     if (has_mask) {                                     // safe_div, egnn_pytorch.py:13-16
-                        const float cnt = nodeacc[nl * NCH + 19];
+                        const float cnt = nodeacc[nl * NCH + (NCH - 1)];
                         val = (cnt == 0.f) ? 0.f : val / fmaxf(cnt, 1e-8f);
                     } else {
                         val = val / (float)K;                           // :330
@@ -542,8 +568,9 @@ __global__ __launch_bounds__(EDGE_THREADS, NM == 1 ? EGNN_EDGE_MINW : 2) void ed
                     static_cast<_Float16*>(p.node_lo)[off] = (_Float16)(val - (float)h);
                 }
             }
-        } else if (ch < 19) {
-            if (p.coors_out) p.coors_out[(bN + i) * 3 + (ch - 16)] = p.coors[(bN + i) * 3 + (ch - 16)] + val;
+        } else if (ch < 16 + ((CDM == 3) ? 3 : p.coor_dim)) {
+            const int C = (CDM == 3) ? 3 : p.coor_dim;
+            if (p.coors_out) p.coors_out[(bN + i) * C + (ch - 16)] = p.coors[(bN + i) * C + (ch - 16)] + val;
         }
     }
 }
@@ -580,13 +607,28 @@ int dispatch_tpi(const egnn_edge_args& a, hipStream_t s)
 
 }  // namespace
 
+#ifndef EGNN_EDGE_GENERIC_C
 extern "C" int egnn_padded_hidden(int H) { return (H + 31) / 32 * 32; }
 
 extern "C" int egnn_edge_mfmas(int S) { return S <= 1 ? 1 : (S <= 4 ? 3 : (S <= 8 ? 6 : 12)); }
 
+#endif
+
+// internal: the two compilations of this file (coordinate dimension 3 / generic)
+int egnn_edge_fused_c3(const egnn_edge_args* args, void* stream);
+int egnn_edge_fused_generic_c(const egnn_edge_args* args, void* stream);
+
+#ifndef EGNN_EDGE_GENERIC_C
 extern "C" int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream)
 {
     if (!args) return EGNN_E_NULLPTR;
+    if (args->coor_dim < 1 || args->coor_dim > 8) return EGNN_E_UNSUPPORTED;
+    return args->coor_dim == 3 ? egnn_edge_fused_c3(args, stream) : egnn_edge_fused_generic_c(args, stream);
+}
+#endif
+
+int EGNN_EDGE_ENTRY(const egnn_edge_args* args, void* stream)
+{
     const egnn_edge_args& a = *args;
     if (!a.Pi || !a.Pj || !a.Wst || !a.W2h || !a.b2 || !a.coors) return EGNN_E_NULLPTR;
     if (!a.m_i && !a.coors_out && !a.node_hi) return EGNN_E_NULLPTR;

@@ -35,6 +35,33 @@ __device__ __forceinline__ float egnn_sqdist(float xi, float yi, float zi, float
     return sxy + sz;
 }
 
+// General coordinate dimension C <= CDM (components >= C of a, b must be 0).  Summation order = what the reference's
+// `(rel_coors ** 2).sum(-1)` does on the CPU (measured, torch 2.10 fp32): left to
+// right for C in {1, 2, 3, 4, 8}; s0, s4, ..., s_{C-1}, s1, s2, s3 for C in {5, 6, 7}.  No FMA contraction.
+template <int CDM>
+__device__ __forceinline__ float egnn_sqdist_n(const float (&a)[CDM], const float (&b)[CDM], int C, float (&rel)[CDM]) {
+#pragma clang fp contract(off)
+    float sq[CDM];
+#pragma unroll
+    for (int c = 0; c < CDM; ++c) {
+        rel[c] = a[c] - b[c];
+        sq[c] = rel[c] * rel[c];
+    }
+    float d = sq[0];
+    if (C >= 5 && C <= 7) {
+#pragma unroll
+        for (int c = 4; c < CDM; ++c)
+            if (c < C) d = d + sq[c];
+#pragma unroll
+        for (int c = 1; c < 4; ++c) d = d + sq[c];
+    } else {
+#pragma unroll
+        for (int c = 1; c < CDM; ++c)
+            if (c < C) d = d + sq[c];
+    }
+    return d;
+}
+
 // Packed ("tile-major") layout of the fp16 GEMM operands: an (R x Kp) matrix, R padded to 32 rows, Kp % 32 == 0, is
 // stored as [R/32][Kp/16][32 rows][2 chunks][8 halves]; the chunk index is XOR-swizzled by ((row >> 3) & 1) so that the
 // 1 KB (row block, K-tile) piece is exactly the bank-conflict-free LDS image the GEMM wants.  nkt = Kp / 16.

@@ -35,18 +35,19 @@ __device__ __forceinline__ void wave_lds_sync() {
 constexpr int KNN_THREADS = 256;
 constexpr int KNN_WAVES = KNN_THREADS / 64;
 
-template <int CPL>
+// CDM: 3 = the fast path (C == 3, distance bit-exact as ((dx^2 + dy^2) + dz^2)); 8 = any 1 <= C <= 8 at run time.
+template <int CPL, int CDM>
 __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
     const float* __restrict__ coors, const uint8_t* __restrict__ mask, const uint8_t* __restrict__ adj,
-    int64_t adj_bstride, int N, int K, int Npad, int Kpad, int rows_per_wg,
+    int64_t adj_bstride, int N, int K, int Npad, int Kpad, int rows_per_wg, int Cdim,
     int32_t* __restrict__ idx_out, float* __restrict__ rank_out)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xs = reinterpret_cast<float*>(smem);
-    float* ys = xs + Npad;
-    float* zs = ys + Npad;
-    uint8_t* ms = reinterpret_cast<uint8_t*>(zs + Npad);
-    uint64_t* selall = reinterpret_cast<uint64_t*>(smem + (size_t)Npad * 13 + 8 - ((size_t)Npad * 13) % 8);
+    const int C = (CDM == 3) ? 3 : Cdim;
+    float* xs = reinterpret_cast<float*>(smem);                         // [C][Npad], component-major
+    uint8_t* ms = reinterpret_cast<uint8_t*>(xs + (size_t)C * Npad);
+    const size_t cbytes = (size_t)Npad * (4 * C + 1);
+    uint64_t* selall = reinterpret_cast<uint64_t*>(smem + cbytes + 8 - cbytes % 8);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -55,16 +56,10 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
     const int row0 = blockIdx.x * rows_per_wg;
     uint64_t* selbuf = selall + (size_t)wave * Kpad;
 
-    const float* cb = coors + (size_t)b * N * 3;
+    const float* cb = coors + (size_t)b * N * C;
     for (int j = tid; j < Npad; j += KNN_THREADS) {
-        if (j < N) {
-            xs[j] = cb[j * 3 + 0];
-            ys[j] = cb[j * 3 + 1];
-            zs[j] = cb[j * 3 + 2];
-            ms[j] = mask ? mask[(size_t)b * N + j] : (uint8_t)1;
-        } else {
-            xs[j] = 0.f; ys[j] = 0.f; zs[j] = 0.f; ms[j] = 0;
-        }
+        for (int c = 0; c < C; ++c) xs[c * Npad + j] = j < N ? cb[j * C + c] : 0.f;
+        ms[j] = j < N ? (mask ? mask[(size_t)b * N + j] : (uint8_t)1) : (uint8_t)0;
     }
     __syncthreads();
 
@@ -73,7 +68,9 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
     for (int r = wave; r < rows_per_wg; r += KNN_WAVES) {
         const int i = row0 + r;
         if (i >= N) break;                       // wave-uniform
-        const float xi = xs[i], yi = ys[i], zi = zs[i];
+        float ci[CDM];
+#pragma unroll
+        for (int c = 0; c < CDM; ++c) ci[c] = c < C ? xs[c * Npad + i] : 0.f;
         const bool mi = ms[i] != 0;
         const uint8_t* adjrow = adj ? adj + (size_t)b * adj_bstride + (size_t)i * N : nullptr;
 
@@ -83,8 +80,16 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
             const int j = c * 64 + lane;
             uint32_t k = 0xFFFFFFFFu;            // padding candidates sort last
             if (j < N) {
-                float dx, dy, dz;
-                float rk = egnn_sqdist(xi, yi, zi, xs[j], ys[j], zs[j], dx, dy, dz);
+                float rk;
+                if (CDM == 3) {
+                    float dx, dy, dz;
+                    rk = egnn_sqdist(ci[0], ci[1], ci[2], xs[j], xs[Npad + j], xs[2 * Npad + j], dx, dy, dz);
+                } else {
+                    float cj[CDM], rel[CDM];
+#pragma unroll
+                    for (int c = 0; c < CDM; ++c) cj[c] = c < C ? xs[c * Npad + j] : 0.f;
+                    rk = egnn_sqdist_n<CDM>(ci, cj, C, rel);
+                }
                 if (!(mi && ms[j] != 0)) rk = 1e5f;                 // :240-242
                 if (adjrow) {
                     if (j == i) rk = -1.0f;                         // :255
@@ -205,47 +210,58 @@ __global__ __launch_bounds__(256) void adj_max_degree_kernel(const uint8_t* __re
     if (lane == 0 && best > 0) atomicMax(out, best);
 }
 
-template <int CPL>
-int launch_knn(const float* coors, const uint8_t* mask, const uint8_t* adj, int64_t adj_bstride, int B, int N,
-               int K, int32_t* idx_out, float* rank_out, hipStream_t s)
+template <int CPL, int CDM>
+int launch_knn_c(const float* coors, const uint8_t* mask, const uint8_t* adj, int64_t adj_bstride, int B, int N,
+                 int K, int C, int32_t* idx_out, float* rank_out, hipStream_t s)
 {
     const int Npad = (N + 63) / 64 * 64;
     const int Kpad = K > 64 ? (K + 1) / 2 * 2 : 64;        // the fast path parks up to 64 survivors
     int rows_per_wg = 32;
     if (N < rows_per_wg) rows_per_wg = (N + 3) / 4 * 4;
-    const size_t coord_bytes = (size_t)Npad * 13 + 8 - ((size_t)Npad * 13) % 8;
+    const size_t cbytes = (size_t)Npad * (4 * C + 1);
+    const size_t coord_bytes = cbytes + 8 - cbytes % 8;
     const size_t lds = coord_bytes + (size_t)KNN_WAVES * Kpad * 8;
     if (lds > 160 * 1024) return EGNN_E_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_select_kernel<CPL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_select_kernel<CPL, CDM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     dim3 grid((N + rows_per_wg - 1) / rows_per_wg, B);
-    hipLaunchKernelGGL(knn_select_kernel<CPL>, grid, dim3(KNN_THREADS), lds, s, coors, mask, adj, adj_bstride, N, K,
-                       Npad, Kpad, rows_per_wg, idx_out, rank_out);
+    hipLaunchKernelGGL((knn_select_kernel<CPL, CDM>), grid, dim3(KNN_THREADS), lds, s, coors, mask, adj, adj_bstride, N, K,
+                       Npad, Kpad, rows_per_wg, C, idx_out, rank_out);
     return egnn_launch_status();
+}
+
+template <int CPL>
+int launch_knn(const float* coors, const uint8_t* mask, const uint8_t* adj, int64_t adj_bstride, int B, int N,
+               int K, int C, int32_t* idx_out, float* rank_out, hipStream_t s)
+{
+    if (C == 3) return launch_knn_c<CPL, 3>(coors, mask, adj, adj_bstride, B, N, K, C, idx_out, rank_out, s);
+    return launch_knn_c<CPL, 8>(coors, mask, adj, adj_bstride, B, N, K, C, idx_out, rank_out, s);
 }
 
 }  // namespace
 
 extern "C" int egnn_knn_select_f32(const float* coors, const uint8_t* mask, const uint8_t* adj,
-                                   int64_t adj_batch_stride, int B, int N, int K, int32_t* idx_out,
+                                   int64_t adj_batch_stride, int B, int N, int K, int coor_dim, int32_t* idx_out,
                                    float* rank_out, void* stream)
 {
     if (!coors || !idx_out || !rank_out) return EGNN_E_NULLPTR;
     if (B <= 0 || N <= 0 || K <= 0) return EGNN_E_SHAPE;
+    if (coor_dim < 1 || coor_dim > 8) return EGNN_E_UNSUPPORTED;
+    const int C = coor_dim;
     if (K > N) return EGNN_E_K_GT_N;
     if (N > 4096 || K > 1024) return EGNN_E_UNSUPPORTED;
     if (B > 65535) return EGNN_E_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (N <= 64) return launch_knn<1>(coors, mask, adj, adj_batch_stride, B, N, K, idx_out, rank_out, s);
-    if (N <= 128) return launch_knn<2>(coors, mask, adj, adj_batch_stride, B, N, K, idx_out, rank_out, s);
-    if (N <= 256) return launch_knn<4>(coors, mask, adj, adj_batch_stride, B, N, K, idx_out, rank_out, s);
-    if (N <= 512) return launch_knn<8>(coors, mask, adj, adj_batch_stride, B, N, K, idx_out, rank_out, s);
-    if (N <= 1024) return launch_knn<16>(coors, mask, adj, adj_batch_stride, B, N, K, idx_out, rank_out, s);
-    if (N <= 2048) return launch_knn<32>(coors, mask, adj, adj_batch_stride, B, N, K, idx_out, rank_out, s);
-    return launch_knn<64>(coors, mask, adj, adj_batch_stride, B, N, K, idx_out, rank_out, s);
+    if (N <= 64) return launch_knn<1>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
+    if (N <= 128) return launch_knn<2>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
+    if (N <= 256) return launch_knn<4>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
+    if (N <= 512) return launch_knn<8>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
+    if (N <= 1024) return launch_knn<16>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
+    if (N <= 2048) return launch_knn<32>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
+    return launch_knn<64>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
 }
 
 extern "C" int egnn_adj_max_degree_u8(const uint8_t* adj, int64_t rows, int N, int32_t* out_dev, void* stream)

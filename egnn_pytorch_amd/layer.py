@@ -101,9 +101,9 @@ class EGNN(nn.Module):
             raise NotImplementedError("the gfx950 path is fp32 only (got "
                                       f"{feats.dtype}/{coors.dtype})")
         if feats.dim() != 3 or coors.dim() != 3 or feats.shape[:2] != coors.shape[:2]:
-            raise ValueError(f"feats {tuple(feats.shape)} / coors {tuple(coors.shape)}: expected (B,N,dim) and (B,N,3)")
-        if coors.shape[-1] != 3:
-            raise NotImplementedError("the gfx950 path supports 3-D coordinates only")
+            raise ValueError(f"feats {tuple(feats.shape)} / coors {tuple(coors.shape)}: expected (B,N,dim) and (B,N,C)")
+        if not 1 <= coors.shape[-1] <= 8:
+            raise NotImplementedError("the gfx950 path supports coordinate dimensions 1..8")
         if feats.shape[-1] != self.dim:
             raise ValueError(f"feats last dim {feats.shape[-1]} != dim {self.dim}")
         if self.training and self.dropout_p > 0:
@@ -190,12 +190,12 @@ class EGNN(nn.Module):
                 a.coors_out = coors_out.data_ptr()
             if self.norm_coors:
                 a.coors_scale = w["coors_scale"].data_ptr()
-            a.coors = coors.data_ptr()
+            a.coors, a.coor_dim = coors.data_ptr(), coors.shape[-1]
             a.edges = _ops._ptr(edges)
             a.mask = _ops._ptr(mask8)
             a.idx, a.rank = _ops._ptr(idx), _ops._ptr(rank)
             order = None
-            if idx is not None and adj_mat is None and 64 <= n <= 4096 and _SPATIAL_ORDER:
+            if idx is not None and adj_mat is None and 64 <= n <= 4096 and _SPATIAL_ORDER and coors.shape[-1] == 3:
                 order = _ops.spatial_order(coors)       # k-NN path: neighbours are spatial -> share gathered rows in L1
                 a.order = order.data_ptr()
             a.valid_radius = float(min(valid_radius, 3.0e38))

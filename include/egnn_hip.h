@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 10
+#define EGNN_ABI_VERSION 11
 
 enum {
     EGNN_OK = 0,
@@ -49,8 +49,10 @@ int egnn_padded_hidden(int H);
  * Neighbour selection: replaces egnn_pytorch.py:232-233 (pairwise rel_coors / rel_dist), :237-256
  * (ranking: masked pairs -> 1e5, with adj_mat: self -> -1, adjacent -> 0) and :258 (topk smallest K,
  * ascending).  Nothing of size N*N is materialised.
- *   coors  (B,N,3) fp32.  rel_dist is computed as ((dx*dx + dy*dy) + dz*dz) with every multiply and
- *          add rounded separately (no FMA) -- bit-identical to the reference's CPU result.
+ *   coors  (B,N,coor_dim) fp32, 1 <= coor_dim <= 8.  For coor_dim == 3 rel_dist is computed as
+ *          ((dx*dx + dy*dy) + dz*dz) with every multiply and add rounded separately (no FMA) -- bit-identical to the
+ *          reference's CPU result; other dimensions follow the summation order measured on the reference
+ *          (left to right for C in {1,2,4,8}; s0, s4 .. s_{C-1}, s1, s2, s3 for C in {5,6,7}).
  *   mask   (B,N) bytes or NULL.
  *   adj    (N,N) bytes (adj_batch_stride = 0) or (B,N,N) bytes (adj_batch_stride = N*N), or NULL.
  *          The diagonal is ignored (the reference clears it, :254).
@@ -59,7 +61,7 @@ int egnn_padded_hidden(int H);
  * Limits: 1 <= K <= min(N, 1024), N <= 4096.
  */
 int egnn_knn_select_f32(const float* coors, const uint8_t* mask, const uint8_t* adj,
-                        int64_t adj_batch_stride, int B, int N, int K,
+                        int64_t adj_batch_stride, int B, int N, int K, int coor_dim,
                         int32_t* idx_out, float* rank_out, void* stream);
 
 /* Replaces `int(adj_mat.float().sum(dim=-1).max().item())` (egnn_pytorch.py:249; the diagonal is
@@ -196,7 +198,8 @@ typedef struct egnn_edge_args {
     const float* b4;            /* (1) */
     const float* coors_scale;   /* (1) CoorsNorm.scale or NULL (norm_coors=False) */
     /* inputs */
-    const float* coors;         /* (B,N,3) */
+    const float* coors;         /* (B,N,coor_dim) */
+    int32_t coor_dim;           /* 1..8 (3 = the fast path); coors_out has the same width */
     const float* edges;         /* (B,N,N,edge_dim) or NULL */
     const uint8_t* mask;        /* (B,N) or NULL */
     const int32_t* idx;         /* (B,N,K) from egnn_knn_select_f32, or NULL = dense (j = k) */
@@ -208,7 +211,7 @@ typedef struct egnn_edge_args {
     int32_t pool_mean;          /* m_pool_method == 'mean' */
     /* outputs */
     float* m_i;                 /* (B*N, m_dim) or NULL */
-    float* coors_out;           /* (B,N,3) or NULL (update_coors=False) */
+    float* coors_out;           /* (B,N,coor_dim) or NULL (update_coors=False) */
     void* node_hi;              /* optional: packed (B*N, node_kp) fp16 (hi, lo) pair = the node_mlp input prepared by */
     void* node_lo;              /*   egnn_node_prep_hl(m_i = NULL); the pooled messages are written into its columns  */
     int32_t node_kp;            /*   [dim, dim + m_dim) (both or neither; node_kp % 32 == 0, >= dim + m_dim)          */

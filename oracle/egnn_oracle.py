@@ -75,13 +75,22 @@ def pairwise(coors):
     rel_coors[b,i,j,:] = coors[b,i] - coors[b,j];  rel_dist = sum_c rel^2.
     For C == 3 the reference's CPU result is bit-identical to ((dx*dx + dy*dy) + dz*dz) with
     separately rounded multiplies and adds; that order is pinned here.
+    Other C (measured against torch 2.10 CPU, fp32, C <= 8): left to right for C in {1, 2, 4, 8}; for C in {5, 6, 7}
+    the order is s0, s4, ..., s_{C-1}, s1, s2, s3 (ATen's 4-wide inner reduction folds the tail into lane 0 first).
     """
     rel = coors[:, :, None, :] - coors[:, None, :, :]
     sq = rel * rel
-    dist = sq[..., 0]
-    for c in range(1, coors.shape[-1]):
-        dist = dist + sq[..., c]
+    dist = None
+    for c in sum_order(coors.shape[-1]):
+        dist = sq[..., c] if dist is None else dist + sq[..., c]
     return rel, dist
+
+
+def sum_order(c):
+    """Order in which the reference's `(rel_coors ** 2).sum(-1)` adds its C terms (see pairwise)."""
+    if c in (5, 6, 7):
+        return [0] + list(range(4, c)) + [1, 2, 3]
+    return list(range(c))
 
 
 def build_ranking(rel_dist, mask, adj_mat):

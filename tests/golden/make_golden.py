@@ -137,6 +137,11 @@ CASES = [
     ("net_global_attn", "network", dict(depth=3, dim=32, num_nearest_neighbors=8, global_linear_attn_every=2,
                                         global_linear_attn_heads=2, global_linear_attn_dim_head=8, num_global_tokens=4,
                                         coor_weights_clamp_value=2.0), 2, 40, dict(mask=True)),
+    # coordinate dimension other than 3 (the reference works for any C; tests/test_equivariance.py uses 5)
+    ("dense_coor_dim5", "layer", dict(dim=32), 1, 16, dict(coor_dim=5)),
+    ("knn8_coor_dim5_normcoors_mask", "layer", dict(dim=32, num_nearest_neighbors=8, norm_coors=True), 2, 40,
+     dict(mask=True, coor_dim=5)),
+    ("knn8_coor_dim2_mask", "layer", dict(dim=32, num_nearest_neighbors=8), 2, 40, dict(mask=True, coor_dim=2)),
 ]
 
 
@@ -147,7 +152,7 @@ def run_case(idx, name, kind, kwargs, b, n, flags):
     feats = torch.randn(b, n, dim, generator=g)
     if flags.get("tokens"):
         feats = torch.randint(0, flags["tokens"], (b, n), generator=g)
-    coors = torch.randn(b, n, 3, generator=g)
+    coors = torch.randn(b, n, flags.get("coor_dim", 3), generator=g)
     edges = torch.randn(b, n, n, edge_dim, generator=g) if flags.get("edges") else None
     if flags.get("edge_tokens"):
         edges = torch.randint(0, flags["edge_tokens"], (b, n, n), generator=g)
@@ -163,6 +168,7 @@ def run_case(idx, name, kind, kwargs, b, n, flags):
     elif flags.get("adj") == "random_batched":
         adj = torch.stack([random_adj(n, g) for _ in range(b)])
 
+    torch.manual_seed(5000 + idx)       # default init feeds the bias magnitudes below: seed it so files regenerate bit for bit
     net = EGNN(**kwargs) if kind == "layer" else EGNN_Network(**kwargs)
     reinit(net, 7000 + idx, coors_out_scale=0.1 if kind == "network" else 1.0)
     net.eval()

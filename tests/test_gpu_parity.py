@@ -69,6 +69,11 @@ CONFIGS = [
      dict(mask=True, edges=True, scale={"edge_mlp.3.weight": 0.3, "coors_mlp.3.weight": 0.3})),
     ("k20_fourier4_edges7_s16", dict(dim=32, num_nearest_neighbors=20, fourier_features=4, edge_dim=7), 2, 50,
      dict(mask=True, edges=True)),
+    # coordinate dimension other than 3 (generic-C compilation of the select and edge kernels)
+    ("coor_dim5_k32_normcoors", dict(dim=32, num_nearest_neighbors=32, norm_coors=True), 2, 64, dict(mask=True, coor_dim=5)),
+    ("coor_dim7_dense_edges", dict(dim=32, edge_dim=2), 1, 40, dict(edges=True, coor_dim=7)),
+    ("coor_dim8_k20_mean", dict(dim=32, num_nearest_neighbors=20, m_pool_method="mean"), 2, 50, dict(mask=True, coor_dim=8)),
+    ("coor_dim1_k8", dict(dim=32, num_nearest_neighbors=8), 1, 30, dict(coor_dim=1)),
     # wide dynamic range of the per-edge scalars (three-part fp16 split): coordinates x 60 -> dist^2 up to ~1e5 with a
     # distance weight damped to keep the pre-activations O(1); edge features up to ~1e3
     ("k32_large_distances", dict(dim=32, num_nearest_neighbors=32, edge_dim=2), 2, 64,
@@ -89,7 +94,7 @@ def test_layer_vs_oracle(name, kwargs, b, n, flags):
         w1[:, 2 * kwargs["dim"]:] *= np.float32(flags["scalar_cols"])
         params["edge_mlp.0.weight"] = w1
     feats = rng.standard_normal((b, n, kwargs["dim"])).astype(np.float32)
-    coors = (rng.standard_normal((b, n, 3)) * flags.get("coors_mul", 1.0)).astype(np.float32)
+    coors = (rng.standard_normal((b, n, flags.get("coor_dim", 3))) * flags.get("coors_mul", 1.0)).astype(np.float32)
     mask = edges = adj = None
     if flags.get("mask"):
         lens = rng.integers(n // 2, n + 1, size=b)
