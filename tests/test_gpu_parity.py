@@ -174,6 +174,26 @@ def test_equivariance(kwargs, n, edge_dim):
 
 
 # ------------------------------------------------------------------ full BASELINE sizes: size-independent properties
+def test_higher_dimension():
+    """tests/test_equivariance.py:36-45 (5-D coordinates run at all) -- plus what the reference does not check there:
+    equivariance under a random orthogonal map + translation of R^5."""
+    from egnn_pytorch_amd import EGNN
+    torch.manual_seed(0)
+    layer = EGNN(dim=512, edge_dim=4).cuda().eval()
+    rng = np.random.default_rng(7)
+    q, _ = np.linalg.qr(rng.standard_normal((5, 5)))
+    R, T = _dev(q.astype(np.float32)), _dev(rng.standard_normal((1, 1, 5)).astype(np.float32))
+    feats = _dev(rng.standard_normal((1, 16, 512)).astype(np.float32))
+    coors = _dev(rng.standard_normal((1, 16, 5)).astype(np.float32))
+    edges = _dev(rng.standard_normal((1, 16, 16, 4)).astype(np.float32))
+    mask = torch.ones(1, 16, dtype=torch.bool, device="cuda")
+    f1, c1 = layer(feats, coors @ R + T, edges, mask=mask)
+    f2, c2 = layer(feats, coors, edges, mask=mask)
+    assert c1.shape == (1, 16, 5)
+    assert torch.allclose(f1, f2, atol=1e-5)
+    assert torch.allclose(c1, c2 @ R + T, atol=1e-5)
+
+
 def test_north_star_full_size_properties():
     """EGNN(dim=512, k=32), B=64, N=1024 (the metric's configuration), xavier-scale weights:
     (1) graphs are independent: running a sub-batch reproduces the same rows bit for bit;
