@@ -42,7 +42,7 @@ template <> struct Cfg<2> { static constexpr int BM = 256, BN = 256, WM = 2, WN 
 // Measured and dropped (north-star projection, 0.82 ms with configuration 1): 128 x 64 per wave with 4-wave workgroups
 // (256 x 128 or 128 x 256 tiles, 2 waves per SIMD) 0.89-0.90 ms; 128 x 128 per wave (256 x 256 tile, accumulators in
 // AGPRs, 1 wave per SIMD) 2.07 ms -- a wave that issues 8 LDS-DMA pieces per K-tile stalls its own MFMA stream and
-// nothing else is resident to cover it.
+// nothing else is resident to cover it; 128 x 128 tiles with a 3- or 2-deep ring (3 - 4 workgroups per CU) 0.90-0.91 ms.
 
 // Pipeline (per K-tile of 16, ONE barrier), S = STAGES:
 //     s_waitcnt vmcnt((S-2) * DPW)   this wave's DMAs of tile kt have landed (tiles kt+1 .. kt+S-2 stay in flight)
