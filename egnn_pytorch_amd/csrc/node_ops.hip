@@ -75,33 +75,72 @@ __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restri
         const float* x = feats + (live ? r : 0) * ldx;
         float mean = 0.f, rstd = 1.f;
         if (gamma) {
+            // statistics over 16-byte chunks per lane (whole 128-B lines per wave instruction), remainder scalar
+            const bool vec = (dim % 4 == 0) && ((ldx % 4) == 0);
             float s = 0.f;
-            for (int c = sub; c < dim; c += 16) s += x[c];
+            if (vec) {
+                for (int c = sub * 4; c < dim; c += 64) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(x + c);
+                    s += (q[0] + q[1]) + (q[2] + q[3]);
+                }
+            } else {
+                for (int c = sub; c < dim; c += 16) s += x[c];
+            }
             mean = sum16(s) / (float)dim;
             float v = 0.f;
-            for (int c = sub; c < dim; c += 16) { const float d = x[c] - mean; v += d * d; }
+            if (vec) {
+                for (int c = sub * 4; c < dim; c += 64) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(x + c) - mean;
+                    v += (q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]);
+                }
+            } else {
+                for (int c = sub; c < dim; c += 16) { const float d = x[c] - mean; v += d * d; }
+            }
             rstd = 1.0f / sqrtf(sum16(v) / (float)dim + eps);
         }
         for (int c0 = sub * 8; c0 < Kmax; c0 += 128) {
             f16x8v h8, l8, rh8, rl8;
+            float xv[8], yv[8];
+            if (live && c0 + 8 <= dim && (dim % 4 == 0) && (ldx % 4) == 0) {      // whole chunk inside the row: 16-byte loads
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(x + c0), q1 = *reinterpret_cast<const f32x4*>(x + c0 + 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { xv[u] = q0[u]; xv[4 + u] = q1[u]; }
+                if (gamma) {
+                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0), g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c0), b1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        yv[u] = (xv[u] - mean) * rstd * g0[u] + b0[u];
+                        yv[4 + u] = (xv[4 + u] - mean) * rstd * g1[u] + b1[u];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) yv[u] = xv[u];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + u;
+                    float y = 0.f, xr = 0.f;
+                    if (live) {
+                        if (c < dim) {
+                            xr = x[c];
+                            y = gamma ? (xr - mean) * rstd * gamma[c] + beta[c] : xr;
+                        } else if (c < dim + m_dim) {
+                            y = m_i ? m_i[r * m_dim + (c - dim)] : 0.f;
+                        }
+                    }
+                    xv[u] = xr; yv[u] = y;
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int c = c0 + u;
-                float y = 0.f, xr = 0.f;
-                if (live) {
-                    if (c < dim) {
-                        xr = x[c];
-                        y = gamma ? (xr - mean) * rstd * gamma[c] + beta[c] : xr;
-                    } else if (c < dim + m_dim) {
-                        y = m_i ? m_i[r * m_dim + (c - dim)] : 0.f;
-                    }
-                }
-                const _Float16 h = (_Float16)y;
+                const _Float16 h = (_Float16)yv[u];
                 h8[u] = h;
-                l8[u] = (_Float16)(y - (float)h);
-                const _Float16 rh = (_Float16)xr;
+                l8[u] = (_Float16)(yv[u] - (float)h);
+                const _Float16 rh = (_Float16)xv[u];
                 rh8[u] = rh;
-                rl8[u] = (_Float16)(xr - (float)rh);
+                rl8[u] = (_Float16)(xv[u] - (float)rh);
             }
             if (c0 < Kp) {
                 const size_t o = egnn_pk_off(r, c0, nkt);
