@@ -32,6 +32,10 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+#ifndef EGNN_KNN_BITS
+#define EGNN_KNN_BITS 16
+#endif
+constexpr int KNN_PREFIX_BITS = EGNN_KNN_BITS;   // key bits resolved by the pruning threshold of the fast path
 constexpr int KNN_THREADS = 256;
 constexpr int KNN_WAVES = KNN_THREADS / 64;
 
@@ -110,28 +114,35 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
             uint32_t lmin = key[0];
 #pragma unroll
             for (int c = 1; c < CPL; ++c) lmin = key[c] < lmin ? key[c] : lmin;
+            // The threshold only has to keep >= K candidates and <= 64 survivors, so 16 key bits (sign, exponent, 7
+            // mantissa bits: 0.8 % granularity) are enough -- half the serial ballot/popcount chain, which runs on the
+            // CU's single scalar unit and was what bound this kernel.
             uint32_t M = 0;
             int belowm = 0;
-            for (int bit = 31; bit >= 0; --bit) {
+            for (int bit = 31; bit >= 32 - KNN_PREFIX_BITS; --bit) {
                 const int cnt = __popcll(__ballot((lmin >> bit) == (M >> bit)));
                 if (belowm + cnt < K) {
                     belowm += cnt;
                     M |= (1u << bit);
                 }
             }
-            int S = 0;
+            M |= (1u << (32 - KNN_PREFIX_BITS)) - 1u;
+            // survivors per lane, exclusive prefix over the wave (vector ops only: no ballots)
+            int cl = 0;
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) S += __popcll(__ballot(key[c] <= M));
+            for (int c = 0; c < CPL; ++c) cl += key[c] <= M ? 1 : 0;
+            int incl = cl;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            const int S = __builtin_amdgcn_readlane(incl, 63);
             if (S <= 64) {                                   // wave-uniform
-                int base = 0;
+                int pos = incl - cl;
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) {
-                    const bool sel = key[c] <= M;
-                    const uint64_t bs = __ballot(sel);
-                    if (sel)
-                        selbuf[base + __popcll(bs & lt_mask)] = ((uint64_t)key[c] << 32) | (uint32_t)(c * 64 + lane);
-                    base += __popcll(bs);
-                }
+                for (int c = 0; c < CPL; ++c)
+                    if (key[c] <= M) selbuf[pos++] = ((uint64_t)key[c] << 32) | (uint32_t)(c * 64 + lane);
                 wave_lds_sync();
                 const uint64_t mine = lane < S ? selbuf[lane] : ~0ull;
                 int rnk = 0;
