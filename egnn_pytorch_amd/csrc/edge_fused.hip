@@ -8,33 +8,37 @@
 //     w_ij   = W4 . SiLU(W3 * m_ij + b3) + b4                      (coors_mlp)
 //     mask, clamp, CoorsNorm;  x_i' = x_i + sum_k w_ij * rel_ij;  m_i = sum_k m_ij  (or mean)
 //
-// What bounds it on MI355X (tools/ubench/overlap_asm.hip, measured): the E x H SiLU evaluations.  The f32-input
-// MFMA (v_mfma_f32_16x16x4_f32) executes on the SAME datapath as the f32 VALU -- MFMA time and VALU time add --
-// while f16/bf16 MFMAs run on the matrix cores and hide completely behind VALU work.  So the H -> 16 contraction
-// is done as a 3-term split-f16 product on v_mfma_f32_16x16x32_f16 (hid = hi + lo, W2 = hi + lo in f16;
-// hi*hi + lo*hi + hi*lo, f32 accumulation: per-product error ~2^-22, i.e. f32 class) and the VALU is left with
-// exactly: 2 ops for x, 4 for SiLU (v_exp_f32, v_rcp_f32 are quarter rate), 2 for the split.
+// What bounds it on MI355X (tools/ubench/overlap_asm.hip, silu_seq.hip; measured): the E x H SiLU evaluations.  The
+// f32-input MFMA (v_mfma_f32_16x16x4_f32) executes on the SAME datapath as the f32 VALU -- MFMA time and VALU time add --
+// while f16/bf16 MFMAs run on the matrix cores and hide completely behind VALU work.  So BOTH Linears of edge_mlp run as
+// split-f16 products on the f16 matrix cores (fp32 accumulation: per-product error ~2^-22, i.e. f32 class) and the VALU
+// is left with exactly 4 instructions for SiLU (v_exp_f32, v_rcp_f32 cost 8.6 cycles, a plain op 2.8) and 2.5 for the
+// hi/lo split of the hidden value (v_cvt_pkrtz_f16_f32 4.65, v_fma_mix_f32 4.6 cycles):
+//   * first Linear: x = C + A B with C = the gathered P_j values (accumulator input), A = per hidden unit the (hi, lo)
+//     pair of P_i and split weight pairs of W_s, B = per edge (1, 1) and the three-part fp16 split of each scalar
+//     (v_mfma_f32_16x16x16_f16, NM chained MFMAs of 4 terms);
+//   * second Linear: hid = hi + lo, W2 = hi + lo in f16; hi*hi + lo*hi + hi*lo on v_mfma_f32_16x16x32_f16.
 //   * Pi/Pj/Ws arrive pre-scaled by -log2(e) (folded into the projection weights) so that SiLU(x) is
-//     -ln2 * y * rcp(1 + exp2(y)) with y the loaded value; the -ln2 and a power-of-two range scale are folded
+//     -ln2 * y * rcp(1 + exp2(y)) with y the MFMA result; the -ln2 and a power-of-two range scale are folded
 //     into the f16 W2 fragments and undone once per tile (w2_inv_scale).
 //
 // Mapping to the machine
 //   * one 256-thread workgroup owns G consecutive nodes (in Morton order) of one graph = up to 128 edge slots
-//     per round; each wave owns 32 slots = 2 MFMA tiles of 16 edges; 128 VGPRs -> 4 waves per SIMD.
-//   * swapped orientation D[channel][edge] = sum_h W2[channel][h] * hidden[edge][h]:  lane l (e = l & 15, g = l >> 4)
-//     owns edge e of its tile and the 8 hidden units h0+8g .. h0+8g+7 of every 32-wide step, so
+//     per round; each wave owns 32 slots = 2 MFMA tiles of 16 edges; 128 VGPRs, 39 KB LDS -> 4 workgroups per CU.
+//   * swapped orientation D[row][edge]: lane l (e = l & 15, g = l >> 4) owns edge e of its tile; after the first-layer
+//     MFMA it holds hidden units 16 hb + 4 g .. + 3 (hb = 0, 1) of every 32-wide step, so
 //        - the gather of Pj fetches WHOLE 128-byte lines (lane l: chunk l&7 of the row of slot 8q + (l>>3)); a
 //          wave-level load is processed line by line (tools/ubench/gather.hip: 16 half-used lines per instruction
-//          9.7 TB/s, 8 full lines 20.9 TB/s), the fragments are then re-dealt through a wave-private LDS buffer,
+//          9.7 TB/s, 8 full lines 20.9 TB/s), the rows are then re-dealt through a wave-private, chunk-swizzled LDS buffer,
 //        - W2 is read from LDS in pre-built fragment order (lane-linear, conflict free),
-//        - the result lands as D[4g + r][e]: every lane keeps "its" edge for the whole epilogue and holds
+//        - the H -> 16 result lands as D[4g + r][e]: every lane keeps "its" edge for the whole epilogue and holds
 //          exactly the B-operand fragments the coors_mlp MFMAs (16 -> 64) need -- no transposes, no LDS.
-//   * hidden activations (E x H) never leave registers; per-edge results go through a 20 KB LDS buffer and
-//     are summed per node in k order (deterministic, no float atomics).
-//   * W2 / Ws are staged through LDS in chunks of HC hidden columns, shared by the 4 waves; the Pi/Pj rows of
-//     step s+1 are requested before step s is computed.
+//   * hidden activations (E x H) never leave registers; per-node sums are a DPP butterfly + a fixed-order cross-wave
+//     sum (K % 32 == 0) or go through LDS and are summed in k order -- deterministic, no float atomics.
+//   * W2 fragments and the W_s table are staged by LDS-DMA in chunks of HC hidden columns, shared by the 4 waves; the
+//     Pi/Pj rows of step s+1 are requested before step s is computed.
 //   * blocks are remapped so that each XCD works on a contiguous range of graphs (Pj rows of a graph stay
-//     in that XCD's L2; measured hit rate 92 %).
+//     in that XCD's L2; measured hit rate 85 %).
 #include "egnn_common.h"
 
 namespace {
