@@ -4,19 +4,26 @@ set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="${1:-$HERE/..}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -Rpass-analysis=kernel-resource-usage"
 mkdir -p "$HERE/obj"
 pids=()
 for f in knn_select spatial_order adj_expand linear_f32 linear_split linear_hl edge_fused node_ops; do
   EXTRA=""
   # the ranking kernel must reproduce the reference's un-fused ((dx*dx+dy*dy)+dz*dz) bit for bit
   [ "$f" = knn_select ] && EXTRA="-ffp-contract=off"
-  ( "$HIPCC" $FLAGS $EXTRA -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" ) &
+  ( "$HIPCC" $FLAGS $EXTRA -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" 2> "$HERE/obj/$f.res" ) &
   pids+=($!)
 done
 # the edge pass a second time for coordinate dimensions other than 3 (compile-time CDM = 8)
-( "$HIPCC" $FLAGS -DEGNN_EDGE_GENERIC_C -c "$HERE/edge_fused.hip" -o "$HERE/obj/edge_fused_c.o" ) &
+( "$HIPCC" $FLAGS -DEGNN_EDGE_GENERIC_C -c "$HERE/edge_fused.hip" -o "$HERE/obj/edge_fused_c.o" 2> "$HERE/obj/edge_fused_c.res" ) &
 pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
+# compiler errors / warnings (the resource-usage remarks are filtered out)
+grep -h -v "remark:\|^ *[0-9]* *|\|^ *|\|\^\|remarks\? generated\|^$" "$HERE"/obj/*.res || true
+# no kernel may use scratch (register spills): see edge_fused.hip::edge_min_blocks
+if grep -h "ScratchSize \[bytes/lane\]: [1-9]" "$HERE"/obj/*.res; then
+  echo "error: a kernel spills registers to scratch (see $HERE/obj/*.res)" >&2
+  exit 1
+fi
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libegnn_hip.so" "$HERE"/obj/*.o
 echo "built $OUT/libegnn_hip.so"

@@ -80,6 +80,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
 }
 
+// Workgroups per CU the register allocator must allow.  Chosen so that NO variant spills: on this part private-segment
+// (scratch) spills of this kernel came back with other lanes' values under full occupancy (multi-round dense launches:
+// wrong coordinate weights, different on every run) -- csrc/build.sh fails the build if any kernel uses scratch.
+constexpr int edge_min_blocks(int nm, int tpi)
+{
+    if (nm >= 12) return 1;
+    if (nm > 1) return 2;
+    return (CDM == 3 && tpi == 2) ? EGNN_EDGE_MINW : 3;
+}
+
 // Sum over the 16 lanes of a DPP row (= the 16 edges of an MFMA tile); every lane ends with the same bits.
 __device__ __forceinline__ float row16_sum(float v)
 {
@@ -108,7 +118,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // TPI: consecutive tiles of a wave that share one node i (K % 32 == 0 -> 2 = both tiles of a wave, P_i rides in the
 // MFMA; else 1 = per-lane P_i rows, added on the VALU).
 template <int NM, int HCT, int TPI>
-__global__ __launch_bounds__(EDGE_THREADS, NM == 1 ? EGNN_EDGE_MINW : 2) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
+__global__ __launch_bounds__(EDGE_THREADS, edge_min_blocks(NM, TPI)) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HC = HCT;
@@ -235,20 +245,18 @@ __global__ __launch_bounds__(EDGE_THREADS, NM == 1 ? EGNN_EDGE_MINW : 2) void ed
         // stores (2 rows x 8 chunks per 16 lanes) and the pick-up loads (16 rows x 1 chunk per 16 lanes) are both
         // bank-conflict free.
         float* xch = xchall + wave * (SLOTS_PER_WAVE * XLD);
-        float* xw[4];
+        // parking: row = 8 qq + (lane >> 3); the swizzle (row >> 1) & 7 = (4 qq + (lane >> 4)) & 7 repeats every 16 rows, so
+        // qq and qq + 2 differ by a constant 16 rows (an immediate offset): two address registers instead of four
+        float* xw[2];
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
+        for (int qq = 0; qq < 2; ++qq) {
             const int row = 8 * qq + (lane >> 3);
             xw[qq] = xch + row * XLD + 4 * ((lane & 7) ^ ((row >> 1) & 7));
         }
-        const float* xr[TILES][2];                                      // lane (e, g): hidden rows 16 hb + 4 g .. + 3 of slot 16 t + e
+        // pick-up: lane (e, g) reads hidden rows 16 hb + 4 g .. + 3 of slot 16 t + e; the swizzle depends on e only
+        const float* xr[2];
 #pragma unroll
-        for (int t = 0; t < TILES; ++t)
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
-                const int row = 16 * t + e;
-                xr[t][hb] = xch + row * XLD + 4 * ((4 * hb + g) ^ ((row >> 1) & 7));
-            }
+        for (int hb = 0; hb < 2; ++hb) xr[hb] = xch + e * XLD + 4 * ((4 * hb + g) ^ ((e >> 1) & 7));
 
         // first-layer A fragments: row (hidden unit) e of the 16-block, split term 4 m + g
         const char* tl = wst + (e * (4 * NM) + g) * 4;
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(EDGE_THREADS, NM == 1 ? EGNN_EDGE_MINW : 2) void ed
 #endif
                 // park the lines fetched for this step, then (same wave, DS ops execute in order) pick the rows up
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f32x4*>(xw[qq]) = gl[qq];
+                for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f32x4*>(xw[qq & 1] + (qq >> 1) * 16 * XLD) = gl[qq];
                 int hnext = hoff + KSTEP;
                 if (hnext >= p.Hp) hnext = hoff;                 // last step: harmless re-read
 #pragma unroll
@@ -318,8 +326,8 @@ __global__ __launch_bounds__(EDGE_THREADS, NM == 1 ? EGNN_EDGE_MINW : 2) void ed
                 f32x4 x[TILES][2];
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
-                    x[t][0] = *reinterpret_cast<const f32x4*>(xr[t][0]);
-                    x[t][1] = *reinterpret_cast<const f32x4*>(xr[t][1]);
+                    x[t][0] = *reinterpret_cast<const f32x4*>(xr[0] + t * 16 * XLD);
+                    x[t][1] = *reinterpret_cast<const f32x4*>(xr[1] + t * 16 * XLD);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -420,9 +428,11 @@ __global__ __launch_bounds__(EDGE_THREADS, NM == 1 ? EGNN_EDGE_MINW : 2) void ed
             for (int t = 0; t < TILES; ++t) part[t] = 0.f;
             // coors_mlp first Linear (16 -> 64) on the matrix cores, same split-f16 scheme: lane (e, g) already holds
             // channels 4g..4g+3 of its edge = the B fragment of v_mfma_f32_16x16x16_f16; A = rows 16 blk + e of W3.
-            // (An earlier version used v_mfma_f32_16x16x4_f32 here and hit a gfx950 source-operand hazard: VALU /
-            // transcendental instructions scheduled into the chain and overwriting its A/B VGPRs corrupted 1-2
-            // coordinate weights per ~1e5 edges, differently on every run; regression:
+            // (Twice during development 1-2 % of the coordinate weights of dense multi-round launches came out wrong,
+            // differently on every run, with the node features intact.  First blamed on a source-operand hazard of
+            // the f32 MFMA used here at the time; the common factor of both occurrences was VGPR spills to scratch in
+            // the K % 32 != 0 variant -- values live across the hidden loop and needed only here.  No variant spills
+            // any more (edge_min_blocks, build.sh guard); regression:
             // tests/test_gpu_parity.py::test_multi_round_stress_is_deterministic_and_correct.)
             f16x4 mhi[TILES], mlo[TILES];
 #pragma unroll

@@ -230,10 +230,10 @@ def test_north_star_full_size_properties():
 
 
 def test_multi_round_stress_is_deterministic_and_correct():
-    """Regression for a gfx950 hazard: VALU / transcendental instructions scheduled into a v_mfma_f32_16x16x4_f32
-    chain and overwriting its source VGPRs corrupted 1-2 coordinate weights per ~1e5 edges, differently on every
-    run (edge_fused.hip fences the chain).  6 graphs x 600 nodes dense (5 rounds per node group, every CU busy),
-    20 repeats: bit-identical, and on parity."""
+    """Regression: dense multi-round launches (5 rounds per node group, every CU busy) once produced 1-2 % wrong
+    coordinate weights, differently on every run, node features intact -- values spilled to scratch across the
+    hidden loop came back wrong (edge_fused.hip::edge_min_blocks; the build now rejects kernels that use scratch).
+    6 graphs x 600 nodes dense, 20 repeats: bit-identical, and on parity."""
     kwargs = dict(dim=32)
     cfg = O.EGNNConfig(**kwargs)
     params = O.random_params(cfg, seed=17)
