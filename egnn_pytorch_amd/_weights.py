@@ -53,7 +53,7 @@ def pow2_scale(amax: float) -> float:
 
 def edge_mfmas(s: int) -> int:
     """Mirror of egnn_edge_mfmas (include/egnn_hip.h): first-layer MFMAs the edge kernel chains for s scalars."""
-    return 1 if s <= 1 else (3 if s <= 4 else (6 if s <= 8 else 12))
+    return 1 if s <= 1 else (3 if s <= 4 else (4 if s <= 5 else (6 if s <= 8 else 12)))
 
 
 def scalar_table(ws: torch.Tensor):

@@ -624,7 +624,7 @@ int dispatch_tpi(const egnn_edge_args& a, hipStream_t s)
 #ifndef EGNN_EDGE_GENERIC_C
 extern "C" int egnn_padded_hidden(int H) { return (H + 31) / 32 * 32; }
 
-extern "C" int egnn_edge_mfmas(int S) { return S <= 1 ? 1 : (S <= 4 ? 3 : (S <= 8 ? 6 : 12)); }
+extern "C" int egnn_edge_mfmas(int S) { return S <= 1 ? 1 : (S <= 4 ? 3 : (S <= 5 ? 4 : (S <= 8 ? 6 : 12))); }
 
 #endif
 
@@ -671,6 +671,7 @@ int EGNN_EDGE_ENTRY(const egnn_edge_args* args, void* stream)
     if (a.S == 1) return dispatch_tpi<1, HC>(a, s);
 #ifndef EGNN_EDGE_TUNING_BUILD
     if (a.S <= 4) return dispatch_tpi<3, 128>(a, s);
+    if (a.S <= 5) return dispatch_tpi<4, 128>(a, s);          // edge_dim = 4 (the README's configuration): 15 terms
     if (a.S <= 8) return dispatch_tpi<6, 64>(a, s);
     return dispatch_tpi<12, 64>(a, s);
 #else

@@ -219,7 +219,7 @@ typedef struct egnn_edge_args {
 
 int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream);
 
-/* Number of chained first-layer MFMAs the edge kernel is instantiated with for S per-edge scalars (>= ceil(3 S / 4)). */
+/* Number of chained first-layer MFMAs the edge kernel is instantiated with for S per-edge scalars (>= ceil(3 S / 4); one of 1, 3, 4, 6, 12). */
 int egnn_edge_mfmas(int S);
 
 #ifdef __cplusplus
