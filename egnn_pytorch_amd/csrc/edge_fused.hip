@@ -80,9 +80,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
 }
 
-// Workgroups per CU the register allocator must allow.  Chosen so that NO variant spills: on this part private-segment
-// (scratch) spills of this kernel came back with other lanes' values under full occupancy (multi-round dense launches:
-// wrong coordinate weights, different on every run) -- csrc/build.sh fails the build if any kernel uses scratch.
+// Workgroups per CU the register allocator must allow, chosen so that no variant spills to scratch (csrc/build.sh
+// checks it: spills are slow on a VALU-bound kernel and one less thing to reason about).
 constexpr int edge_min_blocks(int nm, int tpi)
 {
     if (nm >= 12) return 1;
@@ -90,17 +89,7 @@ constexpr int edge_min_blocks(int nm, int tpi)
     return (CDM == 3 && tpi == 2) ? EGNN_EDGE_MINW : 3;
 }
 
-// Sum over the 16 lanes of a DPP row (= the 16 edges of an MFMA tile); every lane ends with the same bits.
-__device__ __forceinline__ float row16_sum(float v)
-{
-#define EGNN_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
-    EGNN_DPP_ADD(0xB1);      // quad_perm [1,0,3,2]
-    EGNN_DPP_ADD(0x4E);      // quad_perm [2,3,0,1]
-    EGNN_DPP_ADD(0x141);     // row_half_mirror
-    EGNN_DPP_ADD(0x140);     // row_mirror
-#undef EGNN_DPP_ADD
-    return v;
-}
+__device__ __forceinline__ float row16_sum(float v) { return egnn_row16_sum(v); }
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -413,8 +402,7 @@ __global__ __launch_bounds__(EDGE_THREADS, edge_min_blocks(NM, TPI)) void edge_k
             for (int u = 0; u < 4; ++u) m[u] = egnn_silu(acc[t][u] * p.w2_inv_scale + b2r[u]);
             if (p.gate_w) {
                 float part = gwr[0] * m[0] + gwr[1] * m[1] + gwr[2] * m[2] + gwr[3] * m[3];
-                part += __shfl_xor(part, 16);
-                part += __shfl_xor(part, 32);
+                part = egnn_column_sum4(part, xch + 64 * t, lane);          // this wave's exchange rows are free now
                 const float gt = egnn_sigmoid(part + gb);
                 m *= gt;
             }
@@ -429,11 +417,12 @@ __global__ __launch_bounds__(EDGE_THREADS, edge_min_blocks(NM, TPI)) void edge_k
             // coors_mlp first Linear (16 -> 64) on the matrix cores, same split-f16 scheme: lane (e, g) already holds
             // channels 4g..4g+3 of its edge = the B fragment of v_mfma_f32_16x16x16_f16; A = rows 16 blk + e of W3.
             // (Twice during development 1-2 % of the coordinate weights of dense multi-round launches came out wrong,
-            // differently on every run, with the node features intact.  First blamed on a source-operand hazard of
-            // the f32 MFMA used here at the time; the common factor of both occurrences was VGPR spills to scratch in
-            // the K % 32 != 0 variant -- values live across the hidden loop and needed only here.  No variant spills
-            // any more (edge_min_blocks, build.sh guard); regression:
-            // tests/test_gpu_parity.py::test_multi_round_stress_is_deterministic_and_correct.)
+            // differently on every run, with the node features intact; it also showed when two launches ran concurrently
+            // on different streams.  Bisected (tools/concurrency_check.py) to the two ds_bpermute_b32 = `__shfl_xor`
+            // that summed the weight over the four lane groups below: with LDS-DMA traffic of co-resident workgroups in
+            // flight they occasionally returned another value.  No kernel uses the LDS-pipe shuffles any more
+            // (egnn_common.h poisons them); regressions: tests/test_gpu_parity.py::test_multi_round_stress... and
+            // ::test_concurrent_launches_do_not_change_results.)
             f16x4 mhi[TILES], mlo[TILES];
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
@@ -458,15 +447,16 @@ __global__ __launch_bounds__(EDGE_THREADS, edge_min_blocks(NM, TPI)) void edge_k
                     a2 = __builtin_amdgcn_mfma_f32_16x16x16f16(w3lo, mhi[t], a2, 0, 0, 0);
                     a2 = __builtin_amdgcn_mfma_f32_16x16x16f16(w3hi, mlo[t], a2, 0, 0, 0);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) part[t] += w4[u] * egnn_silu(a2[u] * p.w3_inv_scale + b3[u]);
+                    for (int u = 0; u < 4; ++u) {
+                        part[t] += w4[u] * egnn_silu(a2[u] * p.w3_inv_scale + b3[u]);
+                    }
                 }
             }
             const float b4 = p.b4[0];
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
                 float s = part[t];
-                s += __shfl_xor(s, 16);
-                s += __shfl_xor(s, 32);
+                s = egnn_column_sum4(s, xch + 64 * (TILES + t), lane);
                 s += b4;
                 if (has_mask && !fm[t]) s = 0.f;                         // :308-309
                 if (p.clamp >= 0.f) s = fminf(fmaxf(s, -p.clamp), p.clamp);   // :311-313

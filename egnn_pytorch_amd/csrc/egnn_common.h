@@ -9,6 +9,70 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- cross-lane primitives.  All of them are DPP (VALU) operations.  The LDS-pipe shuffles (`__shfl*` =
+// ds_bpermute_b32) are NOT used anywhere: with other launches of these kernels co-resident on the CU (LDS-DMA traffic in
+// flight) ds_bpermute_b32 occasionally returned another value -- tools/concurrency_check.py; the hip shuffle intrinsics are
+// poisoned below so that they cannot come back.
+#define EGNN_DPP(v, ctrl, row_mask, bound) \
+    __builtin_bit_cast(decltype(v), __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xF, bound))
+
+// Sum over the 16 lanes of a DPP row; every lane of the row ends with the same bits.
+template <typename T>
+__device__ __forceinline__ T egnn_row16_sum(T v)
+{
+    v += EGNN_DPP(v, 0xB1, 0xF, true);       // quad_perm [1,0,3,2]
+    v += EGNN_DPP(v, 0x4E, 0xF, true);       // quad_perm [2,3,0,1]
+    v += EGNN_DPP(v, 0x141, 0xF, true);      // row_half_mirror
+    v += EGNN_DPP(v, 0x140, 0xF, true);      // row_mirror
+    return v;
+}
+
+// Sum over the wave; the result is wave-uniform (built from the four row sums with v_readlane).
+__device__ __forceinline__ float egnn_wave_sum(float v)
+{
+    v = egnn_row16_sum(v);
+    const int b = __builtin_bit_cast(int, v);
+    return ((__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32))) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+}
+__device__ __forceinline__ int egnn_wave_sum(int v)
+{
+    v = egnn_row16_sum(v);
+    return ((__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + __builtin_amdgcn_readlane(v, 32)) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
+// For each column e = lane & 15: the sum over the four 16-lane rows, i.e. over lanes e, e+16, e+32, e+48 (what
+// `v += shfl_xor(v, 16); v += shfl_xor(v, 32)` computes), in every lane -- through 64 floats of wave-private LDS
+// (plain ds_write_b32 / ds_read_b32; same-wave DS operations execute in issue order, the waits pin the compiler).
+// (The gfx950 v_permlane16/32_swap builtins would do it in registers, but hipcc 7.2 folds their second result away
+// when both operands are the same value.)
+__device__ __forceinline__ float egnn_column_sum4(float v, float* scratch64, int lane)
+{
+    scratch64[lane] = v;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int e = lane & 15;
+    const float t = ((scratch64[e] + scratch64[16 + e]) + scratch64[32 + e]) + scratch64[48 + e];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    return t;
+}
+
+// Inclusive prefix sum over the 64 lanes (row_shr 1/2/4/8 inside the rows, then row_bcast15 / row_bcast31).
+__device__ __forceinline__ int egnn_wave_inclusive_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);    // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);    // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+#pragma GCC poison __shfl __shfl_xor __shfl_up __shfl_down
+
 // SiLU(x) = x * sigmoid(x) (reference: nn.SiLU, egnn_pytorch.py:56-60).
 // v_exp_f32 + v_rcp_f32; |error| ~1e-7 relative, far inside the 1e-4 parity budget.
 __device__ __forceinline__ float egnn_silu(float x) {

@@ -131,12 +131,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
             int cl = 0;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) cl += key[c] <= M ? 1 : 0;
-            int incl = cl;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(incl, o);
-                if (lane >= o) incl += t;
-            }
+            const int incl = egnn_wave_inclusive_scan(cl);
             const int S = __builtin_amdgcn_readlane(incl, 63);
             if (S <= 64) {                                   // wave-uniform
                 int pos = incl - cl;
@@ -215,7 +210,7 @@ __global__ __launch_bounds__(256) void adj_max_degree_kernel(const uint8_t* __re
         const uint8_t* row = adj + r * N;
         int cnt = 0;
         for (int j = lane; j < N; j += 64) cnt += row[j] ? 1 : 0;
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        cnt = egnn_wave_sum(cnt);
         best = cnt > best ? cnt : best;
     }
     if (lane == 0 && best > 0) atomicMax(out, best);

@@ -1,16 +1,12 @@
 // node_norm + concat feeding node_mlp (reference: egnn_pytorch/egnn_pytorch.py:335-336):
 //     out[r] = [ LayerNorm(feats[r]) (or feats[r]) | m_i[r] ]
-// One wavefront per row; row statistics by wave shuffles (two-pass: mean, then centred variance, as
+// One wavefront per row; row statistics by DPP reductions (two-pass: mean, then centred variance, as
 // torch's LayerNorm); HBM-bound streaming kernel (reads dim + m_dim floats, writes the same).
 #include "egnn_common.h"
 
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return egnn_wave_sum(v); }
 
 __global__ __launch_bounds__(256) void node_prep_kernel(const float* __restrict__ feats, const float* __restrict__ m_i,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -47,12 +43,8 @@ __global__ __launch_bounds__(256) void node_prep_kernel(const float* __restrict_
 // Packed-layout producer: the row [LayerNorm(x) | m_i] (or just x) as the (hi, lo) f16 pair the matrix-core GEMM consumes.
 // 16 lanes per row, 4 consecutive rows per wave: a lane converts 8 consecutive columns (one 16-byte chunk) at a time, so a
 // wave load covers 4 x 512 contiguous bytes and a wave store fills whole 128-byte lines of the packed layout (rows r..r+3
-// of one K-tile are adjacent).  Row statistics: two-pass (mean, centred variance) with 16-lane xor shuffles.
-__device__ __forceinline__ float sum16(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+// of one K-tile are adjacent).  Row statistics: two-pass (mean, centred variance) with 16-lane DPP butterflies.
+__device__ __forceinline__ float sum16(float v) { return egnn_row16_sum(v); }
 
 __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restrict__ feats, int64_t ldx, const float* __restrict__ m_i,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,

@@ -314,9 +314,9 @@ def test_baseline_configs_full_size_properties(name, kind, kwargs, b, n, flags):
 
 def test_multi_round_stress_is_deterministic_and_correct():
     """Regression: dense multi-round launches (5 rounds per node group, every CU busy) once produced 1-2 % wrong
-    coordinate weights, differently on every run, node features intact -- values spilled to scratch across the
-    hidden loop came back wrong (edge_fused.hip::edge_min_blocks; the build now rejects kernels that use scratch).
-    6 graphs x 600 nodes dense, 20 repeats: bit-identical, and on parity."""
+    coordinate weights, differently on every run, node features intact -- ds_bpermute_b32 (`__shfl_xor`) returning
+    another value while LDS-DMA traffic of co-resident workgroups was in flight (see egnn_common.h: the kernels use
+    DPP / explicit LDS exchanges only).  6 graphs x 600 nodes dense, 20 repeats: bit-identical, and on parity."""
     kwargs = dict(dim=32)
     cfg = O.EGNNConfig(**kwargs)
     params = O.random_params(cfg, seed=17)
@@ -338,6 +338,42 @@ def test_multi_round_stress_is_deterministic_and_correct():
         assert torch.equal(node, first[0]) and torch.equal(co, first[1])
     np.testing.assert_allclose(first[0].cpu().numpy(), rn, atol=ATOL, rtol=0)
     np.testing.assert_allclose(first[1].cpu().numpy(), rc, atol=ATOL, rtol=0)
+
+
+def test_concurrent_launches_do_not_change_results():
+    """Two launches of the layer running concurrently on different HIP streams (edge passes next to the other chunk's
+    GEMMs, LDS-DMA traffic of foreign workgroups on every CU) must give bit for bit what the same chunks give one after
+    the other.  (This is how the ds_bpermute_b32 problem of the stress test above reproduces within seconds.)"""
+    from egnn_pytorch_amd import EGNN
+    torch.manual_seed(0)
+    layer = EGNN(dim=512, num_nearest_neighbors=32, soft_edges=True).cuda().eval()
+    with torch.no_grad():
+        for p_ in layer.parameters():                       # xavier-scale so that the gate / coordinate weights matter
+            if p_.ndim == 2:
+                p_.copy_(torch.randn_like(p_) * (2.0 / (p_.shape[0] + p_.shape[1])) ** 0.5)
+    g = torch.Generator().manual_seed(1)
+    b, n, nchunk = 32, 1024, 4
+    feats, coors = torch.randn(b, n, 512, generator=g).cuda(), torch.randn(b, n, 3, generator=g).cuda()
+    mask = torch.ones(b, n, dtype=torch.bool, device="cuda")
+    cs = b // nchunk
+    chunk = lambda c: (feats[c * cs:(c + 1) * cs], coors[c * cs:(c + 1) * cs], mask[c * cs:(c + 1) * cs])
+    seq = [layer(f, x, mask=m) for f, x, m in map(chunk, range(nchunk))]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for _ in range(4):
+        main = torch.cuda.current_stream()
+        for s_ in streams:
+            s_.wait_stream(main)
+        outs = []
+        for c in range(nchunk):
+            with torch.cuda.stream(streams[c % 2]):
+                f, x, m = chunk(c)
+                outs.append(layer(f, x, mask=m))
+        for s_ in streams:
+            main.wait_stream(s_)
+        torch.cuda.synchronize()
+        for o, r in zip(outs, seq):
+            assert torch.equal(o[0], r[0]) and torch.equal(o[1], r[1])
 
 
 def test_cpu_input_raises():
