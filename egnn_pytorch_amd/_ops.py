@@ -6,6 +6,7 @@ enqueues one HIP kernel on torch's current stream.
 from __future__ import annotations
 
 import contextlib
+import os
 from ctypes import byref
 
 import torch
@@ -56,6 +57,22 @@ def _timed(name):
     _timer.records.append((name, e0, e1))
 
 
+_POISON = os.environ.get("EGNN_POISON_ALLOC", "0") == "1"
+
+
+def empty(*shape, dtype, device):
+    """torch.empty for kernel outputs / workspaces.  EGNN_POISON_ALLOC=1 (test aid) fills them with NaN / 0x7f bytes
+    first: an element a kernel forgets to write can then not hide behind stale-but-correct data that the caching
+    allocator hands back from the previous call."""
+    t = torch.empty(*shape, dtype=dtype, device=device)
+    if _POISON:
+        if t.dtype.is_floating_point:
+            t.fill_(float("nan"))
+        else:
+            t.view(torch.uint8).fill_(0x7F)
+    return t
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -76,8 +93,8 @@ def _u8(t):
 def knn_select(coors, mask, adj_mat, k):
     """(idx int32 (B,N,K), rank fp32 (B,N,K)) -- egnn_knn_select_f32."""
     b, n, cdim = coors.shape
-    idx = torch.empty(b, n, k, dtype=torch.int32, device=coors.device)
-    rank = torch.empty(b, n, k, dtype=torch.float32, device=coors.device)
+    idx = empty(b, n, k, dtype=torch.int32, device=coors.device)
+    rank = empty(b, n, k, dtype=torch.float32, device=coors.device)
     m8 = _u8(mask)
     a8 = _u8(adj_mat)
     stride = 0
@@ -98,7 +115,7 @@ def knn_select(coors, mask, adj_mat, k):
 def spatial_order(coors):
     """(B,N) int32 Morton permutation -- egnn_spatial_order_f32 (scheduling aid for the edge pass)."""
     b, n, _ = coors.shape
-    order = torch.empty(b, n, dtype=torch.int32, device=coors.device)
+    order = empty(b, n, dtype=torch.int32, device=coors.device)
     with _timed("spatial_order"):
         rc = _abi.load().egnn_spatial_order_f32(_ptr(coors), b, n, _ptr(order), _stream())
     _abi.check(rc, "egnn_spatial_order_f32")
@@ -114,9 +131,9 @@ def adj_expand(adj_mat, b, num_adj_degrees):
     if a8.dim() == 3 and a8.shape[0] != b:
         raise ValueError(f"adj_mat batch {a8.shape[0]} != {b}")
     dev = a8.device
-    adj_out = torch.empty(b, n, n, dtype=torch.uint8, device=dev)
-    deg = torch.empty(b, n, n, dtype=torch.uint8, device=dev)
-    ws = torch.empty(_abi.load().egnn_adj_expand_workspace_bytes(b, n), dtype=torch.uint8, device=dev)
+    adj_out = empty(b, n, n, dtype=torch.uint8, device=dev)
+    deg = empty(b, n, n, dtype=torch.uint8, device=dev)
+    ws = empty(_abi.load().egnn_adj_expand_workspace_bytes(b, n), dtype=torch.uint8, device=dev)
     with _timed("adj_expand"):
         rc = _abi.load().egnn_adj_expand_u8(_ptr(a8), stride, b, n, num_adj_degrees, _ptr(adj_out), _ptr(deg), _ptr(ws),
                                             _stream())
@@ -140,7 +157,7 @@ def linear(a, w, bias=None, residual=None, act=0, name="linear"):
     m, k = a.shape
     n = w.shape[0]
     assert w.shape[1] == k and a.is_contiguous() and w.is_contiguous()
-    c = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    c = empty(m, n, dtype=torch.float32, device=a.device)
     ldr = 0
     if residual is not None:
         assert residual.shape == (m, n) and residual.is_contiguous()
@@ -158,7 +175,7 @@ def linear_split(a, wsplit, n, bias=None, residual=None, act=0, name="linear"):
     whi, wlo, inv = wsplit
     m, k = a.shape
     assert a.is_contiguous() and whi.shape == wlo.shape and whi.shape[0] >= n and whi.shape[1] >= k
-    c = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    c = empty(m, n, dtype=torch.float32, device=a.device)
     ldr = 0
     if residual is not None:
         assert residual.shape == (m, n) and residual.is_contiguous()
@@ -176,8 +193,9 @@ def _kpad(k):
 
 def _packed_empty(rows, kp, device, zero=False):
     n = (rows + 31) // 32 * 32 * kp
-    alloc = torch.zeros if zero else torch.empty
-    return alloc(n, dtype=torch.float16, device=device)
+    if zero:
+        return torch.zeros(n, dtype=torch.float16, device=device)
+    return empty(n, dtype=torch.float16, device=device)
 
 
 class PackedHL:
@@ -214,7 +232,7 @@ def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32
     m, kp = a.rows, a.kp
     assert whi.numel() == w_rows * kp and w_rows >= n
     dev = a.hi.device
-    c = torch.empty(m, n, dtype=torch.float32, device=dev) if out_f32 else None
+    c = empty(m, n, dtype=torch.float32, device=dev) if out_f32 else None
     out = None
     kp_out = 0
     if out_hl:
@@ -259,7 +277,7 @@ def node_prep_hl(feats2d, m_i, gamma, beta, eps, m_dim, with_raw=False):
 
 def node_prep(feats2d, m_i, gamma, beta, eps, m_dim):
     rows, dim = feats2d.shape
-    out = torch.empty(rows, dim + m_dim, dtype=torch.float32, device=feats2d.device)
+    out = empty(rows, dim + m_dim, dtype=torch.float32, device=feats2d.device)
     with _timed("node_prep"):
         rc = _abi.load().egnn_node_prep_f32(_ptr(feats2d), _ptr(m_i), _ptr(gamma), _ptr(beta), float(eps),
                                             _ptr(out), rows, dim, m_dim, _stream())

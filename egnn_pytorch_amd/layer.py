@@ -186,7 +186,7 @@ class EGNN(nn.Module):
             if self.coors_mlp is not None:
                 a.W3h, a.b3, a.W4, a.b4 = (w[x].data_ptr() for x in ("W3h", "b3", "W4", "b4"))
                 a.w3_inv_scale = w["w3_inv_scale"]
-                coors_out = torch.empty_like(coors)
+                coors_out = _ops.empty(*coors.shape, dtype=coors.dtype, device=coors.device)
                 a.coors_out = coors_out.data_ptr()
             if self.norm_coors:
                 a.coors_scale = w["coors_scale"].data_ptr()
