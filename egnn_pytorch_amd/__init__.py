@@ -8,6 +8,7 @@ include/egnn_hip.h).  PyTorch is used for device memory, streams and torch.distr
 from .layer import EGNN, EGNN_Network, CoorsNorm
 from ._ops import phase_timer
 from . import sharding
+from .graph import graphed
 
-__all__ = ["EGNN", "EGNN_Network", "CoorsNorm", "phase_timer", "sharding"]
+__all__ = ["EGNN", "EGNN_Network", "CoorsNorm", "phase_timer", "sharding", "graphed"]
 __version__ = "0.1.0"
