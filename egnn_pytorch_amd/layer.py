@@ -122,12 +122,16 @@ class EGNN(nn.Module):
 
     @torch.no_grad()
     def forward(self, feats, coors, edges=None, mask=None, adj_mat=None):
+        return self._forward_with_hint(feats, coors, edges, mask, adj_mat, None)[:2]
+
+    def _forward_with_hint(self, feats, coors, edges, mask, adj_mat, order_hint):
+        """forward + the scheduling permutation it used (EGNN_Network hands layer 0's on to the next layers)."""
         self._check_inputs(feats, coors, edges, mask, adj_mat)
         _abi.load()
         with torch.cuda.device(feats.device):
-            return self._forward_hip(feats, coors, edges, mask, adj_mat)
+            return self._forward_hip(feats, coors, edges, mask, adj_mat, order_hint)
 
-    def _forward_hip(self, feats, coors, edges, mask, adj_mat):
+    def _forward_hip(self, feats, coors, edges, mask, adj_mat, order_hint=None):
         b, n, dim = feats.shape
         w = self.packed_weights()
         feats = feats.contiguous()
@@ -155,7 +159,7 @@ class EGNN(nn.Module):
             k = n
 
         node_out, coors_out = feats, coors
-        node_in = None
+        node_in = order = None
         if k > 0:
             # ---- node-level projections P = feats [W_i ; W_j]^T + [b1 ; 0]
             # (K % 32 == 0: the edge pass feeds P_i to its first-layer MFMA as (fp16 hi, fp16 lo) words)
@@ -196,7 +200,11 @@ class EGNN(nn.Module):
             a.idx, a.rank = _ops._ptr(idx), _ops._ptr(rank)
             order = None
             if idx is not None and adj_mat is None and 64 <= n <= 4096 and _SPATIAL_ORDER and coors.shape[-1] == 3:
-                order = _ops.spatial_order(coors)       # k-NN path: neighbours are spatial -> share gathered rows in L1
+                # k-NN path: neighbours are spatial -> workgroups that own Morton-adjacent nodes share gathered rows in L1.
+                # Scheduling only (results do not depend on it), so a stack of layers reuses the first layer's order:
+                # coordinates move by small steps per layer and the locality survives.
+                order = order_hint if (order_hint is not None and tuple(order_hint.shape) == (b, n)) \
+                    else _ops.spatial_order(coors)
                 a.order = order.data_ptr()
             a.valid_radius = float(min(valid_radius, 3.0e38))
             cv = self.coor_weights_clamp_value
@@ -214,7 +222,7 @@ class EGNN(nn.Module):
             hid = _ops.linear_hl(node_in, w["W5_split"], 2 * dim, w["b5"], act=1, out_f32=False, out_hl=True,
                                  name="node_mlp0")
             node_out = _ops.linear_hl(hid, w["W6_split"], dim, w["b6"], residual=feats2d, name="node_mlp1").view(b, n, dim)
-        return node_out, coors_out
+        return node_out, coors_out, order
 
 
 class EGNN_Network(nn.Module):
@@ -279,10 +287,11 @@ class EGNN_Network(nn.Module):
         if self.global_tokens is not None:
             global_tokens = self.global_tokens[None].expand(b, -1, -1)
         coor_changes = [coors]
+        order = None
         for global_attn, egnn in self.layers:
             if global_attn is not None:
                 feats, global_tokens = global_attn(feats, global_tokens, mask=mask)           # :445-446
-            feats, coors = egnn(feats, coors, adj_mat=adj_mat, edges=edges, mask=mask)
+            feats, coors, order = egnn._forward_with_hint(feats, coors, edges, mask, adj_mat, order)
             coor_changes.append(coors)
         if return_coor_changes:
             return feats, coors, coor_changes
