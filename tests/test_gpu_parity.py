@@ -69,6 +69,11 @@ CONFIGS = [
      dict(mask=True, edges=True, scale={"edge_mlp.3.weight": 0.3, "coors_mlp.3.weight": 0.3})),
     ("k20_fourier4_edges7_s16", dict(dim=32, num_nearest_neighbors=20, fourier_features=4, edge_dim=7), 2, 50,
      dict(mask=True, edges=True)),
+    # degenerate sizes: a single node (dense: only the self edge), two nodes, k = 1 (self only), N < one MFMA tile
+    ("tiny_n1_dense", dict(dim=16), 2, 1, dict()),
+    ("tiny_n2_dense_mask", dict(dim=16, edge_dim=1), 3, 2, dict(mask_exact=[2, 1, 2], edges=True)),
+    ("tiny_n5_k1", dict(dim=16, num_nearest_neighbors=1), 2, 5, dict(mask=True)),
+    ("tiny_n3_k3_mean_gate", dict(dim=8, num_nearest_neighbors=3, m_pool_method="mean", soft_edges=True, m_dim=4), 1, 3, dict()),
     # coordinate dimension other than 3 (generic-C compilation of the select and edge kernels)
     ("coor_dim5_k32_normcoors", dict(dim=32, num_nearest_neighbors=32, norm_coors=True), 2, 64, dict(mask=True, coor_dim=5)),
     ("coor_dim7_dense_edges", dict(dim=32, edge_dim=2), 1, 40, dict(edges=True, coor_dim=7)),
@@ -99,6 +104,8 @@ def test_layer_vs_oracle(name, kwargs, b, n, flags):
     if flags.get("mask"):
         lens = rng.integers(n // 2, n + 1, size=b)
         mask = np.arange(n)[None, :] < lens[:, None]
+    if flags.get("mask_exact"):
+        mask = np.arange(n)[None, :] < np.asarray(flags["mask_exact"])[:, None]
     if flags.get("edges"):
         edges = (rng.standard_normal((b, n, n, kwargs["edge_dim"])) * flags.get("edges_mul", 1.0)).astype(np.float32)
     if flags.get("adj") == "chain":
