@@ -146,6 +146,9 @@ class EGNN(nn.Module):
         valid_radius = self.valid_radius
         use_nearest = num_nearest > 0 or self.only_sparse_neighbors
         idx = rank = None
+        if b == 0 or (n == 0 and not use_nearest):
+            # empty batch / empty dense graphs: the reference returns empty outputs (N = 0 on the k-NN path: topk's error)
+            return torch.empty_like(feats), torch.empty_like(coors), None
         if use_nearest:
             if adj_mat is not None and self.only_sparse_neighbors:
                 num_nearest = _ops.adj_max_degree(adj_mat)                # host sync, as upstream (:249)

@@ -403,6 +403,19 @@ def test_hip_graph_replay_matches_eager():
         run(f[:1], c[:1], mask=mask[:1])
 
 
+def test_empty_inputs_behave_like_the_reference():
+    """B = 0 and (dense) N = 0 give empty outputs; N = 0 on the k-NN path raises topk's error (measured on the reference)."""
+    from egnn_pytorch_amd import EGNN
+    dense, knn = EGNN(dim=8).cuda().eval(), EGNN(dim=8, num_nearest_neighbors=2).cuda().eval()
+    for layer in (dense, knn):
+        f, c = layer(torch.randn(0, 5, 8).cuda(), torch.randn(0, 5, 3).cuda())
+        assert f.shape == (0, 5, 8) and c.shape == (0, 5, 3)
+    f, c = dense(torch.randn(2, 0, 8).cuda(), torch.randn(2, 0, 3).cuda())
+    assert f.shape == (2, 0, 8) and c.shape == (2, 0, 3)
+    with pytest.raises(RuntimeError, match="out of range"):
+        knn(torch.randn(2, 0, 8).cuda(), torch.randn(2, 0, 3).cuda())
+
+
 def test_cpu_input_raises():
     from egnn_pytorch_amd import EGNN
     layer = EGNN(dim=8)
