@@ -85,7 +85,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 constexpr int edge_min_blocks(int nm, int tpi)
 {
     if (nm >= 12) return 1;
-    if (nm > 1) return 2;
+    if (nm > 4) return 2;
+    if (nm > 1) return (CDM == 3 && tpi == 2) ? 3 : 2;
     return (CDM == 3 && tpi == 2) ? EGNN_EDGE_MINW : 3;
 }
 
