@@ -107,10 +107,11 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // NM: chained first-layer MFMAs (4 split terms each, 3 terms per per-edge scalar); HCT: hidden columns per LDS chunk;
 // TPI: consecutive tiles of a wave that share one node i (K % 32 == 0 -> 2 = both tiles of a wave, P_i rides in the
 // MFMA; else 1 = per-lane P_i rows, added on the VALU).
+// (The body is a device function of the block index so that a dispatcher kernel can give a workgroup slot either an edge
+// group or a GEMM tile: csrc/mix_probe.hip.)
 template <int NM, int HCT, int TPI>
-__global__ __launch_bounds__(EDGE_THREADS, edge_min_blocks(NM, TPI)) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
+__device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, const int gpg, char* smem, const int bid, const int nblk)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HC = HCT;
     const int S = p.S;
     _Float16* w2s = reinterpret_cast<_Float16*>(smem);                  // [HC/32][hi|lo][64][8] halves = HC * 64 bytes
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(EDGE_THREADS, edge_min_blocks(NM, TPI)) void edge_k
     const int e = lane & 15;
     const int g = lane >> 4;
 
-    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int v = xcd_remap(bid, nblk);
     const int b = v / gpg;
     const int node0 = (v % gpg) * G;
     const int N = p.N, K = p.K;
@@ -578,6 +579,13 @@ __global__ __launch_bounds__(EDGE_THREADS, edge_min_blocks(NM, TPI)) void edge_k
             if (p.coors_out) p.coors_out[(bN + i) * C + (ch - 16)] = p.coors[(bN + i) * C + (ch - 16)] + val;
         }
     }
+}
+
+template <int NM, int HCT, int TPI>
+__global__ __launch_bounds__(EDGE_THREADS, edge_min_blocks(NM, TPI)) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    edge_body<NM, HCT, TPI>(p, G, gpg, smem, blockIdx.x, gridDim.x);
 }
 
 template <int NM, int HCT, int TPI>

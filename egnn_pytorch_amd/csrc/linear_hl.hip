@@ -49,15 +49,15 @@ template <> struct Cfg<2> { static constexpr int BM = 256, BN = 256, WM = 2, WN 
 //     s_barrier                      ... and everyone else's; also: every wave is done reading the ring slot of tile kt-1
 //     issue the DMAs of tile kt+S-1 into that slot
 //     fragments of tile kt -> 3 x TI x TJ MFMAs
+// (Device function of the block index: see edge_fused.hip::edge_body.)
 template <int CFG, int ACT, bool HAS_RES>
-__global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl_kernel(
+__device__ __forceinline__ void linear_hl_body(
     const _Float16* __restrict__ Ahi, const _Float16* __restrict__ Alo,
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
     const float* __restrict__ bias, const float* __restrict__ R, int64_t ldr,
     float* __restrict__ C, int64_t ldc, _Float16* __restrict__ Chi, _Float16* __restrict__ Clo, int nkt_out,
-    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols)
+    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, char* smem, const int bid)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // STAGES x BUF
     using C_ = Cfg<CFG>;
     constexpr int BM = C_::BM, BN = C_::BN, TI = C_::TI, TJ = C_::TJ, STAGES = C_::STAGES;
     constexpr int WAVES = C_::WM * C_::WN;
@@ -75,7 +75,6 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
 
     // ---- block -> tile (XCD-contiguous, bijective; grouped over M)
     const int nblk = ntm * ntn;
-    const int bid = blockIdx.x;
     const int q = nblk >> 3, rr = nblk & 7;
     const int xcd = bid & 7;
     const int v = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
@@ -157,6 +156,7 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
     for (int kt = 0; kt < nk; ++kt) {
         if (STAGES == 4 && DPW == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else if (STAGES == 3 && DPW == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else if (STAGES == 3 && DPW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -269,6 +269,19 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
             }
         }
     }
+}
+
+template <int CFG, int ACT, bool HAS_RES>
+__global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl_kernel(
+    const _Float16* __restrict__ Ahi, const _Float16* __restrict__ Alo,
+    const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
+    const float* __restrict__ bias, const float* __restrict__ R, int64_t ldr,
+    float* __restrict__ C, int64_t ldc, _Float16* __restrict__ Chi, _Float16* __restrict__ Clo, int nkt_out,
+    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // STAGES x BUF
+    linear_hl_body<CFG, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, ntm, ntn,
+                                      out_scale, split_cols, smem, blockIdx.x);
 }
 
 template <int CFG, int ACT, bool HAS_RES>
