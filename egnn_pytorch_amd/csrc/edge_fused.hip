@@ -87,7 +87,7 @@ constexpr int edge_min_blocks(int nm, int tpi)
     if (nm >= 12) return 1;
     if (nm > 4) return 2;
     if (nm > 1) return (CDM == 3 && tpi == 2) ? 3 : 2;
-    return (CDM == 3 && tpi == 2) ? EGNN_EDGE_MINW : 3;
+    return (CDM == 3 && tpi >= 1) ? EGNN_EDGE_MINW : 3;
 }
 
 __device__ __forceinline__ float row16_sum(float v) { return egnn_row16_sum(v); }
@@ -104,9 +104,21 @@ __device__ __forceinline__ uint32_t pack_h2(_Float16 a, _Float16 b)
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff)
+{
+    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(f32x4, (u32x4v)__builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ uint32_t buf_load1(__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff)
+{
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0);
+}
+
 // NM: chained first-layer MFMAs (4 split terms each, 3 terms per per-edge scalar); HCT: hidden columns per LDS chunk;
-// TPI: consecutive tiles of a wave that share one node i (K % 32 == 0 -> 2 = both tiles of a wave, P_i rides in the
-// MFMA; else 1 = per-lane P_i rows, added on the VALU).
+// TPI: how P_i reaches x.  2 (K % 32 == 0): the 32 slots of a wave belong to one node -- its (hi, lo) row rides in the
+// first-layer MFMA (K-slots 0, 1).  1 (K >= 6): the 16 slots of a tile touch at most 4 nodes -- their rows sit in the
+// K-slots 4g, 4g+1 of lane group g and every edge selects its node with a (1, 1) there.  0 (K < 6): fp32 P_i, added per
+// lane on the VALU.
 // (The body is a device function of the block index so that a dispatcher kernel can give a workgroup slot either an edge
 // group or a GEMM tile: csrc/mix_probe.hip.)
 template <int NM, int HCT, int TPI>
@@ -116,7 +128,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
     const int S = p.S;
     _Float16* w2s = reinterpret_cast<_Float16*>(smem);                  // [HC/32][hi|lo][64][8] halves = HC * 64 bytes
     float* xchall = reinterpret_cast<float*>(smem + HC * 64);           // [EDGE_WAVES][32 slots][XLD]: per-wave gather exchange
-    float* ebuf = xchall;                                                // [slots][NCH] aliases it (TPI == 1 epilogue only)
+    float* ebuf = xchall;                                                // [slots][NCH] aliases it (TPI != 2 epilogue only)
     float* nodeacc = xchall + SLOTS_PER_ROUND * XLD;                    // [G][NCH]
     char* wst = reinterpret_cast<char*>(nodeacc + G * NCH);             // [HC][4 NM] dwords: first-layer A fragments
 
@@ -135,15 +147,23 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
     const bool has_mask = p.mask != nullptr;
     const bool has_rank = p.rank != nullptr && p.idx != nullptr;
     const size_t bN = (size_t)b * N;
+    // Buffer resources over this graph's rows of P_j / P_i: the gathers are `buffer_load ... offen` with a 32-bit per-lane
+    // byte offset (one address register per stream) and the hidden-unit offset of the step in the SCALAR offset operand --
+    // no vector address arithmetic inside the loop.
+    const uint32_t prow_bytes = (uint32_t)((size_t)N * p.ldp * 4);
+    const __amdgpu_buffer_rsrc_t pj_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Pj + bN * p.ldp), 0, prow_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pi_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Pi + bN * p.ldp), 0, prow_bytes, 0x00020000);
 
     for (int o = tid; o < G * NCH; o += EDGE_THREADS) nodeacc[o] = 0.f;
 
     for (int round = 0; round < rounds; ++round) {
         // ------------------------------------------------------------------ per-slot setup
-        const float* pip[TILES];                             // TPI == 1: this lane's P_i row (+ 4 g)
-        const uint32_t* piw = nullptr;                       // TPI == 2: the wave's P_i row as (hi, lo) words (+ lane & 15)
+        uint32_t pip[TILES];                                 // TPI == 0: byte offset of this lane's fp32 P_i row (+ 4 g)
+        uint32_t piw[TPI == 1 ? TILES : 1] = {};             // byte offset of: TPI == 2: the wave's P_i row as (hi, lo) words
+                                                             // (+ lane & 15); TPI == 1: per tile, the row of the tile's g-th node
         u32x2 bq[TILES][NM];                                 // B fragments of the first-layer MFMAs (constant over the hidden loop)
-        float rel[TILES][CDM];                               // x_i - x_j (components >= C are 0)
+        int ei[TILES], ej[TILES];                            // node / neighbour of this lane's edge: x_i - x_j is recomputed in the
+                                                             // epilogue instead of living in 2 x CDM registers across the hidden loop
         bool fm[TILES];                                      // edge contributes (valid slot and unmasked)
 
         // TPI == 2 (K % 32 == 0): the 32 slots of a wave belong to ONE node -> node index and first k are wave-uniform
@@ -165,14 +185,18 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             const float* ci = p.coors + (bN + i) * C;
             const float* cj = p.coors + (bN + j) * C;
             float d;
-            if (CDM == 3) {
-                d = egnn_sqdist(ci[0], ci[1], ci[2], cj[0], cj[1], cj[2], rel[t][0], rel[t][1], rel[t][2]);
-            } else {
-                float a[CDM], bb[CDM];
+            {
+                float rel0[CDM];
+                if (CDM == 3) {
+                    d = egnn_sqdist(ci[0], ci[1], ci[2], cj[0], cj[1], cj[2], rel0[0], rel0[1], rel0[2]);
+                } else {
+                    float a[CDM], bb[CDM];
 #pragma unroll
-                for (int c = 0; c < CDM; ++c) { a[c] = c < C ? ci[c] : 0.f; bb[c] = c < C ? cj[c] : 0.f; }
-                d = egnn_sqdist_n<CDM>(a, bb, C, rel[t]);
+                    for (int c = 0; c < CDM; ++c) { a[c] = c < C ? ci[c] : 0.f; bb[c] = c < C ? cj[c] : 0.f; }
+                    d = egnn_sqdist_n<CDM>(a, bb, C, rel0);
+                }
             }
+            ei[t] = i; ej[t] = j;
 
             // Per-edge scalars [sin(d/2^f)..., cos(d/2^f)..., d, edges...] (egnn_pytorch.py:34-41, 282-285) as B
             // fragments of v_mfma_f32_16x16x16_f16: lane group g of MFMA m carries split term tau = 4 m + g of scalar
@@ -187,7 +211,9 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 u32x2 bw = u32x2{0u, 0u};
                 if (sidx < S) {
                     float val;
-                    if (sidx < F) val = sinf(d * exp2f(-(float)sidx));
+                    if (NM == 1 && TPI != 2) val = d;                   // NM == 1 <=> S == 1: d is the only scalar (TPI == 2 keeps the generic
+                                                                        // form: the shortcut tips its register allocation into a spill)
+                    else if (sidx < F) val = sinf(d * exp2f(-(float)sidx));
                     else if (sidx < 2 * F) val = cosf(d * exp2f(-(float)(sidx - F)));
                     else if (sidx == 2 * F) val = d;
                     else val = p.edges[((bN + i) * N + j) * p.edge_dim + (sidx - 2 * F - 1)];
@@ -199,6 +225,11 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                     bw[1] = kind == 0 ? pack_h2(s1, s1) : (kind == 1 ? pack_h2(rh, rh) : pack_h2(rl, (_Float16)0.f));
                 }
                 if (TPI == 2 && m == 0 && g == 0) bw[0] = pack_h2((_Float16)1.f, (_Float16)1.f);   // x (P_i hi, P_i lo)
+                if (TPI == 1 && m == 0) {
+                    // the tile's slots start in node nf and end at most 3 nodes later (K >= 6): lane group g carries node nf + g
+                    const int nf = (qwave + t * 16) / K;
+                    if (nl - nf == g) bw[0] = pack_h2((_Float16)1.f, (_Float16)1.f);
+                }
                 bq[t][m] = bw;
             }
 
@@ -208,15 +239,21 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 if (has_rank) em = em && (p.rank[(bN + i) * K + k] <= p.valid_radius);
             }
             fm[t] = em;
-            pip[t] = p.Pi + (bN + i) * p.ldp + 4 * g;
-            if (TPI == 2 && t == 0) piw = reinterpret_cast<const uint32_t*>(p.Pi) + (bN + i) * p.ldp + e;
+            pip[t] = (uint32_t)(((size_t)i * p.ldp + 4 * g) * 4);
+            if (TPI == 2 && t == 0) piw[0] = (uint32_t)(((size_t)i * p.ldp + e) * 4);
+            if (TPI == 1) {
+                int posg = node0 + (qwave + t * 16) / K + g;                 // the tile's g-th node (any valid row if there is none)
+                if (posg >= N || posg >= node0 + G) posg = node0 < N ? node0 : 0;
+                const int ig = p.order ? p.order[bN + posg] : posg;
+                piw[t] = (uint32_t)(((size_t)ig * p.ldp + e) * 4);
+            }
         }
 
         // Gather addressing.  A wave-level load instruction is processed line by line (measured,
         // tools/ubench/gather.hip: 16 half-used 128-B lines per instruction run at 9.7 TB/s, 8 fully used lines at
         // 20.9 TB/s), so P_j is fetched as whole lines -- lane l reads 16-byte chunk (l & 7) of the row of slot
         // 8*q + (l >> 3) -- and redistributed to the MFMA accumulator layout through a wave-private LDS buffer.
-        const float* gptr[4];
+        uint32_t goff[4];
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
             const int q = qwave + qq * 8 + (lane >> 3);
@@ -227,9 +264,9 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             const int i2 = p.order ? p.order[bN + pos] : pos;
             const int j2 = p.idx ? p.idx[(bN + i2) * K + k] : k;
 #if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 1)
-            gptr[qq] = p.Pj + (bN + (size_t)(i2 & ~7)) * p.ldp + 4 * (lane & 7);
+            goff[qq] = (uint32_t)(((size_t)(i2 & ~7) * p.ldp + 4 * (lane & 7)) * 4);
 #else
-            gptr[qq] = p.Pj + (bN + j2) * p.ldp + 4 * (lane & 7);
+            goff[qq] = (uint32_t)(((size_t)j2 * p.ldp + 4 * (lane & 7)) * 4);
 #endif
         }
         // Exchange buffer: row = slot (128 B), 16-byte chunk c stored at position c ^ ((row >> 1) & 7): the parking
@@ -261,19 +298,22 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
         // Software pipeline: the Pi/Pj rows of step st+1 are requested before step st is computed, so the
         // gather latency (L2 / Infinity Cache) hides under the SiLU work of the current step.
         f32x4 gl[4];
-        f32x4 pin[TPI == 1 ? TILES : 1][2];
-        uint32_t piv[2] = {0u, 0u};
+        f32x4 pin[TPI == 0 ? TILES : 1][2];
+        uint32_t piv[TPI == 1 ? TILES : 1][2] = {};
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) gl[qq] = *reinterpret_cast<const f32x4*>(gptr[qq]);
-        if (TPI == 1) {
+        for (int qq = 0; qq < 4; ++qq) gl[qq] = buf_load4(pj_rsrc, goff[qq], 0);
+        if (TPI == 0) {
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
-                pin[t][0] = *reinterpret_cast<const f32x4*>(pip[t]);
-                pin[t][1] = *reinterpret_cast<const f32x4*>(pip[t] + 16);
+                pin[t][0] = buf_load4(pi_rsrc, pip[t], 0);
+                pin[t][1] = buf_load4(pi_rsrc, pip[t], 64);
             }
         } else {
-            piv[0] = piw[0];
-            piv[1] = piw[16];
+#pragma unroll
+            for (int t = 0; t < (TPI == 1 ? TILES : 1); ++t) {
+                piv[t][0] = buf_load1(pi_rsrc, piw[t], 0);
+                piv[t][1] = buf_load1(pi_rsrc, piw[t], 64);
+            }
         }
 
         for (int c0 = 0; c0 < p.Hp; c0 += HC) {
@@ -307,7 +347,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 int hnext = hoff + KSTEP;
                 if (hnext >= p.Hp) hnext = hoff;                 // last step: harmless re-read
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) gl[qq] = *reinterpret_cast<const f32x4*>(gptr[qq] + hnext);
+                for (int qq = 0; qq < 4; ++qq) gl[qq] = buf_load4(pj_rsrc, goff[qq], hnext * 4);
                 // Same-wave hand-off through LDS: DS operations of one wave execute in issue order; the explicit
                 // lgkmcnt(0) makes the store -> other-lane load dependency independent of that (4 stores, negligible).
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -331,18 +371,28 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 }
                 const f16x8 whi = *reinterpret_cast<const f16x8*>(w2s + ((st * 2 + 0) * 64 + lane) * 8);
                 const f16x8 wlo = *reinterpret_cast<const f16x8*>(w2s + ((st * 2 + 1) * 64 + lane) * 8);
-                if (TPI == 2) {
-                    av[0][0][0] = piv[0];                          // K-slots 4g, 4g+1 (B is zero there for g > 0)
-                    av[0][1][0] = piv[1];
-                    piv[0] = piw[hnext];
-                    piv[1] = piw[hnext + 16];
-                } else {
+                u32x2 a0[TILES][2];                                // first MFMA's A operand: K-slots 4g, 4g+1 = P_i (hi, lo)
+                if (TPI == 0) {
 #pragma unroll
                     for (int t = 0; t < TILES; ++t) {
                         x[t][0] += pin[t][0];
                         x[t][1] += pin[t][1];
-                        pin[t][0] = *reinterpret_cast<const f32x4*>(pip[t] + hnext);
-                        pin[t][1] = *reinterpret_cast<const f32x4*>(pip[t] + hnext + 16);
+                        pin[t][0] = buf_load4(pi_rsrc, pip[t], hnext * 4);
+                        pin[t][1] = buf_load4(pi_rsrc, pip[t], hnext * 4 + 64);
+                        a0[t][0] = av[0][0];
+                        a0[t][1] = av[0][1];
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+                        const int pt = TPI == 1 ? t : 0;           // (TPI == 2: one row for both tiles; B is zero there for g > 0)
+                        a0[t][0] = u32x2{piv[pt][0], av[0][0][1]};
+                        a0[t][1] = u32x2{piv[pt][1], av[0][1][1]};
+                    }
+#pragma unroll
+                    for (int t = 0; t < (TPI == 1 ? TILES : 1); ++t) {
+                        piv[t][0] = buf_load1(pi_rsrc, piw[t], hnext * 4);
+                        piv[t][1] = buf_load1(pi_rsrc, piw[t], hnext * 4 + 64);
                     }
                 }
                 // First Linear of edge_mlp on the matrix cores: x += [P_i | W_s] x [1 | scalars]  (split-f16 products)
@@ -352,7 +402,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                         for (int m = 0; m < NM; ++m)
-                            x[t][hb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, av[m][hb]),
+                            x[t][hb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, m == 0 ? a0[t][hb] : av[m][hb]),
                                                                             __builtin_bit_cast(f16x4, bq[t][m]), x[t][hb], 0, 0, 0);
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
@@ -467,6 +517,17 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             }
         }
 
+        float rel[TILES][CDM];                               // x_i - x_j again (components >= C are 0)
+        {
+            const int C = (CDM == 3) ? 3 : p.coor_dim;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                const float* ci = p.coors + (bN + ei[t]) * C;
+                const float* cj = p.coors + (bN + ej[t]) * C;
+#pragma unroll
+                for (int c = 0; c < CDM; ++c) rel[t][c] = c < C ? ci[c] - cj[c] : 0.f;
+            }
+        }
         if (TPI == 2) {
             // The wave's 32 edges belong to one node: sum them in registers (DPP butterfly over the 16 edges of a
             // tile, fixed order -> deterministic) and hand 20 partials per wave to the cross-wave reduction.
@@ -612,10 +673,11 @@ int launch_edge(const egnn_edge_args& a, hipStream_t s)
 template <int NM, int HCT>
 int dispatch_tpi(const egnn_edge_args& a, hipStream_t s)
 {
-    // both tiles (32 consecutive slots) of a wave share node i when K is a multiple of 32: P_i then rides in the
-    // first-layer MFMA as (hi, lo) words (pi_split), otherwise it is added per lane from the fp32 projection
+    // K % 32 == 0: both tiles of a wave share node i; K >= 6: a tile touches <= 4 nodes -- either way P_i rides in the
+    // first-layer MFMA as (hi, lo) words (pi_split); K < 6: it is added per lane from the fp32 projection
     if (a.K % 32 == 0) return launch_edge<NM, HCT, 2>(a, s);
-    return launch_edge<NM, HCT, 1>(a, s);
+    if (a.K >= 6) return launch_edge<NM, HCT, 1>(a, s);
+    return launch_edge<NM, HCT, 0>(a, s);
 }
 
 }  // namespace
@@ -655,7 +717,7 @@ int EGNN_EDGE_ENTRY(const egnn_edge_args* args, void* stream)
     if (a.S != 2 * a.fourier + 1 + a.edge_dim) return EGNN_E_SHAPE;
     if (a.S > 16) return EGNN_E_UNSUPPORTED;
     if (!(a.ws_inv_scale > 0.f)) return EGNN_E_SHAPE;
-    if ((a.pi_split != 0) != (a.K % 32 == 0)) return EGNN_E_SHAPE;     // P_i format must match the kernel variant
+    if ((a.pi_split != 0) != (a.K >= 6)) return EGNN_E_SHAPE;          // P_i format must match the kernel variant
     if (a.edge_dim > 0 && !a.edges) return EGNN_E_NULLPTR;
     if (a.idx == nullptr && a.K != a.N) return EGNN_E_SHAPE;          // dense path: K == N
     if ((reinterpret_cast<uintptr_t>(a.Pi) & 15) || (reinterpret_cast<uintptr_t>(a.Pj) & 15) ||

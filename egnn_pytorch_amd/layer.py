@@ -165,9 +165,9 @@ class EGNN(nn.Module):
         node_in = order = None
         if k > 0:
             # ---- node-level projections P = feats [W_i ; W_j]^T + [b1 ; 0]
-            # (K % 32 == 0: the edge pass feeds P_i to its first-layer MFMA as (fp16 hi, fp16 lo) words)
+            # (K >= 6: the edge pass feeds P_i to its first-layer MFMA as (fp16 hi, fp16 lo) words)
             hp = w["Hp"]
-            pi_split = k % 32 == 0
+            pi_split = k >= 6
             if self.node_mlp is not None:
                 # one pass over feats: its (hi, lo) split for the projection AND [LayerNorm(feats) | 0] for node_mlp
                 # (egnn_pytorch.py:335-336); the edge pass drops m_i into the zero columns

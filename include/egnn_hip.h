@@ -171,7 +171,7 @@ typedef struct egnn_edge_args {
     int32_t edge_dim;           /* width of `edges` (0 if none) */
     int32_t S;                  /* per-edge scalar inputs: 2F + 1 + edge_dim  (<= 16) */
     int32_t pi_split;           /* format of Pi: 0 = fp32, 1 = (fp16 hi, fp16 lo) words (egnn_linear_hl_f32 split_cols);
-                                   must be 1 exactly when K % 32 == 0 */
+                                   must be 1 exactly when K >= 6 (P_i then rides in the first-layer MFMA) */
     /* node-level projections, produced by egnn_linear_hl_f32 */
     const float* Pi;            /* (B*N, ldp): -log2(e) * (W_i h_i + b1)      (pad columns must be 0) */
     const float* Pj;            /* (B*N, ldp): -log2(e) * W_j h_j, fp32 */
