@@ -36,6 +36,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 #define EGNN_KNN_BITS 16
 #endif
 constexpr int KNN_PREFIX_BITS = EGNN_KNN_BITS;   // key bits resolved by the pruning threshold of the fast path
+constexpr int KNN_SURVIVORS = 128;               // ... and survivors the fast path ranks directly (two per lane)
 constexpr int KNN_THREADS = 256;
 constexpr int KNN_WAVES = KNN_THREADS / 64;
 
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
 
         // ---- fast path (K <= 64): prune with the lane minima.  Let M be the K-th smallest of the 64 per-lane minima:
         // at least K candidates are <= M, so the K smallest candidates all are.  Typically only ~1.3 K candidates
-        // survive (N = 1024, K = 32: ~43); if they fit one per lane they are ranked by counting directly.
+        // survive (N = 1024, K = 32: ~43); if there are at most two per lane they are ranked by counting directly.
         bool done = false;
         if (K <= 64) {
             uint32_t lmin = key[0];
@@ -133,18 +134,31 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
             for (int c = 0; c < CPL; ++c) cl += key[c] <= M ? 1 : 0;
             const int incl = egnn_wave_inclusive_scan(cl);
             const int S = __builtin_amdgcn_readlane(incl, 63);
-            if (S <= 64) {                                   // wave-uniform
+            if (S <= KNN_SURVIVORS) {                        // wave-uniform; up to two survivors per lane
                 int pos = incl - cl;
 #pragma unroll
                 for (int c = 0; c < CPL; ++c)
                     if (key[c] <= M) selbuf[pos++] = ((uint64_t)key[c] << 32) | (uint32_t)(c * 64 + lane);
                 wave_lds_sync();
-                const uint64_t mine = lane < S ? selbuf[lane] : ~0ull;
-                int rnk = 0;
-                for (int u = 0; u < S; ++u) rnk += (selbuf[u] < mine) ? 1 : 0;
-                if (lane < S && rnk < K) {
-                    idx_out[obase + rnk] = (int32_t)(uint32_t)(mine & 0xFFFFFFFFull);
-                    rank_out[obase + rnk] = key2f((uint32_t)(mine >> 32));
+                const uint64_t mine0 = lane < S ? selbuf[lane] : ~0ull;
+                const uint64_t mine1 = lane + 64 < S ? selbuf[lane + 64] : ~0ull;
+                int rnk0 = 0, rnk1 = 0;
+                if (S <= 64) {                                // (wave-uniform) the common case: one survivor per lane
+                    for (int u = 0; u < S; ++u) rnk0 += (selbuf[u] < mine0) ? 1 : 0;
+                } else {
+                    for (int u = 0; u < S; ++u) {
+                        const uint64_t o = selbuf[u];
+                        rnk0 += (o < mine0) ? 1 : 0;
+                        rnk1 += (o < mine1) ? 1 : 0;
+                    }
+                }
+                if (lane < S && rnk0 < K) {
+                    idx_out[obase + rnk0] = (int32_t)(uint32_t)(mine0 & 0xFFFFFFFFull);
+                    rank_out[obase + rnk0] = key2f((uint32_t)(mine0 >> 32));
+                }
+                if (lane + 64 < S && rnk1 < K) {
+                    idx_out[obase + rnk1] = (int32_t)(uint32_t)(mine1 & 0xFFFFFFFFull);
+                    rank_out[obase + rnk1] = key2f((uint32_t)(mine1 >> 32));
                 }
                 wave_lds_sync();
                 done = true;
@@ -221,7 +235,7 @@ int launch_knn_c(const float* coors, const uint8_t* mask, const uint8_t* adj, in
                  int K, int C, int32_t* idx_out, float* rank_out, hipStream_t s)
 {
     const int Npad = (N + 63) / 64 * 64;
-    const int Kpad = K > 64 ? (K + 1) / 2 * 2 : 64;        // the fast path parks up to 64 survivors
+    const int Kpad = K > KNN_SURVIVORS ? (K + 1) / 2 * 2 : KNN_SURVIVORS;      // the fast path parks up to 128 survivors
     int rows_per_wg = 32;
     if (N < rows_per_wg) rows_per_wg = (N + 3) / 4 * 4;
     const size_t cbytes = (size_t)Npad * (4 * C + 1);
