@@ -107,21 +107,32 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
 
         const size_t obase = ((size_t)b * N + i) * K;
 
-        // ---- fast path (K <= 64): prune with the lane minima.  Let M be the K-th smallest of the 64 per-lane minima:
-        // at least K candidates are <= M, so the K smallest candidates all are.  Typically only ~1.3 K candidates
+        // ---- fast path (K <= 64): prune with the lane minima.  Let M be the K-th smallest of the 64 per-lane minima (for
+        // K > 32: of the 128 smallest-two-per-lane keys): at least K candidates are <= M, so the K smallest all are.  Typically only ~1.3 K candidates
         // survive (N = 1024, K = 32: ~43); if there are at most two per lane they are ranked by counting directly.
         bool done = false;
         if (K <= 64) {
-            uint32_t lmin = key[0];
+            uint32_t lmin = key[0], lmin2 = 0xFFFFFFFFu;
+            const bool two = K > 32;                          // wave-uniform: K > 32 prunes with the TWO smallest keys per lane
+            if (two) {
 #pragma unroll
-            for (int c = 1; c < CPL; ++c) lmin = key[c] < lmin ? key[c] : lmin;
+                for (int c = 1; c < CPL; ++c) {
+                    const uint32_t kc = key[c];
+                    lmin2 = kc < lmin ? lmin : (kc < lmin2 ? kc : lmin2);
+                    lmin = kc < lmin ? kc : lmin;
+                }
+            } else {
+#pragma unroll
+                for (int c = 1; c < CPL; ++c) lmin = key[c] < lmin ? key[c] : lmin;
+            }
             // The threshold only has to keep >= K candidates and <= 64 survivors, so 16 key bits (sign, exponent, 7
             // mantissa bits: 0.8 % granularity) are enough -- half the serial ballot/popcount chain, which runs on the
             // CU's single scalar unit and was what bound this kernel.
             uint32_t M = 0;
             int belowm = 0;
             for (int bit = 31; bit >= 32 - KNN_PREFIX_BITS; --bit) {
-                const int cnt = __popcll(__ballot((lmin >> bit) == (M >> bit)));
+                int cnt = __popcll(__ballot((lmin >> bit) == (M >> bit)));
+                if (two) cnt += __popcll(__ballot((lmin2 >> bit) == (M >> bit)));
                 if (belowm + cnt < K) {
                     belowm += cnt;
                     M |= (1u << bit);
