@@ -142,7 +142,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
     const int b = v / gpg;
     const int node0 = (v % gpg) * G;
     const int N = p.N, K = p.K;
-    const int slots_total = G * K;                           // per node group (exceeds one round only if G == 1)
+    const int slots_total = G * K;                           // per node group (one or several rounds of 128 slots)
     const int rounds = (slots_total + SLOTS_PER_ROUND - 1) / SLOTS_PER_ROUND;
     const bool has_mask = p.mask != nullptr;
     const bool has_rank = p.rank != nullptr && p.idx != nullptr;
@@ -652,9 +652,14 @@ __global__ __launch_bounds__(EDGE_THREADS, edge_min_blocks(NM, TPI)) void edge_k
 template <int NM, int HCT, int TPI>
 int launch_edge(const egnn_edge_args& a, hipStream_t s)
 {
+    // nodes per workgroup: as many as fit one round of 128 slots -- or, when that would leave slots idle (K = 24: 120 of
+    // 128, K = 48: 96), the smallest group whose slots fill whole rounds (K = 48: 8 nodes = 3 rounds), up to 16 nodes
     int G = SLOTS_PER_ROUND / a.K;
     if (G < 1) G = 1;
     if (G > GMAX) G = GMAX;
+    if (a.K < SLOTS_PER_ROUND && (G * a.K) % SLOTS_PER_ROUND != 0)
+        for (int g2 = G + 1; g2 <= 16; ++g2)
+            if ((g2 * a.K) % SLOTS_PER_ROUND == 0) { G = g2; break; }
     if (G > a.N) G = a.N;
     const int gpg = (a.N + G - 1) / G;
     const int64_t nblk = (int64_t)a.B * gpg;

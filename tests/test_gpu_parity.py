@@ -69,6 +69,11 @@ CONFIGS = [
      dict(mask=True, edges=True, scale={"edge_mlp.3.weight": 0.3, "coors_mlp.3.weight": 0.3})),
     ("k20_fourier4_edges7_s16", dict(dim=32, num_nearest_neighbors=20, fourier_features=4, edge_dim=7), 2, 50,
      dict(mask=True, edges=True)),
+    # node groups spanning several rounds of 128 slots (K = 48: 8 nodes = 3 rounds; K = 24: 16 nodes; K = 40: 16 nodes = 5 rounds)
+    ("k48_groups_of_8", dict(dim=32, num_nearest_neighbors=48), 2, 100, dict(mask=True, scale={"edge_mlp.3.weight": 0.3, "coors_mlp.3.weight": 0.3})),
+    ("k24_groups_of_16", dict(dim=32, num_nearest_neighbors=24, norm_coors=True), 2, 70, dict(mask=True)),
+    ("k40_groups_of_16", dict(dim=32, num_nearest_neighbors=40, edge_dim=2), 1, 90, dict(edges=True, scale={"edge_mlp.3.weight": 0.3, "coors_mlp.3.weight": 0.3})),
+    ("k96_groups_of_4", dict(dim=32, num_nearest_neighbors=96), 1, 130, dict(mask=True, scale={"edge_mlp.3.weight": 0.2, "coors_mlp.3.weight": 0.2})),
     # degenerate sizes: a single node (dense: only the self edge), two nodes, k = 1 (self only), N < one MFMA tile
     ("tiny_n1_dense", dict(dim=16), 2, 1, dict()),
     ("tiny_n2_dense_mask", dict(dim=16, edge_dim=1), 3, 2, dict(mask_exact=[2, 1, 2], edges=True)),
