@@ -74,6 +74,10 @@ CONFIGS = [
     ("k24_groups_of_16", dict(dim=32, num_nearest_neighbors=24, norm_coors=True), 2, 70, dict(mask=True)),
     ("k40_groups_of_16", dict(dim=32, num_nearest_neighbors=40, edge_dim=2), 1, 90, dict(edges=True, scale={"edge_mlp.3.weight": 0.3, "coors_mlp.3.weight": 0.3})),
     ("k96_groups_of_4", dict(dim=32, num_nearest_neighbors=96), 1, 130, dict(mask=True, scale={"edge_mlp.3.weight": 0.2, "coors_mlp.3.weight": 0.2})),
+    # smallest K whose tiles still carry P_i in the MFMA (a tile of 16 slots touches up to 4 nodes), and the VALU path below it
+    ("k6_four_nodes_per_tile", dict(dim=32, num_nearest_neighbors=6), 2, 45, dict(mask=True)),
+    ("k7_four_nodes_per_tile", dict(dim=32, num_nearest_neighbors=7, edge_dim=1), 2, 45, dict(mask=True, edges=True)),
+    ("k5_valu_pi", dict(dim=32, num_nearest_neighbors=5), 2, 45, dict(mask=True)),
     # degenerate sizes: a single node (dense: only the self edge), two nodes, k = 1 (self only), N < one MFMA tile
     ("tiny_n1_dense", dict(dim=16), 2, 1, dict()),
     ("tiny_n2_dense_mask", dict(dim=16, edge_dim=1), 3, 2, dict(mask_exact=[2, 1, 2], edges=True)),
