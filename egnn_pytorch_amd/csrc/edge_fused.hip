@@ -120,7 +120,7 @@ __device__ __forceinline__ uint32_t buf_load1(__amdgpu_buffer_rsrc_t r, uint32_t
 // K-slots 4g, 4g+1 of lane group g and every edge selects its node with a (1, 1) there.  0 (K < 6): fp32 P_i, added per
 // lane on the VALU.
 // (The body is a device function of the block index so that a dispatcher kernel can give a workgroup slot either an edge
-// group or a GEMM tile: csrc/mix_probe.hip.)
+// group or a GEMM tile: tools/ubench/mix_probe.hip.)
 template <int NM, int HCT, int TPI>
 __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, const int gpg, char* smem, const int bid, const int nblk)
 {

@@ -1,4 +1,4 @@
-"""Experiment: one launch whose workgroup slots alternate between edge groups and projection-GEMM tiles (csrc/mix_probe.hip).
+"""Experiment: one launch whose workgroup slots alternate between edge groups and projection-GEMM tiles (tools/ubench/mix_probe.hip).
 Times, at the north-star shape: the edge pass alone, the GEMM alone (both through the dispatcher kernel), both in one launch
 back to back, and both interleaved."""
 import ctypes, os, subprocess, sys
@@ -10,7 +10,7 @@ from egnn_pytorch_amd import EGNN, _abi, _ops
 csrc = os.path.join(ROOT, "egnn_pytorch_amd", "csrc")
 lib_path = "/tmp/libmix.so"
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-shared",
-                os.path.join(csrc, "mix_probe.hip"), os.path.join(csrc, "node_ops.hip"), "-o", lib_path], check=True)
+                os.path.join(ROOT, "tools", "ubench", "mix_probe.hip"), os.path.join(csrc, "node_ops.hip"), "-o", lib_path], check=True)
 mix = ctypes.CDLL(lib_path)
 vp = ctypes.c_void_p
 mix.egnn_mix_probe.argtypes = [ctypes.POINTER(_abi.EdgeArgs), vp, vp, vp, vp, ctypes.c_float, vp, vp, ctypes.c_int64, ctypes.c_int64,

@@ -1,9 +1,9 @@
 // Experiment (not part of libegnn_hip.so): ONE launch whose workgroup slots alternate between the VALU-bound edge pass
 // and the MFMA-bound projection GEMM of ANOTHER chunk of the batch -- do the two pipes overlap when waves of both kinds
-// share a SIMD?  Built by tools/mix_probe.py into its own shared object; this file includes the two kernel sources.
+// share a SIMD?  Built by tools/mix_probe.py into its own shared object; this file includes the two kernel sources of the package.
 #define EGNN_EDGE_TUNING_BUILD
-#include "edge_fused.hip"
-#include "linear_hl.hip"
+#include "../../egnn_pytorch_amd/csrc/edge_fused.hip"
+#include "../../egnn_pytorch_amd/csrc/linear_hl.hip"
 
 int egnn_edge_fused_generic_c(const egnn_edge_args*, void*) { return EGNN_E_UNSUPPORTED; }   // (not built into the probe)
 
