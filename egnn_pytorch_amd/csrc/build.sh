@@ -4,7 +4,9 @@ set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="${1:-$HERE/..}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -Rpass-analysis=kernel-resource-usage"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -Wno-inline-asm -Rpass-analysis=kernel-resource-usage"
+# start from an empty object directory: the link step and the spill check below must only ever see this run's outputs
+rm -rf "$HERE/obj"
 mkdir -p "$HERE/obj"
 pids=()
 for f in knn_select spatial_order adj_expand linear_f32 linear_split linear_hl edge_fused node_ops; do

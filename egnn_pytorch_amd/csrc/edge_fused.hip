@@ -55,6 +55,19 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #ifndef EGNN_EDGE_MINW
 #define EGNN_EDGE_MINW 4
 #endif
+// hidden value -> (hi, lo) fp16 pair with four v_fma_mix{lo,hi}_f16 per two values (the product y * sigma is fused into
+// the conversion) instead of mul, mul, cvt_pkrtz, fma_mix, fma_mix, cvt_pkrtz
+#ifndef EGNN_EDGE_MIXLO
+#define EGNN_EDGE_MIXLO 1
+#endif
+// W2 / W_s staging as a two-slot ring of HCT/2 columns: the LDS-DMA of chunk c+1 is in flight while chunk c is computed
+// (one barrier per chunk and no exposed DMA latency) instead of barrier, DMA, wait, barrier per HCT columns
+#ifndef EGNN_EDGE_RING
+#define EGNN_EDGE_RING 1
+#endif
+#ifndef EGNN_EDGE_PRIO
+#define EGNN_EDGE_PRIO 0
+#endif
 constexpr int EDGE_THREADS = EGNN_EDGE_THREADS;
 constexpr int EDGE_WAVES = EDGE_THREADS / 64;
 constexpr int TILES = 2;                 // MFMA tiles (16 edges) per wave
@@ -104,6 +117,14 @@ __device__ __forceinline__ uint32_t pack_h2(_Float16 a, _Float16 b)
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+// One LDS-DMA instruction: lane l's 16 bytes at `g` (per-lane address) land at lds_base + 16 l (lds_base wave-uniform).
+// Issued from inline asm on purpose, see the staging ring in edge_body.
+__device__ __forceinline__ void lds_dma16(const char* g, char* lds_base)
+{
+    const uint32_t m0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(m0) : "memory", "m0");
+}
+
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff)
 {
     typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
@@ -124,7 +145,7 @@ __device__ __forceinline__ uint32_t buf_load1(__amdgpu_buffer_rsrc_t r, uint32_t
 template <int NM, int HCT, int TPI>
 __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, const int gpg, char* smem, const int bid, const int nblk)
 {
-    constexpr int HC = HCT;
+    constexpr int HC = EGNN_EDGE_RING ? HCT / 2 : HCT;     // columns per staged chunk (ring: two slots of HCT / 2)
     const int S = p.S;
     _Float16* w2s = reinterpret_cast<_Float16*>(smem);                  // [HC/32][hi|lo][64][8] halves = HC * 64 bytes
     float* xchall = reinterpret_cast<float*>(smem + HC * 64);           // [EDGE_WAVES][32 slots][XLD]: per-wave gather exchange
@@ -316,7 +337,42 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             }
         }
 
-        for (int c0 = 0; c0 < p.Hp; c0 += HC) {
+#if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 4)
+        const int HpLoop = 0;                                            // ablation: setup + epilogue only
+#else
+        const int HpLoop = p.Hp;
+#endif
+#if EGNN_EDGE_RING
+        // Two-slot ring of HC = HCT / 2 columns: the LDS-DMA of chunk c+1 flies while chunk c is computed out of slot c & 1
+        // -- one barrier per chunk and no exposed load latency.  The DMA is issued from inline asm (lds_dma16): with the
+        // builtin the compiler, which cannot tell LDS-DMA writes from the other LDS traffic, waits vmcnt(0) before every
+        // LDS access of the step that follows.  Hidden from its counters the extra loads can only make its own vmcnt
+        // waits stricter (the counter retires in order), never weaker; their completion is waited for explicitly below.
+        // W2 fragments: (Hp/32, 2, 64, 8) halves = 2048 bytes per step; scalar table: NM * 16 bytes per hidden unit.
+        auto stage = [&](int c0s, int slot) {
+            const int hcs = (p.Hp - c0s) < HC ? (p.Hp - c0s) : HC;
+            const char* src = reinterpret_cast<const char*>(p.W2h) + (size_t)c0s * 64 + lane * 16;
+            char* dst = reinterpret_cast<char*>(w2s) + slot * (HC * 64);
+            for (int pc = wave; pc < hcs / 16; pc += EDGE_WAVES) lds_dma16(src + pc * 1024, dst + pc * 1024);
+            const int tbytes = hcs * NM * 16;
+            const char* tsrc = reinterpret_cast<const char*>(p.Wst) + (size_t)c0s * NM * 16 + lane * 16;
+            char* tdst = wst + slot * (HC * NM * 16);
+            for (int pc = wave; pc * 1024 < tbytes; pc += EDGE_WAVES)
+                if (pc * 1024 + lane * 16 < tbytes) lds_dma16(tsrc + pc * 1024, tdst + pc * 1024);
+        };
+        stage(0, 0);               // (the barrier that ended the previous round freed both slots)
+        int slot = 0;
+        for (int c0 = 0; c0 < HpLoop; c0 += HC, slot ^= 1) {
+            const int hc = (p.Hp - c0) < HC ? (p.Hp - c0) : HC;
+            // chunk c0 was requested one chunk ago; the only other loads in flight are the gathers of the coming step, which
+            // the step consumes first thing anyway -> waiting for everything costs nothing extra
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();       // every wave's pieces have landed, and every wave has left the other slot
+            if (c0 + HC < p.Hp) stage(c0 + HC, slot ^ 1);
+            const _Float16* w2c = w2s + slot * (HC * 32);
+            const char* tlc = tl + slot * (HC * NM * 16);
+#else
+        for (int c0 = 0; c0 < HpLoop; c0 += HC) {
             const int hc = (p.Hp - c0) < HC ? (p.Hp - c0) : HC;
             __syncthreads();
             {
@@ -334,12 +390,18 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
+            const _Float16* w2c = w2s;
+            const char* tlc = tl;
+#endif
 
             const int nst = hc / KSTEP;
             for (int st = 0; st < nst; ++st) {
                 const int hoff = c0 + st * KSTEP;
 #if defined(EGNN_EDGE_STEPSYNC) && EGNN_EDGE_STEPSYNC
                 __builtin_amdgcn_s_barrier();      // keep the workgroup's waves on the same step: gathered rows shared via L1
+#endif
+#if EGNN_EDGE_PRIO
+                __builtin_amdgcn_s_setprio(EGNN_EDGE_PRIO);          // hurry through the LDS / MFMA head of the step
 #endif
                 // park the lines fetched for this step, then (same wave, DS ops execute in order) pick the rows up
 #pragma unroll
@@ -366,11 +428,11 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 u32x2 av[NM][2];
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
-                    av[m][0] = u32x2{0u, *reinterpret_cast<const uint32_t*>(tl + m * 16 + st * 2 * tstep)};
-                    av[m][1] = u32x2{0u, *reinterpret_cast<const uint32_t*>(tl + m * 16 + st * 2 * tstep + tstep)};
+                    av[m][0] = u32x2{0u, *reinterpret_cast<const uint32_t*>(tlc + m * 16 + st * 2 * tstep)};
+                    av[m][1] = u32x2{0u, *reinterpret_cast<const uint32_t*>(tlc + m * 16 + st * 2 * tstep + tstep)};
                 }
-                const f16x8 whi = *reinterpret_cast<const f16x8*>(w2s + ((st * 2 + 0) * 64 + lane) * 8);
-                const f16x8 wlo = *reinterpret_cast<const f16x8*>(w2s + ((st * 2 + 1) * 64 + lane) * 8);
+                const f16x8 whi = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 0) * 64 + lane) * 8);
+                const f16x8 wlo = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 1) * 64 + lane) * 8);
                 u32x2 a0[TILES][2];                                // first MFMA's A operand: K-slots 4g, 4g+1 = P_i (hi, lo)
                 if (TPI == 0) {
 #pragma unroll
@@ -404,6 +466,9 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                         for (int m = 0; m < NM; ++m)
                             x[t][hb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, m == 0 ? a0[t][hb] : av[m][hb]),
                                                                             __builtin_bit_cast(f16x4, bq[t][m]), x[t][hb], 0, 0, 0);
+#if EGNN_EDGE_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
                     // x holds y = -log2(e) * (pre-activation); hv = y / (1 + 2^y) = SiLU(pre) / (-ln 2)
@@ -411,6 +476,19 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 #pragma unroll
                     for (int u = 0; u < 8; u += 2) {
                         const float y0 = x[t][u >> 2][u & 3], y1 = x[t][u >> 2][(u & 3) + 1];
+#if EGNN_EDGE_MIXLO
+                        // hi = f16(y * sigma), lo = f16(y * sigma - hi): the product rides in the converting FMA
+                        // (v_fma_mixlo_f16 / v_fma_mixhi_f16 write one half of the destination and keep the other)
+                        const float r0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y0));
+                        const float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y1));
+                        uint32_t hw, lw;
+                        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(hw) : "v"(y0), "v"(r0));
+                        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(hw) : "v"(y1), "v"(r1));
+                        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lw) : "v"(y0), "v"(r0), "v"(hw));
+                        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lw) : "v"(y1), "v"(r1), "v"(hw));
+                        const f16x2 hi = __builtin_bit_cast(f16x2, hw);
+                        const f16x2 lo = __builtin_bit_cast(f16x2, lw);
+#else
 #if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 2)
                         const float h0 = y0 * (1.0f + y0);                  // ablation: no transcendentals
                         const float h1 = y1 * (1.0f + y1);
@@ -422,6 +500,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                         const float l0 = h0 - (float)hi[0];
                         const float l1 = h1 - (float)hi[1];
                         const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+#endif
                         bhi[u] = hi[0]; bhi[u + 1] = hi[1];
                         blo[u] = lo[0]; blo[u + 1] = lo[1];
                     }

@@ -1,5 +1,7 @@
 """Layer / network parity on the MI355X: HIP path (through the drop-in nn.Module and the C ABI)
 against the committed golden vectors of the live reference and against the CPU oracle."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -98,7 +100,7 @@ CONFIGS = [
 
 @pytest.mark.parametrize("name,kwargs,b,n,flags", CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_layer_vs_oracle(name, kwargs, b, n, flags):
-    rng = np.random.default_rng(abs(hash(name)) % (2 ** 31))
+    rng = np.random.default_rng(zlib.crc32(name.encode()))      # stable across processes (hash() is salted)
     cfg = O.EGNNConfig(**kwargs)
     params = O.random_params(cfg, seed=17)
     for key, sc in flags.get("scale", {}).items():

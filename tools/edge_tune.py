@@ -32,7 +32,7 @@ def build(tag, defs, src="edge_fused"):
              "edge_fused_c")
     objs = [os.path.join(CSRC, "obj", f + ".o") for f in names if f != src]
     o = f"{out}/{src}.o"
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-Wno-inline-asm",
            "-DEGNN_EDGE_TUNING_BUILD"] + [f"-DEGNN_{k}={v}" for k, v in defs.items()] + \
           ["-c", os.path.join(CSRC, src + ".hip"), "-o", o]
     subprocess.run(cmd, check=True)
