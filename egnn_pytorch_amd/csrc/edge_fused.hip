@@ -55,11 +55,6 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #ifndef EGNN_EDGE_MINW
 #define EGNN_EDGE_MINW 4
 #endif
-// hidden value -> (hi, lo) fp16 pair with four v_fma_mix{lo,hi}_f16 per two values (the product y * sigma is fused into
-// the conversion) instead of mul, mul, cvt_pkrtz, fma_mix, fma_mix, cvt_pkrtz
-#ifndef EGNN_EDGE_MIXLO
-#define EGNN_EDGE_MIXLO 1
-#endif
 // W2 / W_s staging as a two-slot ring of HCT/2 columns: the LDS-DMA of chunk c+1 is in flight while chunk c is computed
 // (one barrier per chunk and no exposed DMA latency) instead of barrier, DMA, wait, barrier per HCT columns
 #ifndef EGNN_EDGE_RING
@@ -121,8 +116,12 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // Issued from inline asm on purpose, see the staging ring in edge_body.
 __device__ __forceinline__ void lds_dma16(const char* g, char* lds_base)
 {
+#if defined(EGNN_EDGE_DMA_BUILTIN) && EGNN_EDGE_DMA_BUILTIN
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+#else
     const uint32_t m0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds_base);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(m0) : "memory", "m0");
+#endif
 }
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff)
@@ -147,11 +146,11 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 {
     constexpr int HC = EGNN_EDGE_RING ? HCT / 2 : HCT;     // columns per staged chunk (ring: two slots of HCT / 2)
     const int S = p.S;
-    _Float16* w2s = reinterpret_cast<_Float16*>(smem);                  // [HC/32][hi|lo][64][8] halves = HC * 64 bytes
-    float* xchall = reinterpret_cast<float*>(smem + HC * 64);           // [EDGE_WAVES][32 slots][XLD]: per-wave gather exchange
+    _Float16* w2s = reinterpret_cast<_Float16*>(smem);                  // [HCT/32][hi|lo][64][8] halves = HCT * 64 bytes
+    float* xchall = reinterpret_cast<float*>(smem + HCT * 64);           // [EDGE_WAVES][32 slots][XLD]: per-wave gather exchange
     float* ebuf = xchall;                                                // [slots][NCH] aliases it (TPI != 2 epilogue only)
     float* nodeacc = xchall + SLOTS_PER_ROUND * XLD;                    // [G][NCH]
-    char* wst = reinterpret_cast<char*>(nodeacc + G * NCH);             // [HC][4 NM] dwords: first-layer A fragments
+    char* wst = reinterpret_cast<char*>(nodeacc + G * NCH);             // [HCT][4 NM] dwords: first-layer A fragments
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -368,7 +367,11 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             // the step consumes first thing anyway -> waiting for everything costs nothing extra
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();       // every wave's pieces have landed, and every wave has left the other slot
+#if defined(EGNN_EDGE_RING_DBG) && (EGNN_EDGE_RING_DBG & 1)
+            if (c0 + HC < p.Hp) { stage(c0 + HC, slot ^ 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+#else
             if (c0 + HC < p.Hp) stage(c0 + HC, slot ^ 1);
+#endif
             const _Float16* w2c = w2s + slot * (HC * 32);
             const char* tlc = tl + slot * (HC * NM * 16);
 #else
@@ -404,8 +407,12 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 __builtin_amdgcn_s_setprio(EGNN_EDGE_PRIO);          // hurry through the LDS / MFMA head of the step
 #endif
                 // park the lines fetched for this step, then (same wave, DS ops execute in order) pick the rows up
+#if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 32)
+                const f32x4 glx[4] = {gl[0], gl[1], gl[2], gl[3]};      // ablation: no park / pick-up through LDS
+#else
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f32x4*>(xw[qq & 1] + (qq >> 1) * 16 * XLD) = gl[qq];
+#endif
                 int hnext = hoff + KSTEP;
                 if (hnext >= p.Hp) hnext = hoff;                 // last step: harmless re-read
 #pragma unroll
@@ -419,8 +426,13 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 f32x4 x[TILES][2];
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
+#if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 32)
+                    x[t][0] = glx[2 * t];
+                    x[t][1] = glx[2 * t + 1];
+#else
                     x[t][0] = *reinterpret_cast<const f32x4*>(xr[0] + t * 16 * XLD);
                     x[t][1] = *reinterpret_cast<const f32x4*>(xr[1] + t * 16 * XLD);
+#endif
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -464,8 +476,12 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                         for (int m = 0; m < NM; ++m)
+#if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 16)
+                            x[t][hb][0] += __builtin_bit_cast(float, (m == 0 ? a0[t][hb] : av[m][hb])[0] ^ bq[t][m][1]);   // ablation: no first-layer MFMAs
+#else
                             x[t][hb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, m == 0 ? a0[t][hb] : av[m][hb]),
                                                                             __builtin_bit_cast(f16x4, bq[t][m]), x[t][hb], 0, 0, 0);
+#endif
 #if EGNN_EDGE_PRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
@@ -476,19 +492,6 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 #pragma unroll
                     for (int u = 0; u < 8; u += 2) {
                         const float y0 = x[t][u >> 2][u & 3], y1 = x[t][u >> 2][(u & 3) + 1];
-#if EGNN_EDGE_MIXLO
-                        // hi = f16(y * sigma), lo = f16(y * sigma - hi): the product rides in the converting FMA
-                        // (v_fma_mixlo_f16 / v_fma_mixhi_f16 write one half of the destination and keep the other)
-                        const float r0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y0));
-                        const float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y1));
-                        uint32_t hw, lw;
-                        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(hw) : "v"(y0), "v"(r0));
-                        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(hw) : "v"(y1), "v"(r1));
-                        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lw) : "v"(y0), "v"(r0), "v"(hw));
-                        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lw) : "v"(y1), "v"(r1), "v"(hw));
-                        const f16x2 hi = __builtin_bit_cast(f16x2, hw);
-                        const f16x2 lo = __builtin_bit_cast(f16x2, lw);
-#else
 #if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 2)
                         const float h0 = y0 * (1.0f + y0);                  // ablation: no transcendentals
                         const float h1 = y1 * (1.0f + y1);
@@ -500,13 +503,16 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                         const float l0 = h0 - (float)hi[0];
                         const float l1 = h1 - (float)hi[1];
                         const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l0, l1));
-#endif
                         bhi[u] = hi[0]; bhi[u + 1] = hi[1];
                         blo[u] = lo[0]; blo[u + 1] = lo[1];
                     }
+#if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 8)
+                    acc[t][0] += (float)bhi[0] + (float)blo[1] + (float)bhi[2] + (float)blo[3] + (float)bhi[4] + (float)blo[5] + (float)bhi[6] + (float)blo[7] + (float)whi[0] + (float)wlo[0];   // ablation: no second-layer MFMAs
+#else
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bhi, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, bhi, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, blo, acc[t], 0, 0, 0);
+#endif
                 }
             }
         }

@@ -25,7 +25,7 @@ print(json.dumps({k: round(min(v), 4) for k, v in s.items()}))
 ''' % ROOT
 
 
-def build(tag, defs, src="edge_fused"):
+def build(tag, defs, src="edge_fused", tuning=True):
     out = f"/tmp/egnn_{tag}"
     os.makedirs(out, exist_ok=True)
     names = ("knn_select", "spatial_order", "adj_expand", "linear_f32", "linear_split", "linear_hl", "node_ops", "edge_fused",
@@ -33,7 +33,7 @@ def build(tag, defs, src="edge_fused"):
     objs = [os.path.join(CSRC, "obj", f + ".o") for f in names if f != src]
     o = f"{out}/{src}.o"
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-Wno-inline-asm",
-           "-DEGNN_EDGE_TUNING_BUILD"] + [f"-DEGNN_{k}={v}" for k, v in defs.items()] + \
+           ] + (["-DEGNN_EDGE_TUNING_BUILD"] if tuning else []) + [f"-DEGNN_{k}={v}" for k, v in defs.items()] + \
           ["-c", os.path.join(CSRC, src + ".hip"), "-o", o]
     subprocess.run(cmd, check=True)
     lib = f"{out}/libegnn_hip.so"
