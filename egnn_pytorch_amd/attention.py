@@ -29,7 +29,12 @@ class Attention(nn.Module):
         h = self.heads
         q = self.to_q(x).view(b, n, h, -1).transpose(1, 2)                           # (b, h, n, d)
         k, v = self.to_kv(context).view(b, context.shape[1], 2, h, -1).permute(2, 0, 3, 1, 4)
-        attn_mask = None if mask is None else mask[:, None, None, :]               # True = keep (:102-105)
+        attn_mask = None
+        if mask is not None:
+            # the reference fills masked logits with -finfo.max (:102-105): a row whose context is entirely masked (a fully
+            # padded graph) then softmaxes to a uniform distribution with finite outputs; a boolean attn_mask would give NaN
+            attn_mask = torch.zeros(mask.shape, dtype=q.dtype, device=q.device).masked_fill_(~mask, -torch.finfo(q.dtype).max)
+            attn_mask = attn_mask[:, None, None, :]
         out = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, scale=self.scale)
         return self.to_out(out.transpose(1, 2).reshape(b, n, -1))
 

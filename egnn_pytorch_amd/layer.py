@@ -115,14 +115,25 @@ class EGNN(nn.Module):
             raise ValueError(f"edges shape {tuple(edges.shape)} != {(b, n, n, self.edge_dim)}")
         if mask is not None and tuple(mask.shape) != (b, n):
             raise ValueError(f"mask shape {tuple(mask.shape)} != {(b, n)}")
-        if torch.is_grad_enabled() and not self._warned_grad and any(p.requires_grad for p in self.parameters()):
-            warnings.warn("egnn_pytorch_amd.EGNN.forward is inference-only: outputs carry no autograd graph",
-                          stacklevel=3)
+
+    def _check_grad(self, *tensors):
+        """Called BEFORE entering no_grad (inside it torch.is_grad_enabled() is always False)."""
+        if not torch.is_grad_enabled():
+            return
+        wants = any(t is not None and t.is_floating_point() and t.requires_grad for t in tensors)
+        if wants:
+            raise RuntimeError("egnn_pytorch_amd.EGNN.forward is inference-only (no autograd graph is recorded), but an input "
+                               "requires grad: gradients would silently stop here. Call it under torch.no_grad() or detach "
+                               "the inputs.")
+        if not self._warned_grad and any(p.requires_grad for p in self.parameters()):
+            warnings.warn("egnn_pytorch_amd.EGNN.forward is inference-only: outputs carry no autograd graph "
+                          "(call it under torch.no_grad() to silence this)", stacklevel=3)
             self._warned_grad = True
 
-    @torch.no_grad()
     def forward(self, feats, coors, edges=None, mask=None, adj_mat=None):
-        return self._forward_with_hint(feats, coors, edges, mask, adj_mat, None)[:2]
+        self._check_grad(feats, coors, edges)
+        with torch.no_grad():
+            return self._forward_with_hint(feats, coors, edges, mask, adj_mat, None)[:2]
 
     def _forward_with_hint(self, feats, coors, edges, mask, adj_mat, order_hint):
         """forward + the scheduling permutation it used (EGNN_Network hands layer 0's on to the next layers)."""
@@ -263,8 +274,12 @@ class EGNN_Network(nn.Module):
                                       dim_head=global_linear_attn_dim_head) if is_global else None,
                 EGNN(dim=dim, edge_dim=edge_dim + adj_dim, norm_feats=True, **kwargs)]))
 
-    @torch.no_grad()
     def forward(self, feats, coors, adj_mat=None, edges=None, mask=None, return_coor_changes=False):
+        self.layers[0][1]._check_grad(feats, coors, edges)
+        with torch.no_grad():
+            return self._forward(feats, coors, adj_mat, edges, mask, return_coor_changes)
+
+    def _forward(self, feats, coors, adj_mat, edges, mask, return_coor_changes):
         b = feats.shape[0]
         if self.token_emb is not None:
             feats = self.token_emb(feats)

@@ -22,18 +22,27 @@ def shard_bounds(batch: int, rank: int, world: int):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def shard_batch(rank: int, world: int, *tensors, batched_adj: bool = True):
-    """Slice every per-graph tensor (leading dim B) to this rank's graphs.  `None` entries pass through;
-    a 2-D adjacency (shared by all graphs) is replicated, not split."""
-    out = []
-    bsz = next(t.shape[0] for t in tensors if t is not None)
+def shard_batch(rank: int, world: int, *tensors, shared=()):
+    """Slice every per-graph tensor (leading dim B) to this rank's graphs.  `None` entries pass through.  Tensors that
+    all graphs share -- a 2-D `(N, N)` adjacency -- are named explicitly in `shared` (compared by identity) and are
+    replicated, not split; there is no shape heuristic (a `(B, N)` mask with B == N looks exactly like an adjacency).
+    Every other tensor must have the batch as its leading dimension."""
+    shared_ids = {id(t) for t in shared if t is not None}
+    per_graph = [t for t in tensors if t is not None and id(t) not in shared_ids]
+    if not per_graph:
+        raise ValueError("shard_batch needs at least one per-graph tensor")
+    bsz = per_graph[0].shape[0]
     lo, hi = shard_bounds(bsz, rank, world)
+    out = []
     for t in tensors:
         if t is None:
             out.append(None)
-        elif t.dim() == 2 and t.dtype == torch.bool and t.shape[0] == t.shape[1] and t.shape[0] != bsz:
-            out.append(t)                       # (N,N) adjacency shared across the batch
+        elif id(t) in shared_ids:
+            out.append(t)                       # replicated on every rank
         else:
+            if t.shape[0] != bsz:
+                raise ValueError(f"per-graph tensor with leading dim {t.shape[0]} != batch {bsz} "
+                                 f"(pass tensors shared by all graphs via shared=(...))")
             out.append(t[lo:hi])
     return out
 

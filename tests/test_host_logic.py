@@ -62,6 +62,24 @@ def test_no_cpu_fallback():
         EGNN(dim=8)(torch.randn(1, 4, 8), torch.randn(1, 4, 3))
 
 
+def test_inference_only_is_announced_before_no_grad():
+    """the autograd check must run before forward enters no_grad -- an input that requires grad raises (its
+    gradient would silently stop at the layer), parameters that require grad warn once."""
+    from egnn_pytorch_amd import EGNN, EGNN_Network
+    layer = EGNN(dim=8)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        layer(torch.randn(1, 4, 8, requires_grad=True), torch.randn(1, 4, 3))
+    with pytest.warns(UserWarning, match="inference-only"):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            layer(torch.randn(1, 4, 8), torch.randn(1, 4, 3))
+    with torch.no_grad():                                           # no warning, no autograd complaint under no_grad
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            EGNN(dim=8)(torch.randn(1, 4, 8, requires_grad=True), torch.randn(1, 4, 3))
+    net = EGNN_Network(depth=1, dim=8)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        net(torch.randn(1, 4, 8), torch.randn(1, 4, 3, requires_grad=True))
+
+
 def test_product_code_never_imports_oracle():
     pkg = os.path.join(ROOT, "egnn_pytorch_amd")
     for dirpath, _, files in os.walk(pkg):
@@ -100,6 +118,29 @@ def test_global_attention_block_matches_oracle():
     tok = np.broadcast_to(params["global_tokens"][None], (x.shape[0],) + params["global_tokens"].shape).copy()
     with torch.no_grad():
         got_x, got_q = blk(torch.from_numpy(x), torch.from_numpy(tok), mask=torch.from_numpy(mask))
+    ref_x, ref_q = O.global_linear_attention(params, pre, x, tok, kw["global_linear_attn_heads"], mask=mask)
+    np.testing.assert_allclose(got_x.numpy(), ref_x, atol=2e-5, rtol=0)
+    np.testing.assert_allclose(got_q.numpy(), ref_q, atol=2e-5, rtol=0)
+
+
+def test_global_attention_fully_masked_graph_stays_finite():
+    """a graph whose mask row is all False (a fully padded batch entry) -- the reference fills the logits with
+    -finfo.max and softmaxes to a uniform distribution (egnn_pytorch.py:102-107); outputs stay finite and equal the
+    oracle's."""
+    from egnn_pytorch_amd.attention import GlobalLinearAttention
+    from oracle import egnn_oracle as O
+    meta, params, d = load_golden("net_global_attn")
+    kw = meta["kwargs"]
+    blk = GlobalLinearAttention(dim=kw["dim"], heads=kw["global_linear_attn_heads"],
+                                dim_head=kw["global_linear_attn_dim_head"]).eval()
+    pre = "layers.0.0."
+    blk.load_state_dict({k[len(pre):]: torch.from_numpy(v) for k, v in params.items() if k.startswith(pre)}, strict=True)
+    x, mask = d["feats"], d["mask"].copy()
+    mask[0, :] = False
+    tok = np.broadcast_to(params["global_tokens"][None], (x.shape[0],) + params["global_tokens"].shape).copy()
+    with torch.no_grad():
+        got_x, got_q = blk(torch.from_numpy(x), torch.from_numpy(tok), mask=torch.from_numpy(mask))
+    assert torch.isfinite(got_x).all() and torch.isfinite(got_q).all()
     ref_x, ref_q = O.global_linear_attention(params, pre, x, tok, kw["global_linear_attn_heads"], mask=mask)
     np.testing.assert_allclose(got_x.numpy(), ref_x, atol=2e-5, rtol=0)
     np.testing.assert_allclose(got_q.numpy(), ref_q, atol=2e-5, rtol=0)

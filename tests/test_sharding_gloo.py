@@ -47,7 +47,7 @@ def _worker(rank, world, port, batch, out_dir):
     coors = torch.randn(batch, n, 3, generator=g)
     mask = torch.rand(batch, n, generator=g) > 0.2
     adj = torch.eye(n, dtype=torch.bool)
-    f, c, m, a = sharding.shard_batch(rank, world, feats, coors, mask, adj)
+    f, c, m, a = sharding.shard_batch(rank, world, feats, coors, mask, adj, shared=(adj,))
     lo, hi = sharding.shard_bounds(batch, rank, world)
     assert f.shape[0] == hi - lo and a is adj
 
@@ -84,6 +84,24 @@ def test_two_rank_batch_shard(tmp_path, batch):
     np.testing.assert_array_equal(w0, w1)                       # parameters replicated
     t0, t1 = np.load(tmp_path / "t0.npy"), np.load(tmp_path / "t1.npy")
     assert t0 == t1                                             # both ranks report the max over ranks
+
+
+def test_shard_batch_when_batch_equals_nodes():
+    """B == N: a (B, N) mask and a shared (N, N) adjacency have the same shape; only `shared=` tells them apart."""
+    from egnn_pytorch_amd import sharding
+    n = 6
+    feats = torch.randn(n, n, 4)
+    mask = torch.rand(n, n) > 0.3
+    adj = torch.eye(n, dtype=torch.bool)
+    parts = [sharding.shard_batch(r, 2, feats, mask, adj, None, shared=(adj,)) for r in range(2)]
+    for r, (f, m, a, none) in enumerate(parts):
+        lo, hi = sharding.shard_bounds(n, r, 2)
+        assert f.shape[0] == hi - lo and torch.equal(m, mask[lo:hi]) and a is adj and none is None
+    assert torch.equal(torch.cat([p[1] for p in parts]), mask)
+    with pytest.raises(ValueError):
+        sharding.shard_batch(0, 2, feats, torch.zeros(n + 1, n, dtype=torch.bool))      # not a per-graph tensor
+    with pytest.raises(ValueError):
+        sharding.shard_batch(0, 2, adj, shared=(adj,))                                   # nothing to split
 
 
 def test_shard_bounds_cover_batch():
