@@ -15,8 +15,9 @@ Rank 0 prints ONE JSON line: the driver contract plus
   "roofline"     -- the dominant kernel against its roofline, duration measured live with events on
                     the launch stream (the kernels are launched on torch's current stream);
   "kernels"      -- the same for every kernel of the step;
-  "cpu_baseline" -- the CPU oracle (a port of the reference's algorithm, numpy) on a bounded sample
-                    of the same workload on this box's host cores.
+  "cpu_baseline" -- the reference module itself (oracle/_ref, torch CPU, all host cores) on a bounded
+                    sample of the same workload on this box's host cores; the numpy port if the
+                    artefact is absent (`kind` says which).
 """
 import argparse
 import json
@@ -112,7 +113,90 @@ def timed_region(step, steps, warmup, sync, barrier, reduce_max):
     return reduce_max(time.perf_counter() - t0)
 
 
-def cpu_baseline(kwargs, n, budget_s=25.0):
+def _reference_module(kwargs):
+    """The reference itself (oracle/_ref: bytecode of /root/reference built by oracle/build_ref.py), default init."""
+    from oracle.build_ref import import_reference
+    ref = import_reference()
+    torch.manual_seed(0)
+    return (ref.EGNN_Network(**kwargs) if "depth" in kwargs else ref.EGNN(**kwargs)).eval()
+
+
+# RAM-safe batch for the reference on the host (BASELINE.md §2: it materialises E*(Din+2H)*4 bytes of edge activations)
+B_CPU = {"north_star": 16, "c2_dense": 8, "c3_network": 16, "c4_sparse": 2, "c5_shard": 4}
+
+
+def cpu_baseline(workload, kwargs, n, budget_s=25.0):
+    """The reference CPU path on this box's host cores: the unmodified reference module (oracle/_ref,
+    `kind: "reference"`), fp32, eval, no_grad, torch intra-op threads = all host cores, B_cpu graphs, 1 warm-up + min of
+    up to 3 runs inside the time budget.  Falls back to the numpy port (oracle/egnn_oracle.py, `kind: "port"`) when the
+    artefact is absent."""
+    try:
+        layer = _reference_module(kwargs)
+    except ImportError:
+        return cpu_baseline_port(kwargs, n, budget_s)
+    b_cpu = B_CPU.get(workload, 2)
+    g = torch.Generator().manual_seed(1000)
+    feats = torch.randn(b_cpu, n, kwargs["dim"], generator=g)
+    coors = torch.randn(b_cpu, n, 3, generator=g)
+    mask = torch.ones(b_cpu, n, dtype=torch.bool)
+    edges = adj = None
+    if kwargs.get("edge_dim", 0) > 0:
+        edges = torch.randn(b_cpu, n, n, kwargs["edge_dim"], generator=g)
+    if kwargs.get("only_sparse_neighbors"):
+        i = torch.arange(n)
+        adj = (i[:, None] - i[None, :]).abs() <= 1
+    is_net = "depth" in kwargs
+
+    def run():
+        with torch.no_grad():
+            if is_net:
+                layer(feats, coors, adj_mat=adj, edges=edges, mask=mask)
+            else:
+                layer(feats, coors, edges, mask, adj)
+
+    t0 = time.perf_counter()
+    run()                                                   # warm-up (thread pool, allocator)
+    spent = time.perf_counter() - t0
+    best, reps = None, 0
+    while reps < 3 and (reps == 0 or spent + best < budget_s):
+        t0 = time.perf_counter()
+        run()
+        dt = time.perf_counter() - t0
+        spent += dt
+        reps += 1
+        best = dt if best is None else min(best, dt)
+    cpu = ""
+    try:
+        cpu = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
+    return dict(value=round(b_cpu / best, 4), unit="graphs/s", cores=int(torch.get_num_threads()), kind="reference",
+                sample=f"the reference module itself (oracle/_ref, torch {torch.__version__} CPU fp32, eval, no_grad), "
+                       f"{b_cpu} graphs x N={n}, 1 warm-up + min of {reps} runs, {best:.2f} s per forward; "
+                       f"host: {os.cpu_count()} logical cores ({cpu}), torch threads {torch.get_num_threads()}")
+
+
+def reference_gpu_eager(kwargs, b, n, device, steps=3):
+    """Secondary baseline: the reference module run on the MI355X through PyTorch-ROCm eager, timed with
+    events on the current stream.  Context only -- never `value`."""
+    layer = _reference_module(kwargs).to(device)
+    feats, coors, mask = make_inputs(kwargs, b, n, device, seed=1000)
+    with torch.no_grad():
+        layer(feats, coors, mask=mask)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            layer(feats, coors, mask=mask)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return dict(value=round(b / ms * 1e3, 2), unit="graphs/s", ms_per_step=round(ms, 3),
+                sample=f"reference module (oracle/_ref) .cuda(), PyTorch-ROCm eager, B={b} N={n}, mean of {steps} forwards",
+                peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
+
+
+def cpu_baseline_port(kwargs, n, budget_s=25.0):
     """The oracle (numpy port of the reference's unfactorised algorithm) on a bounded sample of the same
     workload: B_cpu graphs of N nodes, default-scale weights, on this box's host cores."""
     import numpy as np
@@ -149,6 +233,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="north_star", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ragged-mask", action="store_true", help="ragged masks (len ~ U{N/2..N}) instead of all-True")
+    ap.add_argument("--reference-eager", action="store_true",
+                    help="also time the reference module on the MI355X through PyTorch eager (secondary baseline)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,7 +256,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
 
-    from egnn_pytorch_amd import EGNN, EGNN_Network, phase_timer
+    from egnn_pytorch_amd import EGNN, EGNN_Network, phase_timer, check_range, _ops
+    # Range status word (include/egnn_hip.h: EGNN_RANGE_*): the default mode reads it back after every forward (one host
+    # synchronisation per step, measured at ~2 % of the step); the timed loop uses the deferred mode -- the word is copied
+    # to pinned memory after each forward and examined at the next call and, for all steps, right after the timed region.
+    _ops.RANGE_CHECK = os.environ.get("EGNN_RANGE_CHECK", "deferred")
 
     kwargs, b, n = WORKLOADS[args.workload]
     torch.manual_seed(0)
@@ -179,6 +270,10 @@ def main():
         from egnn_pytorch_amd.sharding import broadcast_parameters
         broadcast_parameters(layer)                       # the only collective: one-off weight replication
     feats, coors, mask = make_inputs(kwargs, b, n, device, seed=1000 + rank)   # this rank's shard of the batch
+    if args.ragged_mask:                                                        # parity-style ragged batch
+        g = torch.Generator().manual_seed(2000 + rank)
+        lens = torch.randint(n // 2, n + 1, (b,), generator=g)
+        mask = (torch.arange(n)[None, :] < lens[:, None]).to(device)
     edges = adj = None
     if kwargs.get("edge_dim", 0) > 0:
         edges = torch.randn(b, n, n, kwargs["edge_dim"], device=device)
@@ -204,6 +299,7 @@ def main():
         return float(t.item())
 
     elapsed = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, reduce_max)
+    check_range()                                        # raises if any timed step left the representable range
 
     # ---- per-kernel durations (events on the launch stream), outside the timed region
     with phase_timer() as pt:
@@ -219,9 +315,12 @@ def main():
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": args.workload, "kwargs": kwargs, "graphs_per_gpu": b, "nodes": n},
+                          "config": {"workload": args.workload, "kwargs": kwargs, "graphs_per_gpu": b, "nodes": n,
+                                     "mask": "ragged" if args.ragged_mask else "all-true"},
                           "kernel_ms_per_step": {k: round(v * (len(pt.summary()[k]) / 5), 4) for k, v in per_kernel.items()},
-                          "layers": depth}), flush=True)
+                          "layers": depth,
+                          **({} if args.no_cpu_baseline or world != 1 else {"cpu_baseline": cpu_baseline(args.workload, kwargs, n)})}),
+              flush=True)
     elif rank == 0:
         counts, shp = model_counts(kwargs, b, n)
         kernels = [roofline_entry(k, counts, ms) for k, ms in sorted(per_kernel.items(), key=lambda kv: -kv[1])
@@ -235,6 +334,8 @@ def main():
             except Exception:
                 traffic = None
         dominant["traffic"] = traffic
+        dominant["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/profile.sh)" \
+            if traffic is not None else None
         graphs = world * b * args.steps
         value = graphs / elapsed
         out = {
@@ -242,17 +343,20 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "edges_per_s": round(value * n * shp["K"], 1),
+            "edges_per_s": round(value * n * shp["K"], 1), "range_check": _ops.RANGE_CHECK,
             "config": {"workload": f"EGNN(dim={kwargs['dim']}, k={shp['K']}) B={b}/GPU N={n} fp32 masked k-NN"
                        if "num_nearest_neighbors" in kwargs else f"EGNN(dim={kwargs['dim']}) dense B={b}/GPU N={n} fp32",
                        "graphs_per_gpu": b, "nodes": n, "neighbors": shp["K"], "global_batch": world * b,
+                       "mask": "ragged" if args.ragged_mask else "all-true",
                        "parallelism": f"batch-shard x{world} (no data-path collective)"},
             "roofline": dominant,
             "kernels": kernels,
             "sum_kernel_ms": round(sum(per_kernel.values()), 4),
         }
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(kwargs, n)
+            out["cpu_baseline"] = cpu_baseline(args.workload, kwargs, n)
+        if args.reference_eager and world == 1:
+            out["reference_gpu_eager"] = reference_gpu_eager(kwargs, b, n, device)
         print(json.dumps(out), flush=True)
 
     if dist is not None:

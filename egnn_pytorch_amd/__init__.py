@@ -6,9 +6,11 @@ The compute path is libegnn_hip.so (hand-written HIP kernels behind the C ABI of
 include/egnn_hip.h).  PyTorch is used for device memory, streams and torch.distributed only.
 """
 from .layer import EGNN, EGNN_Network, CoorsNorm
-from ._ops import phase_timer
+from ._ops import phase_timer, check_range
+from ._abi import EGNNHipError, EGNNRangeError
 from . import sharding
 from .graph import graphed
 
-__all__ = ["EGNN", "EGNN_Network", "CoorsNorm", "phase_timer", "sharding", "graphed"]
+__all__ = ["EGNN", "EGNN_Network", "CoorsNorm", "phase_timer", "sharding", "graphed", "check_range", "EGNNHipError",
+           "EGNNRangeError"]
 __version__ = "0.1.0"

@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -45,11 +45,26 @@ class EdgeArgs(Structure):
         ("valid_radius", c_float), ("clamp", c_float), ("pool_mean", c_int32),
         ("m_i", c_void_p), ("coors_out", c_void_p),
         ("node_hi", c_void_p), ("node_lo", c_void_p), ("node_kp", c_int32),
+        ("status", c_void_p),
     ]
 
 
 class EGNNHipError(RuntimeError):
     pass
+
+
+class EGNNRangeError(EGNNHipError):
+    """A finite value left the range the split-fp16 arithmetic of the gfx950 path can carry (include/egnn_hip.h:
+    EGNN_RANGE_*).  The outputs of that call are non-finite; the reference (plain fp32) has no such limit."""
+
+
+RANGE_BITS = {
+    1: "a GEMM input (feats / [LayerNorm(feats) | m_i] / node_mlp hidden activation) with |x| >= 65504",
+    2: "a node projection P_i = -log2(e) (W_i h_i + b) with |P| >= 65504",
+    4: "a per-edge scalar (squared distance, fourier term or edge feature) with |s| >= 6e7 * max|its weight column| scale",
+    8: "an edge_mlp hidden activation beyond fp16 range (the edge message came out non-finite)",
+    16: "an edge message / pooled message with |m| >= 65504",
+}
 
 
 _lib = None
@@ -103,12 +118,12 @@ def load():
     lib.egnn_packed_halves.argtypes = [c_int64, c_int]
     lib.egnn_linear_hl_f32.restype = c_int
     lib.egnn_linear_hl_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p,
-                                       c_int64, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]
+                                       c_int64, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.egnn_split_f16.restype = c_int
-    lib.egnn_split_f16.argtypes = [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]
+    lib.egnn_split_f16.argtypes = [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.egnn_node_prep_hl.restype = c_int
     lib.egnn_node_prep_hl.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int,
-                                      c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]
+                                      c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]
     lib.egnn_node_prep_f32.restype = c_int
     lib.egnn_node_prep_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
                                        c_int, c_int, c_void_p]

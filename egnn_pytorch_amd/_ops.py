@@ -90,6 +90,76 @@ def _u8(t):
     return t.contiguous().view(torch.uint8)
 
 
+# ---------------------------------------------------------------------------------------------- numerical-range status
+# One int32 status word per device (include/egnn_hip.h: EGNN_RANGE_*).  Kernels OR bits into it when a finite value leaves
+# what the split-fp16 arithmetic carries (the value turns into inf / NaN).  When it is read back is the caller's choice:
+#   EGNN_RANGE_CHECK=sync      (default) every forward ends with one 4-byte device->host read and raises EGNNRangeError
+#   EGNN_RANGE_CHECK=deferred  no synchronisation: the word is copied to pinned memory after each forward and examined at
+#                              the start of the next one (or by egnn_pytorch_amd.check_range()); bench.py uses this
+#   EGNN_RANGE_CHECK=off       never read (outputs are still non-finite when it happens)
+RANGE_CHECK = os.environ.get("EGNN_RANGE_CHECK", "sync")
+_status = {}
+
+
+class _Status:
+    def __init__(self, device):
+        self.dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.event = None
+
+
+def status_word(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    st = _status.get(key)
+    if st is None:
+        st = _status[key] = _Status(torch.device("cuda", key))
+    return st
+
+
+def _raise_range(bits, when):
+    what = "; ".join(msg for bit, msg in _abi.RANGE_BITS.items() if bits & bit)
+    raise _abi.EGNNRangeError(
+        f"egnn_pytorch_amd ({when}): a value left the range of the split-fp16 arithmetic of the gfx950 path: {what}. "
+        f"The outputs of that call are non-finite. (The reference computes in plain fp32 and has no such limit; rescale the "
+        f"inputs / weights, or see DESIGN.md section 2.)")
+
+
+def range_check_after_forward(device, mode=None):
+    """Called by the modules when a forward has been enqueued."""
+    mode = mode or RANGE_CHECK
+    if mode == "off" or torch.cuda.is_current_stream_capturing():      # (graph capture: graphed() checks after each replay)
+        return
+    st = status_word(device)
+    if mode == "sync":
+        bits = int(st.dev.item())                       # the one host synchronisation of the forward
+        if bits:
+            st.dev.zero_()
+            _raise_range(bits, "this call")
+        return
+    st.host.copy_(st.dev, non_blocking=True)            # deferred: examined by the next call / check_range()
+    st.event = torch.cuda.Event()
+    st.event.record()
+
+
+def check_range(device=None, wait=True):
+    """Examine the status word of earlier (deferred-mode) forwards; raises EGNNRangeError if a value left the range."""
+    for key, st in list(_status.items()):
+        if device is not None and torch.device(device).index not in (None, key):
+            continue
+        if st.event is None:
+            continue
+        if wait:
+            st.event.synchronize()
+        elif not st.event.query():
+            continue
+        bits = int(st.host[0])
+        st.event = None
+        if bits:
+            st.dev.zero_()
+            st.host.zero_()
+            _raise_range(bits, "an earlier call")
+
+
 def knn_select(coors, mask, adj_mat, k):
     """(idx int32 (B,N,K), rank fp32 (B,N,K)) -- egnn_knn_select_f32."""
     b, n, cdim = coors.shape
@@ -218,7 +288,8 @@ def split_f16(x2d):
     hi = _packed_empty(rows, kp, x2d.device)
     lo = _packed_empty(rows, kp, x2d.device)
     with _timed("split_f16"):
-        rc = _abi.load().egnn_split_f16(_ptr(x2d), cols, rows, cols, _ptr(hi), _ptr(lo), kp, _stream())
+        rc = _abi.load().egnn_split_f16(_ptr(x2d), cols, rows, cols, _ptr(hi), _ptr(lo), kp, _ptr(status_word(x2d.device).dev),
+                                        _stream())
     _abi.check(rc, "egnn_split_f16")
     return PackedHL(hi, lo, rows, kp)
 
@@ -247,7 +318,7 @@ def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32
         rc = _abi.load().egnn_linear_hl_f32(_ptr(a.hi), _ptr(a.lo), _ptr(whi), _ptr(wlo), float(inv), _ptr(bias),
                                             _ptr(residual), ldr, _ptr(c), n, _ptr(out.hi) if out else None,
                                             _ptr(out.lo) if out else None, kp_out, m, n, kp, w_rows, act, int(split_cols),
-                                            _stream())
+                                            _ptr(status_word(dev).dev), _stream())
     _abi.check(rc, "egnn_linear_hl_f32")
     if out_f32 and out_hl:
         return c, out
@@ -269,7 +340,8 @@ def node_prep_hl(feats2d, m_i, gamma, beta, eps, m_dim, with_raw=False):
     with _timed("node_prep"):
         rc = _abi.load().egnn_node_prep_hl(_ptr(feats2d), _ptr(m_i), _ptr(gamma), _ptr(beta), float(eps), _ptr(hi), _ptr(lo),
                                            kp, _ptr(raw.hi) if raw else None, _ptr(raw.lo) if raw else None,
-                                           raw.kp if raw else 0, rows, dim, m_dim, _stream())
+                                           raw.kp if raw else 0, rows, dim, m_dim, _ptr(status_word(feats2d.device).dev),
+                                           _stream())
     _abi.check(rc, "egnn_node_prep_hl")
     out = PackedHL(hi, lo, rows, kp)
     return (out, raw) if with_raw else out
@@ -285,7 +357,8 @@ def node_prep(feats2d, m_i, gamma, beta, eps, m_dim):
     return out
 
 
-def edge_fused(args: _abi.EdgeArgs):
+def edge_fused(args: _abi.EdgeArgs, device):
+    args.status = _ptr(status_word(device).dev)
     with _timed("edge_fused"):
         rc = _abi.load().egnn_edge_fused_f32(byref(args), _stream())
     _abi.check(rc, "egnn_edge_fused_f32")

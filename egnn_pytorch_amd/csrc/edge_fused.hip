@@ -45,6 +45,7 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 #ifndef EGNN_EDGE_THREADS
 #define EGNN_EDGE_THREADS 256
@@ -237,7 +238,11 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                     else if (sidx < 2 * F) val = cosf(d * exp2f(-(float)(sidx - F)));
                     else if (sidx == 2 * F) val = d;
                     else val = p.edges[((bN + i) * N + j) * p.edge_dim + (sidx - 2 * F - 1)];
-                    val = fminf(fmaxf(val * p.ws_inv_scale, -6.0e7f), 6.0e7f);
+                    // |s'| beyond 2^10 * 65504 = 6.7e7 does not fit the three fp16 parts: the coarse part overflows to inf and
+                    // the edge's result is NaN (never a silently clamped number); the status word says why
+                    val = val * p.ws_inv_scale;
+                    egnn_flag_range(p.status, valid && fabsf(val) >= 6.0e7f && fabsf(val) < __builtin_inff(), EGNN_RANGE_SCALAR);
+                    if (fabsf(val) >= 6.0e7f) val = __builtin_nanf("");
                     const _Float16 s1 = (_Float16)(val * (1.0f / 1024.0f));
                     const float r = val - (float)s1 * 1024.0f;
                     const _Float16 rh = (_Float16)r;
@@ -262,10 +267,15 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             pip[t] = (uint32_t)(((size_t)i * p.ldp + 4 * g) * 4);
             if (TPI == 2 && t == 0) piw[0] = (uint32_t)(((size_t)i * p.ldp + e) * 4);
             if (TPI == 1) {
-                int posg = node0 + (qwave + t * 16) / K + g;                 // the tile's g-th node (any valid row if there is none)
-                if (posg >= N || posg >= node0 + G) posg = node0 < N ? node0 : 0;
-                const int ig = p.order ? p.order[bN + posg] : posg;
-                piw[t] = (uint32_t)(((size_t)ig * p.ldp + e) * 4);
+                // the tile's g-th node.  Its row meets a zero B coefficient in every edge column that belongs to another node,
+                // and 0 x NaN is NaN on the matrix core: a row that is not needed (no such node, or a masked node -- all its
+                // edges are zeroed anyway, :322) must read as zeros, or non-finite padding behind the mask would leak into
+                // the valid edges of the same tile.  An offset past the buffer resource's range makes the load return 0.
+                const int posg = node0 + (qwave + t * 16) / K + g;
+                const bool exists = posg < N && posg < node0 + G;
+                const int ig = exists ? (p.order ? p.order[bN + posg] : posg) : 0;
+                const bool needed = exists && (!has_mask || p.mask[bN + ig]);
+                piw[t] = needed ? (uint32_t)(((size_t)ig * p.ldp + e) * 4) : 0x80000000u;
             }
         }
 
@@ -499,7 +509,9 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                         const float h0 = y0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y0));
                         const float h1 = y1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y1));
 #endif
-                        const f16x2 hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+                        // v_cvt_pk_f16_f32 (IEEE: beyond 65504 -> inf, so an overflowing hidden value poisons the edge's
+                        // message instead of saturating silently as v_cvt_pkrtz would; same issue cost)
+                        const f16x2 hi = __builtin_convertvector((f32x2v){h0, h1}, f16x2);
                         const float l0 = h0 - (float)hi[0];
                         const float l1 = h1 - (float)hi[1];
                         const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l0, l1));
@@ -535,8 +547,13 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
             f32x4 m;
+            bool bad = false;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) m[u] = egnn_silu(acc[t][u] * p.w2_inv_scale + b2r[u]);
+            for (int u = 0; u < 4; ++u) {
+                bad = bad || !(fabsf(acc[t][u]) < __builtin_inff());
+                m[u] = egnn_silu(acc[t][u] * p.w2_inv_scale + b2r[u]);
+            }
+            egnn_flag_range(p.status, bad && fm[t], EGNN_RANGE_HIDDEN);
             if (p.gate_w) {
                 float part = gwr[0] * m[0] + gwr[1] * m[1] + gwr[2] * m[2] + gwr[3] * m[3];
                 part = egnn_column_sum4(part, xch + 64 * t, lane);          // this wave's exchange rows are free now
@@ -563,6 +580,10 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             f16x4 mhi[TILES], mlo[TILES];
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
+                bool bad = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bad = bad || egnn_beyond_f16(acc[t][u]);
+                egnn_flag_range(p.status, bad && fm[t], EGNN_RANGE_MESSAGE);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const _Float16 h = (_Float16)acc[t][u];
@@ -630,7 +651,8 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 #pragma unroll
                 for (int c = 0; c < CDM; ++c) rn[t][c] = rel[t][c] * inv;
             }
-            f32x4 ms = acc[0] * keep[0] + acc[1] * keep[1];
+            const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 ms = (fm[0] ? acc[0] : zero4) + (fm[1] ? acc[1] : zero4);     // select: masked_fill semantics (:322)
             float cs[CDM + 1];
 #pragma unroll
             for (int c = 0; c < CDM; ++c) cs[c] = cw[0] * rn[0][c] + cw[1] * rn[1][c];
@@ -664,7 +686,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 const int slot = wave * SLOTS_PER_WAVE + t * 16 + e;
                 const float keep = fm[t] ? 1.f : 0.f;
                 float* row = ebuf + slot * NCH;
-                *reinterpret_cast<f32x4*>(row + 4 * g) = acc[t] * keep;
+                *reinterpret_cast<f32x4*>(row + 4 * g) = fm[t] ? acc[t] : f32x4{0.f, 0.f, 0.f, 0.f};     // masked_fill semantics (:322)
                 if (g == 0) {
                     float inv = 1.f;
                     if (p.coors_scale) {                                    // CoorsNorm, egnn_pytorch.py:67-77
@@ -714,6 +736,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 }
                 if (p.m_i) p.m_i[(bN + i) * p.m_dim + ch] = val;
                 if (p.node_hi) {                                        // straight into the node_mlp input, as a (hi, lo) pair
+                    egnn_flag_range(p.status, egnn_beyond_f16(val), EGNN_RANGE_MESSAGE);
                     const _Float16 h = (_Float16)val;
                     const size_t off = egnn_pk_off((int64_t)(bN + i), p.dim + ch, p.node_kp / 16);
                     static_cast<_Float16*>(p.node_hi)[off] = h;

@@ -73,6 +73,14 @@ __device__ __forceinline__ int egnn_wave_inclusive_scan(int v)
 
 #pragma GCC poison __shfl __shfl_xor __shfl_up __shfl_down
 
+// Range status (include/egnn_hip.h: EGNN_RANGE_*): an atomic from the lanes that saw a violation, nothing otherwise.
+__device__ __forceinline__ void egnn_flag_range(int32_t* status, bool bad, int bit)
+{
+    if (status && bad) atomicOr(status, bit);
+}
+// finite but beyond what an fp16 (hi, lo) pair carries
+__device__ __forceinline__ bool egnn_beyond_f16(float x) { const float a = fabsf(x); return a >= 65504.f && a < __builtin_inff(); }
+
 // SiLU(x) = x * sigmoid(x) (reference: nn.SiLU, egnn_pytorch.py:56-60).
 // v_exp_f32 + v_rcp_f32; |error| ~1e-7 relative, far inside the 1e-4 parity budget.
 __device__ __forceinline__ float egnn_silu(float x) {
@@ -139,7 +147,7 @@ __host__ __device__ __forceinline__ size_t egnn_pk_off(int64_t row, int k, int n
 // internal (node_ops.hip): producer of the packed (hi, lo) layout, shared by egnn_node_prep_hl and egnn_split_f16
 int egnn_pack_rows_launch(const float* X, int64_t ldx, const float* m_i, const float* gamma, const float* beta, float eps,
                           void* hi, void* lo, int Kp, void* raw_hi, void* raw_lo, int raw_Kp, int64_t rows, int dim, int m_dim,
-                          void* stream);
+                          int32_t* status, void* stream);
 
 static inline int egnn_launch_status() {
     hipError_t e = hipGetLastError();

@@ -56,7 +56,7 @@ __device__ __forceinline__ void linear_hl_body(
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
     const float* __restrict__ bias, const float* __restrict__ R, int64_t ldr,
     float* __restrict__ C, int64_t ldc, _Float16* __restrict__ Chi, _Float16* __restrict__ Clo, int nkt_out,
-    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, char* smem, const int bid)
+    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, int32_t* __restrict__ status, char* smem, const int bid)
 {
     using C_ = Cfg<CFG>;
     constexpr int BM = C_::BM, BN = C_::BN, TI = C_::TI, TJ = C_::TJ, STAGES = C_::STAGES;
@@ -252,6 +252,7 @@ __device__ __forceinline__ void linear_hl_body(
 #endif
                 if (C) {
                     if (gn < split_cols) {                            // this column as an (fp16 hi, fp16 lo) word
+                        egnn_flag_range(status, egnn_beyond_f16(x), EGNN_RANGE_PROJ);
                         const _Float16 h = (_Float16)x;
                         typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
                         const f16x2 w = {h, (_Float16)(x - (float)h)};
@@ -261,6 +262,7 @@ __device__ __forceinline__ void linear_hl_body(
                     }
                 }
                 if (Chi) {
+                    egnn_flag_range(status, egnn_beyond_f16(x), EGNN_RANGE_A_OPERAND);
                     const _Float16 h = (_Float16)x;
                     const size_t o = egnn_pk_off(gm, gn, nkt_out);
                     Chi[o] = h;
@@ -277,17 +279,17 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
     const float* __restrict__ bias, const float* __restrict__ R, int64_t ldr,
     float* __restrict__ C, int64_t ldc, _Float16* __restrict__ Chi, _Float16* __restrict__ Clo, int nkt_out,
-    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols)
+    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, int32_t* __restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // STAGES x BUF
     linear_hl_body<CFG, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, ntm, ntn,
-                                      out_scale, split_cols, smem, blockIdx.x);
+                                      out_scale, split_cols, status, smem, blockIdx.x);
 }
 
 template <int CFG, int ACT, bool HAS_RES>
 int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, const _Float16* Wlo,
                   const float* bias, const float* R, int64_t ldr, float* C, int64_t ldc, _Float16* Chi, _Float16* Clo,
-                  int nkt_out, int64_t M, int N, int Kp, float out_scale, int split_cols, hipStream_t s)
+                  int nkt_out, int64_t M, int N, int Kp, float out_scale, int split_cols, int32_t* status, hipStream_t s)
 {
     using C_ = Cfg<CFG>;
     const int64_t ntm = (M + C_::BM - 1) / C_::BM;
@@ -298,7 +300,7 @@ int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((linear_hl_kernel<CFG, ACT, HAS_RES>), dim3((unsigned)(ntm * ntn)), dim3(C_::WM * C_::WN * 64), lds, s,
-                       Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale, split_cols);
+                       Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale, split_cols, status);
     return egnn_launch_status();
 }
 
@@ -312,14 +314,14 @@ int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi,
 template <int ACT, bool HAS_RES>
 int launch_hl(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, const _Float16* Wlo,
               const float* bias, const float* R, int64_t ldr, float* C, int64_t ldc, _Float16* Chi, _Float16* Clo,
-              int nkt_out, int64_t M, int N, int Kp, float out_scale, int w_rows, int split_cols, hipStream_t s)
+              int nkt_out, int64_t M, int N, int Kp, float out_scale, int w_rows, int split_cols, int32_t* status, hipStream_t s)
 {
     // Large problems (enough 256 x 128 tiles to fill the chip twice) use the larger tile; small ones the 128 x 128 tile.
     constexpr int BIG = EGNN_HL_CFG;
     const int64_t tbig = ((M + Cfg<BIG>::BM - 1) / Cfg<BIG>::BM) * ((N + Cfg<BIG>::BN - 1) / Cfg<BIG>::BN);
     if (BIG != 0 && tbig >= 512 && w_rows >= (N + Cfg<BIG>::BN - 1) / Cfg<BIG>::BN * Cfg<BIG>::BN)
-        return launch_hl_cfg<BIG, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, split_cols, s);
-    return launch_hl_cfg<0, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, split_cols, s);
+        return launch_hl_cfg<BIG, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, split_cols, status, s);
+    return launch_hl_cfg<0, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, split_cols, status, s);
 }
 
 }  // namespace
@@ -327,7 +329,7 @@ int launch_hl(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, con
 extern "C" int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo,
                                   float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
                                   float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
-                                  int w_rows, int act, int split_cols, void* stream)
+                                  int w_rows, int act, int split_cols, int32_t* status, void* stream)
 {
     if (!A_hi || !A_lo || !W_hi || !W_lo) return EGNN_E_NULLPTR;
     if (!C && !C_hi) return EGNN_E_NULLPTR;
@@ -349,18 +351,18 @@ extern "C" int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void
     _Float16 *ch = static_cast<_Float16*>(C_hi), *cl = static_cast<_Float16*>(C_lo);
     const int nkt_out = Kp_out / 16;
     if (act == 0) {
-        if (residual) return launch_hl<0, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, s);
-        return launch_hl<0, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, s);
+        if (residual) return launch_hl<0, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
+        return launch_hl<0, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
     }
-    if (residual) return launch_hl<1, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, s);
-    return launch_hl<1, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, s);
+    if (residual) return launch_hl<1, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
+    return launch_hl<1, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
 }
 
 extern "C" int64_t egnn_packed_halves(int64_t rows, int Kp) { return (rows + 31) / 32 * 32 * (int64_t)Kp; }
 
-extern "C" int egnn_split_f16(const float* X, int64_t ldx, int64_t rows, int cols, void* hi, void* lo, int Kp, void* stream)
+extern "C" int egnn_split_f16(const float* X, int64_t ldx, int64_t rows, int cols, void* hi, void* lo, int Kp, int32_t* status, void* stream)
 {
     if (!X || !hi || !lo) return EGNN_E_NULLPTR;
     if (rows <= 0 || cols <= 0 || ldx < cols || Kp < cols || (Kp % 32) != 0) return EGNN_E_SHAPE;
-    return egnn_pack_rows_launch(X, ldx, nullptr, nullptr, nullptr, 0.f, hi, lo, Kp, nullptr, nullptr, 0, rows, cols, 0, stream);
+    return egnn_pack_rows_launch(X, ldx, nullptr, nullptr, nullptr, 0.f, hi, lo, Kp, nullptr, nullptr, 0, rows, cols, 0, status, stream);
 }

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float eps, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                                            int Kp, _Float16* __restrict__ raw_hi, _Float16* __restrict__ raw_lo,
-                                                           int raw_Kp, int64_t rows, int dim, int m_dim)
+                                                           int raw_Kp, int64_t rows, int dim, int m_dim, int32_t* __restrict__ status)
 {
     typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
     const int lane = threadIdx.x & 63;
@@ -125,6 +125,10 @@ __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restri
                     xv[u] = xr; yv[u] = y;
                 }
             }
+            bool beyond = false;                                   // finite values the fp16 pair cannot carry (they turn into inf / NaN)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) beyond = beyond || egnn_beyond_f16(yv[u]) || (raw_hi && egnn_beyond_f16(xv[u]));
+            egnn_flag_range(status, beyond, EGNN_RANGE_A_OPERAND);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const _Float16 h = (_Float16)yv[u];
@@ -153,21 +157,21 @@ __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restri
 // internal: shared by egnn_node_prep_hl and egnn_split_f16
 int egnn_pack_rows_launch(const float* X, int64_t ldx, const float* m_i, const float* gamma, const float* beta, float eps,
                           void* hi, void* lo, int Kp, void* raw_hi, void* raw_lo, int raw_Kp, int64_t rows, int dim, int m_dim,
-                          void* stream)
+                          int32_t* status, void* stream)
 {
     const int64_t quads = ((rows + 31) / 32 * 32) / 4;
     int64_t blocks = (quads + 3) / 4;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(node_prep_hl_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), X, ldx, m_i,
                        gamma, beta, eps, static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), Kp,
-                       static_cast<_Float16*>(raw_hi), static_cast<_Float16*>(raw_lo), raw_Kp, rows, dim, m_dim);
+                       static_cast<_Float16*>(raw_hi), static_cast<_Float16*>(raw_lo), raw_Kp, rows, dim, m_dim, status);
     return egnn_launch_status();
 }
 
 
 extern "C" int egnn_node_prep_hl(const float* feats, const float* m_i, const float* gamma, const float* beta, float eps,
                                  void* out_hi, void* out_lo, int Kp, void* raw_hi, void* raw_lo, int raw_Kp,
-                                 int64_t rows, int dim, int m_dim, void* stream)
+                                 int64_t rows, int dim, int m_dim, int32_t* status, void* stream)
 {
     if (!feats || !out_hi || !out_lo) return EGNN_E_NULLPTR;
     if ((gamma == nullptr) != (beta == nullptr)) return EGNN_E_NULLPTR;
@@ -175,7 +179,7 @@ extern "C" int egnn_node_prep_hl(const float* feats, const float* m_i, const flo
     if (rows <= 0 || dim <= 0 || m_dim < 0 || Kp < dim + m_dim || (Kp % 32) != 0) return EGNN_E_SHAPE;
     if (raw_hi && (raw_Kp < dim || (raw_Kp % 32) != 0)) return EGNN_E_SHAPE;
     return egnn_pack_rows_launch(feats, dim, m_i, gamma, beta, eps, out_hi, out_lo, Kp, raw_hi, raw_lo, raw_hi ? raw_Kp : 0,
-                                 rows, dim, m_dim, stream);
+                                 rows, dim, m_dim, status, stream);
 }
 
 extern "C" int egnn_node_prep_f32(const float* feats, const float* m_i, const float* gamma, const float* beta, float eps,

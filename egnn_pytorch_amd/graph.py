@@ -14,6 +14,8 @@ from __future__ import annotations
 
 import torch
 
+from . import _ops
+
 
 def graphed(module, *example_inputs, warmup: int = 2, **example_kwargs):
     """Capture `module(*example_inputs, **example_kwargs)` into a HIP graph; returns `run(*inputs, **kwargs)`."""
@@ -42,6 +44,7 @@ def graphed(module, *example_inputs, warmup: int = 2, **example_kwargs):
             elif dst is not src and dst != src:
                 raise ValueError("graphed(): non-tensor arguments are baked into the graph and cannot change")
         graph.replay()
+        _ops.range_check_after_forward(dev)                 # the captured forward could not read the status word itself
         return outputs
 
     run.graph = graph

@@ -133,7 +133,11 @@ class EGNN(nn.Module):
     def forward(self, feats, coors, edges=None, mask=None, adj_mat=None):
         self._check_grad(feats, coors, edges)
         with torch.no_grad():
-            return self._forward_with_hint(feats, coors, edges, mask, adj_mat, None)[:2]
+            if _ops.RANGE_CHECK == "deferred" and feats.is_cuda:
+                _ops.check_range(feats.device, wait=False)          # an earlier call's status, if it has arrived
+            out = self._forward_with_hint(feats, coors, edges, mask, adj_mat, None)[:2]
+            _ops.range_check_after_forward(feats.device)            # EGNN_RANGE_CHECK: sync (default) | deferred | off
+            return out
 
     def _forward_with_hint(self, feats, coors, edges, mask, adj_mat, order_hint):
         """forward + the scheduling permutation it used (EGNN_Network hands layer 0's on to the next layers)."""
@@ -226,7 +230,7 @@ class EGNN(nn.Module):
             a.pool_mean = int(self.m_pool_method == "mean")
             if self.node_mlp is not None:
                 a.node_hi, a.node_lo, a.node_kp = node_in.hi.data_ptr(), node_in.lo.data_ptr(), node_in.kp
-            _ops.edge_fused(a)
+            _ops.edge_fused(a, feats.device)
             del proj
         elif self.node_mlp is not None:                                   # K == 0: no messages, m_i = 0
             node_in = _ops.node_prep_hl(feats2d, None, w.get("gamma"), w.get("beta"), w.get("ln_eps", 1e-5), self.m_dim)
@@ -277,7 +281,11 @@ class EGNN_Network(nn.Module):
     def forward(self, feats, coors, adj_mat=None, edges=None, mask=None, return_coor_changes=False):
         self.layers[0][1]._check_grad(feats, coors, edges)
         with torch.no_grad():
-            return self._forward(feats, coors, adj_mat, edges, mask, return_coor_changes)
+            if _ops.RANGE_CHECK == "deferred" and coors.is_cuda:
+                _ops.check_range(coors.device, wait=False)
+            out = self._forward(feats, coors, adj_mat, edges, mask, return_coor_changes)
+            _ops.range_check_after_forward(coors.device)            # once per network forward, not per layer
+            return out
 
     def _forward(self, feats, coors, adj_mat, edges, mask, return_coor_changes):
         b = feats.shape[0]

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 11
+#define EGNN_ABI_VERSION 12
 
 enum {
     EGNN_OK = 0,
@@ -36,6 +36,20 @@ enum {
     EGNN_E_UNSUPPORTED = -3,  /* shape outside what the kernels are built for (see each entry) */
     EGNN_E_ALIGN = -4,        /* pointer / leading dimension not aligned as required */
     EGNN_E_K_GT_N = -5        /* K > N: the reference's topk raises here too (egnn_pytorch.py:258) */
+};
+
+/* Numerical-range status word (every product on this path is a split-fp16 product: DESIGN.md §2).  Kernels that
+ * take a `status` pointer (device int32, may be NULL) OR one of these bits into it when a FINITE value leaves the range
+ * the fp16 split can carry; the value itself then becomes inf / NaN (never a silently saturated finite number), so the
+ * outputs of the call are visibly unusable and the host binding can raise.  The caller zeroes the word and reads it
+ * back when it chooses to synchronise (egnn_pytorch_amd: `range_check`).  The reference has no such limits
+ * (egnn_pytorch.py:232-233, 287: plain fp32). */
+enum {
+    EGNN_RANGE_A_OPERAND = 1,  /* a GEMM input (feats, [LayerNorm(feats) | m_i], node_mlp hidden) with |x| >= 65504 */
+    EGNN_RANGE_PROJ = 2,       /* a node projection P_i with |-log2(e) P| >= 65504 (needed as an fp16 pair when K >= 6) */
+    EGNN_RANGE_SCALAR = 4,     /* a per-edge scalar (squared distance, fourier term, edge feature) with |s / ws_scale| > 6e7 */
+    EGNN_RANGE_HIDDEN = 8,     /* an edge_mlp hidden activation beyond fp16 (the edge message came out non-finite) */
+    EGNN_RANGE_MESSAGE = 16    /* an edge message / pooled message m_i with |m| >= 65504 */
 };
 
 int egnn_abi_version(void);
@@ -130,18 +144,19 @@ int64_t egnn_packed_halves(int64_t rows, int Kp);
  *   A_hi, A_lo: packed (M, Kp);  W_hi, W_lo: packed (w_rows, Kp), w_rows >= ceil(N/128)*128 (256 x 256 output tiles are
  *   used when w_rows also covers ceil(N/256)*256), holding w_scale * W with w_inv_scale = 1 / w_scale (a power of two);
  *   C (M,N) fp32 row-major and/or C_hi, C_lo packed (M, Kp_out) (the result re-split for the next GEMM; their pad
- *   columns [N, Kp_out) must be zero on entry);  |A| must stay below 65504.
+ *   columns [N, Kp_out) must be zero on entry);  |A| must stay below 65504 (the producers flag violations, see `status`);
+ *   status: optional range status word -- EGNN_RANGE_A_OPERAND for C_hi / C_lo values, EGNN_RANGE_PROJ for split_cols words.
  *   split_cols (multiple of 32, <= N, needs C and no residual): columns [0, split_cols) of C are written as 32-bit words
  *   holding (fp16 hi | fp16 lo << 16) of the value instead of the fp32 value -- the form in which the edge pass feeds
  *   P_i to its first-layer MFMA (egnn_edge_args.pi_split).  Other arguments as egnn_linear_f32. */
 int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo,
                        float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
                        float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
-                       int w_rows, int act, int split_cols, void* stream);
+                       int w_rows, int act, int split_cols, int32_t* status, void* stream);
 
 /* X (rows, cols) fp32 row-major -> packed (rows, Kp) images hi = fp16(x), lo = fp16(x - hi); pads zero; Kp % 32 == 0,
- * Kp >= cols.  Requires |X| < 65504. */
-int egnn_split_f16(const float* X, int64_t ldx, int64_t rows, int cols, void* hi, void* lo, int Kp, void* stream);
+ * Kp >= cols.  |X| >= 65504 (finite) sets EGNN_RANGE_A_OPERAND in *status (optional) and turns into inf / NaN. */
+int egnn_split_f16(const float* X, int64_t ldx, int64_t rows, int cols, void* hi, void* lo, int Kp, int32_t* status, void* stream);
 
 /* egnn_node_prep_f32 writing the packed (hi, lo) pair directly: (rows, Kp), Kp >= dim + m_dim, Kp % 32 == 0.
  * m_i NULL: those columns are written as zeros (egnn_edge_fused_f32 fills them in place: egnn_edge_args.node_hi).
@@ -149,7 +164,7 @@ int egnn_split_f16(const float* X, int64_t ldx, int64_t rows, int cols, void* hi
  * the A operand of the projection GEMM -- so that one pass over feats serves both consumers. */
 int egnn_node_prep_hl(const float* feats, const float* m_i, const float* gamma, const float* beta, float eps,
                       void* out_hi, void* out_lo, int Kp, void* raw_hi, void* raw_lo, int raw_Kp,
-                      int64_t rows, int dim, int m_dim, void* stream);
+                      int64_t rows, int dim, int m_dim, int32_t* status, void* stream);
 
 /* node_norm + concat (egnn_pytorch.py:335-336): out[r] = [ LayerNorm(feats[r]) | m_i[r] ].
  * gamma/beta NULL -> Identity (norm_feats=False).  out: (rows, dim + m_dim). */
@@ -215,6 +230,7 @@ typedef struct egnn_edge_args {
     void* node_hi;              /* optional: packed (B*N, node_kp) fp16 (hi, lo) pair = the node_mlp input prepared by */
     void* node_lo;              /*   egnn_node_prep_hl(m_i = NULL); the pooled messages are written into its columns  */
     int32_t node_kp;            /*   [dim, dim + m_dim) (both or neither; node_kp % 32 == 0, >= dim + m_dim)          */
+    int32_t* status;            /* optional range status word (EGNN_RANGE_SCALAR / _HIDDEN / _MESSAGE), see the enum above */
 } egnn_edge_args;
 
 int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream);

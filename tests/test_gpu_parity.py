@@ -434,3 +434,98 @@ def test_cpu_input_raises():
     layer = EGNN(dim=8)
     with pytest.raises(RuntimeError):
         layer(torch.randn(1, 4, 8), torch.randn(1, 4, 3))
+
+
+# ---------------------------------------------------------------------------------------------- numerical range
+def _range_layer(kw, seed=11):
+    cfg = O.EGNNConfig(**kw)
+    params = O.random_params(cfg, seed=seed)
+    return cfg, params, _module("layer", kw, params)
+
+
+def test_large_but_representable_inputs_match_at_scale():
+    """Inputs well away from O(1) that the split-fp16 arithmetic still carries -- feats x 100, coordinates x 30 (dist^2 up to
+    ~5e4), edge features x 1e3 -- against the oracle at 1e-4 RELATIVE TO THE OUTPUT'S SCALE, and without tripping the
+    range status."""
+    kw = dict(dim=32, num_nearest_neighbors=16, edge_dim=2)
+    cfg, params, net = _range_layer(kw)
+    rng = np.random.default_rng(zlib.crc32(b"large_inputs"))
+    b, n = 2, 64
+    feats = (rng.standard_normal((b, n, 32)) * 100.0).astype(np.float32)
+    coors = (rng.standard_normal((b, n, 3)) * 30.0).astype(np.float32)
+    edges = (rng.standard_normal((b, n, n, 2)) * 1e3).astype(np.float32)
+    mask = np.arange(n)[None, :] < np.array([[n], [n - 9]])
+    ref_node, ref_co = O.egnn_forward(cfg, params, feats, coors, edges, mask, None)
+    node, co = net(_dev(feats), _dev(coors), _dev(edges), _dev(mask))          # (sync range check: would raise here)
+    for got, ref in ((node, ref_node), (co, ref_co)):
+        scale = float(np.abs(ref).max())
+        assert np.isfinite(got.cpu().numpy()).all()
+        np.testing.assert_allclose(got.cpu().numpy(), ref, atol=ATOL * max(1.0, scale), rtol=0)
+
+
+@pytest.mark.parametrize("what,bit", [("feats", 1), ("coors", 4), ("edges", 4)])
+def test_out_of_range_inputs_raise_instead_of_saturating(what, bit):
+    """feats x 1e6 (|x| >= 65504 entering the fp16 split), coordinates x 1e5 (dist^2 ~ 1e10) and edge features x 1e9: the
+    reference computes these in plain fp32; the gfx950 path cannot -- it must say so (EGNNRangeError naming the cause) and
+    leave non-finite outputs, never silently clamped ones."""
+    from egnn_pytorch_amd import EGNNRangeError, _ops
+    kw = dict(dim=32, num_nearest_neighbors=8, edge_dim=2)
+    cfg, params, net = _range_layer(kw)
+    rng = np.random.default_rng(zlib.crc32(what.encode()))
+    b, n = 2, 48
+    feats = rng.standard_normal((b, n, 32)).astype(np.float32)
+    coors = rng.standard_normal((b, n, 3)).astype(np.float32)
+    edges = rng.standard_normal((b, n, n, 2)).astype(np.float32)
+    if what == "feats":
+        feats *= 1e6
+    elif what == "coors":
+        coors *= 1e5
+    else:
+        edges *= 1e9
+    args = (_dev(feats), _dev(coors), _dev(edges))
+    with pytest.raises(EGNNRangeError) as err:
+        net(*args)
+    assert _abi_bits(str(err.value)) & bit
+    # deferred mode: the call returns (non-finite outputs), the next check raises
+    old = _ops.RANGE_CHECK
+    _ops.RANGE_CHECK = "deferred"
+    try:
+        node, co = net(*args)
+        torch.cuda.synchronize()
+        assert not (torch.isfinite(node).all() and torch.isfinite(co).all())
+        with pytest.raises(EGNNRangeError):
+            _ops.check_range()
+        _ops.check_range()                                   # the word was cleared
+    finally:
+        _ops.RANGE_CHECK = old
+    # and the module keeps working afterwards
+    small = net(_dev(feats * 0 + 1), _dev(rng.standard_normal((b, n, 3)).astype(np.float32)), _dev(edges * 0))
+    assert torch.isfinite(small[0]).all()
+
+
+def _abi_bits(message):
+    from egnn_pytorch_amd import _abi
+    return sum(bit for bit, text in _abi.RANGE_BITS.items() if text in message)
+
+
+def test_nan_padding_behind_the_mask_is_harmless():
+    """Padded nodes may hold anything -- the reference zeroes masked pairs with masked_fill (egnn_pytorch.py:322) and never
+    selects masked neighbours while enough valid ones exist.  NaN-padded and zero-padded batches must give bit-identical
+    outputs on the valid nodes, and the range status must stay clear."""
+    kw = dict(dim=32, num_nearest_neighbors=8)
+    cfg, params, net = _range_layer(kw, seed=5)
+    rng = np.random.default_rng(7)
+    b, n = 2, 40
+    lens = np.array([40, 23])
+    mask = np.arange(n)[None, :] < lens[:, None]
+    feats = rng.standard_normal((b, n, 32)).astype(np.float32)
+    coors = rng.standard_normal((b, n, 3)).astype(np.float32)
+    f0, c0 = feats.copy(), coors.copy()
+    f0[~mask] = 0.0
+    f1 = f0.copy()
+    f1[~mask] = np.nan
+    n0, co0 = net(_dev(f0), _dev(c0), mask=_dev(mask))
+    n1, co1 = net(_dev(f1), _dev(c0), mask=_dev(mask))
+    m = _dev(mask)
+    assert torch.equal(n0[m], n1[m]) and torch.equal(co0[m], co1[m])
+    assert torch.isfinite(n1[m]).all()
