@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -26,6 +26,7 @@ SYMBOLS = (
     "egnn_adj_max_degree_u8", "egnn_linear_f32", "egnn_linear_split_f32", "egnn_node_prep_f32",
     "egnn_edge_fused_f32", "egnn_spatial_order_f32", "egnn_linear_hl_f32", "egnn_split_f16", "egnn_node_prep_hl",
     "egnn_packed_halves", "egnn_adj_expand_u8", "egnn_adj_expand_workspace_bytes", "egnn_edge_mfmas",
+    "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32",
 )
 
 
@@ -47,6 +48,55 @@ class EdgeArgs(Structure):
         ("node_hi", c_void_p), ("node_lo", c_void_p), ("node_kp", c_int32),
         ("status", c_void_p),
     ]
+
+
+class LayerDesc(Structure):
+    """Mirror of `struct egnn_layer_desc` (include/egnn_hip.h)."""
+    _fields_ = [("dim", c_int32), ("edge_dim", c_int32), ("m_dim", c_int32), ("fourier_features", c_int32),
+                ("num_nearest_neighbors", c_int32), ("norm_feats", c_int32), ("norm_coors", c_int32), ("update_feats", c_int32),
+                ("update_coors", c_int32), ("only_sparse_neighbors", c_int32), ("soft_edges", c_int32), ("pool_mean", c_int32),
+                ("valid_radius", c_float), ("coor_weights_clamp_value", c_float), ("ln_eps", c_float)]
+
+
+PARAM_FIELDS = ("edge_mlp_0_weight", "edge_mlp_0_bias", "edge_mlp_3_weight", "edge_mlp_3_bias", "edge_gate_0_weight",
+                "edge_gate_0_bias", "node_norm_weight", "node_norm_bias", "coors_norm_scale", "node_mlp_0_weight",
+                "node_mlp_0_bias", "node_mlp_3_weight", "node_mlp_3_bias", "coors_mlp_0_weight", "coors_mlp_0_bias",
+                "coors_mlp_3_weight", "coors_mlp_3_bias")
+
+
+class LayerParams(Structure):
+    """Mirror of `struct egnn_layer_params`: host pointers to the reference's state_dict tensors (field = key with '.' -> '_')."""
+    _fields_ = [(f, c_void_p) for f in PARAM_FIELDS]
+
+
+INFO_OFFSETS = ("wcat_hi", "wcat_lo", "bcat", "wst", "w2h", "b2", "gate_w", "gate_b", "w3h", "b3", "w4", "b4", "coors_scale",
+                "w5_hi", "w5_lo", "b5", "w6_hi", "w6_lo", "b6", "gamma", "beta")
+
+
+class PackedInfo(Structure):
+    """Mirror of `struct egnn_packed_info`."""
+    _fields_ = [("H", c_int32), ("Hp", c_int32), ("S", c_int32), ("NM", c_int32),
+                ("wcat_rows", c_int32), ("w5_rows", c_int32), ("w6_rows", c_int32),
+                ("wcat_inv_scale", c_float), ("ws_inv_scale", c_float), ("w2_inv_scale", c_float), ("w3_inv_scale", c_float),
+                ("w5_inv_scale", c_float), ("w6_inv_scale", c_float)] + \
+               [(f, ctypes.c_uint64) for f in INFO_OFFSETS] + [("bytes", ctypes.c_uint64)]
+
+
+def layer_desc(layer) -> "LayerDesc":
+    """egnn_layer_desc of an egnn_pytorch_amd.EGNN (or reference EGNN-like) module."""
+    import math
+    d = LayerDesc()
+    d.dim, d.edge_dim, d.m_dim, d.fourier_features = layer.dim, layer.edge_dim, layer.m_dim, layer.fourier_features
+    d.num_nearest_neighbors = layer.num_nearest_neighbors
+    d.norm_feats, d.norm_coors = int(layer.norm_feats), int(layer.norm_coors)
+    d.update_feats, d.update_coors = int(layer.node_mlp is not None), int(layer.coors_mlp is not None)
+    d.only_sparse_neighbors, d.soft_edges = int(layer.only_sparse_neighbors), int(layer.edge_gate is not None)
+    d.pool_mean = int(layer.m_pool_method == "mean")
+    d.valid_radius = 3.0e38 if math.isinf(layer.valid_radius) else float(layer.valid_radius)
+    cv = layer.coor_weights_clamp_value
+    d.coor_weights_clamp_value = -1.0 if cv is None else float(cv)
+    d.ln_eps = float(layer.node_norm.eps) if layer.norm_feats else 1e-5
+    return d
 
 
 class EGNNHipError(RuntimeError):
@@ -133,6 +183,17 @@ def load():
     lib.egnn_edge_mfmas.argtypes = [c_int]
     lib.egnn_edge_fused_f32.restype = c_int
     lib.egnn_edge_fused_f32.argtypes = [POINTER(EdgeArgs), c_void_p]
+
+    lib.egnn_packed_weights_bytes.restype = c_size_t
+    lib.egnn_packed_weights_bytes.argtypes = [POINTER(LayerDesc)]
+    lib.egnn_pack_weights_host.restype = c_int
+    lib.egnn_pack_weights_host.argtypes = [POINTER(LayerDesc), POINTER(LayerParams), c_void_p, POINTER(PackedInfo)]
+    lib.egnn_workspace_bytes.restype = c_size_t
+    lib.egnn_workspace_bytes.argtypes = [POINTER(LayerDesc), c_int, c_int, c_int]
+    lib.egnn_layer_forward_f32.restype = c_int
+    lib.egnn_layer_forward_f32.argtypes = [POINTER(LayerDesc), POINTER(PackedInfo), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                                           c_void_p, c_void_p]
 
     if lib.egnn_abi_version() != ABI_VERSION:
         raise EGNNHipError(f"{path}: ABI version {lib.egnn_abi_version()} != {ABI_VERSION}; rebuild it")

@@ -362,3 +362,54 @@ def edge_fused(args: _abi.EdgeArgs, device):
     with _timed("edge_fused"):
         rc = _abi.load().egnn_edge_fused_f32(byref(args), _stream())
     _abi.check(rc, "egnn_edge_fused_f32")
+
+
+# ---------------------------------------------------------------------------------------------- whole-layer C interface
+def pack_weights_c(layer):
+    """egnn_pack_weights_host on the module's parameters: (desc, info, blob uint8 CPU tensor).  The Python module itself
+    re-lays its weights on the device with _weights.pack (same layout, bit-identical: tests/test_host_logic.py); this is the
+    path a binding without torch takes, and what `forward_c` uses."""
+    import ctypes
+    lib = _abi.load()
+    desc = _abi.layer_desc(layer)
+    sd = {k.replace(".", "_"): v.detach().float().cpu().contiguous() for k, v in layer.state_dict().items()}
+    params = _abi.LayerParams()
+    for f in _abi.PARAM_FIELDS:
+        setattr(params, f, sd[f].data_ptr() if f in sd else None)
+    nbytes = lib.egnn_packed_weights_bytes(byref(desc))
+    if nbytes == 0:
+        raise _abi.EGNNHipError("egnn_packed_weights_bytes: descriptor outside what the gfx950 kernels are built for")
+    blob = torch.zeros(nbytes, dtype=torch.uint8)
+    info = _abi.PackedInfo()
+    _abi.check(lib.egnn_pack_weights_host(byref(desc), byref(params), blob.data_ptr(), byref(info)), "egnn_pack_weights_host")
+    assert info.bytes == nbytes
+    return desc, info, blob
+
+
+def forward_c(layer, feats, coors, edges=None, mask=None, adj_mat=None, packed=None):
+    """One EGNN.forward through the single-call C entry egnn_layer_forward_f32 (what a non-Python binding uses); returns
+    (node_out, coors_out).  `packed` = (desc, info, blob_on_device) to reuse a previous pack."""
+    lib = _abi.load()
+    if packed is None:
+        desc, info, blob = pack_weights_c(layer)
+        packed = (desc, info, blob.to(feats.device))
+    desc, info, blob_dev = packed
+    b, n, _ = feats.shape
+    feats, coors = feats.contiguous(), coors.contiguous()
+    if edges is not None:
+        edges = edges.contiguous().float()
+    m8, a8 = _u8(mask), _u8(adj_mat)
+    stride = n * n if (a8 is not None and a8.dim() == 3) else 0
+    k = layer.num_nearest_neighbors
+    if adj_mat is not None and layer.only_sparse_neighbors:
+        k = adj_max_degree(adj_mat)
+    if not (layer.num_nearest_neighbors > 0 or layer.only_sparse_neighbors):
+        k = n
+    nbytes = lib.egnn_workspace_bytes(byref(desc), b, n, min(k, n))
+    ws = empty(max(nbytes, 1), dtype=torch.uint8, device=feats.device)
+    node_out, coors_out = torch.empty_like(feats), torch.empty_like(coors)
+    rc = lib.egnn_layer_forward_f32(byref(desc), byref(info), _ptr(blob_dev), _ptr(feats), _ptr(coors), _ptr(edges), _ptr(m8),
+                                    _ptr(a8), stride, b, n, k, coors.shape[-1], _ptr(node_out), _ptr(coors_out), _ptr(ws),
+                                    nbytes, _ptr(status_word(feats.device).dev), _stream())
+    _abi.check(rc, "egnn_layer_forward_f32")
+    return node_out, coors_out

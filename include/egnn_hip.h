@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 12
+#define EGNN_ABI_VERSION 13
 
 enum {
     EGNN_OK = 0,
@@ -237,6 +237,75 @@ int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream);
 
 /* Number of chained first-layer MFMAs the edge kernel is instantiated with for S per-edge scalars (>= ceil(3 S / 4); one of 1, 3, 4, 6, 12). */
 int egnn_edge_mfmas(int S);
+
+
+/* =============================================================================================
+ * Whole-layer interface: everything a binding that is NOT the shipped Python one needs to
+ * run `EGNN.forward` (egnn_pytorch.py:224-341) from the reference's own parameters -- no torch, no re-implementation of
+ * the weight re-layout.  tests/c_abi/layer_forward_test.c drives a golden case through exactly these four calls.
+ */
+typedef struct egnn_layer_desc {            /* the constructor arguments of EGNN (egnn_pytorch.py:149-168) */
+    int32_t dim, edge_dim, m_dim, fourier_features, num_nearest_neighbors;
+    int32_t norm_feats, norm_coors, update_feats, update_coors, only_sparse_neighbors, soft_edges;
+    int32_t pool_mean;                      /* m_pool_method == 'mean' */
+    float valid_radius;                     /* +inf (or >= 3e38) = none */
+    float coor_weights_clamp_value;         /* < 0 = None */
+    float ln_eps;                           /* node_norm.eps (1e-5) */
+} egnn_layer_desc;
+
+typedef struct egnn_layer_params {          /* the reference's state_dict, fp32 row-major, HOST pointers; NULL where the module */
+    const float *edge_mlp_0_weight, *edge_mlp_0_bias;      /* (H, Din), (H): Din = 2 dim + 2 F + 1 + edge_dim, H = 2 Din   */
+    const float *edge_mlp_3_weight, *edge_mlp_3_bias;      /* (m_dim, H), (m_dim)                                           */
+    const float *edge_gate_0_weight, *edge_gate_0_bias;    /* (1, m_dim), (1)            -- soft_edges                      */
+    const float *node_norm_weight, *node_norm_bias;        /* (dim), (dim)               -- norm_feats                      */
+    const float *coors_norm_scale;                         /* (1)                        -- norm_coors                      */
+    const float *node_mlp_0_weight, *node_mlp_0_bias;      /* (2 dim, dim + m_dim), (2 dim)   -- update_feats                */
+    const float *node_mlp_3_weight, *node_mlp_3_bias;      /* (dim, 2 dim), (dim)                                           */
+    const float *coors_mlp_0_weight, *coors_mlp_0_bias;    /* (4 m_dim, m_dim), (4 m_dim)     -- update_coors                */
+    const float *coors_mlp_3_weight, *coors_mlp_3_bias;    /* (1, 4 m_dim), (1)                                             */
+} egnn_layer_params;                                       /* does not have the tensor */
+
+/* Where each re-laid-out tensor sits inside the packed weight blob (byte offsets; 0 size = absent), plus the power-of-two
+ * scales the kernels undo.  Filled by egnn_pack_weights_host, consumed by egnn_layer_forward_f32. */
+typedef struct egnn_packed_info {
+    int32_t H, Hp, S, NM;                   /* hidden width, its padding, per-edge scalars, first-layer MFMAs */
+    int32_t wcat_rows, w5_rows, w6_rows;    /* padded row counts of the packed GEMM weights */
+    float wcat_inv_scale, ws_inv_scale, w2_inv_scale, w3_inv_scale, w5_inv_scale, w6_inv_scale;
+    uint64_t wcat_hi, wcat_lo, bcat, wst, w2h, b2, gate_w, gate_b, w3h, b3, w4, b4, coors_scale,
+             w5_hi, w5_lo, b5, w6_hi, w6_lo, b6, gamma, beta;
+    uint64_t bytes;                         /* total blob size */
+} egnn_packed_info;
+
+/* Size of the packed blob for a layer (0 on an invalid descriptor). */
+size_t egnn_packed_weights_bytes(const egnn_layer_desc* desc);
+
+/* The weight re-layout of egnn_pytorch_amd/_weights.py::pack as a HOST function (pure CPU work, no HIP call): factorised
+ * first Linear of edge_mlp (W_i | W_j | W_s, x -log2 e), fp16 (hi, lo) splits with power-of-two scales, packed tile-major
+ * GEMM operands, MFMA fragment orders (see egnn_edge_args).  `blob` (host, egnn_packed_weights_bytes bytes) is what the
+ * caller copies to the device once per set of parameters; bit-identical to the Python packer
+ * (tests/test_host_logic.py::test_c_weight_packer_matches_python). */
+int egnn_pack_weights_host(const egnn_layer_desc* desc, const egnn_layer_params* params, void* blob, egnn_packed_info* info);
+
+/* Device workspace one forward needs (neighbour list, projections P, packed GEMM operands ...) for B graphs of N nodes with
+ * K neighbours per node (K = N on the dense path; K = the largest adjacency row sum with only_sparse_neighbors).  0 on
+ * invalid arguments.  The library still allocates nothing: the caller provides the buffer. */
+size_t egnn_workspace_bytes(const egnn_layer_desc* desc, int B, int N, int K);
+
+/* One EGNN layer forward = the 7 launches of DESIGN.md §1 chained on `stream` (neighbour select, operand prep, projection
+ * GEMM, Morton order, fused edge pass, node_mlp GEMMs); semantics and quirks of egnn_pytorch.py:224-341.
+ *   blob_dev: the packed blob on the device;  feats (B,N,dim), coors (B,N,coor_dim) fp32;  edges (B,N,N,edge_dim) or NULL;
+ *   mask (B,N) bytes or NULL;  adj (N,N) / (B,N,N) bytes or NULL (adj_batch_stride 0 / N*N);
+ *   feats_out (B,N,dim), coors_out (B,N,coor_dim): always written (copies of the inputs when the layer does not update them);
+ *   K: neighbours per node actually used -- pass num_nearest_neighbors, or N on the dense path; with only_sparse_neighbors
+ *      pass the largest adjacency row sum (egnn_adj_max_degree_u8; that device read is the host sync the reference has
+ *      too, :249) -- workspace_bytes must be >= egnn_workspace_bytes(desc, B, N, K);
+ *   status: optional range status word (EGNN_RANGE_*).
+ * Returns EGNN_E_K_GT_N when K > N (the reference's topk error). */
+int egnn_layer_forward_f32(const egnn_layer_desc* desc, const egnn_packed_info* info, const void* blob_dev,
+                           const float* feats, const float* coors, const float* edges, const uint8_t* mask,
+                           const uint8_t* adj, int64_t adj_batch_stride, int B, int N, int K, int coor_dim,
+                           float* feats_out, float* coors_out, void* workspace, size_t workspace_bytes,
+                           int32_t* status, void* stream);
 
 #ifdef __cplusplus
 }

@@ -252,3 +252,64 @@ def test_packed_tile_layout_matches_header_formula():
     assert w_rows == 256 and hi.numel() == 256 * 96 and hi.dtype == torch.float16
     back = (_weights.unpack_tiles(hi, 256, 96).float() + _weights.unpack_tiles(lo, 256, 96).float()) * inv
     assert float(back[130:].abs().max()) == 0 and float(back[:, 70:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("kw", [dict(dim=20, m_dim=8, edge_dim=3, fourier_features=2, soft_edges=True, norm_feats=True, norm_coors=True),
+                                dict(dim=64, num_nearest_neighbors=8), dict(dim=33, edge_dim=1, update_coors=False),
+                                dict(dim=16, update_feats=False), dict(dim=512, num_nearest_neighbors=32)])
+def test_c_weight_packer_matches_python(kw):
+    """egnn_pack_weights_host (C, host) == egnn_pytorch_amd/_weights.py::pack (torch): every re-laid-out tensor and every
+    power-of-two scale, bit for bit -- a binding without torch gets exactly the weights the Python module computes with."""
+    from egnn_pytorch_amd import EGNN, _ops, _weights
+    torch.manual_seed(1)
+    layer = EGNN(**kw)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(torch.randn_like(p) * 0.3)
+    w = _weights.pack(layer)
+    desc, info, blob = _ops.pack_weights_c(layer)
+    assert (info.H, info.Hp, info.S) == (w["H"], w["Hp"], w["S"]) and 4 * info.NM == w["Wst"].shape[1]
+
+    def piece(off, ref):
+        ref = ref.contiguous()
+        nbytes = ref.numel() * ref.element_size()
+        got = blob[off:off + nbytes].view(ref.dtype).view(ref.shape)
+        assert torch.equal(got, ref), off
+
+    hi, lo, inv, rows = w["Wcat_split"]
+    assert info.wcat_rows == rows and info.wcat_inv_scale == inv
+    piece(info.wcat_hi, hi); piece(info.wcat_lo, lo); piece(info.bcat, w["bcat"])
+    piece(info.wst, w["Wst"]); assert info.ws_inv_scale == w["ws_inv_scale"]
+    piece(info.w2h, w["W2h"]); assert info.w2_inv_scale == w["w2_inv_scale"]
+    piece(info.b2, w["b2"])
+    if "gate_w" in w:
+        piece(info.gate_w, w["gate_w"]); piece(info.gate_b, w["gate_b"])
+    if "W3h" in w:
+        piece(info.w3h, w["W3h"]); assert info.w3_inv_scale == w["w3_inv_scale"]
+        piece(info.b3, w["b3"]); piece(info.w4, w["W4"]); piece(info.b4, w["b4"])
+    if "coors_scale" in w:
+        piece(info.coors_scale, w["coors_scale"])
+    if "W5_split" in w:
+        for key, o_hi, o_lo, o_b, inv_c, rows_c in (("W5", info.w5_hi, info.w5_lo, info.b5, info.w5_inv_scale, info.w5_rows),
+                                                    ("W6", info.w6_hi, info.w6_lo, info.b6, info.w6_inv_scale, info.w6_rows)):
+            hi, lo, inv, rows = w[key + "_split"]
+            assert rows_c == rows and inv_c == inv
+            piece(o_hi, hi); piece(o_lo, lo); piece(o_b, w["b" + key[1]])
+    if "gamma" in w:
+        piece(info.gamma, w["gamma"]); piece(info.beta, w["beta"])
+
+
+def test_workspace_bytes_and_descriptor_checks():
+    from ctypes import byref
+    from egnn_pytorch_amd import EGNN, _abi
+    lib = _abi.load()
+    d = _abi.layer_desc(EGNN(dim=512, num_nearest_neighbors=32))
+    need = lib.egnn_workspace_bytes(byref(d), 64, 1024, 32)
+    rows = 64 * 1024
+    hp = lib.egnn_padded_hidden(2 * (2 * 512 + 1))
+    assert need >= rows * 2 * hp * 4 + 2 * rows * 32 * 4                       # at least P and the neighbour list
+    assert need < 2 * (rows * 2 * hp * 4)                                      # ... and not wildly more (P dominates)
+    assert lib.egnn_workspace_bytes(byref(d), 0, 1024, 32) == 0
+    bad = _abi.layer_desc(EGNN(dim=8, m_dim=16))
+    bad.m_dim = 32
+    assert lib.egnn_packed_weights_bytes(byref(bad)) == 0 and lib.egnn_workspace_bytes(byref(bad), 1, 4, 4) == 0
