@@ -5,9 +5,10 @@ positional order of the two entry points), parameter names / shapes of the refer
 `state_dict`, error behaviour (asserts at construction, `topk` out-of-range when K > N).
 Reference: egnn_pytorch/egnn_pytorch.py:148-341 (EGNN), :343-454 (EGNN_Network).
 
-The forward pass is inference-only (no autograd graph is recorded; backward is a SURVEY.md §8f
-item) and runs ONLY on a CUDA(HIP) device in fp32 with 3-D coordinates.  There is no CPU or
-PyTorch-eager fallback: anything the kernels do not cover raises.
+The forward pass runs ONLY on a CUDA(HIP) device in fp32.  There is no CPU or PyTorch-eager fallback for it:
+anything the kernels do not cover raises.  Under autograd (grad mode on and an input or a parameter
+requires grad) the same HIP forward is wrapped in an autograd.Function whose backward recomputes the layer
+a few graphs at a time (egnn_pytorch_amd/autograd.py).
 """
 from __future__ import annotations
 
@@ -17,7 +18,7 @@ import warnings
 import torch
 from torch import nn
 
-from . import _abi, _ops, _weights
+from . import _abi, _ops, _weights, autograd as _autograd
 from .attention import GlobalLinearAttention
 
 _SPATIAL_ORDER = os.environ.get("EGNN_SPATIAL_ORDER", "1") != "0"     # scheduling knob only; results do not depend on it
@@ -82,7 +83,6 @@ class EGNN(nn.Module):
 
         self._packed = None
         self._packed_key = None
-        self._warned_grad = False
 
     # ------------------------------------------------------------------ kernel-side weights
     def packed_weights(self):
@@ -107,7 +107,8 @@ class EGNN(nn.Module):
         if feats.shape[-1] != self.dim:
             raise ValueError(f"feats last dim {feats.shape[-1]} != dim {self.dim}")
         if self.training and self.dropout_p > 0:
-            raise NotImplementedError("dropout in training mode is not supported (inference path); call .eval()")
+            raise NotImplementedError("dropout in training mode is not supported by the gfx950 forward (the fused edge pass "
+                                      "has no dropout mask); use dropout=0 or call .eval()")
         if (edges is not None) != (self.edge_dim > 0):
             raise ValueError("`edges` must be passed if and only if edge_dim > 0")
         b, n = feats.shape[:2]
@@ -116,28 +117,28 @@ class EGNN(nn.Module):
         if mask is not None and tuple(mask.shape) != (b, n):
             raise ValueError(f"mask shape {tuple(mask.shape)} != {(b, n)}")
 
-    def _check_grad(self, *tensors):
-        """Called BEFORE entering no_grad (inside it torch.is_grad_enabled() is always False)."""
-        if not torch.is_grad_enabled():
-            return
-        wants = any(t is not None and t.is_floating_point() and t.requires_grad for t in tensors)
-        if wants:
-            raise RuntimeError("egnn_pytorch_amd.EGNN.forward is inference-only (no autograd graph is recorded), but an input "
-                               "requires grad: gradients would silently stop here. Call it under torch.no_grad() or detach "
-                               "the inputs.")
-        if not self._warned_grad and any(p.requires_grad for p in self.parameters()):
-            warnings.warn("egnn_pytorch_amd.EGNN.forward is inference-only: outputs carry no autograd graph "
-                          "(call it under torch.no_grad() to silence this)", stacklevel=3)
-            self._warned_grad = True
-
     def forward(self, feats, coors, edges=None, mask=None, adj_mat=None):
-        self._check_grad(feats, coors, edges)
-        with torch.no_grad():
-            if _ops.RANGE_CHECK == "deferred" and feats.is_cuda:
-                _ops.check_range(feats.device, wait=False)          # an earlier call's status, if it has arrived
-            out = self._forward_with_hint(feats, coors, edges, mask, adj_mat, None)[:2]
-            _ops.range_check_after_forward(feats.device)            # EGNN_RANGE_CHECK: sync (default) | deferred | off
-            return out
+        out = self._call(feats, coors, edges, mask, adj_mat, None)[:2]
+        _ops.range_check_after_forward(feats.device)                # EGNN_RANGE_CHECK: sync (default) | deferred | off
+        return out
+
+    def _call(self, feats, coors, edges, mask, adj_mat, order_hint):
+        """(node_out, coors_out, order): inference under no_grad, or -- when a graph has to be recorded -- through
+        autograd.EGNNFunction (HIP forward, recompute-in-backward)."""
+        if _ops.RANGE_CHECK == "deferred" and feats.is_cuda:
+            _ops.check_range(feats.device, wait=False)              # an earlier call's status, if it has arrived
+        if _autograd.wants_grad(self, feats, coors, edges):
+            node_out, coors_out = _autograd.EGNNFunction.apply(self, order_hint, mask, adj_mat, feats, coors, edges,
+                                                               *self.parameters())
+            order = None                                            # (scheduling hint only; recomputed by the next layer)
+        else:
+            with torch.no_grad():
+                node_out, coors_out, order = self._forward_with_hint(feats, coors, edges, mask, adj_mat, order_hint)[:3]
+        return node_out, coors_out, order
+
+    def _forward_hip_checked(self, feats, coors, edges, mask, adj_mat, order_hint):
+        """(node_out, coors_out, order, idx, rank, valid_radius) -- what autograd.EGNNFunction.forward needs."""
+        return self._forward_with_hint(feats, coors, edges, mask, adj_mat, order_hint)
 
     def _forward_with_hint(self, feats, coors, edges, mask, adj_mat, order_hint):
         """forward + the scheduling permutation it used (EGNN_Network hands layer 0's on to the next layers)."""
@@ -163,7 +164,7 @@ class EGNN(nn.Module):
         idx = rank = None
         if b == 0 or (n == 0 and not use_nearest):
             # empty batch / empty dense graphs: the reference returns empty outputs (N = 0 on the k-NN path: topk's error)
-            return torch.empty_like(feats), torch.empty_like(coors), None
+            return torch.empty_like(feats), torch.empty_like(coors), None, None, None, valid_radius
         if use_nearest:
             if adj_mat is not None and self.only_sparse_neighbors:
                 num_nearest = _ops.adj_max_degree(adj_mat)                # host sync, as upstream (:249)
@@ -240,7 +241,7 @@ class EGNN(nn.Module):
             hid = _ops.linear_hl(node_in, w["W5_split"], 2 * dim, w["b5"], act=1, out_f32=False, out_hl=True,
                                  name="node_mlp0")
             node_out = _ops.linear_hl(hid, w["W6_split"], dim, w["b6"], residual=feats2d, name="node_mlp1").view(b, n, dim)
-        return node_out, coors_out, order
+        return node_out, coors_out, order, idx, rank, valid_radius
 
 
 class EGNN_Network(nn.Module):
@@ -279,13 +280,17 @@ class EGNN_Network(nn.Module):
                 EGNN(dim=dim, edge_dim=edge_dim + adj_dim, norm_feats=True, **kwargs)]))
 
     def forward(self, feats, coors, adj_mat=None, edges=None, mask=None, return_coor_changes=False):
-        self.layers[0][1]._check_grad(feats, coors, edges)
-        with torch.no_grad():
-            if _ops.RANGE_CHECK == "deferred" and coors.is_cuda:
-                _ops.check_range(coors.device, wait=False)
+        if _ops.RANGE_CHECK == "deferred" and coors.is_cuda:
+            _ops.check_range(coors.device, wait=False)
+        # under autograd the embeddings / attention blocks are ordinary differentiable modules and every EGNN layer records
+        # its own autograd.Function; otherwise nothing is recorded
+        grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
+                                            any(torch.is_tensor(t) and t.is_floating_point() and t.requires_grad
+                                                for t in (feats, coors, edges)))
+        with torch.enable_grad() if grad else torch.no_grad():
             out = self._forward(feats, coors, adj_mat, edges, mask, return_coor_changes)
-            _ops.range_check_after_forward(coors.device)            # once per network forward, not per layer
-            return out
+        _ops.range_check_after_forward(coors.device)                # once per network forward, not per layer
+        return out
 
     def _forward(self, feats, coors, adj_mat, edges, mask, return_coor_changes):
         b = feats.shape[0]
@@ -317,7 +322,7 @@ class EGNN_Network(nn.Module):
         for global_attn, egnn in self.layers:
             if global_attn is not None:
                 feats, global_tokens = global_attn(feats, global_tokens, mask=mask)           # :445-446
-            feats, coors, order = egnn._forward_with_hint(feats, coors, edges, mask, adj_mat, order)
+            feats, coors, order = egnn._call(feats, coors, edges, mask, adj_mat, order)
             coor_changes.append(coors)
         if return_coor_changes:
             return feats, coors, coor_changes

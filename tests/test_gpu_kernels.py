@@ -9,6 +9,14 @@ from tests._util import check_neighbors, golden_names, load_golden
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """These are forward-parity tests: run them the way inference code does (under autograd the modules would record a
+    graph, as the reference does -- that path is tests/test_autograd.py)."""
+    with torch.no_grad():
+        yield
+
+
 def _dev(x):
     return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()
 

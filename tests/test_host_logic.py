@@ -62,22 +62,21 @@ def test_no_cpu_fallback():
         EGNN(dim=8)(torch.randn(1, 4, 8), torch.randn(1, 4, 3))
 
 
-def test_inference_only_is_announced_before_no_grad():
-    """the autograd check must run before forward enters no_grad -- an input that requires grad raises (its
-    gradient would silently stop at the layer), parameters that require grad warn once."""
-    from egnn_pytorch_amd import EGNN, EGNN_Network
+def test_autograd_mode_is_decided_before_no_grad():
+    """ADVICE r1 (superseded by autograd support): whether a graph is recorded is decided BEFORE any no_grad block -- with
+    grad mode on and something requiring grad the call goes through autograd.EGNNFunction, under no_grad it does not.  (On
+    the CPU both end at the no-CPU-fallback error; the GPU behaviour is in tests/test_autograd.py.)"""
+    from egnn_pytorch_amd import EGNN, autograd
     layer = EGNN(dim=8)
-    with pytest.raises(RuntimeError, match="inference-only"):
-        layer(torch.randn(1, 4, 8, requires_grad=True), torch.randn(1, 4, 3))
-    with pytest.warns(UserWarning, match="inference-only"):
-        with pytest.raises(RuntimeError, match="no CPU fallback"):
-            layer(torch.randn(1, 4, 8), torch.randn(1, 4, 3))
-    with torch.no_grad():                                           # no warning, no autograd complaint under no_grad
-        with pytest.raises(RuntimeError, match="no CPU fallback"):
-            EGNN(dim=8)(torch.randn(1, 4, 8, requires_grad=True), torch.randn(1, 4, 3))
-    net = EGNN_Network(depth=1, dim=8)
-    with pytest.raises(RuntimeError, match="inference-only"):
-        net(torch.randn(1, 4, 8), torch.randn(1, 4, 3, requires_grad=True))
+    x = torch.randn(1, 4, 8, requires_grad=True)
+    assert autograd.wants_grad(layer, x) and autograd.wants_grad(layer, torch.randn(1, 4, 8))
+    with torch.no_grad():
+        assert not autograd.wants_grad(layer, x)
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    assert not autograd.wants_grad(layer, torch.randn(1, 4, 8)) and autograd.wants_grad(layer, x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer(x, torch.randn(1, 4, 3))
 
 
 def test_product_code_never_imports_oracle():
