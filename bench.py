@@ -281,6 +281,7 @@ def main():
         i = torch.arange(n, device=device)
         adj = (i[:, None] - i[None, :]).abs() <= 1                              # README chain adjacency incl. diagonal
 
+    @torch.no_grad()                                     # the metric is inference (eval, no_grad): BASELINE.md §2
     def step():
         if is_net:
             layer(feats, coors, adj_mat=adj, edges=edges, mask=mask)

@@ -16,14 +16,14 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
 # every symbol include/egnn_hip.h declares
 SYMBOLS = (
     "egnn_abi_version", "egnn_error_string", "egnn_padded_hidden", "egnn_knn_select_f32",
-    "egnn_adj_max_degree_u8", "egnn_linear_f32", "egnn_linear_split_f32", "egnn_node_prep_f32",
+    "egnn_adj_max_degree_u8",
     "egnn_edge_fused_f32", "egnn_spatial_order_f32", "egnn_linear_hl_f32", "egnn_split_f16", "egnn_node_prep_hl",
     "egnn_packed_halves", "egnn_adj_expand_u8", "egnn_adj_expand_workspace_bytes", "egnn_edge_mfmas",
     "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32",
@@ -154,12 +154,6 @@ def load():
                                         c_void_p, c_void_p, c_void_p]
     lib.egnn_adj_max_degree_u8.restype = c_int
     lib.egnn_adj_max_degree_u8.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_void_p]
-    lib.egnn_linear_f32.restype = c_int
-    lib.egnn_linear_f32.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
-                                    c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]
-    lib.egnn_linear_split_f32.restype = c_int
-    lib.egnn_linear_split_f32.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p,
-                                          c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]
     lib.egnn_adj_expand_workspace_bytes.restype = c_size_t
     lib.egnn_adj_expand_workspace_bytes.argtypes = [c_int, c_int]
     lib.egnn_adj_expand_u8.restype = c_int
@@ -174,9 +168,6 @@ def load():
     lib.egnn_node_prep_hl.restype = c_int
     lib.egnn_node_prep_hl.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int,
                                       c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]
-    lib.egnn_node_prep_f32.restype = c_int
-    lib.egnn_node_prep_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
-                                       c_int, c_int, c_void_p]
     lib.egnn_spatial_order_f32.restype = c_int
     lib.egnn_spatial_order_f32.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.egnn_edge_mfmas.restype = c_int

@@ -222,41 +222,6 @@ def adj_max_degree(adj_mat):
     return int(out.item())
 
 
-def linear(a, w, bias=None, residual=None, act=0, name="linear"):
-    """act(a @ w.T + bias) (+ residual) -- egnn_linear_f32.  a: (M,K) fp32 contiguous; w: (N,K)."""
-    m, k = a.shape
-    n = w.shape[0]
-    assert w.shape[1] == k and a.is_contiguous() and w.is_contiguous()
-    c = empty(m, n, dtype=torch.float32, device=a.device)
-    ldr = 0
-    if residual is not None:
-        assert residual.shape == (m, n) and residual.is_contiguous()
-        ldr = n
-    with _timed(name):
-        rc = _abi.load().egnn_linear_f32(_ptr(a), k, _ptr(w), k, _ptr(bias), _ptr(residual), ldr,
-                                         _ptr(c), n, m, n, k, act, _stream())
-    _abi.check(rc, "egnn_linear_f32")
-    return c
-
-
-def linear_split(a, wsplit, n, bias=None, residual=None, act=0, name="linear"):
-    """act(a @ W.T + bias) (+ residual) on the matrix cores -- egnn_linear_split_f32.
-    `wsplit` = (W_hi, W_lo, inv_scale) from _weights.split_f16_rowmajor; n = true number of output columns."""
-    whi, wlo, inv = wsplit
-    m, k = a.shape
-    assert a.is_contiguous() and whi.shape == wlo.shape and whi.shape[0] >= n and whi.shape[1] >= k
-    c = empty(m, n, dtype=torch.float32, device=a.device)
-    ldr = 0
-    if residual is not None:
-        assert residual.shape == (m, n) and residual.is_contiguous()
-        ldr = n
-    with _timed(name):
-        rc = _abi.load().egnn_linear_split_f32(_ptr(a), k, _ptr(whi), _ptr(wlo), whi.shape[1], float(inv), _ptr(bias),
-                                               _ptr(residual), ldr, _ptr(c), n, m, n, k, act, _stream())
-    _abi.check(rc, "egnn_linear_split_f32")
-    return c
-
-
 def _kpad(k):
     return (k + 31) // 32 * 32
 
@@ -345,16 +310,6 @@ def node_prep_hl(feats2d, m_i, gamma, beta, eps, m_dim, with_raw=False):
     _abi.check(rc, "egnn_node_prep_hl")
     out = PackedHL(hi, lo, rows, kp)
     return (out, raw) if with_raw else out
-
-
-def node_prep(feats2d, m_i, gamma, beta, eps, m_dim):
-    rows, dim = feats2d.shape
-    out = empty(rows, dim + m_dim, dtype=torch.float32, device=feats2d.device)
-    with _timed("node_prep"):
-        rc = _abi.load().egnn_node_prep_f32(_ptr(feats2d), _ptr(m_i), _ptr(gamma), _ptr(beta), float(eps),
-                                            _ptr(out), rows, dim, m_dim, _stream())
-    _abi.check(rc, "egnn_node_prep_f32")
-    return out
 
 
 def edge_fused(args: _abi.EdgeArgs, device):

@@ -115,19 +115,6 @@ def split_f16(w: torch.Tensor):
     return pack_tiles(hi), pack_tiles(lo), 1.0 / scale, npad
 
 
-def split_f16_rowmajor(w: torch.Tensor):
-    """Row-major variant for the reference kernel egnn_linear_split_f32 (A split on the fly)."""
-    n, k = w.shape
-    npad, kpad = (n + 127) // 128 * 128, (k + 31) // 32 * 32
-    amax = float(w.abs().max()) if w.numel() else 0.0
-    scale = 2.0 ** (-math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
-    ws = torch.zeros(npad, kpad, dtype=torch.float32, device=w.device)
-    ws[:n, :k] = w.float() * scale
-    hi = ws.half()
-    lo = (ws - hi.float()).half()
-    return hi.contiguous(), lo.contiguous(), 1.0 / scale
-
-
 def pack(layer) -> dict:
     """Build the kernel-side weight set of one EGNN layer.  All outputs are fp32, contiguous, on the
     parameters' device."""

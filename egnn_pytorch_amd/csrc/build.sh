@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -Wno-inline-a
 rm -rf "$HERE/obj"
 mkdir -p "$HERE/obj"
 pids=()
-for f in knn_select spatial_order adj_expand linear_f32 linear_split linear_hl edge_fused node_ops layer_api; do
+for f in knn_select spatial_order adj_expand linear_hl edge_fused node_ops layer_api linear_f32 linear_split node_prep_ref; do
   EXTRA=""
   # the ranking kernel must reproduce the reference's un-fused ((dx*dx+dy*dy)+dz*dz) bit for bit
   [ "$f" = knn_select ] && EXTRA="-ffp-contract=off"
@@ -27,5 +27,14 @@ if grep -h "ScratchSize \[bytes/lane\]: [1-9]" "$HERE"/obj/*.res; then
   echo "error: a kernel spills registers to scratch (see $HERE/obj/*.res)" >&2
   exit 1
 fi
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libegnn_hip.so" "$HERE"/obj/*.o
+# the product library, and -- separately -- the test-only reference kernels (include/egnn_hip_ref.h; loaded by tests/_reflib.py)
+REF_OBJS=("$HERE/obj/linear_f32.o" "$HERE/obj/linear_split.o" "$HERE/obj/node_prep_ref.o")
+PROD_OBJS=()
+for o in "$HERE"/obj/*.o; do
+  case " ${REF_OBJS[*]} " in *" $o "*) ;; *) PROD_OBJS+=("$o") ;; esac
+done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libegnn_hip.so" "${PROD_OBJS[@]}"
 echo "built $OUT/libegnn_hip.so"
+REF_OUT="${2:-$HERE/../../tests}"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$REF_OUT/libegnn_hip_ref.so" "${REF_OBJS[@]}"
+echo "built $REF_OUT/libegnn_hip_ref.so (test-only)"

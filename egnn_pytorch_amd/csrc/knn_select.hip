@@ -78,6 +78,14 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
         for (int c = 0; c < CDM; ++c) ci[c] = c < C ? xs[c * Npad + i] : 0.f;
         const bool mi = ms[i] != 0;
         const uint8_t* adjrow = adj ? adj + (size_t)b * adj_bstride + (size_t)i * N : nullptr;
+        if (!mi && !adjrow) {
+            // a masked (padded) row: every pair is masked, the whole ranking row is 1e5 (:240-242) and the selection is the
+            // first K indices (ties by ascending index) -- what the general path below would find after a 32-step descent
+            // over N equal keys.  Ragged batches spend a third of their rows here.
+            const size_t ob = ((size_t)b * N + i) * K;
+            for (int k = lane; k < K; k += 64) { idx_out[ob + k] = k; rank_out[ob + k] = 1e5f; }
+            continue;
+        }
 
         uint32_t key[CPL];
 #pragma unroll

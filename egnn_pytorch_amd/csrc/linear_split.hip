@@ -16,6 +16,7 @@
 // 40 halves (80 B): ds_read_b128 fragment reads and the staging writes are bank-conflict free.
 // Block -> tile map: XCD-contiguous, grouped over M (as linear_f32.hip).
 #include "egnn_common.h"
+#include "../../include/egnn_hip_ref.h"       // TEST-ONLY library (tests/libegnn_hip_ref.so)
 
 namespace {
 

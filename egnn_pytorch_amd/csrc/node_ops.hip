@@ -1,44 +1,10 @@
 // node_norm + concat feeding node_mlp (reference: egnn_pytorch/egnn_pytorch.py:335-336):
 //     out[r] = [ LayerNorm(feats[r]) (or feats[r]) | m_i[r] ]
-// One wavefront per row; row statistics by DPP reductions (two-pass: mean, then centred variance, as
-// torch's LayerNorm); HBM-bound streaming kernel (reads dim + m_dim floats, writes the same).
+// as the packed fp16 (hi, lo) operand pair of the GEMM; row statistics two-pass (mean, then centred variance, as torch's
+// LayerNorm); HBM-bound streaming kernel.  (The fp32-output variant is test-only: csrc/node_prep_ref.hip.)
 #include "egnn_common.h"
 
 namespace {
-
-__device__ __forceinline__ float wave_sum(float v) { return egnn_wave_sum(v); }
-
-__global__ __launch_bounds__(256) void node_prep_kernel(const float* __restrict__ feats, const float* __restrict__ m_i,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float eps, float* __restrict__ out, int64_t rows, int dim,
-                                                        int m_dim)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    const int od = dim + m_dim;
-    for (int64_t r = wave0; r < rows; r += nwaves) {
-        const float* x = feats + r * dim;
-        float* y = out + r * od;
-        if (gamma) {
-            float s = 0.f;
-            for (int c = lane; c < dim; c += 64) s += x[c];
-            const float mean = wave_sum(s) / (float)dim;
-            float v = 0.f;
-            for (int c = lane; c < dim; c += 64) { const float d = x[c] - mean; v += d * d; }
-            const float var = wave_sum(v) / (float)dim;
-            const float rstd = 1.0f / sqrtf(var + eps);
-            for (int c = lane; c < dim; c += 64) y[c] = (x[c] - mean) * rstd * gamma[c] + beta[c];
-        } else {
-            for (int c = lane; c < dim; c += 64) y[c] = x[c];
-        }
-        if (m_i) {
-            for (int c = lane; c < m_dim; c += 64) y[dim + c] = m_i[r * m_dim + c];
-        } else {
-            for (int c = lane; c < m_dim; c += 64) y[dim + c] = 0.f;
-        }
-    }
-}
 
 // Packed-layout producer: the row [LayerNorm(x) | m_i] (or just x) as the (hi, lo) f16 pair the matrix-core GEMM consumes.
 // 16 lanes per row, 4 consecutive rows per wave: a lane converts 8 consecutive columns (one 16-byte chunk) at a time, so a
@@ -180,19 +146,6 @@ extern "C" int egnn_node_prep_hl(const float* feats, const float* m_i, const flo
     if (raw_hi && (raw_Kp < dim || (raw_Kp % 32) != 0)) return EGNN_E_SHAPE;
     return egnn_pack_rows_launch(feats, dim, m_i, gamma, beta, eps, out_hi, out_lo, Kp, raw_hi, raw_lo, raw_hi ? raw_Kp : 0,
                                  rows, dim, m_dim, status, stream);
-}
-
-extern "C" int egnn_node_prep_f32(const float* feats, const float* m_i, const float* gamma, const float* beta, float eps,
-                                  float* out, int64_t rows, int dim, int m_dim, void* stream)
-{
-    if (!feats || !out) return EGNN_E_NULLPTR;
-    if ((gamma == nullptr) != (beta == nullptr)) return EGNN_E_NULLPTR;
-    if (rows <= 0 || dim <= 0 || m_dim < 0) return EGNN_E_SHAPE;
-    int64_t blocks = (rows + 3) / 4;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(node_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), feats,
-                       m_i, gamma, beta, eps, out, rows, dim, m_dim);
-    return egnn_launch_status();
 }
 
 extern "C" int egnn_abi_version(void) { return EGNN_ABI_VERSION; }

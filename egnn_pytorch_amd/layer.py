@@ -22,6 +22,11 @@ from . import _abi, _ops, _weights, autograd as _autograd
 from .attention import GlobalLinearAttention
 
 _SPATIAL_ORDER = os.environ.get("EGNN_SPATIAL_ORDER", "1") != "0"     # scheduling knob only; results do not depend on it
+# The kernels compute in fp32-class arithmetic (split-f16 products, fp32 accumulation: DESIGN.md §2).  Other floating dtypes
+# -- the reference is dtype-generic and its own tests run in float64 -- are accepted at the boundary: inputs are converted to
+# fp32, outputs back to the callers' dtype.  For bf16 / fp16 that is at least the reference's precision; for float64 it is
+# NOT (products carry ~22 significant bits): the reference's 1e-6 fp64 equivariance bars hold only for small weights.
+_FLOAT_DTYPES = (torch.float32, torch.float64, torch.float16, torch.bfloat16)
 
 
 def _mlp(d_in, d_hidden, d_out, dropout, final_act):
@@ -97,9 +102,8 @@ class EGNN(nn.Module):
         if not feats.is_cuda:
             raise RuntimeError("egnn_pytorch_amd.EGNN runs only on an MI355X (cuda/HIP) device; "
                                "there is no CPU fallback (move the module and inputs with .cuda())")
-        if feats.dtype != torch.float32 or coors.dtype != torch.float32:
-            raise NotImplementedError("the gfx950 path is fp32 only (got "
-                                      f"{feats.dtype}/{coors.dtype})")
+        if feats.dtype not in _FLOAT_DTYPES or coors.dtype not in _FLOAT_DTYPES:
+            raise NotImplementedError(f"the gfx950 path takes floating-point feats / coors (got {feats.dtype}/{coors.dtype})")
         if feats.dim() != 3 or coors.dim() != 3 or feats.shape[:2] != coors.shape[:2]:
             raise ValueError(f"feats {tuple(feats.shape)} / coors {tuple(coors.shape)}: expected (B,N,dim) and (B,N,C)")
         if not 1 <= coors.shape[-1] <= 8:
@@ -144,8 +148,12 @@ class EGNN(nn.Module):
         """forward + the scheduling permutation it used (EGNN_Network hands layer 0's on to the next layers)."""
         self._check_inputs(feats, coors, edges, mask, adj_mat)
         _abi.load()
+        f_dtype, c_dtype = feats.dtype, coors.dtype
         with torch.cuda.device(feats.device):
-            return self._forward_hip(feats, coors, edges, mask, adj_mat, order_hint)
+            out = self._forward_hip(feats.float(), coors.float(), None if edges is None else edges.float(), mask, adj_mat, order_hint)
+        if f_dtype != torch.float32 or c_dtype != torch.float32:
+            out = (out[0].to(f_dtype), out[1].to(c_dtype)) + tuple(out[2:])
+        return out
 
     def _forward_hip(self, feats, coors, edges, mask, adj_mat, order_hint=None):
         b, n, dim = feats.shape

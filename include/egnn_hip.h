@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 13
+#define EGNN_ABI_VERSION 14
 
 enum {
     EGNN_OK = 0,
@@ -101,31 +101,13 @@ int egnn_adj_expand_u8(const uint8_t* adj, int64_t adj_batch_stride, int B, int 
                        uint8_t* adj_out, uint8_t* degree_out, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Dense layer, exact-fp32 variant (v_mfma_f32_32x32x2_f32): C = act(A * W^T + bias) (+ residual).
- * Kept as the numerically exact reference implementation of egnn_linear_split_f32 (A/B tests, odd shapes).
- * Used for (a) the node-level projections P = feats * [W_i ; W_j]^T + [b1 ; 0] that replace the
- * per-edge first Linear of edge_mlp (egnn_pytorch.py:178-179, 279-287: Linear(cat(h_i,h_j,d,e)) =
+ * Dense layers: C = act(A * W^T + bias) (+ residual).  Used for (a) the node-level projections P = feats * [W_i ; W_j]^T +
+ * [b1 ; 0] that replace the per-edge first Linear of edge_mlp (egnn_pytorch.py:178-179, 279-287: Linear(cat(h_i,h_j,d,e)) =
  * W_i h_i + W_j h_j + w_d d + W_e e + b), and (b) node_mlp (egnn_pytorch.py:196-201, 336-337).
- *   A (M,K) lda;  W (N,K) ldw (nn.Linear weight layout);  bias (N) or NULL;
- *   residual (M,N) ldr or NULL;  C (M,N) ldc;  act: 0 = identity, 1 = SiLU.
- * v_mfma_f32_32x32x2_f32: exact fp32 products/accumulation.
- */
-int egnn_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
-                    const float* residual, int64_t ldr, float* C, int64_t ldc,
-                    int64_t M, int N, int K, int act, void* stream);
-
-/* The same operation on the matrix cores (the production path): fp32 in / fp32 out, every product evaluated as
- * a 3-term split-f16 product with fp32 accumulation on v_mfma_f32_32x32x16_f16
- * (a = a_hi + a_lo, w = w_hi + w_lo;  a_hi w_hi + a_lo w_hi + a_hi w_lo;  dropped term <= 2^-22 |a w|: fp32-class
- * accuracy at 3/16 of the f32-MFMA cost -- on gfx950 the f32-input MFMA runs at vector rate on the vector datapath).
- *   W_hi, W_lo: (Np, ldw) fp16 images of w_scale * W, split on the host (egnn_pytorch_amd/_weights.py::split_f16):
- *               Np = N rounded up to 128, ldw = K rounded up to 32, zero padded; w_inv_scale = 1 / w_scale
- *               (a power of two that brings max|W| into [1,2)).
- *   A is split on the fly; requires |A| < 65504.  Other arguments as egnn_linear_f32.
- */
-int egnn_linear_split_f32(const float* A, int64_t lda, const void* W_hi, const void* W_lo, int64_t ldw,
-                          float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
-                          float* C, int64_t ldc, int64_t M, int N, int K, int act, void* stream);
+ *   A (M,K);  W (N,K) (nn.Linear weight layout);  bias (N) or NULL;  residual (M,N) ldr or NULL;  C (M,N) ldc;
+ *   act: 0 = identity, 1 = SiLU.
+ * (The exact-fp32 and split-on-the-fly reference implementations of this operation, kept for A/B tests, live in the
+ * test-only library: include/egnn_hip_ref.h.) */
 
 /* Packed ("tile-major") layout of the fp16 GEMM operands.  An (R x Kp) fp16 matrix -- R padded up to a multiple of 32
  * rows, Kp % 32 == 0, both pads zero -- is stored as [R/32][Kp/16][32 rows][2 chunks][8 halves] with the 16-byte chunk
@@ -148,7 +130,7 @@ int64_t egnn_packed_halves(int64_t rows, int Kp);
  *   status: optional range status word -- EGNN_RANGE_A_OPERAND for C_hi / C_lo values, EGNN_RANGE_PROJ for split_cols words.
  *   split_cols (multiple of 32, <= N, needs C and no residual): columns [0, split_cols) of C are written as 32-bit words
  *   holding (fp16 hi | fp16 lo << 16) of the value instead of the fp32 value -- the form in which the edge pass feeds
- *   P_i to its first-layer MFMA (egnn_edge_args.pi_split).  Other arguments as egnn_linear_f32. */
+ *   P_i to its first-layer MFMA (egnn_edge_args.pi_split).  Other arguments as above. */
 int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo,
                        float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
                        float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
@@ -158,18 +140,14 @@ int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void* W_hi, con
  * Kp >= cols.  |X| >= 65504 (finite) sets EGNN_RANGE_A_OPERAND in *status (optional) and turns into inf / NaN. */
 int egnn_split_f16(const float* X, int64_t ldx, int64_t rows, int cols, void* hi, void* lo, int Kp, int32_t* status, void* stream);
 
-/* egnn_node_prep_f32 writing the packed (hi, lo) pair directly: (rows, Kp), Kp >= dim + m_dim, Kp % 32 == 0.
+/* node_norm + concat (egnn_pytorch.py:335-336), out[r] = [ LayerNorm(feats[r]) | m_i[r] ] (gamma / beta NULL -> Identity,
+ * norm_feats=False), written as the packed (hi, lo) pair the GEMM consumes: (rows, Kp), Kp >= dim + m_dim, Kp % 32 == 0.
  * m_i NULL: those columns are written as zeros (egnn_edge_fused_f32 fills them in place: egnn_edge_args.node_hi).
  * raw_hi / raw_lo (optional, both or neither): additionally the un-normalised feats as a packed (rows, raw_Kp) pair --
  * the A operand of the projection GEMM -- so that one pass over feats serves both consumers. */
 int egnn_node_prep_hl(const float* feats, const float* m_i, const float* gamma, const float* beta, float eps,
                       void* out_hi, void* out_lo, int Kp, void* raw_hi, void* raw_lo, int raw_Kp,
                       int64_t rows, int dim, int m_dim, int32_t* status, void* stream);
-
-/* node_norm + concat (egnn_pytorch.py:335-336): out[r] = [ LayerNorm(feats[r]) | m_i[r] ].
- * gamma/beta NULL -> Identity (norm_feats=False).  out: (rows, dim + m_dim). */
-int egnn_node_prep_f32(const float* feats, const float* m_i, const float* gamma, const float* beta,
-                       float eps, float* out, int64_t rows, int dim, int m_dim, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The fused edge pass: replaces egnn_pytorch.py:262-266, 270-285 (gathers, fourier, concat), :287

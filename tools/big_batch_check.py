@@ -2,6 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+torch.set_grad_enabled(False)          # these tools time / check inference
 from egnn_pytorch_amd import EGNN
 torch.manual_seed(0)
 layer = EGNN(dim=512, num_nearest_neighbors=32).cuda().eval()

@@ -3,6 +3,7 @@ streams (edge passes next to GEMMs of the other chunk) and compare with the same
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+torch.set_grad_enabled(False)          # these tools time / check inference
 from egnn_pytorch_amd import EGNN
 
 torch.manual_seed(0)

@@ -10,6 +10,7 @@ CSRC = os.path.join(ROOT, "egnn_pytorch_amd", "csrc")
 
 TIMER = r'''
 import sys, json, torch
+torch.set_grad_enabled(False)
 sys.path.insert(0, %r)
 from egnn_pytorch_amd import EGNN, phase_timer
 torch.manual_seed(0)
@@ -28,8 +29,7 @@ print(json.dumps({k: round(min(v), 4) for k, v in s.items()}))
 def build(tag, defs, src="edge_fused", tuning=True):
     out = f"/tmp/egnn_{tag}"
     os.makedirs(out, exist_ok=True)
-    names = ("knn_select", "spatial_order", "adj_expand", "linear_f32", "linear_split", "linear_hl", "node_ops", "edge_fused",
-             "edge_fused_c", "layer_api")
+    names = ("knn_select", "spatial_order", "adj_expand", "linear_hl", "node_ops", "edge_fused", "edge_fused_c", "layer_api")
     objs = [os.path.join(CSRC, "obj", f + ".o") for f in names if f != src]
     o = f"{out}/{src}.o"
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-Wno-inline-asm",

@@ -2,6 +2,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+torch.set_grad_enabled(False)          # these tools time / check inference
 from egnn_pytorch_amd import EGNN_Network, graphed
 
 def timeit(fn, n=50):

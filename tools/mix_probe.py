@@ -5,6 +5,7 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+torch.set_grad_enabled(False)          # these tools time / check inference
 from egnn_pytorch_amd import EGNN, _abi, _ops
 
 csrc = os.path.join(ROOT, "egnn_pytorch_amd", "csrc")

@@ -3,6 +3,7 @@ another share the CUs?  (Needs workgroups of both kernels to fit the same LDS / 
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+torch.set_grad_enabled(False)          # these tools time / check inference
 from egnn_pytorch_amd import EGNN
 
 torch.manual_seed(0)
