@@ -10,13 +10,14 @@ derived, padded copies built here and cached per parameter version:
                            `scalar_table`)
      all three multiplied by -log2(e): the edge kernel evaluates SiLU(x) = -ln2 * y / (1 + 2^y), y = -log2(e) x,
      with v_exp_f32 (= 2^y) and no extra multiply.
-  edge_mlp.3.weight (m, H) -> W2h (Hp/32, 2, 64, 8) fp16: (-ln2 * w2_scale * W2) split into hi + lo halves
-     (hi = fp16(w), lo = fp16(w - hi): 22 significant bits), in v_mfma_f32_16x16x32_f16 fragment order:
-     [step][hi|lo][lane = 16*g + channel][t] = W2[channel, 32*step + hidden_slot(g, t)], hidden_slot(g, t) =
+  edge_mlp.3.weight (m, H) -> W2h (Hp/32, NB, 2, 64, 8) fp16: (-ln2 * w2_scale * W2) split into hi + lo halves
+     (hi = fp16(w), lo = fp16(w - hi): 22 significant bits), in v_mfma_f32_16x16x32_f16 fragment order, NB = m_blocks(m)
+     blocks of 16 channels:
+     [step][nb][hi|lo][lane = 16*g + c][t] = W2[16*nb + c, 32*step + hidden_slot(g, t)], hidden_slot(g, t) =
      4*g + t (t < 4), 16 + 4*g + (t - 4) (t >= 4) -- the order in which the first-layer MFMA leaves the hidden
      units in a lane.  w2_scale is the power of two that brings max|W2| into [1, 2) so hi and lo stay in fp16's
      normal range; the kernel multiplies by 1/w2_scale.
-  coors_mlp.* / edge_gate.* -> zero padded to 16 channels / 64 hidden units
+  coors_mlp.* / edge_gate.* -> zero padded to 16 NB channels / 64 NB hidden units
 Zero padding is exact: padded hidden units see y = 0 -> 0 / (1 + 1) = 0 and meet zero W2 columns.
 """
 from __future__ import annotations
@@ -30,8 +31,14 @@ NEG_LN2 = -0.6931471805599453
 
 S_MAX = 16                              # per-edge scalar inputs the edge kernel is instantiated for
 SCALAR_SHIFT = 1024.0                   # 2^10: the coarse part of a per-edge scalar is carried as fp16(s / 2^10)
-M_PAD = 16                              # channels of one 16x16 MFMA tile
-C_PAD = 64                              # coors_mlp hidden units (4 * 16)
+M_MAX = 64                              # largest m_dim the edge kernel is instantiated for
+
+
+def m_blocks(m: int) -> int:
+    """16-channel accumulator tiles per edge tile (the kernel's NB): 1 for m_dim <= 16, 2 up to 32, 4 up to 64."""
+    if m > M_MAX:
+        raise NotImplementedError(f"m_dim={m} > {M_MAX} is not supported by the gfx950 edge kernel")
+    return 1 if m <= 16 else (2 if m <= 32 else 4)
 
 
 def padded_hidden(h: int) -> int:
@@ -126,8 +133,8 @@ def pack(layer) -> dict:
     dim, m = layer.dim, layer.m_dim
     h, din = w1.shape
     s = din - 2 * dim
-    if m > M_PAD:
-        raise NotImplementedError(f"m_dim={m} > {M_PAD} is not supported by the gfx950 edge kernel")
+    nb = m_blocks(m)
+    M_PAD, C_PAD = 16 * nb, 64 * nb
     hp = padded_hidden(h)
     check_scalars(s)
     z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
@@ -148,9 +155,10 @@ def pack(layer) -> dict:
     w2s = w2p * w2_scale                                   # max |.| in [1, 2)
     w2_hi = w2s.half()
     w2_lo = (w2s - w2_hi.float()).half()
-    # h = 32 step + 16 hb + 4 g + r:  (channel, step, hb, g, r) -> (step, g, channel, hb, r) -> (step, lane = 16 g + channel, t = 4 hb + r)
-    frag = lambda t: t.view(M_PAD, hp // 32, 2, 4, 4).permute(1, 3, 0, 2, 4).contiguous().view(hp // 32, 64, 8)
-    w2h = torch.stack([frag(w2_hi), frag(w2_lo)], dim=1).contiguous()      # (Hp/32, 2, 64, 8) fp16
+    # channel = 16 nb + c, h = 32 step + 16 hb + 4 g + r:
+    # (nb, c, step, hb, g, r) -> (step, nb, g, c, hb, r) -> (step, nb, lane = 16 g + c, t = 4 hb + r)
+    frag = lambda t: t.view(nb, 16, hp // 32, 2, 4, 4).permute(2, 0, 4, 1, 3, 5).contiguous().view(hp // 32, nb, 64, 8)
+    w2h = torch.stack([frag(w2_hi), frag(w2_lo)], dim=2).contiguous()      # (Hp/32, NB, 2, 64, 8) fp16
     b2p = z(M_PAD)
     b2p[:m] = b2
 
@@ -170,7 +178,7 @@ def pack(layer) -> dict:
         w3_scale = 2.0 ** (-math.floor(math.log2(a3))) if a3 > 0 and math.isfinite(a3) else 1.0
         w3s = w3p * w3_scale
         w3_hi = w3s.half()
-        w3h = torch.stack([w3_hi, (w3s - w3_hi.float()).half()]).contiguous()        # (2, 64, 16) fp16: hi | lo
+        w3h = torch.stack([w3_hi, (w3s - w3_hi.float()).half()]).contiguous()        # (2, 64 NB, 16 NB) fp16: hi | lo
         b3p = z(C_PAD)
         b3p[:4 * m] = layer.coors_mlp[0].bias.detach().float()
         w4p = z(C_PAD)

@@ -80,7 +80,8 @@ constexpr int CDM = 8;
 constexpr int CDM = 3;
 #define EGNN_EDGE_ENTRY egnn_edge_fused_c3
 #endif
-constexpr int NCH = 17 + CDM;            // per-edge channels reduced per node: 16 m | CDM coords | 1 count
+// per-edge channels reduced per node: 16 NB message channels | CDM coords | 1 count (NB = 16-channel blocks of m_dim)
+constexpr int nch_of(int nb) { return 16 * nb + CDM + 1; }
 constexpr int GMAX = 64;                 // nodes per workgroup
 constexpr int XLD = 32;                  // floats per row of the gather exchange buffer (one 128 B line, chunk-swizzled)
 
@@ -91,8 +92,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // Workgroups per CU the register allocator must allow, chosen so that no variant spills to scratch (csrc/build.sh
 // checks it: spills are slow on a VALU-bound kernel and one less thing to reason about).
-constexpr int edge_min_blocks(int nm, int tpi)
+constexpr int edge_min_blocks(int nm, int tpi, int nb)
 {
+    if (nb >= 4) return 1;                      // m_dim > 32: four accumulator tiles per edge tile
+    if (nb == 2) return nm > 4 ? 1 : 2;
     if (nm >= 12) return 1;
     if (nm > 4) return 2;
     if (nm > 1) return (CDM == 3 && tpi == 2) ? 3 : 2;
@@ -142,15 +145,18 @@ __device__ __forceinline__ uint32_t buf_load1(__amdgpu_buffer_rsrc_t r, uint32_t
 // lane on the VALU.
 // (The body is a device function of the block index so that a dispatcher kernel can give a workgroup slot either an edge
 // group or a GEMM tile: tools/ubench/mix_probe.hip.)
-template <int NM, int HCT, int TPI>
+template <int NM, int HCT, int TPI, int NB>
 __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, const int gpg, char* smem, const int bid, const int nblk)
 {
     constexpr int HC = EGNN_EDGE_RING ? HCT / 2 : HCT;     // columns per staged chunk (ring: two slots of HCT / 2)
+    constexpr int NCH = nch_of(NB);
+    constexpr int W2B = 64 * NB;                           // bytes of W2 fragments per hidden column: NB blocks x (hi | lo) x 16 channels
     const int S = p.S;
-    _Float16* w2s = reinterpret_cast<_Float16*>(smem);                  // [HCT/32][hi|lo][64][8] halves = HCT * 64 bytes
-    float* xchall = reinterpret_cast<float*>(smem + HCT * 64);           // [EDGE_WAVES][32 slots][XLD]: per-wave gather exchange
+    _Float16* w2s = reinterpret_cast<_Float16*>(smem);                  // [HCT/32][NB][hi|lo][64][8] halves = HCT * 64 NB bytes
+    float* xchall = reinterpret_cast<float*>(smem + HCT * W2B);           // [EDGE_WAVES][32 slots][XLD]: per-wave gather exchange
     float* ebuf = xchall;                                                // [slots][NCH] aliases it (TPI != 2 epilogue only)
-    float* nodeacc = xchall + SLOTS_PER_ROUND * XLD;                    // [G][NCH]
+    constexpr int XCH_FLOATS = (TPI != 2 && SLOTS_PER_ROUND * NCH > SLOTS_PER_ROUND * XLD) ? SLOTS_PER_ROUND * NCH : SLOTS_PER_ROUND * XLD;
+    float* nodeacc = xchall + XCH_FLOATS;                               // [G][NCH]
     char* wst = reinterpret_cast<char*>(nodeacc + G * NCH);             // [HCT][4 NM] dwords: first-layer A fragments
 
     const int tid = threadIdx.x;
@@ -320,9 +326,11 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
         const char* tl = wst + (e * (4 * NM) + g) * 4;
         constexpr int tstep = 16 * 4 * NM * 4;                          // bytes per 16 hidden units
 
-        f32x4 acc[TILES];
+        f32x4 acc[TILES][NB];
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[t][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         // ------------------------------------------------------------------ main loop over hidden units
         // Software pipeline: the Pi/Pj rows of step st+1 are requested before step st is computed, so the
@@ -360,9 +368,9 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
         // W2 fragments: (Hp/32, 2, 64, 8) halves = 2048 bytes per step; scalar table: NM * 16 bytes per hidden unit.
         auto stage = [&](int c0s, int slot) {
             const int hcs = (p.Hp - c0s) < HC ? (p.Hp - c0s) : HC;
-            const char* src = reinterpret_cast<const char*>(p.W2h) + (size_t)c0s * 64 + lane * 16;
-            char* dst = reinterpret_cast<char*>(w2s) + slot * (HC * 64);
-            for (int pc = wave; pc < hcs / 16; pc += EDGE_WAVES) lds_dma16(src + pc * 1024, dst + pc * 1024);
+            const char* src = reinterpret_cast<const char*>(p.W2h) + (size_t)c0s * W2B + lane * 16;
+            char* dst = reinterpret_cast<char*>(w2s) + slot * (HC * W2B);
+            for (int pc = wave; pc < hcs * NB / 16; pc += EDGE_WAVES) lds_dma16(src + pc * 1024, dst + pc * 1024);
             const int tbytes = hcs * NM * 16;
             const char* tsrc = reinterpret_cast<const char*>(p.Wst) + (size_t)c0s * NM * 16 + lane * 16;
             char* tdst = wst + slot * (HC * NM * 16);
@@ -382,7 +390,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 #else
             if (c0 + HC < p.Hp) stage(c0 + HC, slot ^ 1);
 #endif
-            const _Float16* w2c = w2s + slot * (HC * 32);
+            const _Float16* w2c = w2s + slot * (HC * (W2B / 2));
             const char* tlc = tl + slot * (HC * NM * 16);
 #else
         for (int c0 = 0; c0 < HpLoop; c0 += HC) {
@@ -391,8 +399,8 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             {
                 // LDS-DMA, 1 KB (64 lanes x 16 B) per instruction: no VGPR round trip, no VALU address loop.
                 // W2 fragments: (Hp/32, 2, 64, 8) halves = 2048 bytes per step; scalar table: NM * 16 bytes per hidden unit.
-                const char* src = reinterpret_cast<const char*>(p.W2h) + (size_t)c0 * 64 + lane * 16;
-                for (int pc = wave; pc < hc / 16; pc += EDGE_WAVES)
+                const char* src = reinterpret_cast<const char*>(p.W2h) + (size_t)c0 * W2B + lane * 16;
+                for (int pc = wave; pc < hc * NB / 16; pc += EDGE_WAVES)
                     __builtin_amdgcn_global_load_lds((glb_void*)(src + pc * 1024),
                                                      (lds_void*)(reinterpret_cast<char*>(w2s) + pc * 1024), 16, 0, 0);
                 const int tbytes = hc * NM * 16;
@@ -453,8 +461,12 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                     av[m][0] = u32x2{0u, *reinterpret_cast<const uint32_t*>(tlc + m * 16 + st * 2 * tstep)};
                     av[m][1] = u32x2{0u, *reinterpret_cast<const uint32_t*>(tlc + m * 16 + st * 2 * tstep + tstep)};
                 }
-                const f16x8 whi = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 0) * 64 + lane) * 8);
-                const f16x8 wlo = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 1) * 64 + lane) * 8);
+                f16x8 whi[NB], wlo[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    whi[nb] = *reinterpret_cast<const f16x8*>(w2c + (((st * NB + nb) * 2 + 0) * 64 + lane) * 8);
+                    wlo[nb] = *reinterpret_cast<const f16x8*>(w2c + (((st * NB + nb) * 2 + 1) * 64 + lane) * 8);
+                }
                 u32x2 a0[TILES][2];                                // first MFMA's A operand: K-slots 4g, 4g+1 = P_i (hi, lo)
                 if (TPI == 0) {
 #pragma unroll
@@ -519,48 +531,61 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                         blo[u] = lo[0]; blo[u + 1] = lo[1];
                     }
 #if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 8)
-                    acc[t][0] += (float)bhi[0] + (float)blo[1] + (float)bhi[2] + (float)blo[3] + (float)bhi[4] + (float)blo[5] + (float)bhi[6] + (float)blo[7] + (float)whi[0] + (float)wlo[0];   // ablation: no second-layer MFMAs
+                    acc[t][0][0] += (float)bhi[0] + (float)blo[1] + (float)bhi[2] + (float)blo[3] + (float)bhi[4] + (float)blo[5] + (float)bhi[6] + (float)blo[7] + (float)whi[0][0] + (float)wlo[0][0];   // ablation: no second-layer MFMAs
 #else
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bhi, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, bhi, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, blo, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[nb], bhi, acc[t][nb], 0, 0, 0);
+                        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[nb], bhi, acc[t][nb], 0, 0, 0);
+                        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[nb], blo, acc[t][nb], 0, 0, 0);
+                    }
 #endif
                 }
             }
         }
 
         // ------------------------------------------------------------------ per-edge epilogue (registers)
-        f32x4 b2r;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) b2r[u] = p.b2[4 * g + u];
-        f32x4 gwr = f32x4{0.f, 0.f, 0.f, 0.f};
+        // channel of (block nb, lane group g, register u) = 16 nb + 4 g + u
+        f32x4 b2r[NB], gwr[NB];
         float gb = 0.f;
-        if (p.gate_w) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) gwr[u] = p.gate_w[4 * g + u];
-            gb = p.gate_b[0];
+        for (int nb = 0; nb < NB; ++nb) {
+            gwr[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b2r[nb][u] = p.b2[16 * nb + 4 * g + u];
+            if (p.gate_w) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gwr[nb][u] = p.gate_w[16 * nb + 4 * g + u];
+            }
         }
+        if (p.gate_w) gb = p.gate_b[0];
         float cscale = 0.f;
         if (p.coors_scale) cscale = p.coors_scale[0];
 
         float cw[TILES];
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
-            f32x4 m;
+            f32x4 m[NB];
             bool bad = false;
+            float part = 0.f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                bad = bad || !(fabsf(acc[t][u]) < __builtin_inff());
-                m[u] = egnn_silu(acc[t][u] * p.w2_inv_scale + b2r[u]);
+            for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    bad = bad || !(fabsf(acc[t][nb][u]) < __builtin_inff());
+                    m[nb][u] = egnn_silu(acc[t][nb][u] * p.w2_inv_scale + b2r[nb][u]);
+                }
+                part += gwr[nb][0] * m[nb][0] + gwr[nb][1] * m[nb][1] + gwr[nb][2] * m[nb][2] + gwr[nb][3] * m[nb][3];
             }
             egnn_flag_range(p.status, bad && fm[t], EGNN_RANGE_HIDDEN);
             if (p.gate_w) {
-                float part = gwr[0] * m[0] + gwr[1] * m[1] + gwr[2] * m[2] + gwr[3] * m[3];
                 part = egnn_column_sum4(part, xch + 64 * t, lane);          // this wave's exchange rows are free now
                 const float gt = egnn_sigmoid(part + gb);
-                m *= gt;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) m[nb] *= gt;
             }
-            acc[t] = m;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[t][nb] = m[nb];
             cw[t] = 0.f;
         }
 
@@ -577,33 +602,49 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             // flight they occasionally returned another value.  No kernel uses the LDS-pipe shuffles any more
             // (egnn_common.h poisons them); regressions: tests/test_gpu_parity.py::test_multi_round_stress... and
             // ::test_concurrent_launches_do_not_change_results.)
-            f16x4 mhi[TILES], mlo[TILES];
+            f16x4 mhi[TILES][NB], mlo[TILES][NB];
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
                 bool bad = false;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) bad = bad || egnn_beyond_f16(acc[t][u]);
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) bad = bad || egnn_beyond_f16(acc[t][nb][u]);
                 egnn_flag_range(p.status, bad && fm[t], EGNN_RANGE_MESSAGE);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const _Float16 h = (_Float16)acc[t][u];
-                    mhi[t][u] = h;
-                    mlo[t][u] = (_Float16)(acc[t][u] - (float)h);
-                }
-            }
-            const _Float16* w3h = static_cast<const _Float16*>(p.W3h);
+                for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int blk = 0; blk < 4; ++blk) {
-                const f16x4 w3hi = *reinterpret_cast<const f16x4*>(w3h + (16 * blk + e) * 16 + 4 * g);
-                const f16x4 w3lo = *reinterpret_cast<const f16x4*>(w3h + 64 * 16 + (16 * blk + e) * 16 + 4 * g);
+                    for (int u = 0; u < 4; ++u) {
+                        const _Float16 h = (_Float16)acc[t][nb][u];
+                        mhi[t][nb][u] = h;
+                        mlo[t][nb][u] = (_Float16)(acc[t][nb][u] - (float)h);
+                    }
+            }
+            // W3h: (2, 64 NB, 16 NB) fp16, hi image then lo image of coors_mlp.0.weight zero padded; the (16 NB -> 64 NB)
+            // product runs as 4 NB row blocks x NB K-blocks of v_mfma_f32_16x16x16_f16
+            const _Float16* w3h = static_cast<const _Float16*>(p.W3h);
+            constexpr int W3LD = 16 * NB, W3IMG = 64 * NB * 16 * NB;
+#pragma unroll
+            for (int blk = 0; blk < 4 * NB; ++blk) {
                 const f32x4 b3 = *reinterpret_cast<const f32x4*>(p.b3 + 16 * blk + 4 * g);
                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.W4 + 16 * blk + 4 * g);
+                f32x4 a2t[TILES];
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) a2t[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) {
+                    const f16x4 w3hi = *reinterpret_cast<const f16x4*>(w3h + (16 * blk + e) * W3LD + 16 * kb + 4 * g);
+                    const f16x4 w3lo = *reinterpret_cast<const f16x4*>(w3h + W3IMG + (16 * blk + e) * W3LD + 16 * kb + 4 * g);
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+                        a2t[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(w3hi, mhi[t][kb], a2t[t], 0, 0, 0);
+                        a2t[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(w3lo, mhi[t][kb], a2t[t], 0, 0, 0);
+                        a2t[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(w3hi, mlo[t][kb], a2t[t], 0, 0, 0);
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
-                    f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    a2 = __builtin_amdgcn_mfma_f32_16x16x16f16(w3hi, mhi[t], a2, 0, 0, 0);
-                    a2 = __builtin_amdgcn_mfma_f32_16x16x16f16(w3lo, mhi[t], a2, 0, 0, 0);
-                    a2 = __builtin_amdgcn_mfma_f32_16x16x16f16(w3hi, mlo[t], a2, 0, 0, 0);
+                    const f32x4 a2 = a2t[t];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         part[t] += w4[u] * egnn_silu(a2[u] * p.w3_inv_scale + b3[u]);
@@ -652,20 +693,28 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 for (int c = 0; c < CDM; ++c) rn[t][c] = rel[t][c] * inv;
             }
             const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 ms = (fm[0] ? acc[0] : zero4) + (fm[1] ? acc[1] : zero4);     // select: masked_fill semantics (:322)
+            f32x4 ms[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                ms[nb] = (fm[0] ? acc[0][nb] : zero4) + (fm[1] ? acc[1][nb] : zero4);     // select: masked_fill semantics (:322)
             float cs[CDM + 1];
 #pragma unroll
             for (int c = 0; c < CDM; ++c) cs[c] = cw[0] * rn[0][c] + cw[1] * rn[1][c];
             cs[CDM] = keep[0] + keep[1];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ms[u] = row16_sum(ms[u]);
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ms[nb][u] = row16_sum(ms[nb][u]);
 #pragma unroll
             for (int c = 0; c <= CDM; ++c) cs[c] = row16_sum(cs[c]);
             // the wave's own exchange rows double as its partial-sum row (no other wave touches them)
-            if (e == 0) *reinterpret_cast<f32x4*>(xch + 4 * g) = ms;
+            if (e == 0) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) *reinterpret_cast<f32x4*>(xch + 16 * nb + 4 * g) = ms[nb];
+            }
             if (lane == 0) {
 #pragma unroll
-                for (int c = 0; c <= CDM; ++c) xch[16 + c] = cs[c];
+                for (int c = 0; c <= CDM; ++c) xch[16 * NB + c] = cs[c];
             }
             __syncthreads();
             const int kw = K / SLOTS_PER_WAVE;                           // waves per node
@@ -686,7 +735,9 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 const int slot = wave * SLOTS_PER_WAVE + t * 16 + e;
                 const float keep = fm[t] ? 1.f : 0.f;
                 float* row = ebuf + slot * NCH;
-                *reinterpret_cast<f32x4*>(row + 4 * g) = fm[t] ? acc[t] : f32x4{0.f, 0.f, 0.f, 0.f};     // masked_fill semantics (:322)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)                              // masked_fill semantics (:322)
+                    *reinterpret_cast<f32x4*>(row + 16 * nb + 4 * g) = fm[t] ? acc[t][nb] : f32x4{0.f, 0.f, 0.f, 0.f};
                 if (g == 0) {
                     float inv = 1.f;
                     if (p.coors_scale) {                                    // CoorsNorm, egnn_pytorch.py:67-77
@@ -696,8 +747,8 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                         inv = cscale / fmaxf(sqrtf(n2), 1e-8f);
                     }
 #pragma unroll
-                    for (int c = 0; c < CDM; ++c) row[16 + c] = cw[t] * (rel[t][c] * inv);
-                    row[16 + CDM] = keep;
+                    for (int c = 0; c < CDM; ++c) row[16 * NB + c] = cw[t] * (rel[t][c] * inv);
+                    row[16 * NB + CDM] = keep;
                 }
             }
             __syncthreads();
@@ -724,7 +775,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
         if (node0 + nl >= N) continue;
         const int i = p.order ? p.order[bN + node0 + nl] : node0 + nl;
         float val = nodeacc[o];
-        if (ch < 16) {
+        if (ch < 16 * NB) {
             if (ch < p.m_dim && (p.m_i || p.node_hi)) {
                 if (p.pool_mean) {
                     if (has_mask) {                                     // safe_div, egnn_pytorch.py:13-16
@@ -743,23 +794,24 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                     static_cast<_Float16*>(p.node_lo)[off] = (_Float16)(val - (float)h);
                 }
             }
-        } else if (ch < 16 + ((CDM == 3) ? 3 : p.coor_dim)) {
+        } else if (ch < 16 * NB + ((CDM == 3) ? 3 : p.coor_dim)) {
             const int C = (CDM == 3) ? 3 : p.coor_dim;
-            if (p.coors_out) p.coors_out[(bN + i) * C + (ch - 16)] = p.coors[(bN + i) * C + (ch - 16)] + val;
+            if (p.coors_out) p.coors_out[(bN + i) * C + (ch - 16 * NB)] = p.coors[(bN + i) * C + (ch - 16 * NB)] + val;
         }
     }
 }
 
-template <int NM, int HCT, int TPI>
-__global__ __launch_bounds__(EDGE_THREADS, edge_min_blocks(NM, TPI)) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
+template <int NM, int HCT, int TPI, int NB>
+__global__ __launch_bounds__(EDGE_THREADS, edge_min_blocks(NM, TPI, NB)) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    edge_body<NM, HCT, TPI>(p, G, gpg, smem, blockIdx.x, gridDim.x);
+    edge_body<NM, HCT, TPI, NB>(p, G, gpg, smem, blockIdx.x, gridDim.x);
 }
 
-template <int NM, int HCT, int TPI>
+template <int NM, int HCT, int TPI, int NB>
 int launch_edge(const egnn_edge_args& a, hipStream_t s)
 {
+    constexpr int NCH = nch_of(NB);
     // nodes per workgroup: as many as fit one round of 128 slots -- or, when that would leave slots idle (K = 24: 120 of
     // 128, K = 48: 96), the smallest group whose slots fill whole rounds (K = 48: 8 nodes = 3 rounds), up to 16 nodes
     int G = SLOTS_PER_ROUND / a.K;
@@ -773,24 +825,39 @@ int launch_edge(const egnn_edge_args& a, hipStream_t s)
     const int64_t nblk = (int64_t)a.B * gpg;
     if (nblk > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
     // W2 fragments | gather exchange | node accumulators | first-layer A fragments (40 KB = 4 workgroups per CU at S = 1)
-    const size_t lds = (size_t)HCT * 64 + sizeof(float) * ((size_t)SLOTS_PER_ROUND * XLD + (size_t)G * NCH) + (size_t)HCT * NM * 16;
+    const size_t xch_floats = (TPI != 2 && NCH > XLD) ? (size_t)SLOTS_PER_ROUND * NCH : (size_t)SLOTS_PER_ROUND * XLD;
+    const size_t lds = (size_t)HCT * 64 * NB + sizeof(float) * (xch_floats + (size_t)G * NCH) + (size_t)HCT * NM * 16;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_kernel<NM, HCT, TPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_kernel<NM, HCT, TPI, NB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((edge_kernel<NM, HCT, TPI>), dim3((unsigned)nblk), dim3(EDGE_THREADS), lds, s, a, G, gpg);
+    hipLaunchKernelGGL((edge_kernel<NM, HCT, TPI, NB>), dim3((unsigned)nblk), dim3(EDGE_THREADS), lds, s, a, G, gpg);
     return egnn_launch_status();
 }
 
-template <int NM, int HCT>
-int dispatch_tpi(const egnn_edge_args& a, hipStream_t s)
+template <int NM, int HCT, int NB>
+int dispatch_tpi_nb(const egnn_edge_args& a, hipStream_t s)
 {
     // K % 32 == 0: both tiles of a wave share node i; K >= 6: a tile touches <= 4 nodes -- either way P_i rides in the
     // first-layer MFMA as (hi, lo) words (pi_split); K < 6: it is added per lane from the fp32 projection
-    if (a.K % 32 == 0) return launch_edge<NM, HCT, 2>(a, s);
-    if (a.K >= 6) return launch_edge<NM, HCT, 1>(a, s);
-    return launch_edge<NM, HCT, 0>(a, s);
+    if (a.K % 32 == 0) return launch_edge<NM, HCT, 2, NB>(a, s);
+    if (a.K >= 6) return launch_edge<NM, HCT, 1, NB>(a, s);
+    return launch_edge<NM, HCT, 0, NB>(a, s);
+}
+
+// m_dim <= 16: one accumulator tile per edge tile (every BASELINE config); 17..32: two; 33..64: four, with the staged
+// chunk shrunk so that the W2 fragments keep their LDS footprint (HCT * 64 NB bytes)
+template <int NM, int HCT>
+int dispatch_tpi(const egnn_edge_args& a, hipStream_t s)
+{
+    if (a.m_dim <= 16) return dispatch_tpi_nb<NM, HCT, 1>(a, s);
+#ifndef EGNN_EDGE_TUNING_BUILD
+    if (a.m_dim <= 32) return dispatch_tpi_nb<NM, (HCT / 2 >= 64 ? HCT / 2 : 64), 2>(a, s);
+    return dispatch_tpi_nb<NM, 64, 4>(a, s);
+#else
+    return EGNN_E_UNSUPPORTED;
+#endif
 }
 
 }  // namespace
@@ -826,7 +893,7 @@ int EGNN_EDGE_ENTRY(const egnn_edge_args* args, void* stream)
     if (a.gate_w && !a.gate_b) return EGNN_E_NULLPTR;
     if (a.B <= 0 || a.N <= 0 || a.K <= 0 || a.H <= 0) return EGNN_E_SHAPE;
     if (a.Hp != egnn_padded_hidden(a.H) || a.ldp < a.Hp || (a.ldp % 4) != 0 || !(a.w2_inv_scale > 0.f)) return EGNN_E_SHAPE;
-    if (a.m_dim < 1 || a.m_dim > 16) return EGNN_E_UNSUPPORTED;
+    if (a.m_dim < 1 || a.m_dim > 64) return EGNN_E_UNSUPPORTED;
     if (a.S != 2 * a.fourier + 1 + a.edge_dim) return EGNN_E_SHAPE;
     if (a.S > 16) return EGNN_E_UNSUPPORTED;
     if (!(a.ws_inv_scale > 0.f)) return EGNN_E_SHAPE;

@@ -15,8 +15,7 @@ namespace {
 
 constexpr float NEG_LOG2E = -1.4426950408889634f;
 constexpr float NEG_LN2 = -0.6931471805599453f;
-constexpr int M_PAD = 16;         // channels of one 16 x 16 MFMA tile
-constexpr int C_PAD = 64;         // coors_mlp hidden units (4 x 16)
+constexpr int M_MAX = 64;         // largest m_dim the edge kernel is instantiated for
 constexpr int S_MAX = 16;
 
 inline int pad32(int x) { return (x + 31) / 32 * 32; }
@@ -33,13 +32,14 @@ inline float pow2_scale(float amax)
 
 struct Dims {
     int dim, m, F, edge_dim, din, H, Hp, S, NM, kp_dim, kp_node, kp_hid;
+    int NB, M_PAD, C_PAD;          // 16-channel blocks of m_dim (1, 2 or 4); padded channels 16 NB; coors_mlp hidden 64 NB
     bool ok;
 };
 
 Dims dims_of(const egnn_layer_desc* d)
 {
     Dims x{};
-    if (!d || d->dim <= 0 || d->m_dim < 1 || d->m_dim > M_PAD || d->edge_dim < 0 || d->fourier_features < 0) return x;
+    if (!d || d->dim <= 0 || d->m_dim < 1 || d->m_dim > M_MAX || d->edge_dim < 0 || d->fourier_features < 0) return x;
     x.dim = d->dim; x.m = d->m_dim; x.F = d->fourier_features; x.edge_dim = d->edge_dim;
     x.S = 2 * x.F + 1 + x.edge_dim;
     if (x.S > S_MAX) return x;
@@ -47,6 +47,9 @@ Dims dims_of(const egnn_layer_desc* d)
     x.H = 2 * x.din;
     x.Hp = egnn_padded_hidden(x.H);
     x.NM = egnn_edge_mfmas(x.S);
+    x.NB = x.m <= 16 ? 1 : (x.m <= 32 ? 2 : 4);
+    x.M_PAD = 16 * x.NB;
+    x.C_PAD = 64 * x.NB;
     x.kp_dim = pad32(x.dim);
     x.kp_node = pad32(x.dim + x.m);
     x.kp_hid = pad32(2 * x.dim);
@@ -68,13 +71,13 @@ void layout(const egnn_layer_desc* d, const Dims& x, egnn_packed_info* info)
     take(info->wcat_lo, (size_t)info->wcat_rows * x.kp_dim * 2);
     take(info->bcat, (size_t)2 * x.Hp * 4);
     take(info->wst, (size_t)x.Hp * 4 * x.NM * 2 * 2);
-    take(info->w2h, (size_t)(x.Hp / 32) * 2 * 64 * 8 * 2);
-    take(info->b2, M_PAD * 4);
-    if (d->soft_edges) { take(info->gate_w, M_PAD * 4); take(info->gate_b, 4); }
+    take(info->w2h, (size_t)(x.Hp / 32) * x.NB * 2 * 64 * 8 * 2);
+    take(info->b2, (size_t)x.M_PAD * 4);
+    if (d->soft_edges) { take(info->gate_w, (size_t)x.M_PAD * 4); take(info->gate_b, 4); }
     if (d->update_coors) {
-        take(info->w3h, (size_t)2 * C_PAD * M_PAD * 2);
-        take(info->b3, C_PAD * 4);
-        take(info->w4, C_PAD * 4);
+        take(info->w3h, (size_t)2 * x.C_PAD * x.M_PAD * 2);
+        take(info->b3, (size_t)x.C_PAD * 4);
+        take(info->w4, (size_t)x.C_PAD * 4);
         take(info->b4, 4);
     }
     if (d->norm_coors) take(info->coors_scale, 4);
@@ -184,13 +187,13 @@ extern "C" int egnn_pack_weights_host(const egnn_layer_desc* desc, const egnn_la
             for (int h = 0; h < H; ++h) amax = std::fmax(amax, std::fabs(p->edge_mlp_3_weight[(size_t)c * H + h] * NEG_LN2));
         const float scale = pow2_scale(amax);
         info->w2_inv_scale = 1.f / scale;
-        _Float16* w2h = reinterpret_cast<_Float16*>(base + info->w2h);     // (Hp/32, 2, 64, 8)
+        _Float16* w2h = reinterpret_cast<_Float16*>(base + info->w2h);     // (Hp/32, NB, 2, 64, 8)
         for (int c = 0; c < m; ++c)
             for (int h = 0; h < H; ++h) {
                 const float v = (p->edge_mlp_3_weight[(size_t)c * H + h] * NEG_LN2) * scale;
                 const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
                 const int step = h / 32, hb = (h % 32) / 16, g = (h % 16) / 4, r = h % 4;
-                const size_t o = (((size_t)step * 2 + 0) * 64 + (16 * g + c)) * 8 + (4 * hb + r);
+                const size_t o = ((((size_t)step * x.NB + c / 16) * 2 + 0) * 64 + (16 * g + c % 16)) * 8 + (4 * hb + r);
                 w2h[o] = hi;
                 w2h[o + 64 * 8] = lo;
             }
@@ -208,7 +211,8 @@ extern "C" int egnn_pack_weights_host(const egnn_layer_desc* desc, const egnn_la
             for (int c = 0; c < m; ++c) amax = std::fmax(amax, std::fabs(p->coors_mlp_0_weight[(size_t)j * m + c]));
         const float scale = pow2_scale(amax);
         info->w3_inv_scale = 1.f / scale;
-        _Float16* w3h = reinterpret_cast<_Float16*>(base + info->w3h);     // (2, 64, 16): hi image | lo image
+        _Float16* w3h = reinterpret_cast<_Float16*>(base + info->w3h);     // (2, 64 NB, 16 NB): hi image | lo image
+        const int M_PAD = x.M_PAD, C_PAD = x.C_PAD;
         for (int j = 0; j < 4 * m; ++j)
             for (int c = 0; c < m; ++c) {
                 const float v = p->coors_mlp_0_weight[(size_t)j * m + c] * scale;

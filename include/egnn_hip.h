@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 14
+#define EGNN_ABI_VERSION 15
 
 enum {
     EGNN_OK = 0,
@@ -158,7 +158,7 @@ typedef struct egnn_edge_args {
     /* shapes */
     int32_t B, N, K;            /* K = neighbours per node (= N on the dense all-pairs path) */
     int32_t dim;                /* feature width (first message column of node_hi / node_lo) */
-    int32_t m_dim;              /* <= 16 */
+    int32_t m_dim;              /* <= 64; NB = 1 (m_dim <= 16), 2 (<= 32) or 4 blocks of 16 channels */
     int32_t H, Hp;              /* hidden width 2*Din and its padding (egnn_padded_hidden) */
     int32_t fourier;            /* F = fourier_features */
     int32_t edge_dim;           /* width of `edges` (0 if none) */
@@ -176,18 +176,18 @@ typedef struct egnn_edge_args {
                                    terms 3s .. 3s+2:  (hi, lo) of 2^10 w | (hi, lo) of w | (hi, 0) of w;  rest zero */
     int32_t wst_terms;          /* = 4 * egnn_edge_mfmas(S) */
     float ws_inv_scale;         /* 1 / ws_scale (a power of two): the kernel multiplies the per-edge scalars by it */
-    const void* W2h;            /* (Hp/32, 2, 64, 8) fp16: -ln2 * w2_scale * edge_mlp.3.weight split into hi | lo halves,
-                                   in v_mfma_f32_16x16x32_f16 fragment order: [step][hi|lo][lane = 16 g + channel][t] =
-                                   W2[channel][32 step + (t < 4 ? 4 g + t : 16 + 4 g + t - 4)] */
+    const void* W2h;            /* (Hp/32, NB, 2, 64, 8) fp16: -ln2 * w2_scale * edge_mlp.3.weight split into hi | lo halves,
+                                   in v_mfma_f32_16x16x32_f16 fragment order: [step][nb][hi|lo][lane = 16 g + c][t] =
+                                   W2[16 nb + c][32 step + (t < 4 ? 4 g + t : 16 + 4 g + t - 4)] */
     float w2_inv_scale;         /* 1 / w2_scale (a power of two), applied to the accumulated H -> m_dim product */
-    const float* b2;            /* (16) edge_mlp.3.bias, zero padded */
-    const float* gate_w;        /* (16) edge_gate.0.weight or NULL (soft_edges=False) */
+    const float* b2;            /* (16 NB) edge_mlp.3.bias, zero padded */
+    const float* gate_w;        /* (16 NB) edge_gate.0.weight or NULL (soft_edges=False) */
     const float* gate_b;        /* (1) */
-    const void* W3h;            /* (2,64,16) fp16: w3_scale * coors_mlp.0.weight zero padded, hi image then lo image,
+    const void* W3h;            /* (2, 64 NB, 16 NB) fp16: w3_scale * coors_mlp.0.weight zero padded, hi image then lo image,
                                    or NULL (update_coors=False) */
     float w3_inv_scale;         /* 1 / w3_scale (a power of two) */
-    const float* b3;            /* (64) */
-    const float* W4;            /* (64) coors_mlp.3.weight */
+    const float* b3;            /* (64 NB) */
+    const float* W4;            /* (64 NB) coors_mlp.3.weight */
     const float* b4;            /* (1) */
     const float* coors_scale;   /* (1) CoorsNorm.scale or NULL (norm_coors=False) */
     /* inputs */

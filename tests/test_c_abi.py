@@ -78,7 +78,8 @@ def test_c_program_reproduces_golden(c_program, tmp_path, name):
 @pytest.mark.parametrize("kw,n,flags", [(dict(dim=64, num_nearest_neighbors=16), 200, dict(mask=True)),
                                         (dict(dim=32, edge_dim=3, fourier_features=2, soft_edges=True, norm_coors=True,
                                               norm_feats=True, m_pool_method="mean"), 40, dict(mask=True, edges=True)),
-                                        (dict(dim=48, only_sparse_neighbors=True, edge_dim=2), 64, dict(mask=True, edges=True, adj=True))])
+                                        (dict(dim=48, only_sparse_neighbors=True, edge_dim=2), 64, dict(mask=True, edges=True, adj=True)),
+                                        (dict(dim=32, m_dim=40, num_nearest_neighbors=16, soft_edges=True), 80, dict(mask=True))])
 def test_c_layer_forward_matches_module(kw, n, flags):
     """egnn_layer_forward_f32 (weights re-laid by the C host packer) and the Python module (torch packer, 7 separate calls)
     launch the same kernels on the same operands: bit-identical outputs."""

@@ -98,6 +98,13 @@ CONFIGS = [
     ("coor_dim7_dense_edges", dict(dim=32, edge_dim=2), 1, 40, dict(edges=True, coor_dim=7)),
     ("coor_dim8_k20_mean", dict(dim=32, num_nearest_neighbors=20, m_pool_method="mean"), 2, 50, dict(mask=True, coor_dim=8)),
     ("coor_dim1_k8", dict(dim=32, num_nearest_neighbors=8), 1, 30, dict(coor_dim=1)),
+    # m_dim beyond one 16-channel MFMA tile: two / four accumulator tiles per edge tile (the reference has no limit, :153)
+    ("m32_k32", dict(dim=64, m_dim=32, num_nearest_neighbors=32, soft_edges=True, norm_coors=True), 2, 96,
+     dict(mask=True, scale={"edge_mlp.3.weight": 0.5})),
+    ("m32_k8_edges", dict(dim=32, m_dim=32, num_nearest_neighbors=8, edge_dim=3, m_pool_method="mean"), 2, 50, dict(mask=True, edges=True)),
+    ("m24_dense", dict(dim=32, m_dim=24), 2, 20, dict(mask=True)),
+    ("m64_k32", dict(dim=48, m_dim=64, num_nearest_neighbors=32, soft_edges=True), 2, 64, dict(mask=True, scale={"edge_mlp.3.weight": 0.5})),
+    ("m48_k5_fourier", dict(dim=32, m_dim=48, num_nearest_neighbors=5, fourier_features=2), 2, 40, dict(mask=True)),
     # wide dynamic range of the per-edge scalars (three-part fp16 split): coordinates x 60 -> dist^2 up to ~1e5 with a
     # distance weight damped to keep the pre-activations O(1); edge features up to ~1e3
     ("k32_large_distances", dict(dim=32, num_nearest_neighbors=32, edge_dim=2), 2, 64,

@@ -161,7 +161,7 @@ def test_constructor_contract():
 
 
 @pytest.mark.parametrize("kw", [dict(dim=20, m_dim=8, edge_dim=3, fourier_features=2, soft_edges=True),
-                                dict(dim=64), dict(dim=33, edge_dim=1)])
+                                dict(dim=64), dict(dim=33, edge_dim=1), dict(dim=24, m_dim=32), dict(dim=16, m_dim=40)])
 def test_weight_relayout_is_exact(kw):
     """Evaluate the factorised / padded / fragment-ordered weights with plain numpy on random edges and
     compare with the oracle's unfactorised Linear(cat(h_i, h_j, scal)): same numbers to fp32 round-off."""
@@ -202,25 +202,27 @@ def test_weight_relayout_is_exact(kw):
         + np.einsum("es,hs->eh", rl, tab[:, :, 2, 0])
     np.testing.assert_allclose(ys, sc.astype(np.float64) @ w["Ws"].astype(np.float64), atol=2e-6)
     # ... hidden = y / (1 + 2^y) = SiLU(x) / (-ln 2), contracted with hi + lo fp16 fragments of -ln2 * scale * W2
-    w2h = w["W2h"].astype(np.float64)                                 # (Hp/32, 2, 64, 8)
-    assert w["W2h"].dtype == np.float16 and w2h.shape == (hp // 32, 2, 64, 8)
-    # [step][lane = 16 g + channel][t = 4 hb + r] holds hidden unit 32 step + 16 hb + 4 g + r
-    unfrag = lambda f: f.reshape(hp // 32, 4, 16, 2, 4).transpose(2, 0, 3, 1, 4).reshape(16, hp)
-    w2 = (unfrag(w2h[:, 0]) + unfrag(w2h[:, 1])) * w["w2_inv_scale"]
+    nb = _weights.m_blocks(m)
+    mp = 16 * nb
+    w2h = w["W2h"].astype(np.float64)                                 # (Hp/32, NB, 2, 64, 8)
+    assert w["W2h"].dtype == np.float16 and w2h.shape == (hp // 32, nb, 2, 64, 8)
+    # [step][nb][lane = 16 g + c][t = 4 hb + r] holds channel 16 nb + c, hidden unit 32 step + 16 hb + 4 g + r
+    unfrag = lambda f: f.reshape(hp // 32, nb, 4, 16, 2, 4).transpose(1, 3, 0, 4, 2, 5).reshape(mp, hp)
+    w2 = (unfrag(w2h[:, :, 0]) + unfrag(w2h[:, :, 1])) * w["w2_inv_scale"]
     # 22 significant bits for elements near the tensor's max; lo of much smaller elements falls into fp16
     # subnormals (spacing 2^-24 of the scaled max), i.e. the absolute error stays at fp32 level of the max
     w2_true = -np.log(2.0) * sd["edge_mlp.3.weight"].astype(np.float64)
     np.testing.assert_allclose(w2[:m, :h], w2_true, rtol=4e-7, atol=2.0 ** -24 * np.abs(w2_true).max())
     assert np.all(w2[m:] == 0) and np.all(w2[:, h:] == 0)
     lg = np.log2(w["w2_inv_scale"])
-    assert lg == np.round(lg) and 1.0 <= np.abs(unfrag(w2h[:, 0])).max() < 2.0      # power-of-two range scale
+    assert lg == np.round(lg) and 1.0 <= np.abs(unfrag(w2h[:, :, 0])).max() < 2.0      # power-of-two range scale
     hid = y.astype(np.float64) / (1.0 + np.exp2(y.astype(np.float64)))
     m_ref = O.silu(O.silu(x_ref) @ sd["edge_mlp.3.weight"].T + sd["edge_mlp.3.bias"])
     m_new = O.silu((hid @ w2.T + w["b2"]).astype(np.float32))
     np.testing.assert_allclose(m_new[:, :m], m_ref, atol=2e-5)
     assert np.all(m_new[:, m:] == 0)
     np.testing.assert_array_equal(w["W3"][:4 * m, :m], sd["coors_mlp.0.weight"])
-    assert w["W3"].shape == (64, 16) and np.all(w["W3"][4 * m:] == 0)
+    assert w["W3"].shape == (64 * nb, 16 * nb) and np.all(w["W3"][4 * m:] == 0)
 
 
 def test_packed_weights_cache_tracks_parameter_updates():
@@ -255,7 +257,9 @@ def test_packed_tile_layout_matches_header_formula():
 
 @pytest.mark.parametrize("kw", [dict(dim=20, m_dim=8, edge_dim=3, fourier_features=2, soft_edges=True, norm_feats=True, norm_coors=True),
                                 dict(dim=64, num_nearest_neighbors=8), dict(dim=33, edge_dim=1, update_coors=False),
-                                dict(dim=16, update_feats=False), dict(dim=512, num_nearest_neighbors=32)])
+                                dict(dim=16, update_feats=False), dict(dim=512, num_nearest_neighbors=32),
+                                dict(dim=24, m_dim=32, soft_edges=True), dict(dim=24, m_dim=40, edge_dim=2),
+                                dict(dim=16, m_dim=64, fourier_features=1)])
 def test_c_weight_packer_matches_python(kw):
     """egnn_pack_weights_host (C, host) == egnn_pytorch_amd/_weights.py::pack (torch): every re-laid-out tensor and every
     power-of-two scale, bit for bit -- a binding without torch gets exactly the weights the Python module computes with."""
@@ -310,5 +314,5 @@ def test_workspace_bytes_and_descriptor_checks():
     assert need < 2 * (rows * 2 * hp * 4)                                      # ... and not wildly more (P dominates)
     assert lib.egnn_workspace_bytes(byref(d), 0, 1024, 32) == 0
     bad = _abi.layer_desc(EGNN(dim=8, m_dim=16))
-    bad.m_dim = 32
+    bad.m_dim = 65                                                             # beyond the four accumulator tiles
     assert lib.egnn_packed_weights_bytes(byref(bad)) == 0 and lib.egnn_workspace_bytes(byref(bad), 1, 4, 4) == 0

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, 3) void mix_kernel(const egnn_edge_args ea, co
             linear_hl_body<6, 0, false>(ga.Ahi, ga.Alo, ga.Whi, ga.Wlo, ga.bias, nullptr, 0, ga.C, ga.ldc, nullptr, nullptr, 0,
                                         ga.M, ga.N, ga.Kp, ga.ntm, ga.ntn, ga.out_scale, ga.split_cols, nullptr, smem, id);
     } else {
-        if (id < n_edge) edge_body<1, 256, 2>(ea, G, gpg, smem, id, n_edge);
+        if (id < n_edge) edge_body<1, 256, 2, 1>(ea, G, gpg, smem, id, n_edge);
     }
 }
 
