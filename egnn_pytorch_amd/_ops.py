@@ -77,6 +77,18 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_side = {}
+
+
+def side_stream(device):
+    """One extra HIP stream per device for work that is independent of the main launch sequence (layer.py)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    st = _side.get(key)
+    if st is None:
+        st = _side[key] = torch.cuda.Stream(device=torch.device("cuda", key))
+    return st
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 

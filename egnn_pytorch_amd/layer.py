@@ -22,6 +22,7 @@ from . import _abi, _ops, _weights, autograd as _autograd
 from .attention import GlobalLinearAttention
 
 _SPATIAL_ORDER = os.environ.get("EGNN_SPATIAL_ORDER", "1") != "0"     # scheduling knob only; results do not depend on it
+_SIDE_STREAM = os.environ.get("EGNN_SIDE_STREAM", "1") != "0"         # neighbour selection beside the projection GEMM
 # The kernels compute in fp32-class arithmetic (split-f16 products, fp32 accumulation: DESIGN.md §2).  Other floating dtypes
 # -- the reference is dtype-generic and its own tests run in float64 -- are accepted at the boundary: inputs are converted to
 # fp32, outputs back to the callers' dtype.  For bf16 / fp16 that is at least the reference's precision; for float64 it is
@@ -181,9 +182,30 @@ class EGNN(nn.Module):
             if k > n:
                 raise RuntimeError("selected index k out of range")      # torch.topk's error upstream
             if k > 0:
-                idx, rank = _ops.knn_select(coors, mask, adj_mat, k)
+                # Neighbour selection (VALU / scalar bound, no MFMA) and the Morton order (one workgroup per graph) depend on
+                # the coordinates only; the projection GEMM that follows (MFMA bound) depends on the features only.  Forked onto
+                # a side stream they share the CUs instead of queueing (EGNN_SIDE_STREAM=0: one stream); joined before the
+                # edge pass.
+                want_order = adj_mat is None and 64 <= n <= 4096 and _SPATIAL_ORDER and coors.shape[-1] == 3
+                have_hint = order_hint is not None and tuple(order_hint.shape) == (b, n)
+                # (not while per-kernel timing is on: events on two streams would charge one kernel's wait to another)
+                use_side = _SIDE_STREAM and _ops._timer is None
+                side = _ops.side_stream(feats.device) if use_side else None
+                if side is not None:
+                    cur = torch.cuda.current_stream()
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        idx, rank = _ops.knn_select(coors, mask, adj_mat, k)
+                        if want_order and not have_hint:
+                            order_hint, have_hint = _ops.spatial_order(coors), True
+                    for t in (idx, rank, order_hint):
+                        if t is not None:
+                            t.record_stream(cur)
+                else:
+                    idx, rank = _ops.knn_select(coors, mask, adj_mat, k)
         else:
             k = n
+        side_join = use_nearest and k > 0 and _SIDE_STREAM and _ops._timer is None
 
         node_out, coors_out = feats, coors
         node_in = order = None
@@ -224,6 +246,8 @@ class EGNN(nn.Module):
             a.coors, a.coor_dim = coors.data_ptr(), coors.shape[-1]
             a.edges = _ops._ptr(edges)
             a.mask = _ops._ptr(mask8)
+            if side_join:
+                torch.cuda.current_stream().wait_stream(_ops.side_stream(feats.device))
             a.idx, a.rank = _ops._ptr(idx), _ops._ptr(rank)
             order = None
             if idx is not None and adj_mat is None and 64 <= n <= 4096 and _SPATIAL_ORDER and coors.shape[-1] == 3:
