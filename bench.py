@@ -233,6 +233,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="north_star", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--standin-backend", default=None, choices=["gloo"],
+                    help="TEST AID (tests/test_sharding_gloo.py): run the rank logic -- env parsing, process group, broadcast-free "
+                         "barrier / max-over-ranks timing, rank-0 JSON -- on CPU with this backend and a dummy step; no GPU work, "
+                         "no numbers of any meaning")
     ap.add_argument("--ragged-mask", action="store_true", help="ragged masks (len ~ U{N/2..N}) instead of all-True")
     ap.add_argument("--reference-eager", action="store_true",
                     help="also time the reference module on the MI355X through PyTorch eager (secondary baseline)")
@@ -245,16 +249,51 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
         args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path to time")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    standin = args.standin_backend is not None
+    if standin:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path to time")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
 
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
+        if standin:
+            dist.init_process_group(args.standin_backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def reduce_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    if standin:
+        # the rank logic only: a dummy step, the same timed region, the same rank-0 line (marked as a stand-in)
+        b = WORKLOADS[args.workload][1]
+        x = torch.randn(64, 64)
+        elapsed = timed_region(lambda: (x @ x).sum().item(), args.steps, args.warmup, lambda: None, barrier, reduce_max)
+        if rank == 0:
+            print(json.dumps({"metric": "EGNN.forward graphs/sec", "value": round(world * b * args.steps / elapsed, 2),
+                              "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                              "data": f"STAND-IN ({args.standin_backend}, CPU, dummy step): rank logic only, not a measurement",
+                              "config": {"workload": args.workload, "graphs_per_gpu": b, "global_batch": world * b}}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from egnn_pytorch_amd import EGNN, EGNN_Network, phase_timer, check_range, _ops
     # Range status word (include/egnn_hip.h: EGNN_RANGE_*): the default mode reads it back after every forward (one host
@@ -287,17 +326,6 @@ def main():
             layer(feats, coors, adj_mat=adj, edges=edges, mask=mask)
         else:
             layer(feats, coors, edges, mask, adj)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    def reduce_max(x):
-        if dist is None:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
 
     elapsed = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, reduce_max)
     check_range()                                        # raises if any timed step left the representable range

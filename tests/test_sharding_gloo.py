@@ -115,3 +115,28 @@ def test_shard_bounds_cover_batch():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         sharding.shard_bounds(4, 2, 2)
+
+
+def test_bench_rank_logic_end_to_end_with_gloo_standin():
+    """bench.py's `--gpus 2` code path as the driver launches it (torch.distributed.run, one process per rank, env parsing,
+    process group, barrier + max-over-ranks timed region, ONE JSON line from rank 0), with the backend switched to gloo and a
+    dummy CPU step (`--standin-backend gloo`): the nccl branch differs only in the backend string and the device."""
+    import json
+    import subprocess
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--standin-backend", "gloo"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 2 * d["config"]["graphs_per_gpu"] and d["value"] > 0
+    assert "STAND-IN" in d["data"]
+    # asking for 2 GPUs without the launcher is an error, not a silent 1-rank run
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--standin-backend", "gloo"],
+                        capture_output=True, text=True, timeout=120, cwd=ROOT, env={k: v for k, v in os.environ.items()
+                                                                                     if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r1.returncode != 0 and "torch.distributed.run" in (r1.stderr + r1.stdout)
