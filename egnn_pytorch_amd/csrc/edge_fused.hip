@@ -523,9 +523,26 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 #endif
                         // v_cvt_pk_f16_f32 (IEEE: beyond 65504 -> inf, so an overflowing hidden value poisons the edge's
                         // message instead of saturating silently as v_cvt_pkrtz would; same issue cost)
-                        const f16x2 hi = __builtin_convertvector((f32x2v){h0, h1}, f16x2);
+                        // (the empty asm keeps the two products scalar: SLP-packed into v_pk_mul_f32 they cost 9.3 cycles per
+                        // pair against 2 x 2.8, tools/ubench/mix_rates.hip)
+                        float h0s = h0, h1s = h1;
+                        asm("" : "+v"(h0s));
+                        asm("" : "+v"(h1s));
+                        const f16x2 hi = __builtin_convertvector((f32x2v){h0s, h1s}, f16x2);
+#if (defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 2)) || (defined(EGNN_EDGE_LO_PLAIN) && EGNN_EDGE_LO_PLAIN)
                         const float l0 = h0 - (float)hi[0];
                         const float l1 = h1 - (float)hi[1];
+#else
+                        // lo = y * sigma - hi as ONE v_fma_mix_f32 per value (the f16 operand is read in place).  Written out:
+                        // behind the round-to-nearest conversion above hipcc no longer forms it by itself and converts hi
+                        // back with two extra v_cvt_f32_f16 per pair (+8 % VALU instructions on this VALU-bound loop).
+                        const float r0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y0));
+                        const float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y1));
+                        const uint32_t hw = __builtin_bit_cast(uint32_t, hi);
+                        float l0, l1;
+                        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(y0), "v"(r0), "v"(hw));
+                        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(y1), "v"(r1), "v"(hw));
+#endif
                         const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l0, l1));
                         bhi[u] = hi[0]; bhi[u + 1] = hi[1];
                         blo[u] = lo[0]; blo[u + 1] = lo[1];
