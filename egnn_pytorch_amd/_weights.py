@@ -164,6 +164,18 @@ def pack(layer) -> dict:
 
     out = dict(H=h, Hp=hp, S=s, Wcat=wcat, Wcat_split=split_f16(wcat), bcat=bcat, Ws=ws, Wst=wst,
                ws_inv_scale=ws_inv_scale, W2h=w2h, w2_inv_scale=1.0 / w2_scale, b2=b2p)
+    if nb == 1:
+        # backward (egnn_edge_bwd_dz_f32): W2^T in natural units as A fragments of v_mfma_f32_16x16x16_f16,
+        # [step][hb][hi|lo][lane = 16 g + r][u] = W2[4 g + u][32 step + 16 hb + r]
+        w2t = z(hp, 16)
+        w2t[:h, :m] = w2.t()
+        t_scale = pow2_scale(float(w2t.abs().max()) if w2t.numel() else 0.0)
+        w2ts = w2t * t_scale
+        t_hi = w2ts.half()
+        t_lo = (w2ts - t_hi.float()).half()
+        fragt = lambda t: t.view(hp // 32, 2, 16, 4, 4).permute(0, 1, 3, 2, 4).contiguous().view(hp // 32, 2, 64, 4)
+        out["W2Th"] = torch.stack([fragt(t_hi), fragt(t_lo)], dim=2).contiguous()      # (Hp/32, 2, 2, 64, 4) fp16
+        out["w2t_scale"] = t_scale
 
     if layer.edge_gate is not None:
         gw = z(M_PAD)

@@ -1,13 +1,22 @@
 """Autograd support for the gfx950 EGNN layer (the reference is trained in practice,
 denoise_sparse.py:70-78, and every op of egnn_pytorch.py:224-341 is differentiable).
 
-Forward  = the HIP path (neighbour selection, fused edge pass, split-f16 GEMMs) -- nothing of size E x H is kept.
-Backward = recompute-in-backward: the layer is re-evaluated for a few graphs at a time as a differentiable chain of ATen
-           ops (library GEMMs, gathers along the neighbour list the HIP kernel selected) and differentiated by PyTorch's
-           autograd engine; the chunking bounds the E x (Din + 2H) activations the reference materialises for the whole batch.
-This is the functional backward (gradients of feats / coors / edges / every parameter agree with the reference's autograd,
-tests/test_autograd.py); a fused HIP backward edge kernel (same tiling as the forward, deterministic scatter over the
-transposed neighbour list) is the next step and would slot in behind the same autograd.Function.
+Forward  = the HIP path (neighbour selection, fused edge pass, split-f16 GEMMs).  Nothing of size E x H is kept: the saved
+           tensors are the inputs, the neighbour list and u (E x 16), the output of edge_mlp's second Linear, which the
+           forward edge kernel writes on the side when a graph is being recorded.
+Backward = `_backward_native` (fp32, coordinate dimension 3, m_dim <= 16):
+             * the small tail behind u (second SiLU, gate, masks, coors_mlp, CoorsNorm, clamp, pooling, node_norm, node_mlp:
+               E x 16 / E x 64 / node-level tensors) is differentiated by autograd from u  ->  gU and those parameters' gradients;
+             * egnn_edge_bwd_dz_f32 (csrc/edge_fused.hip, MODE 2) recomputes the pre-activation z of the first SiLU exactly as
+               the forward does and writes a = SiLU(z) and dz = (W2^T gU) * SiLU'(z), the W2^T product on the matrix cores;
+             * reductions and plain library GEMMs over dz / a give d/d feats, d/d edge_mlp.{0,3}, d/d scalars (-> coors, edges).
+           `_backward_recompute` (everything else, and the native path's reference in the tests): the whole layer re-evaluated
+           a few graphs at a time as a differentiable chain of ATen ops over the neighbour list the HIP kernel selected,
+           factorised like the forward, and differentiated by autograd.
+Gradients of feats / coors / edges / every parameter agree with the reference's autograd (tests/test_autograd.py).  Still
+ATen: the scatter of d/d P_j over the neighbour list (`scatter_add_`, atomics -- as non-deterministic as the reference's
+own gather backward) and the fp32 library GEMMs; folding the per-node sums into the kernel and a deterministic scatter over
+the transposed neighbour list are the next steps.
 
 `layer_given_neighbors` is a restatement of egnn_pytorch.py:262-341 that takes the neighbour list as an input (the selection
 itself, :237-260, is not differentiable: topk indices and the `<= valid_radius` comparison carry no gradient upstream
@@ -15,8 +24,14 @@ either).  It is also what the CPU tests compare with the reference, independentl
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
+
+# EGNN_NATIVE_BACKWARD=0: always the pure-ATen recompute (the reference implementation of the backward)
+_NATIVE = os.environ.get("EGNN_NATIVE_BACKWARD", "1") != "0"
+_NATIVE_BUDGET_BYTES = 24 << 30                      # dZ + SiLU(z), 2 x E x Hp fp32, per chunk of graphs
 
 # activations of the recompute per edge: a few E x H tensors (pre-activation, activation, gradients); 16 GB of the 288 GB
 _BYTES_PER_EDGE_FACTOR = 5.0
@@ -30,48 +45,38 @@ def _fourier(dist, num_encodings):
     return torch.cat((x.sin(), x.cos(), dist), dim=-1)
 
 
-def layer_given_neighbors(layer, feats, coors, edges, mask, idx, rank, valid_radius, factorised=True):
-    """EGNN.forward (egnn_pytorch.py:262-341) for given neighbours.
-    idx (B,N,K) int64 / rank (B,N,K): the selection of :258 (None, None = dense all-pairs, K = N).
-    Differentiable in feats, coors, edges and the parameters of `layer`.
-    factorised: evaluate the first Linear of edge_mlp as (W_i h_i + b) + W_j h_j + W_s s_ij with the dim-wide products done
-    once per node -- the same factorisation the HIP forward uses (DESIGN.md §2), 16x fewer flops than Linear(cat(...)) at
-    the north-star shape, identical mathematics; False = the reference's literal cat + Linear."""
-    b, n, dim = feats.shape
-    dense = idx is None
-    if dense:
+def edge_scalars(layer, coors, edges, idx):
+    """rel = x_i - x_j and the per-edge scalars [fourier(d), d, e_ij] in the column order of edge_mlp.0.weight (:282-285)."""
+    b, n, _ = coors.shape
+    if idx is None:
         rel = coors[:, :, None, :] - coors[:, None, :, :]                          # (B,N,N,C)
         e_ij = edges
     else:
         k = idx.shape[-1]
-        bi = torch.arange(b, device=feats.device)[:, None, None]
+        bi = torch.arange(b, device=coors.device)[:, None, None]
         rel = coors[:, :, None, :] - coors[bi, idx]                               # (B,N,K,C)
         e_ij = None if edges is None else torch.gather(edges, 2, idx[..., None].expand(b, n, k, edges.shape[-1]))
     dist = (rel ** 2).sum(dim=-1, keepdim=True)
     scal = _fourier(dist, layer.fourier_features) if layer.fourier_features > 0 else dist
     if e_ij is not None:
-        scal = torch.cat((scal, e_ij), dim=-1)                                    # column order of edge_mlp.0.weight (:282-285)
-    if factorised:
-        lin = layer.edge_mlp[0]
-        w_i, w_j, w_s = lin.weight[:, :dim], lin.weight[:, dim:2 * dim], lin.weight[:, 2 * dim:]
-        p_i = feats @ w_i.t() + lin.bias                                          # (B,N,H)
-        p_j = feats @ w_j.t()
-        z = p_i[:, :, None, :] + (p_j[:, None, :, :] if dense else p_j[bi, idx]) + scal @ w_s.t()
-        m_ij = z
-        for mod in list(layer.edge_mlp)[1:]:                                      # dropout | Identity, SiLU, Linear, SiLU
-            m_ij = mod(m_ij)
-    else:
-        feats_j = feats[:, None, :, :].expand(b, n, n, dim) if dense else feats[bi, idx]
-        feats_i = feats[:, :, None, :].expand_as(feats_j)
-        m_ij = layer.edge_mlp(torch.cat((feats_i, feats_j, scal), dim=-1))        # (:287)
+        scal = torch.cat((scal, e_ij), dim=-1)
+    return rel, scal
+
+
+def layer_tail(layer, feats, coors, u, rel, mask, idx, rank, valid_radius):
+    """Everything of EGNN.forward behind the second Linear of edge_mlp (:183-341): u (B,N,K,m_dim) = edge_mlp[3](...) ->
+    second SiLU, gate, masks, coors_mlp / CoorsNorm / clamp / coordinate update, pooling, node_norm + node_mlp + residual."""
+    b = feats.shape[0]
+    m_ij = layer.edge_mlp[4](u)
     if layer.edge_gate is not None:
         m_ij = m_ij * layer.edge_gate(m_ij)                                       # (:289-290)
 
     pair_mask = None
     if mask is not None:                                                          # (:292-300) -- the radius / sparse-only cut
-        if dense:                                                                 # exists only together with `mask`
+        if idx is None:                                                           # exists only together with `mask`
             pair_mask = mask[:, :, None] & mask[:, None, :]
         else:
+            bi = torch.arange(b, device=feats.device)[:, None, None]
             pair_mask = mask[:, :, None] & mask[bi, idx] & (rank <= valid_radius)
 
     coors_out = coors
@@ -104,6 +109,34 @@ def layer_given_neighbors(layer, feats, coors, edges, mask, idx, rank, valid_rad
     return node_out, coors_out
 
 
+def layer_given_neighbors(layer, feats, coors, edges, mask, idx, rank, valid_radius, factorised=True):
+    """EGNN.forward (egnn_pytorch.py:262-341) for given neighbours.
+    idx (B,N,K) int64 / rank (B,N,K): the selection of :258 (None, None = dense all-pairs, K = N).
+    Differentiable in feats, coors, edges and the parameters of `layer`.
+    factorised: evaluate the first Linear of edge_mlp as (W_i h_i + b) + W_j h_j + W_s s_ij with the dim-wide products done
+    once per node -- the same factorisation the HIP forward uses (DESIGN.md §2), 16x fewer flops than Linear(cat(...)) at
+    the north-star shape, identical mathematics; False = the reference's literal cat + Linear."""
+    b, n, dim = feats.shape
+    dense = idx is None
+    rel, scal = edge_scalars(layer, coors, edges, idx)
+    lin = layer.edge_mlp[0]
+    if factorised:
+        w_i, w_j, w_s = lin.weight[:, :dim], lin.weight[:, dim:2 * dim], lin.weight[:, 2 * dim:]
+        p_i = feats @ w_i.t() + lin.bias                                          # (B,N,H)
+        p_j = feats @ w_j.t()
+        bi = None if dense else torch.arange(b, device=feats.device)[:, None, None]
+        z = p_i[:, :, None, :] + (p_j[:, None, :, :] if dense else p_j[bi, idx]) + scal @ w_s.t()
+    else:
+        bi = None if dense else torch.arange(b, device=feats.device)[:, None, None]
+        feats_j = feats[:, None, :, :].expand(b, n, n, dim) if dense else feats[bi, idx]
+        feats_i = feats[:, :, None, :].expand_as(feats_j)
+        z = lin(torch.cat((feats_i, feats_j, scal), dim=-1))                      # (:287, first Linear)
+    u = z
+    for mod in list(layer.edge_mlp)[1:4]:                                         # dropout | Identity, SiLU, Linear
+        u = mod(u)
+    return layer_tail(layer, feats, coors, u, rel, mask, idx, rank, valid_radius)
+
+
 def _chunk_graphs(layer, n, k, batch):
     din = 2 * layer.dim + 2 * layer.fourier_features + 1 + layer.edge_dim
     per_graph = n * k * (2 * din) * 4.0 * _BYTES_PER_EDGE_FACTOR          # E x H pre-activation, activation, their gradients
@@ -115,9 +148,13 @@ class EGNNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, layer, order_hint, mask, adj_mat, feats, coors, edges, *params):
+        native = (_NATIVE and layer.m_dim <= 16 and coors.shape[-1] == 3 and feats.dtype == torch.float32
+                  and coors.dtype == torch.float32 and (edges is None or edges.dtype == torch.float32))
         with torch.no_grad():
-            node_out, coors_out, order, idx, rank, valid_radius = layer._forward_hip_checked(feats, coors, edges, mask, adj_mat, order_hint)
+            node_out, coors_out, order, idx, rank, valid_radius, u_pre = layer._forward_hip_checked(
+                feats, coors, edges, mask, adj_mat, order_hint, want_u=native)
         ctx.layer = layer
+        ctx.u_pre = u_pre                                # (E, 16) fp32 or None: E x 16, not E x H
         ctx.valid_radius = valid_radius
         ctx.has_edges = edges is not None
         ctx.save_for_backward(feats, coors, edges if edges is not None else feats.new_empty(0),
@@ -134,6 +171,151 @@ class EGNNFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_node, g_coors):
+        if ctx.u_pre is not None:
+            return _backward_native(ctx, g_node, g_coors)
+        return _backward_recompute(ctx, g_node, g_coors)
+
+
+def _unpack(ctx):
+    feats, coors, edges, mask, idx, rank = ctx.saved_tensors
+    has_mask, has_idx = ctx.flags
+    return (feats, coors, edges if ctx.has_edges else None, mask if has_mask else None,
+            idx if has_idx else None, rank if has_idx else None)
+
+
+def _backward_native(ctx, g_node, g_coors):
+    """The backward with the E x H work on the HIP kernel egnn_edge_bwd_dz_f32 (include/egnn_hip.h):
+       1. everything behind edge_mlp's second Linear (second SiLU, gate, masks, coors_mlp, CoorsNorm, clamp, pooling, node_norm,
+          node_mlp) is small -- E x 16 / E x 64 / node-level -- and is differentiated by autograd from u = ctx.u_pre, which
+          the forward kernel wrote: gives gU = d loss / d u and the gradients of those modules' parameters;
+       2. the kernel recomputes z (gathers + first-layer MFMAs, exactly the forward's) and writes a = SiLU(z) and
+          dz = (W2^T gU) * SiLU'(z);
+       3. what remains are reductions and plain GEMMs over dz and a:  d/d P_i = sum over a node's edges,  d/d P_j = scatter by
+          neighbour,  d/d W_i, W_j, b_1 from those and feats,  d/d W_s = dz^T s,  d/d s = dz W_s (-> coors, edges through
+          the scalars' own small graph),  d/d W_2 = gU^T a,  d/d b_2 = sum gU.
+    Graphs are processed in chunks so that dz and a (2 x E x Hp fp32) stay inside a fixed budget."""
+    from . import _abi, _ops, _weights
+    layer = ctx.layer
+    feats, coors, edges, mask, idx32, rank = _unpack(ctx)
+    params = list(layer.parameters())
+    need = ctx.needs_input_grad                          # (layer, order_hint, mask, adj, feats, coors, edges, *params)
+    b, n, dim = feats.shape
+    k = idx32.shape[-1] if idx32 is not None else n
+    m = layer.m_dim
+    w = layer.packed_weights()
+    h, hp, s_in = w["H"], w["Hp"], w["S"]
+    lin0, lin3 = layer.edge_mlp[0], layer.edge_mlp[3]
+    head = {id(lin0.weight), id(lin0.bias), id(lin3.weight), id(lin3.bias)}
+    tail_params = [p for p in params if id(p) not in head]
+    grads_by_id = {id(p): torch.zeros_like(p) for p in params}
+    g_feats = torch.zeros_like(feats)
+    g_coors_in = torch.zeros_like(coors)
+    g_edges = torch.zeros_like(edges) if edges is not None else None
+    if g_node is None:
+        g_node = torch.zeros_like(feats)
+    if g_coors is None:
+        g_coors = torch.zeros_like(coors)
+    u_all = ctx.u_pre.view(b, n, k, 16)
+    per_graph = 2.0 * n * k * hp * 4
+    step = max(1, min(b, int(_NATIVE_BUDGET_BYTES // per_graph)))
+    w_i, w_j, w_s = lin0.weight[:, :dim].detach(), lin0.weight[:, dim:2 * dim].detach(), lin0.weight[:, 2 * dim:].detach()
+    pi_split = k >= 6
+    for lo in range(0, b, step):
+        hi_ = min(b, lo + step)
+        bc = hi_ - lo
+        f0, c0 = feats[lo:hi_].contiguous(), coors[lo:hi_].contiguous()
+        e0 = None if edges is None else edges[lo:hi_].contiguous()
+        m0 = None if mask is None else mask[lo:hi_]
+        i32 = None if idx32 is None else idx32[lo:hi_].contiguous()
+        i64 = None if i32 is None else i32.long()
+        r0 = None if rank is None else rank[lo:hi_]
+        # ---- 1. the small tail, through autograd
+        with torch.enable_grad():
+            f = f0.detach().requires_grad_(True)
+            c = c0.detach().requires_grad_(True)
+            e = None if e0 is None else e0.detach().requires_grad_(True)
+            u = u_all[lo:hi_, :, :, :m].detach().requires_grad_(True)
+            rel, scal = edge_scalars(layer, c, e, i64)
+            out_n, out_c = layer_tail(layer, f, c, u, rel, m0, i64, r0, ctx.valid_radius)
+            outs, gouts = [], []
+            for o, g in ((out_n, g_node[lo:hi_]), (out_c, g_coors[lo:hi_])):
+                if o.requires_grad:
+                    outs.append(o)
+                    gouts.append(g)
+            wrt = [u, f, c] + tail_params
+            tg = torch.autograd.grad(outs, wrt, gouts, allow_unused=True, retain_graph=True)
+        g_u = tg[0] if tg[0] is not None else torch.zeros_like(u)
+        if tg[1] is not None:
+            g_feats[lo:hi_] += tg[1]
+        if tg[2] is not None:
+            g_coors_in[lo:hi_] += tg[2]
+        for p, g in zip(tail_params, tg[3:]):
+            if g is not None:
+                grads_by_id[id(p)] += g
+        # ---- 2. dz and SiLU(z) on the HIP kernel
+        ec = bc * n * k
+        gu16 = torch.zeros(ec, 16, dtype=torch.float32, device=feats.device)
+        gu16[:, :m] = g_u.reshape(ec, m)
+        amax = float(gu16.abs().max())
+        gu_scale = _weights.pow2_scale(amax) if amax > 0 else 1.0
+        with torch.no_grad():
+            f2d = f0.view(bc * n, dim)
+            feats_hl = _ops.split_f16(f2d)
+            proj = _ops.linear_hl(feats_hl, w["Wcat_split"], 2 * hp, w["bcat"], name="bwd_node_proj", split_cols=hp if pi_split else 0)
+            dz = _ops.empty(ec, hp, dtype=torch.float32, device=feats.device)
+            act = _ops.empty(ec, hp, dtype=torch.float32, device=feats.device)
+            a = _abi.EdgeArgs()
+            a.B, a.N, a.K, a.dim, a.m_dim = bc, n, k, dim, m
+            a.H, a.Hp = h, hp
+            a.fourier, a.edge_dim, a.S, a.pi_split = layer.fourier_features, layer.edge_dim, s_in, int(pi_split)
+            a.Pi, a.Pj, a.ldp = proj.data_ptr(), proj.data_ptr() + 4 * hp, 2 * hp
+            a.Wst, a.wst_terms, a.ws_inv_scale = w["Wst"].data_ptr(), w["Wst"].shape[1], w["ws_inv_scale"]
+            a.coors, a.coor_dim = c0.data_ptr(), 3
+            a.edges = _ops._ptr(e0)
+            a.idx = _ops._ptr(i32)
+            a.W2Th = w["W2Th"].data_ptr()
+            a.gU, a.gu_scale = gu16.data_ptr(), gu_scale
+            a.bwd_inv_scale = 1.0 / (gu_scale * w["w2t_scale"])
+            a.dZ, a.A_out, a.ldz = dz.data_ptr(), act.data_ptr(), hp
+            with _ops._timed("edge_bwd_dz"):
+                rc = _abi.load().egnn_edge_bwd_dz_f32(_ops.byref(a), _ops._stream())
+            _abi.check(rc, "egnn_edge_bwd_dz_f32")
+            del proj, feats_hl
+            # ---- 3. reductions and plain GEMMs over dz / a
+            dz3 = dz.view(bc, n, k, hp)[..., :h]
+            gz_i = dz3.sum(dim=2)                                                  # (bc, n, H)   d loss / d P_i
+            if i64 is None:
+                gz_j = dz3.sum(dim=1)                                              # dense: neighbour k IS node j
+            else:
+                gz_j = torch.zeros(bc, n, h, dtype=torch.float32, device=feats.device)
+                gz_j.scatter_add_(1, i64.view(bc, n * k, 1).expand(bc, n * k, h), dz3.reshape(bc, n * k, h))
+            g_feats[lo:hi_] += gz_i @ w_i + gz_j @ w_j
+            gw1 = grads_by_id[id(lin0.weight)]
+            gw1[:, :dim] += gz_i.reshape(-1, h).t() @ f2d
+            gw1[:, dim:2 * dim] += gz_j.reshape(-1, h).t() @ f2d
+            dz2 = dz3.reshape(ec, h)
+            sc2 = scal.detach().reshape(ec, s_in)
+            gw1[:, 2 * dim:] += dz2.t() @ sc2
+            grads_by_id[id(lin0.bias)] += gz_i.sum(dim=(0, 1))
+            g_scal = (dz2 @ w_s).view_as(scal)
+            grads_by_id[id(lin3.weight)] += gu16[:, :m].t() @ act[:, :h]
+            grads_by_id[id(lin3.bias)] += gu16[:, :m].sum(dim=0)
+            del dz, act, dz3, dz2
+        # d loss / d scalars -> coordinates (through d = |x_i - x_j|^2 and the fourier terms) and edge features
+        sg = torch.autograd.grad([scal], [c] + ([e] if e is not None else []), [g_scal], allow_unused=True)
+        if sg[0] is not None:
+            g_coors_in[lo:hi_] += sg[0]
+        if e is not None and sg[1] is not None:
+            g_edges[lo:hi_] += sg[1]
+    out_params = [grads_by_id[id(p)] if need[7 + i] else None for i, p in enumerate(params)]
+    return (None, None, None, None, g_feats if need[4] else None, g_coors_in if need[5] else None,
+            g_edges if (edges is not None and need[6]) else None, *out_params)
+
+
+def _backward_recompute(ctx, g_node, g_coors):
+    """The pure-ATen backward: chunked recompute of the whole layer through autograd (module docstring).  Used for the shapes
+    the native kernel does not cover (m_dim > 16, coordinate dimension != 3, non-fp32) and as its reference in the tests."""
+    if True:
         layer = ctx.layer
         feats, coors, edges, mask, idx, rank = ctx.saved_tensors
         has_mask, has_idx = ctx.flags

@@ -145,9 +145,16 @@ __device__ __forceinline__ uint32_t buf_load1(__amdgpu_buffer_rsrc_t r, uint32_t
 // lane on the VALU.
 // (The body is a device function of the block index so that a dispatcher kernel can give a workgroup slot either an edge
 // group or a GEMM tile: tools/ubench/mix_probe.hip.)
-template <int NM, int HCT, int TPI, int NB>
+// MODE = 2: the backward companion (egnn_edge_bwd_dz_f32).  Same slot setup, same gathers, same first-layer MFMAs -- the
+// pre-activation x is RECOMPUTED, nothing of size E x H was kept by the forward -- but instead of SiLU + the H -> m_dim
+// contraction each step evaluates   ga = W2^T gU  (v_mfma_f32_16x16x16_f16 against W2^T fragments: the result lands in x's
+// own layout),   a = SiLU(x),   dz = ga * SiLU'(x)   and streams a and dz to HBM (fp32, natural units).  No epilogue.
+template <int NM, int HCT, int TPI, int NB, int MODE = 0>
 __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, const int gpg, char* smem, const int bid, const int nblk)
 {
+    // MODE 0: inference forward.  1: forward that also writes u (args.U_out) for the backward -- its own instantiation, the
+    // inference kernels sit at the register limit of 4 workgroups per CU.  2: backward (egnn_edge_bwd_dz_f32).
+    constexpr bool BWD = MODE == 2;
     constexpr int HC = EGNN_EDGE_RING ? HCT / 2 : HCT;     // columns per staged chunk (ring: two slots of HCT / 2)
     constexpr int NCH = nch_of(NB);
     constexpr int W2B = 64 * NB;                           // bytes of W2 fragments per hidden column: NB blocks x (hi | lo) x 16 channels
@@ -192,6 +199,8 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
         int ei[TILES], ej[TILES];                            // node / neighbour of this lane's edge: x_i - x_j is recomputed in the
                                                              // epilogue instead of living in 2 x CDM registers across the hidden loop
         bool fm[TILES];                                      // edge contributes (valid slot and unmasked)
+        int64_t erow[TILES];                                 // global edge index (b, i, k) of this lane's edge, -1 = padding slot
+        f16x4 guhi[TILES], gulo[TILES];                      // BWD: d loss / d u of this lane's edge (B fragments)
 
         // TPI == 2 (K % 32 == 0): the 32 slots of a wave belong to ONE node -> node index and first k are wave-uniform
         const int qwave = round * SLOTS_PER_ROUND + wave * SLOTS_PER_WAVE;
@@ -224,6 +233,19 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 }
             }
             ei[t] = i; ej[t] = j;
+            if (BWD) erow[t] = valid ? (int64_t)((bN + i) * (size_t)K + k) : (int64_t)-1;
+            if (BWD) {
+                // B fragment of the W2^T product: channels 4g .. 4g+3 of this edge's d loss / d u, as a split-f16 pair
+                f32x4 gu = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (valid) gu = *reinterpret_cast<const f32x4*>(p.gU + erow[t] * 16 + 4 * g);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float v = gu[u] * p.gu_scale;
+                    const _Float16 h = (_Float16)v;
+                    guhi[t][u] = h;
+                    gulo[t][u] = (_Float16)(v - (float)h);
+                }
+            }
 
             // Per-edge scalars [sin(d/2^f)..., cos(d/2^f)..., d, edges...] (egnn_pytorch.py:34-41, 282-285) as B
             // fragments of v_mfma_f32_16x16x16_f16: lane group g of MFMA m carries split term tau = 4 m + g of scalar
@@ -368,7 +390,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
         // W2 fragments: (Hp/32, 2, 64, 8) halves = 2048 bytes per step; scalar table: NM * 16 bytes per hidden unit.
         auto stage = [&](int c0s, int slot) {
             const int hcs = (p.Hp - c0s) < HC ? (p.Hp - c0s) : HC;
-            const char* src = reinterpret_cast<const char*>(p.W2h) + (size_t)c0s * W2B + lane * 16;
+            const char* src = reinterpret_cast<const char*>(BWD ? p.W2Th : p.W2h) + (size_t)c0s * W2B + lane * 16;
             char* dst = reinterpret_cast<char*>(w2s) + slot * (HC * W2B);
             for (int pc = wave; pc < hcs * NB / 16; pc += EDGE_WAVES) lds_dma16(src + pc * 1024, dst + pc * 1024);
             const int tbytes = hcs * NM * 16;
@@ -399,7 +421,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             {
                 // LDS-DMA, 1 KB (64 lanes x 16 B) per instruction: no VGPR round trip, no VALU address loop.
                 // W2 fragments: (Hp/32, 2, 64, 8) halves = 2048 bytes per step; scalar table: NM * 16 bytes per hidden unit.
-                const char* src = reinterpret_cast<const char*>(p.W2h) + (size_t)c0 * W2B + lane * 16;
+                const char* src = reinterpret_cast<const char*>(BWD ? p.W2Th : p.W2h) + (size_t)c0 * W2B + lane * 16;
                 for (int pc = wave; pc < hc * NB / 16; pc += EDGE_WAVES)
                     __builtin_amdgcn_global_load_lds((glb_void*)(src + pc * 1024),
                                                      (lds_void*)(reinterpret_cast<char*>(w2s) + pc * 1024), 16, 0, 0);
@@ -507,6 +529,36 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 #if EGNN_EDGE_PRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
+                if constexpr (BWD) {
+                    // W2^T fragments of this step: [hb][hi|lo][lane = 16 g + r][4 halves]: row 16 hb + r, channels 4g .. 4g+3
+                    const f16x4* wt = reinterpret_cast<const f16x4*>(w2c + (size_t)st * (W2B / 2) * 32);
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {
+                        const f16x4 wthi = wt[(hb * 2 + 0) * 64 + lane], wtlo = wt[(hb * 2 + 1) * 64 + lane];
+#pragma unroll
+                        for (int t = 0; t < TILES; ++t) {
+                            f32x4 ga = f32x4{0.f, 0.f, 0.f, 0.f};
+                            ga = __builtin_amdgcn_mfma_f32_16x16x16f16(wthi, guhi[t], ga, 0, 0, 0);
+                            ga = __builtin_amdgcn_mfma_f32_16x16x16f16(wtlo, guhi[t], ga, 0, 0, 0);
+                            ga = __builtin_amdgcn_mfma_f32_16x16x16f16(wthi, gulo[t], ga, 0, 0, 0);
+                            f32x4 av4, dz4;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                // y = -log2(e) x;  sigma(x) = 1 / (1 + 2^y);  SiLU(x) = x sigma;  SiLU'(x) = sigma (1 + x (1 - sigma))
+                                const float y = x[t][hb][u];
+                                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
+                                const float xn = y * -0.6931471805599453f;
+                                av4[u] = xn * r;
+                                dz4[u] = ga[u] * p.bwd_inv_scale * (r * (1.0f + xn * (1.0f - r)));
+                            }
+                            if (erow[t] >= 0) {
+                                const size_t o = (size_t)erow[t] * p.ldz + hoff + 16 * hb + 4 * g;
+                                *reinterpret_cast<f32x4*>(p.A_out + o) = av4;
+                                *reinterpret_cast<f32x4*>(p.dZ + o) = dz4;
+                            }
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
                     // x holds y = -log2(e) * (pre-activation); hv = y / (1 + 2^y) = SiLU(pre) / (-ln 2)
@@ -558,7 +610,12 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                     }
 #endif
                 }
+                }
             }
+        }
+        if constexpr (BWD) {
+            __syncthreads();                                 // (multi-round groups: both staging slots free again)
+            continue;
         }
 
         // ------------------------------------------------------------------ per-edge epilogue (registers)
@@ -595,6 +652,19 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 part += gwr[nb][0] * m[nb][0] + gwr[nb][1] * m[nb][1] + gwr[nb][2] * m[nb][2] + gwr[nb][3] * m[nb][3];
             }
             egnn_flag_range(p.status, bad && fm[t], EGNN_RANGE_HIDDEN);
+            if constexpr (MODE == 1) {                       // u = W2 SiLU(x) + b2: what the backward differentiates from
+                // (the slot -> (node, k) decode of the setup again: keeping the edge index live through the hidden loop costs
+                // four registers the TPI = 1 variant does not have)
+                const int q = qwave + t * 16 + e;
+                const int nl = (TPI == 2) ? nl_w : q / K;
+                const int kk = (TPI == 2) ? k_w + t * 16 + e : q - nl * K;
+                if (q < slots_total && node0 + nl < N) {
+                    f32x4 uu;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) uu[u] = acc[t][0][u] * p.w2_inv_scale + b2r[0][u];
+                    *reinterpret_cast<f32x4*>(p.U_out + ((bN + ei[t]) * (size_t)K + kk) * 16 + 4 * g) = uu;
+                }
+            }
             if (p.gate_w) {
                 part = egnn_column_sum4(part, xch + 64 * t, lane);          // this wave's exchange rows are free now
                 const float gt = egnn_sigmoid(part + gb);
@@ -786,6 +856,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
     }
     __syncthreads();
 
+    if constexpr (BWD) return;
     // ---------------------------------------------------------------------- node outputs
     for (int o = tid; o < G * NCH; o += EDGE_THREADS) {
         const int nl = o / NCH, ch = o - nl * NCH;
@@ -818,14 +889,14 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
     }
 }
 
-template <int NM, int HCT, int TPI, int NB>
-__global__ __launch_bounds__(EDGE_THREADS, edge_min_blocks(NM, TPI, NB)) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
+template <int NM, int HCT, int TPI, int NB, int MODE = 0>
+__global__ __launch_bounds__(EDGE_THREADS, (MODE == 1 && edge_min_blocks(NM, TPI, NB) > 1) ? edge_min_blocks(NM, TPI, NB) - 1 : edge_min_blocks(NM, TPI, NB)) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    edge_body<NM, HCT, TPI, NB>(p, G, gpg, smem, blockIdx.x, gridDim.x);
+    edge_body<NM, HCT, TPI, NB, MODE>(p, G, gpg, smem, blockIdx.x, gridDim.x);
 }
 
-template <int NM, int HCT, int TPI, int NB>
+template <int NM, int HCT, int TPI, int NB, int MODE = 0>
 int launch_edge(const egnn_edge_args& a, hipStream_t s)
 {
     constexpr int NCH = nch_of(NB);
@@ -845,22 +916,30 @@ int launch_edge(const egnn_edge_args& a, hipStream_t s)
     const size_t xch_floats = (TPI != 2 && NCH > XLD) ? (size_t)SLOTS_PER_ROUND * NCH : (size_t)SLOTS_PER_ROUND * XLD;
     const size_t lds = (size_t)HCT * 64 * NB + sizeof(float) * (xch_floats + (size_t)G * NCH) + (size_t)HCT * NM * 16;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_kernel<NM, HCT, TPI, NB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_kernel<NM, HCT, TPI, NB, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((edge_kernel<NM, HCT, TPI, NB>), dim3((unsigned)nblk), dim3(EDGE_THREADS), lds, s, a, G, gpg);
+    hipLaunchKernelGGL((edge_kernel<NM, HCT, TPI, NB, MODE>), dim3((unsigned)nblk), dim3(EDGE_THREADS), lds, s, a, G, gpg);
     return egnn_launch_status();
 }
 
-template <int NM, int HCT, int NB>
+template <int NM, int HCT, int NB, int MODE = 0>
 int dispatch_tpi_nb(const egnn_edge_args& a, hipStream_t s)
 {
     // K % 32 == 0: both tiles of a wave share node i; K >= 6: a tile touches <= 4 nodes -- either way P_i rides in the
     // first-layer MFMA as (hi, lo) words (pi_split); K < 6: it is added per lane from the fp32 projection
-    if (a.K % 32 == 0) return launch_edge<NM, HCT, 2, NB>(a, s);
-    if (a.K >= 6) return launch_edge<NM, HCT, 1, NB>(a, s);
-    return launch_edge<NM, HCT, 0, NB>(a, s);
+    if (a.K % 32 == 0) return launch_edge<NM, HCT, 2, NB, MODE>(a, s);
+    if (a.K >= 6) return launch_edge<NM, HCT, 1, NB, MODE>(a, s);
+    return launch_edge<NM, HCT, 0, NB, MODE>(a, s);
+}
+
+template <int NM, int HCT>
+int dispatch_bwd(const egnn_edge_args& a, hipStream_t s)
+{
+    if (a.K % 32 == 0) return launch_edge<NM, HCT, 2, 1, 2>(a, s);
+    if (a.K >= 6) return launch_edge<NM, HCT, 1, 1, 2>(a, s);
+    return launch_edge<NM, HCT, 0, 1, 2>(a, s);
 }
 
 // m_dim <= 16: one accumulator tile per edge tile (every BASELINE config); 17..32: two; 33..64: four, with the staged
@@ -868,6 +947,9 @@ int dispatch_tpi_nb(const egnn_edge_args& a, hipStream_t s)
 template <int NM, int HCT>
 int dispatch_tpi(const egnn_edge_args& a, hipStream_t s)
 {
+#ifndef EGNN_EDGE_GENERIC_C
+    if (a.m_dim <= 16 && a.U_out) return dispatch_tpi_nb<NM, HCT, 1, 1>(a, s);      // forward under autograd: also writes u
+#endif
     if (a.m_dim <= 16) return dispatch_tpi_nb<NM, HCT, 1>(a, s);
 #ifndef EGNN_EDGE_TUNING_BUILD
     if (a.m_dim <= 32) return dispatch_tpi_nb<NM, (HCT / 2 >= 64 ? HCT / 2 : 64), 2>(a, s);
@@ -895,7 +977,37 @@ extern "C" int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream)
 {
     if (!args) return EGNN_E_NULLPTR;
     if (args->coor_dim < 1 || args->coor_dim > 8) return EGNN_E_UNSUPPORTED;
+    if (args->gU || args->dZ || args->A_out) return EGNN_E_SHAPE;          // backward fields belong to egnn_edge_bwd_dz_f32
     return args->coor_dim == 3 ? egnn_edge_fused_c3(args, stream) : egnn_edge_fused_generic_c(args, stream);
+}
+
+extern "C" int egnn_edge_bwd_dz_f32(const egnn_edge_args* args, void* stream)
+{
+    if (!args) return EGNN_E_NULLPTR;
+    const egnn_edge_args& a = *args;
+    if (!a.Pi || !a.Pj || !a.Wst || !a.W2Th || !a.coors || !a.gU || !a.dZ || !a.A_out) return EGNN_E_NULLPTR;
+    if (a.coor_dim != 3 || a.m_dim < 1 || a.m_dim > 16) return EGNN_E_UNSUPPORTED;   // the fast-path shapes only
+    if (a.B <= 0 || a.N <= 0 || a.K <= 0 || a.H <= 0) return EGNN_E_SHAPE;
+    if (a.Hp != egnn_padded_hidden(a.H) || a.ldp < a.Hp || (a.ldp % 4) != 0 || a.ldz < a.Hp || (a.ldz % 4) != 0) return EGNN_E_SHAPE;
+    if (a.S != 2 * a.fourier + 1 + a.edge_dim || a.S > 16 || a.wst_terms != 4 * egnn_edge_mfmas(a.S)) return EGNN_E_SHAPE;
+    if (!(a.ws_inv_scale > 0.f) || !(a.gu_scale > 0.f) || !(a.bwd_inv_scale > 0.f)) return EGNN_E_SHAPE;
+    if ((a.pi_split != 0) != (a.K >= 6)) return EGNN_E_SHAPE;
+    if (a.edge_dim > 0 && !a.edges) return EGNN_E_NULLPTR;
+    if (a.idx == nullptr && a.K != a.N) return EGNN_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(a.Pi) & 15) || (reinterpret_cast<uintptr_t>(a.Pj) & 15) || (reinterpret_cast<uintptr_t>(a.Wst) & 15) ||
+        (reinterpret_cast<uintptr_t>(a.W2Th) & 15) || (reinterpret_cast<uintptr_t>(a.gU) & 15) || (reinterpret_cast<uintptr_t>(a.dZ) & 15) ||
+        (reinterpret_cast<uintptr_t>(a.A_out) & 15))
+        return EGNN_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a.S == 1) return dispatch_bwd<1, HC>(a, s);
+#ifndef EGNN_EDGE_TUNING_BUILD
+    if (a.S <= 4) return dispatch_bwd<3, 128>(a, s);
+    if (a.S <= 5) return dispatch_bwd<4, 128>(a, s);
+    if (a.S <= 8) return dispatch_bwd<6, 64>(a, s);
+    return dispatch_bwd<12, 64>(a, s);
+#else
+    return EGNN_E_UNSUPPORTED;
+#endif
 }
 #endif
 

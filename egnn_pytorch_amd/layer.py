@@ -141,22 +141,24 @@ class EGNN(nn.Module):
                 node_out, coors_out, order = self._forward_with_hint(feats, coors, edges, mask, adj_mat, order_hint)[:3]
         return node_out, coors_out, order
 
-    def _forward_hip_checked(self, feats, coors, edges, mask, adj_mat, order_hint):
-        """(node_out, coors_out, order, idx, rank, valid_radius) -- what autograd.EGNNFunction.forward needs."""
-        return self._forward_with_hint(feats, coors, edges, mask, adj_mat, order_hint)
+    def _forward_hip_checked(self, feats, coors, edges, mask, adj_mat, order_hint, want_u=False):
+        """(node_out, coors_out, order, idx, rank, valid_radius, u) -- what autograd.EGNNFunction.forward needs; u = the
+        (B*N*K, 16) pre-activation of edge_mlp's second SiLU when `want_u` (the native backward differentiates from it)."""
+        return self._forward_with_hint(feats, coors, edges, mask, adj_mat, order_hint, want_u=want_u)
 
-    def _forward_with_hint(self, feats, coors, edges, mask, adj_mat, order_hint):
+    def _forward_with_hint(self, feats, coors, edges, mask, adj_mat, order_hint, want_u=False):
         """forward + the scheduling permutation it used (EGNN_Network hands layer 0's on to the next layers)."""
         self._check_inputs(feats, coors, edges, mask, adj_mat)
         _abi.load()
         f_dtype, c_dtype = feats.dtype, coors.dtype
         with torch.cuda.device(feats.device):
-            out = self._forward_hip(feats.float(), coors.float(), None if edges is None else edges.float(), mask, adj_mat, order_hint)
+            out = self._forward_hip(feats.float(), coors.float(), None if edges is None else edges.float(), mask, adj_mat, order_hint,
+                                    want_u=want_u)
         if f_dtype != torch.float32 or c_dtype != torch.float32:
             out = (out[0].to(f_dtype), out[1].to(c_dtype)) + tuple(out[2:])
         return out
 
-    def _forward_hip(self, feats, coors, edges, mask, adj_mat, order_hint=None):
+    def _forward_hip(self, feats, coors, edges, mask, adj_mat, order_hint=None, want_u=False):
         b, n, dim = feats.shape
         w = self.packed_weights()
         feats = feats.contiguous()
@@ -173,7 +175,7 @@ class EGNN(nn.Module):
         idx = rank = None
         if b == 0 or (n == 0 and not use_nearest):
             # empty batch / empty dense graphs: the reference returns empty outputs (N = 0 on the k-NN path: topk's error)
-            return torch.empty_like(feats), torch.empty_like(coors), None, None, None, valid_radius
+            return torch.empty_like(feats), torch.empty_like(coors), None, None, None, valid_radius, None
         if use_nearest:
             if adj_mat is not None and self.only_sparse_neighbors:
                 num_nearest = _ops.adj_max_degree(adj_mat)                # host sync, as upstream (:249)
@@ -208,7 +210,7 @@ class EGNN(nn.Module):
         side_join = use_nearest and k > 0 and _SIDE_STREAM and _ops._timer is None
 
         node_out, coors_out = feats, coors
-        node_in = order = None
+        node_in = order = u_pre = None
         if k > 0:
             # ---- node-level projections P = feats [W_i ; W_j]^T + [b1 ; 0]
             # (K >= 6: the edge pass feeds P_i to its first-layer MFMA as (fp16 hi, fp16 lo) words)
@@ -263,6 +265,9 @@ class EGNN(nn.Module):
             a.pool_mean = int(self.m_pool_method == "mean")
             if self.node_mlp is not None:
                 a.node_hi, a.node_lo, a.node_kp = node_in.hi.data_ptr(), node_in.lo.data_ptr(), node_in.kp
+            if want_u and self.m_dim <= 16:
+                u_pre = _ops.empty(b * n * k, 16, dtype=torch.float32, device=feats.device)
+                a.U_out = u_pre.data_ptr()
             _ops.edge_fused(a, feats.device)
             del proj
         elif self.node_mlp is not None:                                   # K == 0: no messages, m_i = 0
@@ -273,7 +278,7 @@ class EGNN(nn.Module):
             hid = _ops.linear_hl(node_in, w["W5_split"], 2 * dim, w["b5"], act=1, out_f32=False, out_hl=True,
                                  name="node_mlp0")
             node_out = _ops.linear_hl(hid, w["W6_split"], dim, w["b6"], residual=feats2d, name="node_mlp1").view(b, n, dim)
-        return node_out, coors_out, order, idx, rank, valid_radius
+        return node_out, coors_out, order, idx, rank, valid_radius, u_pre
 
 
 class EGNN_Network(nn.Module):

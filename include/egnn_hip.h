@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 15
+#define EGNN_ABI_VERSION 16
 
 enum {
     EGNN_OK = 0,
@@ -209,9 +209,30 @@ typedef struct egnn_edge_args {
     void* node_lo;              /*   egnn_node_prep_hl(m_i = NULL); the pooled messages are written into its columns  */
     int32_t node_kp;            /*   [dim, dim + m_dim) (both or neither; node_kp % 32 == 0, >= dim + m_dim)          */
     int32_t* status;            /* optional range status word (EGNN_RANGE_SCALAR / _HIDDEN / _MESSAGE), see the enum above */
+    /* autograd support (all NULL / 0 for plain inference) */
+    float* U_out;               /* forward, optional, m_dim <= 16: (B*N*K, 16) fp32 u = edge_mlp.3(SiLU(edge_mlp.0(.))) before the second
+                                   SiLU (egnn_pytorch.py:181-183), one row per edge (b, i, k), pad channels 0 */
+    const void* W2Th;           /* backward: (Hp/32, 2, 2, 64, 4) fp16: w2t_scale * edge_mlp.3.weight^T (natural units) as A fragments
+                                   of v_mfma_f32_16x16x16_f16: [step][hb][hi|lo][lane = 16 g + r][u] = W2[4 g + u][32 step + 16 hb + r] */
+    const float* gU;            /* backward: (B*N*K, 16) fp32 d loss / d u */
+    float gu_scale;             /* power of two the kernel multiplies gU by before the fp16 split */
+    float bwd_inv_scale;        /* 1 / (w2t_scale * gu_scale) */
+    float* dZ;                  /* backward out: (B*N*K, ldz) fp32 d loss / d z, z = pre-activation of the first SiLU (natural units) */
+    float* A_out;               /* backward out: (B*N*K, ldz) fp32 SiLU(z) */
+    int64_t ldz;                /* >= Hp, multiple of 4 */
 } egnn_edge_args;
 
 int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream);
+
+/* Backward companion of the edge pass (autograd of egnn_pytorch.py:279-287).  Recomputes the pre-activation
+ * z of edge_mlp's first SiLU exactly as the forward does (gathers of P_j, first-layer MFMAs) and, from gU = d loss / d u
+ * (u = the second Linear's output, args->U_out of the forward), writes per edge
+ *     A_out = SiLU(z)                  (what d loss / d edge_mlp.3.weight = gU^T A_out needs)
+ *     dZ    = (W2^T gU) * SiLU'(z)     (d loss / d z: summed over a node's edges -> d/d P_i, scattered by neighbour -> d/d P_j,
+ *                                        times the per-edge scalars -> d/d W_s, times W_s -> d/d scalars)
+ * in fp32, natural units.  Nothing of size E x H is read: 2 E Hp floats are written.  Shapes: coor_dim 3, m_dim <= 16;
+ * fields used: shapes, Pi / Pj / ldp / pi_split, Wst & scales, coors, edges, idx, order and the backward fields. */
+int egnn_edge_bwd_dz_f32(const egnn_edge_args* args, void* stream);
 
 /* Number of chained first-layer MFMAs the edge kernel is instantiated with for S per-edge scalars (>= ceil(3 S / 4); one of 1, 3, 4, 6, 12). */
 int egnn_edge_mfmas(int S);

@@ -196,3 +196,43 @@ def test_inference_paths_record_nothing():
     n2, c2 = layer(f, c)                                    # grad mode on, parameters require grad -> a graph, as upstream
     assert n2.requires_grad and n2.grad_fn is not None
     assert torch.equal(n1, n2.detach()) and torch.equal(c1, c2.detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,n,flags", [
+    (dict(dim=64, num_nearest_neighbors=32, norm_feats=True), 128, dict(mask=True)),                      # P_i shared by the wave
+    (dict(dim=32, num_nearest_neighbors=8, edge_dim=3, fourier_features=2, soft_edges=True), 48, dict(mask=True, edges=True)),
+    (dict(dim=32), 20, dict(mask=True)),                                                                   # dense all-pairs
+    (dict(dim=16, num_nearest_neighbors=5, m_dim=8, m_pool_method="mean", coor_weights_clamp_value=1.0), 30, dict(mask=False)),
+    (dict(dim=24, num_nearest_neighbors=48), 96, dict(mask=True)),                                         # multi-round node groups
+])
+def test_native_backward_kernel_matches_the_aten_recompute(kw, n, flags):
+    """egnn_edge_bwd_dz_f32 path (E x H work on the HIP kernel, reductions / GEMMs around it) against the pure-ATen recompute
+    backward of the same Function: every gradient within 1e-4 of its scale.  (The recompute itself is pinned to the reference's
+    autograd in float64 on the CPU.)"""
+    from egnn_pytorch_amd import EGNN, autograd
+    torch.manual_seed(9)
+    layer = EGNN(**kw).cuda()
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.mul_(60.0)
+    g = torch.Generator().manual_seed(4)
+    b = 3
+    feats, coors = torch.randn(b, n, kw["dim"], generator=g).cuda(), torch.randn(b, n, 3, generator=g).cuda()
+    mask = (torch.arange(n)[None] < torch.tensor([[n], [n - 5], [n // 2 + 4]])).cuda() if flags.get("mask") else None
+    edges = torch.randn(b, n, n, kw.get("edge_dim", 0), generator=g).cuda() if flags.get("edges") else None
+    results = []
+    for native in (True, False):
+        old = autograd._NATIVE
+        autograd._NATIVE = native
+        try:
+            f, c = feats.clone().requires_grad_(True), coors.clone().requires_grad_(True)
+            e = None if edges is None else edges.clone().requires_grad_(True)
+            results.append(_grads(layer, lambda: layer(f, c, e, mask), (f, c, e))[0])
+        finally:
+            autograd._NATIVE = old
+    for pos, (a, r) in enumerate(zip(*results)):
+        assert (a is None) == (r is None)
+        if a is not None:
+            scale = max(1.0, float(r.abs().max()))
+            np.testing.assert_allclose(a.numpy(), r.numpy(), atol=1e-4 * scale, rtol=0, err_msg=f"gradient #{pos}")
