@@ -331,6 +331,17 @@ def edge_fused(args: _abi.EdgeArgs, device):
     _abi.check(rc, "egnn_edge_fused_f32")
 
 
+def rows_gather_sum(rows, order, seg_ptr, n_out):
+    """out[r] = sum of rows[order[p]] over p in [seg_ptr[r], seg_ptr[r+1]), fixed order -- egnn_rows_gather_sum_f32."""
+    cols = rows.shape[1]
+    out = empty(n_out, cols, dtype=torch.float32, device=rows.device)
+    with _timed("rows_gather_sum"):
+        rc = _abi.load().egnn_rows_gather_sum_f32(_ptr(rows), rows.stride(0), _ptr(order), _ptr(seg_ptr), n_out, cols, _ptr(out),
+                                                  cols, _stream())
+    _abi.check(rc, "egnn_rows_gather_sum_f32")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- whole-layer C interface
 def pack_weights_c(layer):
     """egnn_pack_weights_host on the module's parameters: (desc, info, blob uint8 CPU tensor).  The Python module itself

@@ -13,10 +13,9 @@ Backward = `_backward_native` (fp32, coordinate dimension 3, m_dim <= 16):
            `_backward_recompute` (everything else, and the native path's reference in the tests): the whole layer re-evaluated
            a few graphs at a time as a differentiable chain of ATen ops over the neighbour list the HIP kernel selected,
            factorised like the forward, and differentiated by autograd.
-Gradients of feats / coors / edges / every parameter agree with the reference's autograd (tests/test_autograd.py).  Still
-ATen: the scatter of d/d P_j over the neighbour list (`scatter_add_`, atomics -- as non-deterministic as the reference's
-own gather backward) and the fp32 library GEMMs; folding the per-node sums into the kernel and a deterministic scatter over
-the transposed neighbour list are the next steps.
+Gradients of feats / coors / edges / every parameter agree with the reference's autograd (tests/test_autograd.py).  d/d P_j is a
+fixed-order gather over the transposed neighbour list (egnn_rows_gather_sum_f32: no float atomics); the remaining ATen pieces
+are the per-node sums, the fp32 library GEMMs and the small tail.
 
 `layer_given_neighbors` is a restatement of egnn_pytorch.py:262-341 that takes the neighbour list as an input (the selection
 itself, :237-260, is not differentiable: topk indices and the `<= valid_radius` comparison carry no gradient upstream
@@ -218,7 +217,11 @@ def _backward_native(ctx, g_node, g_coors):
     u_all = ctx.u_pre.view(b, n, k, 16)
     per_graph = 2.0 * n * k * hp * 4
     step = max(1, min(b, int(_NATIVE_BUDGET_BYTES // per_graph)))
-    w_i, w_j, w_s = lin0.weight[:, :dim].detach(), lin0.weight[:, dim:2 * dim].detach(), lin0.weight[:, 2 * dim:].detach()
+    # the first Linear's blocks, zero padded to the kernel's hidden width Hp: everything below works on the contiguous
+    # (E, Hp) buffers the kernel wrote (slicing [:, :H] first would copy 17 GB per use at the north-star shape)
+    w1p = torch.zeros(hp, lin0.weight.shape[1], dtype=torch.float32, device=feats.device)
+    w1p[:h] = lin0.weight.detach()
+    w_i, w_j, w_s = w1p[:, :dim].contiguous(), w1p[:, dim:2 * dim].contiguous(), w1p[:, 2 * dim:].contiguous()
     pi_split = k >= 6
     for lo in range(0, b, step):
         hi_ = min(b, lo + step)
@@ -282,25 +285,28 @@ def _backward_native(ctx, g_node, g_coors):
             _abi.check(rc, "egnn_edge_bwd_dz_f32")
             del proj, feats_hl
             # ---- 3. reductions and plain GEMMs over dz / a
-            dz3 = dz.view(bc, n, k, hp)[..., :h]
-            gz_i = dz3.sum(dim=2)                                                  # (bc, n, H)   d loss / d P_i
+            dz4 = dz.view(bc, n, k, hp)
+            gz_i = dz4.sum(dim=2).view(bc * n, hp)                                 # d loss / d P_i (pad columns are 0)
             if i64 is None:
-                gz_j = dz3.sum(dim=1)                                              # dense: neighbour k IS node j
+                gz_j = dz4.sum(dim=1).view(bc * n, hp)                             # dense: neighbour k IS node j
             else:
-                gz_j = torch.zeros(bc, n, h, dtype=torch.float32, device=feats.device)
-                gz_j.scatter_add_(1, i64.view(bc, n * k, 1).expand(bc, n * k, h), dz3.reshape(bc, n * k, h))
-            g_feats[lo:hi_] += gz_i @ w_i + gz_j @ w_j
+                # scatter by neighbour as a fixed-order gather over the transposed neighbour list (edges sorted stably by
+                # destination): no float atomics, bit-reproducible
+                dest = (i64 + (torch.arange(bc, device=feats.device) * n)[:, None, None]).view(-1)
+                dest_sorted, by_dest = torch.sort(dest, stable=True)
+                seg = torch.searchsorted(dest_sorted, torch.arange(bc * n + 1, device=feats.device))
+                gz_j = _ops.rows_gather_sum(dz, by_dest, seg, bc * n)
+            g_feats[lo:hi_] += (gz_i @ w_i + gz_j @ w_j).view(bc, n, dim)
             gw1 = grads_by_id[id(lin0.weight)]
-            gw1[:, :dim] += gz_i.reshape(-1, h).t() @ f2d
-            gw1[:, dim:2 * dim] += gz_j.reshape(-1, h).t() @ f2d
-            dz2 = dz3.reshape(ec, h)
+            gw1[:, :dim] += (gz_i.t() @ f2d)[:h]
+            gw1[:, dim:2 * dim] += (gz_j.t() @ f2d)[:h]
             sc2 = scal.detach().reshape(ec, s_in)
-            gw1[:, 2 * dim:] += dz2.t() @ sc2
-            grads_by_id[id(lin0.bias)] += gz_i.sum(dim=(0, 1))
-            g_scal = (dz2 @ w_s).view_as(scal)
-            grads_by_id[id(lin3.weight)] += gu16[:, :m].t() @ act[:, :h]
+            gw1[:, 2 * dim:] += (dz.t() @ sc2)[:h]
+            grads_by_id[id(lin0.bias)] += gz_i.sum(dim=0)[:h]
+            g_scal = (dz @ w_s).view_as(scal)
+            grads_by_id[id(lin3.weight)] += (gu16.t() @ act)[:m, :h]
             grads_by_id[id(lin3.bias)] += gu16[:, :m].sum(dim=0)
-            del dz, act, dz3, dz2
+            del dz, act, dz4
         # d loss / d scalars -> coordinates (through d = |x_i - x_j|^2 and the fourier terms) and edge features
         sg = torch.autograd.grad([scal], [c] + ([e] if e is not None else []), [g_scal], allow_unused=True)
         if sg[0] is not None:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 16
+#define EGNN_ABI_VERSION 17
 
 enum {
     EGNN_OK = 0,
@@ -233,6 +233,13 @@ int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream);
  * in fp32, natural units.  Nothing of size E x H is read: 2 E Hp floats are written.  Shapes: coor_dim 3, m_dim <= 16;
  * fields used: shapes, Pi / Pj / ldp / pi_split, Wst & scales, coors, edges, idx, order and the backward fields. */
 int egnn_edge_bwd_dz_f32(const egnn_edge_args* args, void* stream);
+
+/* Backward of the neighbour gather (egnn_pytorch.py:275): out[r, :] = sum of rows[order[p], :] for p in [seg_ptr[r], seg_ptr[r+1]),
+ * in that order -- with `order` = the edges sorted (stably) by destination node this is d loss / d P_j from dZ, a fixed-order
+ * read-only reduction (no float atomics: bit-reproducible).  rows (n_rows, ld) fp32, out (n_out, ldo) fp32, cols % 4 == 0,
+ * order / seg_ptr int64 (seg_ptr has n_out + 1 entries). */
+int egnn_rows_gather_sum_f32(const float* rows, int64_t ld, const int64_t* order, const int64_t* seg_ptr, int64_t n_out,
+                             int cols, float* out, int64_t ldo, void* stream);
 
 /* Number of chained first-layer MFMAs the edge kernel is instantiated with for S per-edge scalars (>= ceil(3 S / 4); one of 1, 3, 4, 6, 12). */
 int egnn_edge_mfmas(int S);
