@@ -331,6 +331,18 @@ def edge_fused(args: _abi.EdgeArgs, device):
     _abi.check(rc, "egnn_edge_fused_f32")
 
 
+def edge_features_gather(lookup, idx, b, n, k):
+    """(B,N,K,edge_dim) features of the selected pairs from EGNN_Network's look-up tables -- egnn_edge_features_gather_f32."""
+    dev = (lookup.deg if lookup.deg is not None else (lookup.tok if lookup.tok is not None else lookup.edges)).device
+    out = empty(b, n, k, lookup.width, dtype=torch.float32, device=dev)
+    with _timed("edge_features"):
+        rc = _abi.load().egnn_edge_features_gather_f32(_ptr(lookup.edges), _ptr(lookup.tok), _ptr(lookup.tok_emb), lookup.d1,
+                                                       _ptr(lookup.deg), _ptr(lookup.deg_emb), lookup.d2, _ptr(idx), b, n, k,
+                                                       _ptr(out), _stream())
+    _abi.check(rc, "egnn_edge_features_gather_f32")
+    return out
+
+
 def rows_gather_sum(rows, order, seg_ptr, n_out):
     """out[r] = sum of rows[order[p]] over p in [seg_ptr[r], seg_ptr[r+1]), fixed order -- egnn_rows_gather_sum_f32."""
     cols = rows.shape[1]

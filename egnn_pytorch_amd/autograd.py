@@ -383,6 +383,6 @@ def wants_grad(layer, *tensors):
     """True when a forward under the current autograd mode has to record a graph."""
     if not torch.is_grad_enabled():
         return False
-    if any(t is not None and torch.is_tensor(t) and t.is_floating_point() and t.requires_grad for t in tensors):
+    if any(torch.is_tensor(t) and t.is_floating_point() and t.requires_grad for t in tensors):
         return True
     return any(p.requires_grad for p in layer.parameters())

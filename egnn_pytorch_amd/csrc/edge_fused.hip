@@ -265,7 +265,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                     else if (sidx < F) val = sinf(d * exp2f(-(float)sidx));
                     else if (sidx < 2 * F) val = cosf(d * exp2f(-(float)(sidx - F)));
                     else if (sidx == 2 * F) val = d;
-                    else val = p.edges[((bN + i) * N + j) * p.edge_dim + (sidx - 2 * F - 1)];
+                    else val = p.edges[(p.edges_by_k ? (bN + i) * (size_t)K + k : (bN + i) * (size_t)N + j) * p.edge_dim + (sidx - 2 * F - 1)];
                     // |s'| beyond 2^10 * 65504 = 6.7e7 does not fit the three fp16 parts: the coarse part overflows to inf and
                     // the edge's result is NaN (never a silently clamped number); the status word says why
                     val = val * p.ws_inv_scale;

@@ -42,3 +42,49 @@ extern "C" int egnn_rows_gather_sum_f32(const float* rows, int64_t ld, const int
                        seg_ptr, cols, out, ldo);
     return egnn_launch_status();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// EGNN_Network front-end (egnn_pytorch.py:410-432): the per-pair edge features of the K selected pairs of every node, looked up
+// from the embedding tables -- see include/egnn_hip.h::egnn_edge_features_gather_f32.  One thread per (edge, column).
+namespace {
+
+__global__ __launch_bounds__(256) void edge_features_gather_kernel(const float* __restrict__ edges, const int64_t* __restrict__ tok,
+                                                                   const float* __restrict__ tok_emb, int d1,
+                                                                   const uint8_t* __restrict__ deg, const float* __restrict__ deg_emb,
+                                                                   int d2, const int32_t* __restrict__ idx, int N, int K, int64_t total,
+                                                                   float* __restrict__ out)
+{
+    const int w = d1 + d2;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t edge = o / w;
+        const int col = (int)(o - edge * w);
+        const int64_t node = edge / K;                              // b * N + i
+        const int k = (int)(edge - node * K);
+        const int j = idx ? idx[edge] : k;
+        const int64_t pair = node * N + j;
+        float v;
+        if (col < d1) v = tok ? tok_emb[tok[pair] * d1 + col] : edges[pair * d1 + col];
+        else v = deg_emb[(int64_t)deg[pair] * d2 + (col - d1)];
+        out[o] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int egnn_edge_features_gather_f32(const float* edges, const int64_t* edge_tok, const float* edge_tok_emb, int d1,
+                                             const uint8_t* adj_deg, const float* adj_deg_emb, int d2, const int32_t* idx,
+                                             int B, int N, int K, float* out, void* stream)
+{
+    if (!out) return EGNN_E_NULLPTR;
+    if (B <= 0 || N <= 0 || K <= 0 || d1 < 0 || d2 < 0 || d1 + d2 <= 0) return EGNN_E_SHAPE;
+    if (d1 > 0 && !edges && !(edge_tok && edge_tok_emb)) return EGNN_E_NULLPTR;
+    if (d2 > 0 && (!adj_deg || !adj_deg_emb)) return EGNN_E_NULLPTR;
+    if (!idx && K != N) return EGNN_E_SHAPE;
+    const int64_t total = (int64_t)B * N * K * (d1 + d2);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(edge_features_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), edges,
+                       edge_tok, edge_tok_emb, d1, adj_deg, adj_deg_emb, d2, idx, N, K, total, out);
+    return egnn_launch_status();
+}

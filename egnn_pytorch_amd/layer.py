@@ -30,6 +30,26 @@ _SIDE_STREAM = os.environ.get("EGNN_SIDE_STREAM", "1") != "0"         # neighbou
 _FLOAT_DTYPES = (torch.float32, torch.float64, torch.float16, torch.bfloat16)
 
 
+class EdgeLookup:
+    """Per-pair edge features given as look-up tables instead of a materialised (B,N,N,edge_dim) tensor: what EGNN_Network's
+    front-end produces (egnn_pytorch.py:410-432) -- [edge_emb(edge tokens) or float edges | adj_emb(adjacency-degree labels)].
+    The edge kernel reads the tables for the K selected pairs of each node (include/egnn_hip.h: egnn_edge_args.edge_tok ...);
+    inference only (under autograd the network materialises the tensor so that the embeddings receive gradients)."""
+
+    def __init__(self, edges=None, tok=None, tok_emb=None, deg=None, deg_emb=None):
+        self.edges = None if edges is None else edges.contiguous().float()
+        self.tok = None if tok is None else tok.contiguous().long()
+        self.tok_emb = None if tok_emb is None else tok_emb.detach().contiguous().float()
+        self.deg = None if deg is None else deg.contiguous()
+        self.deg_emb = None if deg_emb is None else deg_emb.detach().contiguous().float()
+        self.d1 = self.tok_emb.shape[1] if self.tok is not None else (self.edges.shape[-1] if self.edges is not None else 0)
+        self.d2 = self.deg_emb.shape[1] if self.deg is not None else 0
+
+    @property
+    def width(self):
+        return self.d1 + self.d2
+
+
 def _mlp(d_in, d_hidden, d_out, dropout, final_act):
     """Linear -> dropout|Identity -> SiLU -> Linear [-> SiLU]; indices 0 and 3 hold the Linears, which is
     what gives the reference's state_dict keys (`edge_mlp.0.*`, `edge_mlp.3.*`, ...)."""
@@ -117,7 +137,10 @@ class EGNN(nn.Module):
         if (edges is not None) != (self.edge_dim > 0):
             raise ValueError("`edges` must be passed if and only if edge_dim > 0")
         b, n = feats.shape[:2]
-        if edges is not None and tuple(edges.shape) != (b, n, n, self.edge_dim):
+        if isinstance(edges, EdgeLookup):
+            if edges.width != self.edge_dim:
+                raise ValueError(f"edge look-up tables give {edges.width} features per pair, edge_dim is {self.edge_dim}")
+        elif edges is not None and tuple(edges.shape) != (b, n, n, self.edge_dim):
             raise ValueError(f"edges shape {tuple(edges.shape)} != {(b, n, n, self.edge_dim)}")
         if mask is not None and tuple(mask.shape) != (b, n):
             raise ValueError(f"mask shape {tuple(mask.shape)} != {(b, n)}")
@@ -152,7 +175,8 @@ class EGNN(nn.Module):
         _abi.load()
         f_dtype, c_dtype = feats.dtype, coors.dtype
         with torch.cuda.device(feats.device):
-            out = self._forward_hip(feats.float(), coors.float(), None if edges is None else edges.float(), mask, adj_mat, order_hint,
+            out = self._forward_hip(feats.float(), coors.float(),
+                                    edges if (edges is None or isinstance(edges, EdgeLookup)) else edges.float(), mask, adj_mat, order_hint,
                                     want_u=want_u)
         if f_dtype != torch.float32 or c_dtype != torch.float32:
             out = (out[0].to(f_dtype), out[1].to(c_dtype)) + tuple(out[2:])
@@ -164,7 +188,10 @@ class EGNN(nn.Module):
         feats = feats.contiguous()
         coors = coors.contiguous()
         feats2d = feats.view(b * n, dim)
-        if edges is not None:
+        lookup = edges if isinstance(edges, EdgeLookup) else None
+        if lookup is not None:
+            edges = lookup.edges
+        elif edges is not None:
             edges = edges.contiguous().float()
         mask8 = _ops._u8(mask)
 
@@ -246,6 +273,12 @@ class EGNN(nn.Module):
             if self.norm_coors:
                 a.coors_scale = w["coors_scale"].data_ptr()
             a.coors, a.coor_dim = coors.data_ptr(), coors.shape[-1]
+            if lookup is not None:
+                # the features of the K selected pairs only, read by the kernel in neighbour-list order
+                if side_join:
+                    torch.cuda.current_stream().wait_stream(_ops.side_stream(feats.device))
+                edges = _ops.edge_features_gather(lookup, idx, b, n, k)
+                a.edges_by_k = 1
             a.edges = _ops._ptr(edges)
             a.mask = _ops._ptr(mask8)
             if side_join:
@@ -338,8 +371,16 @@ class EGNN_Network(nn.Module):
             assert n <= self.num_positions, \
                 f"given sequence length {n} must be less than the number of positions {self.num_positions} set at init"
             feats = feats + self.pos_emb(torch.arange(n, device=feats.device))[None]
+        # Edge features for the layers.  Inference: look-up tables (EdgeLookup) -- the (B,N,N,edge_dim+adj_dim) tensor of :410-432
+        # is never materialised, the edge kernel reads the embedding rows of the K selected pairs of each node.  Under autograd:
+        # the tensor, so that the embeddings receive gradients.
+        lazy = not torch.is_grad_enabled()
+        tok = tok_emb = None
         if edges is not None and self.edge_emb is not None:
-            edges = self.edge_emb(edges)
+            if lazy:
+                tok, tok_emb, edges = edges, self.edge_emb.weight, None
+            else:
+                edges = self.edge_emb(edges)
 
         if self.num_adj_degrees is not None:
             assert adj_mat is not None, "adjacency matrix must be passed in (keyword argument adj_mat)"
@@ -348,8 +389,14 @@ class EGNN_Network(nn.Module):
             # N-degree expansion (egnn_pytorch.py:414-427) as bit-set algebra on the device instead of float matmuls
             adj_mat, adj_indices = _ops.adj_expand(adj_mat, b, self.num_adj_degrees)
             if self.adj_emb is not None:
-                adj_emb = self.adj_emb(adj_indices.long())
-                edges = torch.cat((edges, adj_emb), dim=-1) if edges is not None else adj_emb
+                if lazy:
+                    edges = EdgeLookup(edges=edges, tok=tok, tok_emb=tok_emb, deg=adj_indices, deg_emb=self.adj_emb.weight)
+                    tok = None
+                else:
+                    adj_emb = self.adj_emb(adj_indices.long())
+                    edges = torch.cat((edges, adj_emb), dim=-1) if edges is not None else adj_emb
+        if tok is not None:                                         # edge tokens without adjacency degrees
+            edges = EdgeLookup(tok=tok, tok_emb=tok_emb)
 
         global_tokens = None
         if self.global_tokens is not None:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 17
+#define EGNN_ABI_VERSION 18
 
 enum {
     EGNN_OK = 0,
@@ -220,9 +220,20 @@ typedef struct egnn_edge_args {
     float* dZ;                  /* backward out: (B*N*K, ldz) fp32 d loss / d z, z = pre-activation of the first SiLU (natural units) */
     float* A_out;               /* backward out: (B*N*K, ldz) fp32 SiLU(z) */
     int64_t ldz;                /* >= Hp, multiple of 4 */
+    int32_t edges_by_k;         /* 0: `edges` is (B,N,N,edge_dim), read at [b,i,j];  1: `edges` is (B,N,K,edge_dim), the features of the
+                                   selected pairs in neighbour-list order (egnn_edge_features_gather_f32), read at [b,i,k] */
 } egnn_edge_args;
 
 int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream);
+
+/* EGNN_Network's per-pair edge features (egnn_pytorch.py:410-432: cat(edge_emb(edge tokens) | float edges, adj_emb(adjacency-degree
+ * labels))) for the K SELECTED pairs of every node only -- the (B,N,N,edge_dim+adj_dim) tensor is never materialised:
+ *   out[b,i,k,:] = [ edge_tok ? edge_tok_emb[edge_tok[b,i,j]] : edges[b,i,j,:d1]  |  adj_deg_emb[adj_deg[b,i,j]] ],  j = idx[b,i,k]
+ * (idx NULL: dense, j = k, K = N).  edges (B,N,N,d1) fp32 or NULL; edge_tok (B,N,N) int64 or NULL with edge_tok_emb (T,d1);
+ * adj_deg (B,N,N) bytes or NULL with adj_deg_emb (D+1,d2);  out (B,N,K,d1+d2) fp32, fed to egnn_edge_fused_f32 with edges_by_k = 1. */
+int egnn_edge_features_gather_f32(const float* edges, const int64_t* edge_tok, const float* edge_tok_emb, int d1,
+                                  const uint8_t* adj_deg, const float* adj_deg_emb, int d2, const int32_t* idx,
+                                  int B, int N, int K, float* out, void* stream);
 
 /* Backward companion of the edge pass (autograd of egnn_pytorch.py:279-287).  Recomputes the pre-activation
  * z of edge_mlp's first SiLU exactly as the forward does (gathers of P_j, first-layer MFMAs) and, from gU = d loss / d u

@@ -637,3 +637,32 @@ def test_full_batch_against_the_reference_module_itself(name, kwargs, b, n, chun
         worst_c = max(worst_c, float((co[lo:lo + chunk] - rc).abs().max()))
     print(f"{name}: {b} graphs x {n} nodes vs the reference module on the GPU: max|d feats| = {worst_n:.2e}, max|d coors| = {worst_c:.2e}")
     assert worst_n <= ATOL and worst_c <= ATOL, (worst_n, worst_c)
+
+
+def test_network_edge_lookup_equals_the_materialised_tensor():
+    """EGNN_Network's per-pair edge features (edge-token and adjacency-degree embeddings, egnn_pytorch.py:410-432): under no_grad
+    they are looked up for the K selected pairs only (EdgeLookup / egnn_edge_features_gather_f32); under autograd the
+    (B,N,N,edge_dim+adj_dim) tensor is materialised as upstream.  Same numbers, bit for bit."""
+    from egnn_pytorch_amd import EGNN_Network
+    torch.manual_seed(3)
+    for kw in (dict(num_tokens=10, num_edge_tokens=5, edge_dim=4, num_adj_degrees=2, adj_dim=3, num_nearest_neighbors=8),
+               dict(num_tokens=10, num_adj_degrees=3, adj_dim=2, only_sparse_neighbors=True),
+               dict(num_tokens=10, num_edge_tokens=7, edge_dim=5)):                       # dense, edge tokens only
+        net = EGNN_Network(depth=2, dim=32, **kw).cuda()
+        with torch.no_grad():
+            for p in net.parameters():
+                if p.dim() > 1 and p.shape[0] > 1 and p.shape[1] > 1:
+                    p.mul_(20.0)
+        g = torch.Generator().manual_seed(1)
+        b, n = 2, 40
+        seq = torch.randint(0, 10, (b, n), generator=g).cuda()
+        coors = torch.randn(b, n, 3, generator=g).cuda()
+        i = torch.arange(n)
+        adj = ((i[:, None] - i[None, :]).abs() <= 1).cuda() if "num_adj_degrees" in kw else None
+        etok = torch.randint(0, kw["num_edge_tokens"], (b, n, n), generator=g).cuda() if "num_edge_tokens" in kw else None
+        mask = (torch.arange(n)[None] < torch.tensor([[n], [n - 7]])).cuda()
+        lazy = net(seq, coors, adj_mat=adj, edges=etok, mask=mask)                       # (autouse fixture: no_grad)
+        with torch.enable_grad():
+            full = net(seq, coors, adj_mat=adj, edges=etok, mask=mask)
+        assert full[0].requires_grad
+        assert torch.equal(lazy[0], full[0].detach()) and torch.equal(lazy[1], full[1].detach()), kw
