@@ -321,62 +321,61 @@ def _backward_native(ctx, g_node, g_coors):
 def _backward_recompute(ctx, g_node, g_coors):
     """The pure-ATen backward: chunked recompute of the whole layer through autograd (module docstring).  Used for the shapes
     the native kernel does not cover (m_dim > 16, coordinate dimension != 3, non-fp32) and as its reference in the tests."""
-    if True:
-        layer = ctx.layer
-        feats, coors, edges, mask, idx, rank = ctx.saved_tensors
-        has_mask, has_idx = ctx.flags
-        edges = edges if ctx.has_edges else None
-        mask = mask if has_mask else None
-        idx = idx.long() if has_idx else None
-        rank = rank if has_idx else None
-        params = [p for p in layer.parameters()]
-        b, n, _ = feats.shape
-        k = idx.shape[-1] if idx is not None else n
-        step = _chunk_graphs(layer, n, k, b)
-        need = ctx.needs_input_grad                      # (layer, order_hint, mask, adj, feats, coors, edges, *params)
-        g_feats = torch.zeros_like(feats) if need[4] else None
-        g_coors_in = torch.zeros_like(coors) if need[5] else None
-        g_edges = torch.zeros_like(edges) if (edges is not None and need[6]) else None
-        g_params = [torch.zeros_like(p) if need[7 + i] else None for i, p in enumerate(params)]
-        if g_node is None:
-            g_node = torch.zeros_like(feats)
-        if g_coors is None:
-            g_coors = torch.zeros_like(coors)
-        for lo in range(0, b, step):
-            hi = min(b, lo + step)
-            with torch.enable_grad():
-                f = feats[lo:hi].detach().requires_grad_(need[4])
-                c = coors[lo:hi].detach().requires_grad_(need[5])
-                e = None if edges is None else edges[lo:hi].detach().requires_grad_(bool(need[6]))
-                out_n, out_c = layer_given_neighbors(layer, f, c, e, None if mask is None else mask[lo:hi],
-                                                     None if idx is None else idx[lo:hi], None if rank is None else rank[lo:hi],
-                                                     ctx.valid_radius)
-                wrt = [t for t in (f, c, e) if t is not None and t.requires_grad] + [p for p, g in zip(params, g_params) if g is not None]
-                outs, gouts = [], []
-                for o, g in ((out_n, g_node[lo:hi]), (out_c, g_coors[lo:hi])):
-                    if o.requires_grad:
-                        outs.append(o)
-                        gouts.append(g)
-                grads = torch.autograd.grad(outs, wrt, gouts, allow_unused=True) if outs and wrt else [None] * len(wrt)
-            it = iter(grads)
-            if f.requires_grad:
+    layer = ctx.layer
+    feats, coors, edges, mask, idx, rank = ctx.saved_tensors
+    has_mask, has_idx = ctx.flags
+    edges = edges if ctx.has_edges else None
+    mask = mask if has_mask else None
+    idx = idx.long() if has_idx else None
+    rank = rank if has_idx else None
+    params = [p for p in layer.parameters()]
+    b, n, _ = feats.shape
+    k = idx.shape[-1] if idx is not None else n
+    step = _chunk_graphs(layer, n, k, b)
+    need = ctx.needs_input_grad                      # (layer, order_hint, mask, adj, feats, coors, edges, *params)
+    g_feats = torch.zeros_like(feats) if need[4] else None
+    g_coors_in = torch.zeros_like(coors) if need[5] else None
+    g_edges = torch.zeros_like(edges) if (edges is not None and need[6]) else None
+    g_params = [torch.zeros_like(p) if need[7 + i] else None for i, p in enumerate(params)]
+    if g_node is None:
+        g_node = torch.zeros_like(feats)
+    if g_coors is None:
+        g_coors = torch.zeros_like(coors)
+    for lo in range(0, b, step):
+        hi = min(b, lo + step)
+        with torch.enable_grad():
+            f = feats[lo:hi].detach().requires_grad_(need[4])
+            c = coors[lo:hi].detach().requires_grad_(need[5])
+            e = None if edges is None else edges[lo:hi].detach().requires_grad_(bool(need[6]))
+            out_n, out_c = layer_given_neighbors(layer, f, c, e, None if mask is None else mask[lo:hi],
+                                                 None if idx is None else idx[lo:hi], None if rank is None else rank[lo:hi],
+                                                 ctx.valid_radius)
+            wrt = [t for t in (f, c, e) if t is not None and t.requires_grad] + [p for p, g in zip(params, g_params) if g is not None]
+            outs, gouts = [], []
+            for o, g in ((out_n, g_node[lo:hi]), (out_c, g_coors[lo:hi])):
+                if o.requires_grad:
+                    outs.append(o)
+                    gouts.append(g)
+            grads = torch.autograd.grad(outs, wrt, gouts, allow_unused=True) if outs and wrt else [None] * len(wrt)
+        it = iter(grads)
+        if f.requires_grad:
+            g = next(it)
+            if g is not None:
+                g_feats[lo:hi] = g
+        if c.requires_grad:
+            g = next(it)
+            if g is not None:
+                g_coors_in[lo:hi] = g
+        if e is not None and e.requires_grad:
+            g = next(it)
+            if g is not None:
+                g_edges[lo:hi] = g
+        for i, gp in enumerate(g_params):
+            if gp is not None:
                 g = next(it)
                 if g is not None:
-                    g_feats[lo:hi] = g
-            if c.requires_grad:
-                g = next(it)
-                if g is not None:
-                    g_coors_in[lo:hi] = g
-            if e is not None and e.requires_grad:
-                g = next(it)
-                if g is not None:
-                    g_edges[lo:hi] = g
-            for i, gp in enumerate(g_params):
-                if gp is not None:
-                    g = next(it)
-                    if g is not None:
-                        gp.add_(g)
-        return (None, None, None, None, g_feats, g_coors_in, g_edges, *g_params)
+                    gp.add_(g)
+    return (None, None, None, None, g_feats, g_coors_in, g_edges, *g_params)
 
 
 def wants_grad(layer, *tensors):
