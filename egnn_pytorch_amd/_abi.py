@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -28,6 +28,7 @@ SYMBOLS = (
     "egnn_packed_halves", "egnn_adj_expand_u8", "egnn_adj_expand_workspace_bytes", "egnn_edge_mfmas",
     "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32",
     "egnn_edge_bwd_dz_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
+    "egnn_induced_attn_f32", "egnn_token_attn_f32",
 )
 
 
@@ -180,6 +181,12 @@ def load():
     lib.egnn_edge_fused_f32.argtypes = [POINTER(EdgeArgs), c_void_p]
     lib.egnn_edge_bwd_dz_f32.restype = c_int
     lib.egnn_edge_bwd_dz_f32.argtypes = [POINTER(EdgeArgs), c_void_p]
+    lib.egnn_induced_attn_f32.restype = c_int
+    lib.egnn_induced_attn_f32.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
+                                          c_void_p]
+    lib.egnn_token_attn_f32.restype = c_int
+    lib.egnn_token_attn_f32.argtypes = [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64,
+                                        c_void_p]
     lib.egnn_edge_features_gather_f32.restype = c_int
     lib.egnn_edge_features_gather_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                                   c_int, c_int, c_int, c_void_p, c_void_p]

@@ -343,6 +343,28 @@ def edge_features_gather(lookup, idx, b, n, k):
     return out
 
 
+def induced_attn(q, kv, mask, b, n, heads, dim_head, scale):
+    """attn1 core of the induced-set attention block: T tokens attend over the nodes -- egnn_induced_attn_f32."""
+    t = q.shape[1]
+    out = empty(b, t, heads * dim_head, dtype=torch.float32, device=kv.device)
+    with _timed("induced_attn"):
+        rc = _abi.load().egnn_induced_attn_f32(_ptr(q.contiguous()), _ptr(kv), kv.stride(0), _ptr(_u8(mask)), b, n, t, heads, dim_head,
+                                               float(scale), _ptr(out), _stream())
+    _abi.check(rc, "egnn_induced_attn_f32")
+    return out
+
+
+def token_attn(q, kv_tok, b, n, heads, dim_head, scale):
+    """attn2 core: every node attends over the T induced tokens -- egnn_token_attn_f32."""
+    t = kv_tok.shape[1]
+    out = empty(b * n, heads * dim_head, dtype=torch.float32, device=q.device)
+    with _timed("token_attn"):
+        rc = _abi.load().egnn_token_attn_f32(_ptr(q), q.stride(0), _ptr(kv_tok.contiguous()), b, n, t, heads, dim_head, float(scale),
+                                             _ptr(out), out.stride(0), _stream())
+    _abi.check(rc, "egnn_token_attn_f32")
+    return out
+
+
 def rows_gather_sum(rows, order, seg_ptr, n_out):
     """out[r] = sum of rows[order[p]] over p in [seg_ptr[r], seg_ptr[r+1]), fixed order -- egnn_rows_gather_sum_f32."""
     cols = rows.shape[1]

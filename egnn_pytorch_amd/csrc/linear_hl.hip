@@ -246,6 +246,7 @@ __device__ __forceinline__ void linear_hl_body(
                 if (gm >= M) continue;
                 float x = acc[i][j][r] * out_scale + bv;
                 if (ACT == 1) x = egnn_silu(x);
+                if (ACT == 2) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));     // exact GELU (nn.GELU default, :130)
                 if (HAS_RES) x += R[gm * ldr + gn];
 #if defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 1)
                 if (x == 123.456f)                                   // ablation: no output stores
@@ -339,7 +340,8 @@ extern "C" int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void
     if (C && ldc < N) return EGNN_E_SHAPE;
     if (C_hi && (Kp_out < N || (Kp_out % 32) != 0)) return EGNN_E_SHAPE;
     if (residual && ldr < N) return EGNN_E_SHAPE;
-    if (act != 0 && act != 1) return EGNN_E_UNSUPPORTED;
+    if (act < 0 || act > 2) return EGNN_E_UNSUPPORTED;
+    if (act == 2 && residual) return EGNN_E_UNSUPPORTED;
     if (!(w_inv_scale > 0.f)) return EGNN_E_SHAPE;
     if (split_cols < 0 || split_cols > N || (split_cols % 32) != 0 || (split_cols && (!C || residual))) return EGNN_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(A_hi) & 15) || (reinterpret_cast<uintptr_t>(A_lo) & 15) ||
@@ -354,6 +356,7 @@ extern "C" int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void
         if (residual) return launch_hl<0, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
         return launch_hl<0, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
     }
+    if (act == 2) return launch_hl<2, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
     if (residual) return launch_hl<1, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
     return launch_hl<1, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
 }

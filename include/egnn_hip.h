@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 18
+#define EGNN_ABI_VERSION 19
 
 enum {
     EGNN_OK = 0,
@@ -105,7 +105,7 @@ int egnn_adj_expand_u8(const uint8_t* adj, int64_t adj_batch_stride, int B, int 
  * [b1 ; 0] that replace the per-edge first Linear of edge_mlp (egnn_pytorch.py:178-179, 279-287: Linear(cat(h_i,h_j,d,e)) =
  * W_i h_i + W_j h_j + w_d d + W_e e + b), and (b) node_mlp (egnn_pytorch.py:196-201, 336-337).
  *   A (M,K);  W (N,K) (nn.Linear weight layout);  bias (N) or NULL;  residual (M,N) ldr or NULL;  C (M,N) ldc;
- *   act: 0 = identity, 1 = SiLU.
+ *   act: 0 = identity, 1 = SiLU, 2 = exact GELU (egnn_linear_hl_f32 only, no residual).
  * (The exact-fp32 and split-on-the-fly reference implementations of this operation, kept for A/B tests, live in the
  * test-only library: include/egnn_hip_ref.h.) */
 
@@ -255,6 +255,19 @@ int egnn_rows_gather_sum_f32(const float* rows, int64_t ld, const int64_t* order
 /* Number of chained first-layer MFMAs the edge kernel is instantiated with for S per-edge scalars (>= ceil(3 S / 4); one of 1, 3, 4, 6, 12). */
 int egnn_edge_mfmas(int S);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * EGNN_Network's induced-set attention block (egnn_pytorch.py:83-144): the two attention cores.  The
+ * projections around them are egnn_linear_hl_f32 calls (act = 2: exact GELU for the feed-forward).
+ *   egnn_induced_attn_f32: out[b,t,(h d)] = softmax_n(scale q[b,t,h,:] . k[b,n,h,:], masked nodes -> -FLT_MAX) v[b,n,h,:]
+ *       q (B,T,heads*dim_head) fp32;  kv (B*N, ldkv) fp32 = attn1.to_kv(LayerNorm(x)): k in columns [0, inner), v in [inner, 2 inner);
+ *       mask (B,N) bytes or NULL;  out (B,T,inner).  T <= 8, dim_head <= 256.
+ *   egnn_token_attn_f32:   out[r,(h d)] = softmax_t(scale q[r,h,:] . k_tok[b,t,h,:]) v_tok[b,t,h,:],  r = b N + n
+ *       q (B*N, ldq);  kv_tok (B,T,2*inner) fp32 = attn2.to_kv(induced);  out (B*N, ldo). */
+int egnn_induced_attn_f32(const float* q, const float* kv, int64_t ldkv, const uint8_t* mask, int B, int N, int T, int heads,
+                          int dim_head, float scale, float* out, void* stream);
+int egnn_token_attn_f32(const float* q, int64_t ldq, const float* kv_tok, int B, int N, int T, int heads, int dim_head,
+                        float scale, float* out, int64_t ldo, void* stream);
 
 /* =============================================================================================
  * Whole-layer interface: everything a binding that is NOT the shipped Python one needs to

@@ -666,3 +666,32 @@ def test_network_edge_lookup_equals_the_materialised_tensor():
             full = net(seq, coors, adj_mat=adj, edges=etok, mask=mask)
         assert full[0].requires_grad
         assert torch.equal(lazy[0], full[0].detach()) and torch.equal(lazy[1], full[1].detach()), kw
+
+
+@pytest.mark.parametrize("dim,heads,dim_head,tokens", [(32, 2, 16, 4), (64, 8, 64, 4), (48, 3, 80, 6)])
+def test_global_attention_block_on_the_hip_kernels(dim, heads, dim_head, tokens):
+    """GlobalLinearAttention (egnn_pytorch.py:115-144) on the device kernels -- projections on the split-f16 GEMM, LayerNorms
+    in its operand packing, GELU in its epilogue, the two attention cores as HIP kernels -- against the oracle's restatement,
+    ragged mask with one fully masked graph (uniform softmax, finite)."""
+    from egnn_pytorch_amd.attention import GlobalLinearAttention
+    torch.manual_seed(dim)
+    blk = GlobalLinearAttention(dim=dim, heads=heads, dim_head=dim_head).cuda().eval()
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() > 1:
+                p.mul_(2.0)
+    g = torch.Generator().manual_seed(2)
+    b, n = 3, 70
+    x = torch.randn(b, n, dim, generator=g).cuda()
+    q = torch.randn(b, tokens, dim, generator=g).cuda()
+    mask = (torch.arange(n)[None] < torch.tensor([[n], [n - 20], [0]])).cuda()
+    got_x, got_q = blk(x, q, mask=mask)
+    params = {"blk." + k: v.detach().cpu().numpy() for k, v in blk.state_dict().items()}
+    ref_x, ref_q = O.global_linear_attention(params, "blk.", x.cpu().numpy(), q.cpu().numpy(), heads, mask=mask.cpu().numpy())
+    assert torch.isfinite(got_x).all() and torch.isfinite(got_q).all()
+    np.testing.assert_allclose(got_x.cpu().numpy(), ref_x, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(got_q.cpu().numpy(), ref_q, atol=ATOL, rtol=0)
+    # and the plain module (ATen) agrees too: the path autograd uses
+    with torch.enable_grad():
+        at_x, at_q = blk(x, q, mask=mask)
+    np.testing.assert_allclose(got_x.cpu().numpy(), at_x.detach().cpu().numpy(), atol=ATOL, rtol=0)
