@@ -563,6 +563,35 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 for (int t = 0; t < TILES; ++t) {
                     // x holds y = -log2(e) * (pre-activation); hv = y / (1 + 2^y) = SiLU(pre) / (-ln 2)
                     f16x8 bhi, blo;
+#if defined(EGNN_EDGE_STAGEWISE) && EGNN_EDGE_STAGEWISE
+                    // stage-wise over SW of the tile's 8 values: SW independent chains between dependent instructions
+                    constexpr int SW = EGNN_EDGE_STAGEWISE;
+#pragma unroll
+                    for (int u0 = 0; u0 < 8; u0 += SW) {
+                        float yv[SW], rv[SW], hv[SW];
+#pragma unroll
+                        for (int u = 0; u < SW; ++u) yv[u] = x[t][(u0 + u) >> 2][(u0 + u) & 3];
+#pragma unroll
+                        for (int u = 0; u < SW; ++u) rv[u] = __builtin_amdgcn_exp2f(yv[u]);
+#pragma unroll
+                        for (int u = 0; u < SW; ++u) rv[u] = 1.0f + rv[u];
+#pragma unroll
+                        for (int u = 0; u < SW; ++u) rv[u] = __builtin_amdgcn_rcpf(rv[u]);
+#pragma unroll
+                        for (int u = 0; u < SW; ++u) { hv[u] = yv[u] * rv[u]; asm("" : "+v"(hv[u])); }
+#pragma unroll
+                        for (int u = 0; u < SW; u += 2) {
+                            const f16x2 hi = __builtin_convertvector((f32x2v){hv[u], hv[u + 1]}, f16x2);
+                            const uint32_t hw = __builtin_bit_cast(uint32_t, hi);
+                            float l0, l1;
+                            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(yv[u]), "v"(rv[u]), "v"(hw));
+                            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(yv[u + 1]), "v"(rv[u + 1]), "v"(hw));
+                            const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+                            bhi[u0 + u] = hi[0]; bhi[u0 + u + 1] = hi[1];
+                            blo[u0 + u] = lo[0]; blo[u0 + u + 1] = lo[1];
+                        }
+                    }
+#else
 #pragma unroll
                     for (int u = 0; u < 8; u += 2) {
                         const float y0 = x[t][u >> 2][u & 3], y1 = x[t][u >> 2][(u & 3) + 1];
@@ -599,6 +628,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                         bhi[u] = hi[0]; bhi[u + 1] = hi[1];
                         blo[u] = lo[0]; blo[u + 1] = lo[1];
                     }
+#endif
 #if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 8)
                     acc[t][0][0] += (float)bhi[0] + (float)blo[1] + (float)bhi[2] + (float)blo[3] + (float)bhi[4] + (float)blo[5] + (float)bhi[6] + (float)blo[7] + (float)whi[0][0] + (float)wlo[0][0];   // ablation: no second-layer MFMAs
 #else
