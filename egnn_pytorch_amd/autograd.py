@@ -265,8 +265,10 @@ def _backward_native(ctx, g_node, g_coors):
             f2d = f0.view(bc * n, dim)
             feats_hl = _ops.split_f16(f2d)
             proj = _ops.linear_hl(feats_hl, w["Wcat_split"], 2 * hp, w["bcat"], name="bwd_node_proj", split_cols=hp if pi_split else 0)
-            dz = _ops.empty(ec, hp, dtype=torch.float32, device=feats.device)
-            act = _ops.empty(ec, hp, dtype=torch.float32, device=feats.device)
+            # (one spare row each: where the kernel's padding slots store, include/egnn_hip.h)
+            dz_buf = _ops.empty(ec + 1, hp, dtype=torch.float32, device=feats.device)
+            act_buf = _ops.empty(ec + 1, hp, dtype=torch.float32, device=feats.device)
+            dz, act = dz_buf[:ec], act_buf[:ec]
             a = _abi.EdgeArgs()
             a.B, a.N, a.K, a.dim, a.m_dim = bc, n, k, dim, m
             a.H, a.Hp = h, hp
@@ -306,7 +308,7 @@ def _backward_native(ctx, g_node, g_coors):
             g_scal = (dz @ w_s).view_as(scal)
             grads_by_id[id(lin3.weight)] += (gu16.t() @ act)[:m, :h]
             grads_by_id[id(lin3.bias)] += gu16[:, :m].sum(dim=0)
-            del dz, act, dz4
+            del dz, act, dz4, dz_buf, act_buf
         # d loss / d scalars -> coordinates (through d = |x_i - x_j|^2 and the fourier terms) and edge features
         sg = torch.autograd.grad([scal], [c] + ([e] if e is not None else []), [g_scal], allow_unused=True)
         if sg[0] is not None:

@@ -217,8 +217,9 @@ typedef struct egnn_edge_args {
     const float* gU;            /* backward: (B*N*K, 16) fp32 d loss / d u */
     float gu_scale;             /* power of two the kernel multiplies gU by before the fp16 split */
     float bwd_inv_scale;        /* 1 / (w2t_scale * gu_scale) */
-    float* dZ;                  /* backward out: (B*N*K, ldz) fp32 d loss / d z, z = pre-activation of the first SiLU (natural units) */
-    float* A_out;               /* backward out: (B*N*K, ldz) fp32 SiLU(z) */
+    float* dZ;                  /* backward out: (B*N*K + 1, ldz) fp32 d loss / d z, z = pre-activation of the first SiLU (natural units);
+                                   the last row is scratch (padding slots of the kernel's tiles store there) */
+    float* A_out;               /* backward out: (B*N*K + 1, ldz) fp32 SiLU(z), last row scratch */
     int64_t ldz;                /* >= Hp, multiple of 4 */
     int32_t edges_by_k;         /* 0: `edges` is (B,N,N,edge_dim), read at [b,i,j];  1: `edges` is (B,N,K,edge_dim), the features of the
                                    selected pairs in neighbour-list order (egnn_edge_features_gather_f32), read at [b,i,k] */
@@ -241,7 +242,8 @@ int egnn_edge_features_gather_f32(const float* edges, const int64_t* edge_tok, c
  *     A_out = SiLU(z)                  (what d loss / d edge_mlp.3.weight = gU^T A_out needs)
  *     dZ    = (W2^T gU) * SiLU'(z)     (d loss / d z: summed over a node's edges -> d/d P_i, scattered by neighbour -> d/d P_j,
  *                                        times the per-edge scalars -> d/d W_s, times W_s -> d/d scalars)
- * in fp32, natural units.  Nothing of size E x H is read: 2 E Hp floats are written.  Shapes: coor_dim 3, m_dim <= 16;
+ * in fp32, natural units.  Nothing of size E x H is read: 2 E Hp floats are written (both arrays need one spare row behind the
+ * B*N*K edge rows: the padding slots of the kernel's tiles store there, so that every store is unconditional).  Shapes: coor_dim 3, m_dim <= 16;
  * fields used: shapes, Pi / Pj / ldp / pi_split, Wst & scales, coors, edges, idx, order and the backward fields. */
 int egnn_edge_bwd_dz_f32(const egnn_edge_args* args, void* stream);
 
