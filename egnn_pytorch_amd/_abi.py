@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -27,7 +27,7 @@ SYMBOLS = (
     "egnn_edge_fused_f32", "egnn_spatial_order_f32", "egnn_linear_hl_f32", "egnn_split_f16", "egnn_node_prep_hl",
     "egnn_packed_halves", "egnn_adj_expand_u8", "egnn_adj_expand_workspace_bytes", "egnn_edge_mfmas",
     "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32",
-    "egnn_edge_bwd_dz_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
+    "egnn_edge_bwd_dz_f32", "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
     "egnn_induced_attn_f32", "egnn_token_attn_f32",
 )
 
@@ -52,6 +52,20 @@ class EdgeArgs(Structure):
         ("U_out", c_void_p), ("W2Th", c_void_p), ("gU", c_void_p), ("gu_scale", c_float), ("bwd_inv_scale", c_float),
         ("dZ", c_void_p), ("A_out", c_void_p), ("ldz", c_int64),
         ("edges_by_k", c_int32),
+    ]
+
+
+class EdgeBwdArgs(Structure):
+    """Mirror of `struct egnn_edge_bwd_args` (include/egnn_hip.h) -- field order and types must match."""
+    _fields_ = [
+        ("B", c_int32), ("N", c_int32), ("K", c_int32), ("Hp", c_int32), ("S", c_int32), ("by_dest", c_int32),
+        ("n_slabs", c_int32), ("wst_terms", c_int32),
+        ("L", c_int64), ("E", c_int64),
+        ("ent", c_void_p), ("Pi", c_void_p), ("Pj", c_void_p), ("ldp", c_int64),
+        ("Wst", c_void_p), ("ws_inv_scale", c_float), ("idx", c_void_p), ("W2Th", c_void_p), ("gU", c_void_p),
+        ("gu_scale", c_float), ("inv_scale", c_float), ("scal", c_void_p), ("Ws", c_void_p),
+        ("part_rows", c_void_p), ("ld_rows", c_int64),
+        ("dW2_part", c_void_p), ("dWs_part", c_void_p), ("ds_part", c_void_p),
     ]
 
 
@@ -181,6 +195,10 @@ def load():
     lib.egnn_edge_fused_f32.argtypes = [POINTER(EdgeArgs), c_void_p]
     lib.egnn_edge_bwd_dz_f32.restype = c_int
     lib.egnn_edge_bwd_dz_f32.argtypes = [POINTER(EdgeArgs), c_void_p]
+    lib.egnn_edge_bwd_pass_f32.restype = c_int
+    lib.egnn_edge_bwd_pass_f32.argtypes = [POINTER(EdgeBwdArgs), c_void_p]
+    lib.egnn_edge_bwd_chunk_steps.restype = c_int
+    lib.egnn_edge_bwd_chunk_steps.argtypes = []
     lib.egnn_induced_attn_f32.restype = c_int
     lib.egnn_induced_attn_f32.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                           c_void_p]

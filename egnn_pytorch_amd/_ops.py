@@ -376,6 +376,59 @@ def rows_gather_sum(rows, order, seg_ptr, n_out):
     return out
 
 
+# rounds (of 128 entries) one workgroup of egnn_edge_bwd_pass_f32 streams through its column chunk: short enough that the
+# workgroups of one graph and one chunk (they share the gathered rows) are many and run side by side on an XCD
+ROUNDS_PER_SLAB = int(os.environ.get("EGNN_BWD_ROUNDS_PER_SLAB", "8"))
+
+
+def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, ws_nat=None, want_w2=False, n_slabs=None):
+    """One pass of egnn_edge_bwd_pass_f32 (include/egnn_hip.h) over the entry list ent (autograd.entry_list).  proj = (B*N, 2 Hp)
+    fp32 P_i | P_j rows.  Returns a dict: rows (L / 16, Hp) partial rows, one per tile; with want_w2: w2 = d/d W_2 (16, Hp); with ws_nat (the
+    natural-units scalar weights (Hp, S)): ws = d/d W_s (Hp, S) and scal = d/d scalars (E, S) -- the partial arrays of the
+    kernel already summed (fixed order)."""
+    lib = _abi.load()
+    hp, s_in = w["Hp"], w["S"]
+    dev = proj.device
+    e = b * n * k
+    l = ent.numel()
+    if n_slabs is None:
+        n_slabs = max(1, (l // 128 + ROUNDS_PER_SLAB - 1) // ROUNDS_PER_SLAB)
+    n_rows = l // 16
+    rows = empty(n_rows + 1, hp, dtype=torch.float32, device=dev)
+    a = _abi.EdgeBwdArgs()
+    a.B, a.N, a.K, a.Hp, a.S, a.by_dest, a.n_slabs = b, n, k, hp, s_in, int(by_dest), n_slabs
+    a.wst_terms = w["Wst"].shape[1]
+    a.L, a.E = l, e
+    a.ent = ent.data_ptr()
+    a.Pi, a.Pj, a.ldp = proj.data_ptr(), proj.data_ptr() + 4 * hp, proj.stride(0)
+    a.Wst, a.ws_inv_scale = w["Wst"].data_ptr(), w["ws_inv_scale"]
+    a.idx = _ptr(idx32)
+    a.W2Th, a.gU, a.gu_scale = w["W2Th"].data_ptr(), gu16.data_ptr(), gu_scale
+    a.inv_scale = 1.0 / (gu_scale * w["w2t_scale"])
+    a.scal = scal.data_ptr()
+    a.part_rows, a.ld_rows = rows.data_ptr(), hp
+    if want_w2:
+        dw2 = empty(n_slabs * 4, 16, hp, dtype=torch.float32, device=dev)
+        a.dW2_part = dw2.data_ptr()
+    if ws_nat is not None:
+        ch = lib.egnn_edge_bwd_chunk_steps()
+        n_chunks = (hp // 32 + ch - 1) // ch
+        ws_nat = ws_nat.contiguous()
+        dws = empty(n_slabs * 16, s_in, hp, dtype=torch.float32, device=dev)
+        ds = empty(n_chunks, e, s_in, dtype=torch.float32, device=dev)
+        a.Ws, a.dWs_part, a.ds_part = ws_nat.data_ptr(), dws.data_ptr(), ds.data_ptr()
+    with _timed("edge_bwd_by_dest" if by_dest else "edge_bwd_by_src"):
+        rc = lib.egnn_edge_bwd_pass_f32(byref(a), _stream())
+    _abi.check(rc, "egnn_edge_bwd_pass_f32")
+    out = {"rows": rows[:n_rows]}
+    if want_w2:
+        out["w2"] = dw2.sum(dim=0)
+    if ws_nat is not None:
+        out["ws"] = dws.sum(dim=0).t().contiguous()
+        out["scal"] = ds.sum(dim=0)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- whole-layer C interface
 def pack_weights_c(layer):
     """egnn_pack_weights_host on the module's parameters: (desc, info, blob uint8 CPU tensor).  The Python module itself

@@ -29,7 +29,11 @@ import torch
 from torch import nn
 
 # EGNN_NATIVE_BACKWARD=0: always the pure-ATen recompute (the reference implementation of the backward)
-_NATIVE = os.environ.get("EGNN_NATIVE_BACKWARD", "1") != "0"
+# EGNN_NATIVE_BACKWARD=dz: the first native backward (egnn_edge_bwd_dz_f32: dz and SiLU(z) through HBM, library reductions)
+_NATIVE_MODE = os.environ.get("EGNN_NATIVE_BACKWARD", "1")
+_NATIVE = _NATIVE_MODE != "0"
+# which pass of the fused backward carries d/d W_2: "dest" (default), "both" = the by-source pass carries everything (tuning knob)
+_FUSED_SPLIT = os.environ.get("EGNN_BWD_SPLIT", "dest")
 _NATIVE_BUDGET_BYTES = 24 << 30                      # dZ + SiLU(z), 2 x E x Hp fp32, per chunk of graphs
 
 # activations of the recompute per edge: a few E x H tensors (pre-activation, activation, gradients); 16 GB of the 288 GB
@@ -182,6 +186,110 @@ def _unpack(ctx):
             idx if has_idx else None, rank if has_idx else None)
 
 
+def _edge_tables(layer, w, f2d, pi_split):
+    """fp32 P_i | P_j rows (incl. bias, in the forward's -log2(e) units) of the nodes in f2d: (rows, 2 Hp)."""
+    from . import _ops
+    hp = w["Hp"]
+    feats_hl = _ops.split_f16(f2d)
+    return _ops.linear_hl(feats_hl, w["Wcat_split"], 2 * hp, w["bcat"], name="bwd_node_proj", split_cols=hp if pi_split else 0)
+
+
+def _edge_contract_dz(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split):
+    """egnn_edge_bwd_dz_f32 writes dz and a = SiLU(z) (2 x E x Hp fp32); reductions / library GEMMs over them.
+    Returns d/d P_i (rows, Hp), d/d P_j (rows, Hp), d/d W_s (Hp, S), d/d scalars (E, S), d/d W_2 (16, Hp)."""
+    from . import _abi, _ops
+    h, hp, s_in = w["H"], w["Hp"], w["S"]
+    dev = f2d.device
+    ec = bc * n * k
+    proj = _edge_tables(layer, w, f2d, pi_split)
+    # (one spare row each: where the kernel's padding slots store, include/egnn_hip.h)
+    dz_buf = _ops.empty(ec + 1, hp, dtype=torch.float32, device=dev)
+    act_buf = _ops.empty(ec + 1, hp, dtype=torch.float32, device=dev)
+    dz, act = dz_buf[:ec], act_buf[:ec]
+    a = _abi.EdgeArgs()
+    a.B, a.N, a.K, a.dim, a.m_dim = bc, n, k, layer.dim, layer.m_dim
+    a.H, a.Hp = h, hp
+    a.fourier, a.edge_dim, a.S, a.pi_split = layer.fourier_features, layer.edge_dim, s_in, int(pi_split)
+    a.Pi, a.Pj, a.ldp = proj.data_ptr(), proj.data_ptr() + 4 * hp, 2 * hp
+    a.Wst, a.wst_terms, a.ws_inv_scale = w["Wst"].data_ptr(), w["Wst"].shape[1], w["ws_inv_scale"]
+    a.coors, a.coor_dim = c0.data_ptr(), 3
+    a.edges = _ops._ptr(e0)
+    a.idx = _ops._ptr(i32)
+    a.W2Th = w["W2Th"].data_ptr()
+    a.gU, a.gu_scale = gu16.data_ptr(), gu_scale
+    a.bwd_inv_scale = 1.0 / (gu_scale * w["w2t_scale"])
+    a.dZ, a.A_out, a.ldz = dz.data_ptr(), act.data_ptr(), hp
+    with _ops._timed("edge_bwd_dz"):
+        rc = _abi.load().egnn_edge_bwd_dz_f32(_ops.byref(a), _ops._stream())
+    _abi.check(rc, "egnn_edge_bwd_dz_f32")
+    del proj
+    dz4 = dz.view(bc, n, k, hp)
+    gz_i = dz4.sum(dim=2).view(bc * n, hp)                                 # d loss / d P_i (pad columns are 0)
+    if i32 is None:
+        gz_j = dz4.sum(dim=1).view(bc * n, hp)                             # dense: neighbour k IS node j
+    else:
+        # scatter by neighbour as a fixed-order gather over the transposed neighbour list (edges sorted stably by
+        # destination): no float atomics, bit-reproducible
+        dest = (i32.long() + (torch.arange(bc, device=dev) * n)[:, None, None]).view(-1)
+        dest_sorted, by_dest = torch.sort(dest, stable=True)
+        seg = torch.searchsorted(dest_sorted, torch.arange(bc * n + 1, device=dev))
+        gz_j = _ops.rows_gather_sum(dz, by_dest, seg, bc * n)
+    g_ws = dz.t() @ sc2
+    g_scal = dz @ w_s
+    g_w2 = gu16.t() @ act
+    return gz_i, gz_j, g_ws, g_scal, g_w2
+
+
+def entry_list(eids, keys, n_keys):
+    """The entry list of one egnn_edge_bwd_pass_f32 call (include/egnn_hip.h): edge ids `eids` (E,) ordered so that their keys
+    `keys` (E,) -- the node each entry is grouped by -- are non-decreasing.  Every node's entries are padded with -1 to whole
+    16-entry tiles, the list to a multiple of 128.  Returns (ent int32 (L,), seg int64 (n_keys + 1,)): seg = the range of tiles
+    (= partial rows) of each key."""
+    dev = eids.device
+    e = eids.numel()
+    deg = torch.bincount(keys, minlength=n_keys)
+    tiles = (deg + 15) // 16
+    seg = torch.zeros(n_keys + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(tiles, 0, out=seg[1:])
+    first = torch.zeros(n_keys + 1, dtype=torch.int64, device=dev)              # first entry of each key in the sorted list
+    torch.cumsum(deg, 0, out=first[1:])
+    pos = seg[:-1][keys] * 16 + (torch.arange(e, device=dev) - first[:-1][keys])
+    l = (int(seg[-1]) * 16 + 127) // 128 * 128
+    ent = torch.full((max(l, 128),), -1, dtype=torch.int32, device=dev)
+    ent[pos] = eids.to(torch.int32)
+    return ent, seg
+
+
+def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split):
+    """egnn_edge_bwd_pass_f32 (csrc/edge_bwd.hip) twice -- entries grouped by source node, then by neighbour: z, SiLU(z) and dz
+    are recomputed and contracted in registers, nothing of size E x H reaches memory.  Same returns as _edge_contract_dz."""
+    from . import _ops
+    dev = f2d.device
+    ec = bc * n * k
+    proj = _edge_tables(layer, w, f2d, False)
+    eids = torch.arange(ec, device=dev)
+    ent, seg = entry_list(eids, eids // k, bc * n)
+    # the contractions over all edges ride along: d/d W_s and d/d scalars with the first pass, d/d W_2 with the second (each keeps
+    # its accumulators in registers; one pass carrying both drops from 3 to 2 workgroups per CU)
+    o = _ops.edge_bwd_pass(w, proj, i32, gu16, gu_scale, sc2, ent, bc, n, k, by_dest=False, ws_nat=w_s, want_w2=_FUSED_SPLIT == "both")
+    g_ws, g_scal, g_w2 = o["ws"], o["scal"], o.get("w2")
+    ident = torch.arange(o["rows"].shape[0], device=dev)
+    gz_i = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n)
+    del o
+    if i32 is None:
+        dest = (torch.arange(k, device=dev)[None, None, :] + (torch.arange(bc, device=dev) * n)[:, None, None]).expand(bc, n, k).reshape(-1)
+    else:
+        dest = (i32.long() + (torch.arange(bc, device=dev) * n)[:, None, None]).view(-1)
+    dest_sorted, by_dest = torch.sort(dest, stable=True)
+    ent, seg = entry_list(by_dest, dest_sorted, bc * n)
+    o = _ops.edge_bwd_pass(w, proj, i32, gu16, gu_scale, sc2, ent, bc, n, k, by_dest=True, want_w2=g_w2 is None)
+    if g_w2 is None:
+        g_w2 = o["w2"]
+    ident = torch.arange(o["rows"].shape[0], device=dev)
+    gz_j = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n)
+    return gz_i, gz_j, g_ws, g_scal, g_w2
+
+
 def _backward_native(ctx, g_node, g_coors):
     """The backward with the E x H work on the HIP kernel egnn_edge_bwd_dz_f32 (include/egnn_hip.h):
        1. everything behind edge_mlp's second Linear (second SiLU, gate, masks, coors_mlp, CoorsNorm, clamp, pooling, node_norm,
@@ -215,8 +323,14 @@ def _backward_native(ctx, g_node, g_coors):
     if g_coors is None:
         g_coors = torch.zeros_like(coors)
     u_all = ctx.u_pre.view(b, n, k, 16)
-    per_graph = 2.0 * n * k * hp * 4
-    step = max(1, min(b, int(_NATIVE_BUDGET_BYTES // per_graph)))
+    fused = _NATIVE_MODE != "dz" and s_in == 1           # (the by-source pass of egnn_edge_bwd_pass_f32 is built for S = 1)
+    if fused:
+        # nothing of size E x H: graphs are only chunked to keep the P table below 4 GB (32-bit buffer offsets) and E below 2^31
+        step = max(1, min(b, int(((1 << 32) - 1) // (n * 2 * hp * 4)), int(((1 << 31) - 1) // (n * k)),
+                          int(((1 << 32) - 1) // ((n * k // 16 + n + 16) * hp * 4))))         # (... and the partial rows)
+    else:
+        per_graph = 2.0 * n * k * hp * 4
+        step = max(1, min(b, int(_NATIVE_BUDGET_BYTES // per_graph)))
     # the first Linear's blocks, zero padded to the kernel's hidden width Hp: everything below works on the contiguous
     # (E, Hp) buffers the kernel wrote (slicing [:, :H] first would copy 17 GB per use at the north-star shape)
     w1p = torch.zeros(hp, lin0.weight.shape[1], dtype=torch.float32, device=feats.device)
@@ -255,7 +369,7 @@ def _backward_native(ctx, g_node, g_coors):
         for p, g in zip(tail_params, tg[3:]):
             if g is not None:
                 grads_by_id[id(p)] += g
-        # ---- 2. dz and SiLU(z) on the HIP kernel
+        # ---- 2. the E x H work: d/d P_i, d/d P_j (per node), d/d W_s, d/d scalars, d/d W_2
         ec = bc * n * k
         gu16 = torch.zeros(ec, 16, dtype=torch.float32, device=feats.device)
         gu16[:, :m] = g_u.reshape(ec, m)
@@ -263,52 +377,20 @@ def _backward_native(ctx, g_node, g_coors):
         gu_scale = _weights.pow2_scale(amax) if amax > 0 else 1.0
         with torch.no_grad():
             f2d = f0.view(bc * n, dim)
-            feats_hl = _ops.split_f16(f2d)
-            proj = _ops.linear_hl(feats_hl, w["Wcat_split"], 2 * hp, w["bcat"], name="bwd_node_proj", split_cols=hp if pi_split else 0)
-            # (one spare row each: where the kernel's padding slots store, include/egnn_hip.h)
-            dz_buf = _ops.empty(ec + 1, hp, dtype=torch.float32, device=feats.device)
-            act_buf = _ops.empty(ec + 1, hp, dtype=torch.float32, device=feats.device)
-            dz, act = dz_buf[:ec], act_buf[:ec]
-            a = _abi.EdgeArgs()
-            a.B, a.N, a.K, a.dim, a.m_dim = bc, n, k, dim, m
-            a.H, a.Hp = h, hp
-            a.fourier, a.edge_dim, a.S, a.pi_split = layer.fourier_features, layer.edge_dim, s_in, int(pi_split)
-            a.Pi, a.Pj, a.ldp = proj.data_ptr(), proj.data_ptr() + 4 * hp, 2 * hp
-            a.Wst, a.wst_terms, a.ws_inv_scale = w["Wst"].data_ptr(), w["Wst"].shape[1], w["ws_inv_scale"]
-            a.coors, a.coor_dim = c0.data_ptr(), 3
-            a.edges = _ops._ptr(e0)
-            a.idx = _ops._ptr(i32)
-            a.W2Th = w["W2Th"].data_ptr()
-            a.gU, a.gu_scale = gu16.data_ptr(), gu_scale
-            a.bwd_inv_scale = 1.0 / (gu_scale * w["w2t_scale"])
-            a.dZ, a.A_out, a.ldz = dz.data_ptr(), act.data_ptr(), hp
-            with _ops._timed("edge_bwd_dz"):
-                rc = _abi.load().egnn_edge_bwd_dz_f32(_ops.byref(a), _ops._stream())
-            _abi.check(rc, "egnn_edge_bwd_dz_f32")
-            del proj, feats_hl
-            # ---- 3. reductions and plain GEMMs over dz / a
-            dz4 = dz.view(bc, n, k, hp)
-            gz_i = dz4.sum(dim=2).view(bc * n, hp)                                 # d loss / d P_i (pad columns are 0)
-            if i64 is None:
-                gz_j = dz4.sum(dim=1).view(bc * n, hp)                             # dense: neighbour k IS node j
-            else:
-                # scatter by neighbour as a fixed-order gather over the transposed neighbour list (edges sorted stably by
-                # destination): no float atomics, bit-reproducible
-                dest = (i64 + (torch.arange(bc, device=feats.device) * n)[:, None, None]).view(-1)
-                dest_sorted, by_dest = torch.sort(dest, stable=True)
-                seg = torch.searchsorted(dest_sorted, torch.arange(bc * n + 1, device=feats.device))
-                gz_j = _ops.rows_gather_sum(dz, by_dest, seg, bc * n)
+            sc2 = scal.detach().reshape(ec, s_in).contiguous()
+            contract = _edge_contract_fused if fused else _edge_contract_dz
+            gz_i, gz_j, g_ws, g_scal, g_w2 = contract(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split)
+            # ---- 3. node-level GEMMs
             g_feats[lo:hi_] += (gz_i @ w_i + gz_j @ w_j).view(bc, n, dim)
             gw1 = grads_by_id[id(lin0.weight)]
             gw1[:, :dim] += (gz_i.t() @ f2d)[:h]
             gw1[:, dim:2 * dim] += (gz_j.t() @ f2d)[:h]
-            sc2 = scal.detach().reshape(ec, s_in)
-            gw1[:, 2 * dim:] += (dz.t() @ sc2)[:h]
+            gw1[:, 2 * dim:] += g_ws[:h]
             grads_by_id[id(lin0.bias)] += gz_i.sum(dim=0)[:h]
-            g_scal = (dz @ w_s).view_as(scal)
-            grads_by_id[id(lin3.weight)] += (gu16.t() @ act)[:m, :h]
+            g_scal = g_scal.view_as(scal)
+            grads_by_id[id(lin3.weight)] += g_w2[:m, :h]
             grads_by_id[id(lin3.bias)] += gu16[:, :m].sum(dim=0)
-            del dz, act, dz4, dz_buf, act_buf
+            del gz_i, gz_j
         # d loss / d scalars -> coordinates (through d = |x_i - x_j|^2 and the fourier terms) and edge features
         sg = torch.autograd.grad([scal], [c] + ([e] if e is not None else []), [g_scal], allow_unused=True)
         if sg[0] is not None:

@@ -1,0 +1,483 @@
+// egnn_edge_bwd_pass_f32 -- the backward of the edge pass WITHOUT anything of size E x H in memory (gfx950).
+//
+// Reference semantics: autograd through egnn_pytorch.py:279-287 (edge_mlp's first Linear and SiLU and the second Linear's
+// weight); include/egnn_hip.h documents the entry.  With z = P_i[i] + P_j[j] + W_s s the pre-activation of the first SiLU,
+// a = SiLU(z), gU = d loss / d (second Linear's output) and dz = (W2^T gU) * SiLU'(z), the gradients that need all E x H
+// values are contractions -- over the hidden index (d/d s = dz W_s) or over edges:
+//     d/d P_i[n] = sum of dz over the edges that leave n,      d/d P_j[n] = sum of dz over the edges that arrive at n,
+//     d/d W_2    = gU^T a,                                      d/d W_s    = dz^T s.
+// The first backward kernel (egnn_edge_bwd_dz_f32) wrote dz and a to HBM (35 GB at the north-star shape) for library
+// reductions to read back five times; this one recomputes z and contracts in registers.
+//
+// Layout.  The forward kernel holds z as (hidden rows) x (edge columns) in the MFMA accumulator layout; contracting over
+// edges on the matrix cores needs the transpose -- edges along the K dimension of the B operand.  Swapping the operands of
+// every MFMA of the forward's first layer gives exactly that: with A = the per-edge fragment and B = the per-hidden-unit
+// fragment, D[m = edge][n = hidden unit] lands with lane (g, h) holding edges 4g .. 4g+3 of the tile for hidden unit h, and
+// those four registers ARE the B fragment [k = edge][n = hidden] of v_mfma_f32_16x16x16_f16.  Then
+//     d/d P partial = Ind x dz      (A = one-hot rows "edge e belongs to the tile's m-th node": the segmented sum over a node's
+//                                    edges for any K and for ragged in-degrees alike; the tile's rows go to a compact array of
+//                                    partial rows that egnn_rows_gather_sum_f32 adds up in fixed order -- no float atomics),
+//     d/d W_2 +=     gU^T x a       (A = this tile's gU transposed; accumulated in registers),
+// (dz and a as split-f16 pairs: the indicator is exact, gU is split as well -> fp32-class sums), while d/d W_s and d/d s are
+// plain FMAs on the values (S of them each).
+//
+// Persistence.  d/d W_2 and d/d W_s are sums over ALL edges per hidden column, so a workgroup owns CH x 32 hidden columns
+// (its W2^T / W_s fragments staged in LDS once) and streams a slab of the edge list through them: grid = slabs x column
+// chunks, the per-edge setup is redone per chunk (cheap next to 5 steps of SiLU work), and every (slab, wave) ends with one
+// small partial of d/d W_2 / d/d W_s that the host sums in fixed order.
+//
+// Two passes over the edges: grouped by source node (d/d P_i, d/d W_2, d/d W_s, d/d s) and grouped by neighbour, i.e. over
+// the edge list sorted stably by destination (d/d P_j only).  z is rebuilt from fp32 P_i and P_j rows: the neighbour's rows as
+// whole 128-byte lines parked in wave-private LDS and picked up transposed, the node's own row (shared by the consecutive
+// entries of a group: L1 hits) by direct loads.
+#include "egnn_common.h"
+
+namespace {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+#ifndef EGNN_BWD_DEST_BLOCKS
+#define EGNN_BWD_DEST_BLOCKS 4
+#endif
+#ifndef EGNN_BWD_W2_BLOCKS
+#define EGNN_BWD_W2_BLOCKS 3
+#endif
+#ifndef EGNN_BWD_S_BLOCKS
+#define EGNN_BWD_S_BLOCKS 3
+#endif
+#ifndef EGNN_BWD_CHUNK_STEPS
+#define EGNN_BWD_CHUNK_STEPS 4
+#endif
+#ifndef EGNN_BWD_GROUP_SLABS
+#define EGNN_BWD_GROUP_SLABS 32
+#endif
+constexpr int GS = EGNN_BWD_GROUP_SLABS;     // slabs whose workgroups run next to each other on one XCD, chunk by chunk
+constexpr int BW_THREADS = 256;
+constexpr int BW_WAVES = 4;
+constexpr int CH_S = EGNN_BWD_CHUNK_STEPS;   // steps of 32 hidden columns a workgroup owns (the variant that writes ds_part: sizes it)
+constexpr int CH_W2 = 3;                     // ... of the variant with the d/d W_2 tiles only: one step fewer keeps it at 3 workgroups per CU
+constexpr int XLD = 36;                      // floats per exchange row: 144 B -> rows 4 apart sit 16 banks apart (transposed pick-up)
+constexpr float DZ_UP = 256.f;               // dz (scaled units, < 2^7) x 2^8 before the f16 split: keeps small values off the subnormals
+constexpr float A_UP = 64.f;                 // SiLU(z) and the transposed gU likewise (x 2^6 each): the lo halves of values below ~0.25 are
+constexpr float GT_UP = 64.f;                //   f16 subnormals otherwise, and d/d W_2 came out at hi-only accuracy (2e-5) in the tests
+
+__device__ __forceinline__ uint32_t pack_h2(_Float16 a, _Float16 b)
+{
+    const f16x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff)
+{
+    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(f32x4, (u32x4v)__builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load1f(__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff)
+{
+    return __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store1f(__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, (int)voff, soff, 0);
+}
+__device__ __forceinline__ int xcd_remap(int bid, int nblk)
+{
+    const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+    return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+}
+// (hi, lo) split of four fp32 values into two f16x4 fragments
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const _Float16 h = (_Float16)v[u];
+        hi[u] = h;
+        lo[u] = (_Float16)(v[u] - (float)h);
+    }
+}
+
+// NM: first-layer MFMAs of the scalar term (egnn_edge_mfmas(S)); ST: register bound on S (per-edge scalars);
+// WANT_W: also d/d W_2, d/d W_s, d/d s (the by-source pass)
+template <int NM, int ST, bool WANT_W2, bool WANT_S, int CH>
+__global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EGNN_BWD_W2_BLOCKS : (WANT_S ? EGNN_BWD_S_BLOCKS : EGNN_BWD_DEST_BLOCKS))) void edge_bwd_kernel(const egnn_edge_bwd_args p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* w2t = reinterpret_cast<_Float16*>(smem);                                  // [CH][hb][hi|lo][64][4] halves
+    uint32_t* wstl = reinterpret_cast<uint32_t*>(smem + CH * 2048);                     // [CH * 32][4 NM] words
+    float* xchall = reinterpret_cast<float*>(smem + CH * 2048 + CH * 32 * 4 * NM * 4);  // [waves][32][XLD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hq = lane & 15;                    // n index of the MFMA layouts: hidden unit (data), edge / row (A fragments)
+    const int g = lane >> 4;
+    const int S = p.S, K = p.K, N = p.N;
+    const float rows_scale = p.inv_scale * (1.0f / DZ_UP);      // everything derived from dz leaves in natural units
+    const float w2_out_scale = 1.0f / (p.gu_scale * GT_UP * A_UP);
+
+    // Workgroup -> (slab of the entry list, column chunk).  What a workgroup gathers is the chunk's CH x 128 bytes of the rows
+    // its entries point at; rows are shared between the entries of one graph only.  So the workgroups that are resident on an
+    // XCD together (its L2) should work on the same graph and the same chunk: blocks go round robin over the 8 XCDs, v is the
+    // position within the XCD's contiguous share of the grid, and consecutive v walk the GS slabs of a group before the next
+    // chunk (measured: with chunk fastest the gathers hit L2 at 38 %, the forward's, which walks all columns of a graph's rows
+    // together, at 85 %).
+    const int n_chunks = (p.Hp / 32 + CH - 1) / CH;
+    const int nblk = gridDim.x;
+    const int v = xcd_remap(blockIdx.x, nblk);
+    const int per_group = n_chunks * GS;
+    const int group = v / per_group, rem = v - group * per_group;
+    const int chunk = rem / GS;
+    const int slab = group * GS + (rem - chunk * GS);
+    if (slab >= p.n_slabs) return;                               // (the last group may be partial)
+    const int st0 = chunk * CH;
+    const int nst = (p.Hp / 32 - st0) < CH ? (p.Hp / 32 - st0) : CH;
+
+    // the chunk's W2^T fragments and scalar-weight table: once per workgroup
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.W2Th) + (size_t)st0 * 2048);
+        for (int o = tid; o < nst * 128; o += BW_THREADS) reinterpret_cast<uint4*>(w2t)[o] = src[o];
+        const uint32_t* ts = reinterpret_cast<const uint32_t*>(p.Wst) + (size_t)st0 * 32 * 4 * NM;
+        for (int o = tid; o < nst * 32 * 4 * NM; o += BW_THREADS) wstl[o] = ts[o];
+    }
+    __syncthreads();
+
+    const float* Town = p.by_dest ? p.Pj : p.Pi;
+    const float* Toth = p.by_dest ? p.Pi : p.Pj;
+    const uint32_t tab_bytes = (uint32_t)((size_t)p.B * N * p.ldp * 4);
+    const __amdgpu_buffer_rsrc_t own_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Town), 0, tab_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t oth_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Toth), 0, tab_bytes, 0x00020000);
+
+    // partial rows: row = tile index, 32-bit offsets as well; only lane group 0 holds row 0 of the indicator product, the other
+    // lanes store to the spare row behind the last one -- the store is unconditional
+    const uint32_t row_bytes = (uint32_t)(p.ld_rows * 4);
+    const uint32_t n_tiles = (uint32_t)(p.L >> 4);
+    const __amdgpu_buffer_rsrc_t rows_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.part_rows, 0, (n_tiles + 1) * row_bytes, 0x00020000);
+    const uint32_t spare_lane = n_tiles * row_bytes + hq * 4;
+    // (32-bit offsets here as well: a 64-bit per-lane address per half step would be hoisted out of the round loop -- 2 registers each)
+    const __amdgpu_buffer_rsrc_t ws_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(WANT_S ? p.Ws : p.Pi), 0, (uint32_t)((size_t)p.Hp * S * 4), 0x00020000);
+
+    float* xch = xchall + wave * (32 * XLD);
+    // parking: lane l holds 16-byte chunk l & 7 of the line of entry 8 qq + (l >> 3)
+    float* xw = xch + (lane >> 3) * XLD + 4 * (lane & 7);
+    // transposed pick-up: lane (g, hq) reads hidden unit 16 hb + hq of entries 16 t + 4 g + r
+    const float* xr = xch + (4 * g) * XLD + hq;
+
+    f32x4 dW2[WANT_W2 ? 2 * CH : 1];              // d/d W_2: rows c = 4g + r, column = chunk column 16 blk + hq
+    float dws[WANT_S ? 2 * CH : 1][ST];          // d/d W_s partial over this lane group's edges
+#pragma unroll
+    for (int bl = 0; bl < (WANT_W2 ? 2 * CH : 1); ++bl) dW2[bl] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int bl = 0; bl < (WANT_S ? 2 * CH : 1); ++bl)
+#pragma unroll
+        for (int c = 0; c < ST; ++c) dws[bl][c] = 0.f;
+
+    const int64_t rounds_total = p.L / 128;
+    const int64_t per_slab = (rounds_total + p.n_slabs - 1) / p.n_slabs;
+    const int64_t rd0 = (int64_t)slab * per_slab;
+    const int64_t rd1 = (rd0 + per_slab) < rounds_total ? (rd0 + per_slab) : rounds_total;
+
+    for (int64_t round = rd0; round < rd1; ++round) {
+        const int q0 = (int)round * 128 + wave * 32;            // (L < 2^31: 32-bit entry indices keep the list addresses in scalar base + offset form)
+        // ---------------------------------------------------------------- per-entry setup
+        // A fragments indexed by edge (m = hq): gU (channels 4g .. 4g+3) and the scalar terms of the first layer
+        f16x4 guhi[2], gulo[2];
+        u32x2 bq[2][NM];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int eid = p.ent[q0 + 16 * t + hq];
+            const bool valid = eid >= 0;
+            f32x4 gu = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (valid) gu = *reinterpret_cast<const f32x4*>(p.gU + (size_t)eid * 16 + 4 * g);
+            split4(gu * (p.gu_scale * DZ_UP), guhi[t], gulo[t]);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                // split term tau = 4 m + g of scalar tau / 3, exactly the forward's (csrc/edge_fused.hip, _weights.py::scalar_table)
+                const int tau = 4 * m + g;
+                const int sidx = tau / 3, kind = tau - 3 * sidx;
+                u32x2 bw = u32x2{0u, 0u};
+                if (sidx < S && valid) {
+                    float val = p.scal[(size_t)eid * S + sidx] * p.ws_inv_scale;
+                    if (fabsf(val) >= 6.0e7f) val = __builtin_nanf("");
+                    const _Float16 s1 = (_Float16)(val * (1.0f / 1024.0f));
+                    const float r = val - (float)s1 * 1024.0f;
+                    const _Float16 rh = (_Float16)r;
+                    const _Float16 rl = (_Float16)(r - (float)rh);
+                    bw[1] = kind == 0 ? pack_h2(s1, s1) : (kind == 1 ? pack_h2(rh, rh) : pack_h2(rl, (_Float16)0.f));
+                }
+                bq[t][m] = bw;
+            }
+        }
+        // per register r: entry 16 t + 4 g + r (the edges this lane's data registers belong to).  The 16 entries of a tile share
+        // their key node (the host pads every node's entries to whole tiles): one own row and one partial row per tile.
+        uint32_t ownoff[2];                        // byte offset of the tile's own row (+ hq)
+        uint32_t rowbase[2];                       // byte offset of the tile's partial row (+ hq); lane groups g > 0 hold no row of D
+        float sv[2][4][ST];
+        f16x4 gth[2], gtl[2], ind[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const i32x4 e4 = *reinterpret_cast<const i32x4*>(p.ent + q0 + 16 * t + 4 * g);
+            const int e0 = __builtin_amdgcn_readfirstlane(p.ent[q0 + 16 * t]);      // (padding sits behind a node's entries)
+            const int ev0 = e0 >= 0 ? e0 : 0;
+            const int ig0 = ev0 / K;                                 // global node (b N + i)
+            const int jg0 = p.idx ? (ig0 / N) * N + p.idx[ev0] : (ig0 / N) * N + (ev0 - ig0 * K);
+            ownoff[t] = (uint32_t)(((size_t)(p.by_dest ? jg0 : ig0) * p.ldp + hq) * 4);
+            rowbase[t] = g == 0 ? (uint32_t)((size_t)((q0 + 16 * t) >> 4) * row_bytes) + hq * 4 : spare_lane;
+            f32x4 gt = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int eid = e4[r];
+                const bool valid = eid >= 0;
+                ind[t][r] = (valid && hq == 0) ? (_Float16)1.f : (_Float16)0.f;      // row 0 of D = the tile's sum over its valid entries
+                if constexpr (WANT_S) {
+#pragma unroll
+                    for (int c = 0; c < ST; ++c) sv[t][r][c] = (valid && c < S) ? p.scal[(size_t)eid * S + c] : 0.f;
+                }
+                if constexpr (WANT_W2) {
+                    if (valid) gt[r] = p.gU[(size_t)eid * 16 + hq];
+                }
+            }
+            if constexpr (WANT_W2) split4(gt * (p.gu_scale * GT_UP), gth[t], gtl[t]);
+        }
+        // whole-line gathers of the other endpoint's rows: lane l fetches chunk l & 7 of entry 8 qq + (l >> 3)
+        uint32_t goff[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int eid = p.ent[q0 + 8 * qq + (lane >> 3)];
+            const int ev = eid >= 0 ? eid : 0;
+            const int ig = ev / K;
+            const int jg = p.idx ? (ig / N) * N + p.idx[ev] : (ig / N) * N + (ev - ig * K);
+            const int othrow = eid >= 0 ? (p.by_dest ? ig : jg) : 0;
+            goff[qq] = (uint32_t)(((size_t)othrow * p.ldp + 4 * (lane & 7)) * 4);
+        }
+
+        float ps[WANT_S ? 2 : 1][4][ST];          // d/d s of entry (t, r): this lane's hidden units only (summed over hq at the end)
+#pragma unroll
+        for (int t = 0; t < (WANT_S ? 2 : 1); ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < ST; ++c) ps[t][r][c] = 0.f;
+
+        // ---------------------------------------------------------------- the chunk's steps, one step of loads ahead
+        f32x4 gl[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) gl[qq] = buf_load4(oth_rsrc, goff[qq], st0 * 32 * 4);
+        float ownpf[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) ownpf[t][hb] = buf_load1f(own_rsrc, ownoff[t], (st0 * 32 + 16 * hb) * 4);
+        // One step of 32 hidden columns (a lambda so that the unrolled loop below indexes the accumulator tiles with constants)
+        auto step = [&](const int st) __attribute__((always_inline)) {
+            const int hoff = (st0 + st) * 32;
+            const int hnext = (st + 1 < nst) ? hoff + 32 : hoff;            // last step: harmless re-read
+            // The tile's own row: every step reads a new 128-byte line of it (an L1 miss each time), fetched one step ahead like
+            // the gathers.
+            float ow[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    ow[t][hb] = ownpf[t][hb];
+                    ownpf[t][hb] = buf_load1f(own_rsrc, ownoff[t], (hnext + 16 * hb) * 4);
+                }
+            // park the neighbour lines of this step, pick them up transposed (same wave: DS operations execute in order)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f32x4*>(xw + qq * 8 * XLD) = gl[qq];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) gl[qq] = buf_load4(oth_rsrc, goff[qq], hnext * 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const int col = hoff + 16 * hb + hq;
+                // z^T of this half step: the parked neighbour rows, transposed, + the own rows
+                f32x4 x[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[t][r] = xr[(16 * t + r) * XLD + 16 * hb] + ow[t][hb];
+                // first Linear's scalar term, operands swapped against the forward: D[edge][hidden] += [scalars] x [W_s]
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const u32x2 bv = u32x2{0u, wstl[(st * 32 + 16 * hb + hq) * (4 * NM) + 4 * m + g]};
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        x[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, bq[t][m]), __builtin_bit_cast(f16x4, bv), x[t], 0, 0, 0);
+                }
+                // W2^T fragments: [step][hb][hi|lo][lane = 16 g + hq][u] = W2[4 g + u][32 step + 16 hb + hq]  (B operand: k = channel)
+                const f16x4* wt = reinterpret_cast<const f16x4*>(w2t) + (size_t)(st * 2 + hb) * 2 * 64;
+                const f16x4 wthi = wt[lane], wtlo = wt[64 + lane];
+                float wsn[ST];
+                if constexpr (WANT_S) {
+#pragma unroll
+                    for (int c = 0; c < ST; ++c) wsn[c] = c < S ? buf_load1f(ws_rsrc, (uint32_t)((hq * S + c) * 4), (hoff + 16 * hb) * S * 4) : 0.f;
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 ga = f32x4{0.f, 0.f, 0.f, 0.f};
+                    ga = __builtin_amdgcn_mfma_f32_16x16x16f16(guhi[t], wthi, ga, 0, 0, 0);
+                    ga = __builtin_amdgcn_mfma_f32_16x16x16f16(guhi[t], wtlo, ga, 0, 0, 0);
+                    ga = __builtin_amdgcn_mfma_f32_16x16x16f16(gulo[t], wthi, ga, 0, 0, 0);
+                    // y = -log2(e) z;  sigma = 1 / (1 + 2^y);  a = SiLU(z) = z sigma;  SiLU'(z) = sigma + a (1 - sigma).
+                    // Units: a carries A_UP, dz = ga SiLU' carries gu_scale x w2t_scale x DZ_UP (DZ_UP rides in the gU fragments),
+                    // so that the (hi, lo) f16 halves of small values stay off the subnormals; undone at the outputs.
+                    float sgv[4], znv[4], spv[4];
+                    f32x4 av4, dz4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float y = x[t][r];
+                        sgv[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
+                        znv[r] = y * (-0.6931471805599453f * A_UP);
+                        av4[r] = znv[r] * sgv[r];
+                        const float t1 = __builtin_fmaf(sgv[r], -1.0f / A_UP, 1.0f / A_UP);      // (1 - sigma) / A_UP
+                        spv[r] = __builtin_fmaf(av4[r], t1, sgv[r]);
+                        dz4[r] = ga[r] * spv[r];
+                        asm("" : "+v"(dz4[r]));                    // (scalar multiplies: v_pk_mul_f32 costs 9.3 cycles per pair against 2 x 2.9)
+                    }
+                    if constexpr (WANT_S) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int c = 0; c < ST; ++c) {
+                                ps[t][r][c] = __builtin_fmaf(dz4[r], wsn[c], ps[t][r][c]);
+                                dws[2 * st + hb][c] = __builtin_fmaf(dz4[r], sv[t][r][c], dws[2 * st + hb][c]);
+                            }
+                    }
+                    // (hi, lo) halves: hi = RNE pair conversion, lo = product - hi as ONE v_fma_mix_f32 per value (the f16 operand read in place)
+                    f16x4 dh, dl;
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const f16x2 hi = __builtin_convertvector((f32x2v){dz4[r], dz4[r + 1]}, f16x2);
+                        const uint32_t hw = __builtin_bit_cast(uint32_t, hi);
+                        float l0, l1;
+                        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(ga[r]), "v"(spv[r]), "v"(hw));
+                        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(ga[r + 1]), "v"(spv[r + 1]), "v"(hw));
+                        const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+                        dh[r] = hi[0]; dh[r + 1] = hi[1];
+                        dl[r] = lo[0]; dl[r + 1] = lo[1];
+                    }
+                    // sum over each node's edges of the tile: rows = the tile's local nodes
+                    f32x4 dP = f32x4{0.f, 0.f, 0.f, 0.f};
+                    dP = __builtin_amdgcn_mfma_f32_16x16x16f16(ind[t], dh, dP, 0, 0, 0);
+                    dP = __builtin_amdgcn_mfma_f32_16x16x16f16(ind[t], dl, dP, 0, 0, 0);
+                    // (no branch around the store: the step stays one basic block and the scheduler interleaves the two tiles)
+                    buf_store1f(rows_rsrc, rowbase[t], (hoff + 16 * hb) * 4, dP[0] * rows_scale);
+                    if constexpr (WANT_W2) {
+                        f16x4 ah, al;
+#pragma unroll
+                        for (int r = 0; r < 4; r += 2) {
+                            float a0 = av4[r], a1 = av4[r + 1];
+                            asm("" : "+v"(a0));
+                            asm("" : "+v"(a1));
+                            const f16x2 hi = __builtin_convertvector((f32x2v){a0, a1}, f16x2);
+                            const uint32_t hw = __builtin_bit_cast(uint32_t, hi);
+                            float l0, l1;
+                            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(znv[r]), "v"(sgv[r]), "v"(hw));
+                            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(znv[r + 1]), "v"(sgv[r + 1]), "v"(hw));
+                            const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+                            ah[r] = hi[0]; ah[r + 1] = hi[1];
+                            al[r] = lo[0]; al[r + 1] = lo[1];
+                        }
+                        f32x4 d = dW2[2 * st + hb];
+                        d = __builtin_amdgcn_mfma_f32_16x16x16f16(gth[t], ah, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x16f16(gth[t], al, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x16f16(gtl[t], ah, d, 0, 0, 0);
+                        dW2[2 * st + hb] = d;
+                    }
+                }
+            }
+            // the next step's parking stores come after this step's pick-up loads (same wave: DS operations execute in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_sched_barrier(0);          // keep the unrolled steps apart: hoisting the next step's loads costs registers
+        };
+#pragma unroll
+        for (int st = 0; st < CH; ++st)
+            if (st < nst) step(st);
+        if constexpr (WANT_S) {
+            // d/d s of this chunk's columns: sum over the 16 hidden units of the row, one partial per (chunk, edge)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const i32x4 e4 = *reinterpret_cast<const i32x4*>(p.ent + q0 + 16 * t + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < ST; ++c) {
+                        const float v = egnn_row16_sum(ps[t][r][c]) * rows_scale;
+                        if (hq == 0 && c < S && e4[r] >= 0) p.ds_part[((size_t)chunk * p.E + e4[r]) * S + c] = v;
+                    }
+            }
+        }
+    }
+
+    if constexpr (WANT_W2 || WANT_S) {
+        const size_t w = (size_t)slab * BW_WAVES + wave;
+#pragma unroll
+        for (int bl = 0; bl < 2 * CH; ++bl) {
+            if (bl < 2 * nst) {
+                const int col = st0 * 32 + 16 * bl + hq;
+                if constexpr (WANT_W2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p.dW2_part[(w * 16 + 4 * g + r) * p.Hp + col] = dW2[bl][r] * w2_out_scale;
+                }
+                if constexpr (WANT_S) {
+#pragma unroll
+                    for (int c = 0; c < ST; ++c)
+                        if (c < S) p.dWs_part[((w * 4 + g) * S + c) * p.Hp + col] = dws[bl][c] * rows_scale;
+                }
+            }
+        }
+    }
+}
+
+template <int NM, int ST, bool W2, bool SS, int CH>
+int launch_v(const egnn_edge_bwd_args& a, hipStream_t s)
+{
+    const int n_chunks = (a.Hp / 32 + CH - 1) / CH;
+    const size_t lds = (size_t)CH * 2048 + (size_t)CH * 32 * 4 * NM * 4 + (size_t)BW_WAVES * 32 * XLD * 4;
+    const dim3 grid((unsigned)((a.n_slabs + GS - 1) / GS * GS * n_chunks));
+    hipLaunchKernelGGL((edge_bwd_kernel<NM, ST, W2, SS, CH>), grid, dim3(BW_THREADS), lds, s, a);
+    return egnn_launch_status();
+}
+
+template <int NM, int ST>
+int launch(const egnn_edge_bwd_args& a, hipStream_t s)
+{
+    if (a.dW2_part && a.dWs_part) return launch_v<NM, ST, true, true, CH_S>(a, s);
+    if (a.dW2_part) return launch_v<NM, ST, true, false, CH_W2>(a, s);
+    if (a.dWs_part) return launch_v<NM, ST, false, true, CH_S>(a, s);
+    return launch_v<NM, ST, false, false, CH_S>(a, s);
+}
+
+}  // namespace
+
+extern "C" int egnn_edge_bwd_chunk_steps(void) { return CH_S; }
+
+extern "C" int egnn_edge_bwd_pass_f32(const egnn_edge_bwd_args* args, void* stream)
+{
+    if (!args) return EGNN_E_NULLPTR;
+    const egnn_edge_bwd_args& a = *args;
+    if (!a.ent || !a.Pi || !a.Pj || !a.Wst || !a.W2Th || !a.gU || !a.scal || !a.part_rows) return EGNN_E_NULLPTR;
+    if ((a.dWs_part == nullptr) != (a.ds_part == nullptr)) return EGNN_E_NULLPTR;
+    if (a.dWs_part && !a.Ws) return EGNN_E_NULLPTR;
+    if (a.B <= 0 || a.N <= 0 || a.K <= 0 || a.Hp <= 0 || (a.Hp % 32) != 0 || a.S < 1 || a.n_slabs < 1) return EGNN_E_SHAPE;
+    if (a.L <= 0 || (a.L % 128) != 0 || a.ldp < a.Hp || (a.ldp % 4) != 0 || a.ld_rows < a.Hp) return EGNN_E_SHAPE;
+    if (a.E != (int64_t)a.B * a.N * a.K || a.E >= ((int64_t)1 << 31) || a.L >= ((int64_t)1 << 31)) return EGNN_E_SHAPE;
+    if ((size_t)a.B * a.N * a.ldp * 4 >= ((size_t)1 << 32)) return EGNN_E_UNSUPPORTED;           // 32-bit buffer offsets into the P tables
+    if (((size_t)(a.L >> 4) + 1) * a.ld_rows * 4 >= ((size_t)1 << 32)) return EGNN_E_UNSUPPORTED;    // ... and into the partial rows
+    // built for S = 1 (the distance is the only per-edge scalar: every BASELINE config but c4): the by-source pass keeps 8 S
+    // registers of scalars, 8 S of d/d s and 2 CH S of d/d W_s next to the d/d W_2 tiles.  More scalars take egnn_edge_bwd_dz_f32.
+    if (a.S != 1 || a.wst_terms != 4) return EGNN_E_UNSUPPORTED;
+    if (!(a.ws_inv_scale > 0.f) || !(a.gu_scale > 0.f) || !(a.inv_scale > 0.f)) return EGNN_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(a.Pi) & 15) || (reinterpret_cast<uintptr_t>(a.Pj) & 15) || (reinterpret_cast<uintptr_t>(a.W2Th) & 15) ||
+        (reinterpret_cast<uintptr_t>(a.gU) & 15) || (reinterpret_cast<uintptr_t>(a.ent) & 15) ||
+        (reinterpret_cast<uintptr_t>(a.Wst) & 3))
+        return EGNN_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return launch<1, 1>(a, s);
+}

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 19
+#define EGNN_ABI_VERSION 20
 
 enum {
     EGNN_OK = 0,
@@ -246,6 +246,53 @@ int egnn_edge_features_gather_f32(const float* edges, const int64_t* edge_tok, c
  * B*N*K edge rows: the padding slots of the kernel's tiles store there, so that every store is unconditional).  Shapes: coor_dim 3, m_dim <= 16;
  * fields used: shapes, Pi / Pj / ldp / pi_split, Wst & scales, coors, edges, idx, order and the backward fields. */
 int egnn_edge_bwd_dz_f32(const egnn_edge_args* args, void* stream);
+
+/* Backward of the edge pass without anything of size E x H in memory (autograd of egnn_pytorch.py:279-287;
+ * csrc/edge_bwd.hip).  One call = one pass over a list of L entries (edges) grouped by a key node: by the source node i
+ * (by_dest = 0) or by the neighbour j (by_dest = 1: the edge ids sorted stably by destination).  Layout of the list: the entries
+ * of one key node are consecutive and padded with -1 to a multiple of 16, so that every 16-entry tile belongs to one node;
+ * L is a multiple of 128 (whole tiles of -1 at the end).  The pass recomputes z = P_i[i] + P_j[j] + W_s s per edge, a = SiLU(z),
+ * dz = (W2^T gU) SiLU'(z), and contracts them in registers:
+ *     part_rows[q / 16, :]   = sum of dz over tile q / 16     (d/d P_i or d/d P_j after egnn_rows_gather_sum_f32 over each node's
+ *                              consecutive tiles -- fixed order, no float atomics)
+ *     dW2_part (n_slabs * 4, 16, Hp),  if not NULL:  partial sums of gU^T a  -> d loss / d edge_mlp.3.weight  = sum over dim 0
+ *     dWs_part (n_slabs * 16, S, Hp) and ds_part (n_chunks, E, S), if not NULL (both or neither): partial sums of s^T dz
+ *                              -> d loss / d (scalar columns of edge_mlp.0.weight), and dz W_s over each column chunk
+ *                              -> d loss / d scalars = sum over dim 0   (n_chunks = ceil(Hp / 32 / egnn_edge_bwd_chunk_steps()))
+ * The all-edge contractions can ride with either pass (each edge appears once in both lists).  Every element of the outputs is
+ * written (no zero-fill needed).  Limits: S = 1 (the distance is the only per-edge scalar; EGNN_E_UNSUPPORTED otherwise --
+ * egnn_edge_bwd_dz_f32 covers those), m_dim <= 16, B*N*K < 2^31, the P table and the partial rows below 4 GB each.  All pointers
+ * device memory. */
+typedef struct egnn_edge_bwd_args {
+    int B, N, K;
+    int Hp, S;                  /* padded hidden width (egnn_padded_hidden), per-edge scalars */
+    int by_dest;                /* key of the grouping: 0 = source node i (own row P_i, gathered row P_j), 1 = neighbour j */
+    int n_slabs;                /* the entry list is cut into n_slabs contiguous slabs of 128-entry rounds (grid = n_slabs x n_chunks) */
+    int wst_terms;              /* 4 * egnn_edge_mfmas(S) */
+    int64_t L;                  /* entries, a multiple of 128 */
+    int64_t E;                  /* B * N * K */
+    const int32_t* ent;         /* (L) edge id (b*N + i)*K + k of each entry, -1 = padding */
+    const float* Pi;            /* (B*N, ldp) fp32 P_i rows incl. bias, in the forward's units (x -log2 e) */
+    const float* Pj;            /* (B*N, ldp) fp32 P_j rows */
+    int64_t ldp;
+    const void* Wst;            /* (Hp, wst_terms, 2) fp16: the forward's scalar-weight table */
+    float ws_inv_scale;
+    const int32_t* idx;         /* (B*N*K) neighbour of each edge, NULL = dense (K == N, j = k) */
+    const void* W2Th;           /* (Hp/32, 2, 2, 64, 4) fp16: W2^T fragments (egnn_edge_args.W2Th) */
+    const float* gU;            /* (E, 16) fp32 d loss / d u */
+    float gu_scale;             /* power of two applied to gU before its fp16 split */
+    float inv_scale;            /* 1 / (gu_scale * scale of W2Th) */
+    const float* scal;          /* (E, S) fp32 per-edge scalars [fourier..., dist, edges...] in natural units */
+    const float* Ws;            /* (Hp, S) fp32 scalar columns of edge_mlp.0.weight, rows >= H zero (by-source pass) */
+    float* part_rows;           /* out: (L / 16 + 1, ld_rows) fp32, one row per tile, the last row scratch */
+    int64_t ld_rows;
+    float* dW2_part;            /* out or NULL */
+    float* dWs_part;            /* out or NULL (with ds_part) */
+    float* ds_part;             /* out or NULL (with dWs_part) */
+} egnn_edge_bwd_args;
+
+int egnn_edge_bwd_pass_f32(const egnn_edge_bwd_args* args, void* stream);
+int egnn_edge_bwd_chunk_steps(void);    /* hidden steps (of 32 columns) one workgroup owns: sizes ds_part */
 
 /* Backward of the neighbour gather (egnn_pytorch.py:275): out[r, :] = sum of rows[order[p], :] for p in [seg_ptr[r], seg_ptr[r+1]),
  * in that order -- with `order` = the edges sorted (stably) by destination node this is d loss / d P_j from dZ, a fixed-order

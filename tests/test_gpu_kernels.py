@@ -1,4 +1,6 @@
 """Per-kernel parity on the MI355X, through the C ABI (egnn_pytorch_amd._ops -> libegnn_hip.so)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -319,3 +321,66 @@ def test_rows_gather_sum_fixed_order():
         assert torch.equal(out[r], acc), r
     ref = torch.zeros(n_out, cols, dtype=torch.float64, device="cuda").index_add_(0, dest, rows.double())
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize("b,n,k,dim,hub", [(2, 40, 8, 32, False), (1, 64, 32, 64, False), (3, 50, 5, 32, True), (1, 33, 16, 32, True)])
+def test_edge_bwd_pass_contractions_match_float64(b, n, k, dim, hub):
+    """egnn_edge_bwd_pass_f32 (nothing of size E x H in memory: z, SiLU(z), dz recomputed and contracted in registers) and
+    egnn_edge_bwd_dz_f32 (dz / SiLU(z) through HBM + library reductions) against the same contractions in float64:
+    d/d P_i, d/d P_j (per node), d/d W_s, d/d scalars, d/d W_2.  K below / equal / above a 16-entry tile, and `hub` = a few nodes
+    with very large in-degree (one key over many tiles) next to nodes nobody points to."""
+    from egnn_pytorch_amd import EGNN, _weights, autograd
+    g = torch.Generator().manual_seed(100 * n + k)
+    layer = EGNN(dim=dim, num_nearest_neighbors=k).cuda()
+    w = layer.packed_weights()
+    h, hp, m = w["H"], w["Hp"], layer.m_dim
+    feats = torch.randn(b, n, dim, generator=g).cuda()
+    idx = torch.randint(0, n, (b, n, k), generator=g)
+    if hub:
+        idx[:, :, 0] = 3
+        idx[:, ::2, 1] = 7
+    idx32 = idx.to(torch.int32).cuda()
+    e = b * n * k
+    coors = (torch.randn(b, n, 3, generator=g) * 1.5).cuda()
+    scal = autograd.edge_scalars(layer, coors, None, idx32.long())[1].reshape(e, 1).contiguous()        # squared distances
+    gu = torch.randn(e, m, generator=g) * 1e-3
+    gu[torch.rand(e, generator=g) < 0.2] = 0.0                                  # masked edges carry no gradient
+    gu16 = torch.zeros(e, 16)
+    gu16[:, :m] = gu
+    gu16 = gu16.cuda()
+    gu_scale = _weights.pow2_scale(float(gu16.abs().max()))
+    lin0, lin3 = layer.edge_mlp[0], layer.edge_mlp[3]
+    w1 = lin0.weight.detach()
+    w_s = torch.zeros(hp, 1, device="cuda")
+    w_s[:h] = w1[:, 2 * dim:]
+    f2d = feats.view(b * n, dim)
+    outs = {}
+    for name, fn in (("fused", autograd._edge_contract_fused), ("dz", autograd._edge_contract_dz)):
+        with torch.no_grad():
+            outs[name] = fn(layer, w, f2d, coors, None, scal, idx32, gu16, gu_scale, w_s, b, n, k, k >= 6)
+    with torch.no_grad():
+        again = autograd._edge_contract_fused(layer, w, f2d, coors, None, scal, idx32, gu16, gu_scale, w_s, b, n, k, k >= 6)
+    assert all(torch.equal(x, y) for x, y in zip(outs["fused"], again))        # fixed summation order: bit-reproducible
+    # float64 reference
+    w1d, b1d, w2d = w1.double(), lin0.bias.detach().double(), lin3.weight.detach().double()
+    fd = f2d.double()
+    p_i = fd @ w1d[:, :dim].t() + b1d
+    p_j = fd @ w1d[:, dim:2 * dim].t()
+    src = torch.arange(b * n, device="cuda").repeat_interleave(k)
+    dst = (idx32.long() + (torch.arange(b, device="cuda") * n)[:, None, None]).reshape(-1)
+    z = p_i[src] + p_j[dst] + scal.double() @ w1d[:, 2 * dim:].t()
+    sg = torch.sigmoid(z)
+    act = z * sg
+    dz = (gu16[:, :m].double() @ w2d) * (sg * (1 + z * (1 - sg)))
+    ref = dict(gz_i=torch.zeros(b * n, h, dtype=torch.float64, device="cuda").index_add_(0, src, dz),
+               gz_j=torch.zeros(b * n, h, dtype=torch.float64, device="cuda").index_add_(0, dst, dz),
+               g_ws=dz.t() @ scal.double(), g_scal=dz @ w1d[:, 2 * dim:], g_w2=gu16[:, :m].double().t() @ act)
+    for name, (gz_i, gz_j, g_ws, g_scal, g_w2) in outs.items():
+        got = dict(gz_i=gz_i[:, :h], gz_j=gz_j[:, :h], g_ws=g_ws[:h], g_scal=g_scal, g_w2=g_w2[:m, :h])
+        for key, r in ref.items():
+            scale = float(r.abs().max())
+            err = float((got[key].double() - r).abs().max())
+            if os.environ.get("EGNN_TEST_VERBOSE"):
+                print(f"{name:6s} {key:7s} rel err {err / scale:.2e}")
+            assert err <= 5e-6 * scale + 1e-12, (name, key, err, scale)
+        assert float(gz_i[:, h:].abs().max()) == 0.0 and float(gz_j[:, h:].abs().max()) == 0.0, name      # pad columns
