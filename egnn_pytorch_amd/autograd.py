@@ -48,6 +48,55 @@ def _fourier(dist, num_encodings):
     return torch.cat((x.sin(), x.cos(), dist), dim=-1)
 
 
+def _tn(a, b):
+    """a^T @ b for tall a (R, ca), b (R, cb): the contraction runs over the R rows and the output is small, so a single library
+    GEMM leaves most of the 256 CUs idle (2.2 ms for 65536 x 2080 x 512, 1.8 ms for 2M x 64 x 16).  Split-K by hand: slabs of rows
+    as a batched GEMM, partial products summed in fixed order (1.2 / 0.2 ms)."""
+    r, ca = a.shape
+    cb = b.shape[1]
+    if not a.is_cuda or r < (1 << 14):
+        return a.t() @ b
+    tiles = ((ca + 127) // 128) * ((cb + 127) // 128)
+    s = 1
+    while s < 256 and tiles * s < 512 and r % (2 * s) == 0 and r // (2 * s) >= 512:
+        s *= 2
+    if s == 1:
+        return a.t() @ b
+    return torch.bmm(a.view(s, r // s, ca).transpose(1, 2), b.view(s, r // s, cb)).sum(dim=0)
+
+
+class _TallLinear(torch.autograd.Function):
+    """F.linear for per-edge inputs (millions of rows, a few dozen features): the weight gradient is a `_tn` product."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        gx = (g2 @ w).view_as(x) if ctx.needs_input_grad[0] else None
+        gw = _tn(g2, x.reshape(-1, x.shape[-1])) if ctx.needs_input_grad[1] else None
+        gb = g2.sum(dim=0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def _per_edge(module, x):
+    """module(x) for the small per-edge heads (edge_gate, coors_mlp: Sequentials of Linear / Dropout / SiLU / Sigmoid) with the
+    Linears' weight gradients computed by `_tn`."""
+    if not x.is_cuda:
+        return module(x)
+    for sub in (module if isinstance(module, nn.Sequential) else [module]):
+        if isinstance(sub, nn.Linear):
+            x = _TallLinear.apply(x, sub.weight, sub.bias)
+        else:
+            x = sub(x)
+    return x
+
+
 def edge_scalars(layer, coors, edges, idx):
     """rel = x_i - x_j and the per-edge scalars [fourier(d), d, e_ij] in the column order of edge_mlp.0.weight (:282-285)."""
     b, n, _ = coors.shape
@@ -72,7 +121,7 @@ def layer_tail(layer, feats, coors, u, rel, mask, idx, rank, valid_radius):
     b = feats.shape[0]
     m_ij = layer.edge_mlp[4](u)
     if layer.edge_gate is not None:
-        m_ij = m_ij * layer.edge_gate(m_ij)                                       # (:289-290)
+        m_ij = m_ij * _per_edge(layer.edge_gate, m_ij)                            # (:289-290)
 
     pair_mask = None
     if mask is not None:                                                          # (:292-300) -- the radius / sparse-only cut
@@ -84,7 +133,7 @@ def layer_tail(layer, feats, coors, u, rel, mask, idx, rank, valid_radius):
 
     coors_out = coors
     if layer.coors_mlp is not None:
-        w = layer.coors_mlp(m_ij).squeeze(-1)                                     # (:303-304)
+        w = _per_edge(layer.coors_mlp, m_ij).squeeze(-1)                          # (:303-304)
         if layer.norm_coors:                                                      # CoorsNorm (:67-77)
             norm = rel.norm(dim=-1, keepdim=True)
             rel = rel / norm.clamp(min=layer.coors_norm.eps) * layer.coors_norm.scale
@@ -383,8 +432,8 @@ def _backward_native(ctx, g_node, g_coors):
             # ---- 3. node-level GEMMs
             g_feats[lo:hi_] += (gz_i @ w_i + gz_j @ w_j).view(bc, n, dim)
             gw1 = grads_by_id[id(lin0.weight)]
-            gw1[:, :dim] += (gz_i.t() @ f2d)[:h]
-            gw1[:, dim:2 * dim] += (gz_j.t() @ f2d)[:h]
+            gw1[:, :dim] += _tn(gz_i, f2d)[:h]
+            gw1[:, dim:2 * dim] += _tn(gz_j, f2d)[:h]
             gw1[:, 2 * dim:] += g_ws[:h]
             grads_by_id[id(lin0.bias)] += gz_i.sum(dim=0)[:h]
             g_scal = g_scal.view_as(scal)

@@ -47,7 +47,7 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 #define EGNN_BWD_W2_BLOCKS 3
 #endif
 #ifndef EGNN_BWD_S_BLOCKS
-#define EGNN_BWD_S_BLOCKS 3
+#define EGNN_BWD_S_BLOCKS 4
 #endif
 #ifndef EGNN_BWD_CHUNK_STEPS
 #define EGNN_BWD_CHUNK_STEPS 4
@@ -59,7 +59,10 @@ constexpr int GS = EGNN_BWD_GROUP_SLABS;     // slabs whose workgroups run next 
 constexpr int BW_THREADS = 256;
 constexpr int BW_WAVES = 4;
 constexpr int CH_S = EGNN_BWD_CHUNK_STEPS;   // steps of 32 hidden columns a workgroup owns (the variant that writes ds_part: sizes it)
-constexpr int CH_W2 = 3;                     // ... of the variant with the d/d W_2 tiles only: one step fewer keeps it at 3 workgroups per CU
+#ifndef EGNN_BWD_CH_W2
+#define EGNN_BWD_CH_W2 4
+#endif
+constexpr int CH_W2 = EGNN_BWD_CH_W2;                     // ... of the variant with the d/d W_2 tiles only: one step fewer keeps it at 3 workgroups per CU
 constexpr int XLD = 36;                      // floats per exchange row: 144 B -> rows 4 apart sit 16 banks apart (transposed pick-up)
 constexpr float DZ_UP = 256.f;               // dz (scaled units, < 2^7) x 2^8 before the f16 split: keeps small values off the subnormals
 constexpr float A_UP = 64.f;                 // SiLU(z) and the transposed gU likewise (x 2^6 each): the lo halves of values below ~0.25 are
@@ -150,12 +153,10 @@ __global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EG
     const __amdgpu_buffer_rsrc_t own_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Town), 0, tab_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t oth_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Toth), 0, tab_bytes, 0x00020000);
 
-    // partial rows: row = tile index, 32-bit offsets as well; only lane group 0 holds row 0 of the indicator product, the other
-    // lanes store to the spare row behind the last one -- the store is unconditional
+    // partial rows: row = tile index; wave-uniform, so it rides in the scalar offset and the lane contributes 4 hq only
     const uint32_t row_bytes = (uint32_t)(p.ld_rows * 4);
-    const uint32_t n_tiles = (uint32_t)(p.L >> 4);
-    const __amdgpu_buffer_rsrc_t rows_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.part_rows, 0, (n_tiles + 1) * row_bytes, 0x00020000);
-    const uint32_t spare_lane = n_tiles * row_bytes + hq * 4;
+    const __amdgpu_buffer_rsrc_t rows_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.part_rows, 0, (uint32_t)(p.L >> 4) * row_bytes, 0x00020000);
+    const uint32_t hq4 = hq * 4;
     // (32-bit offsets here as well: a 64-bit per-lane address per half step would be hoisted out of the round loop -- 2 registers each)
     const __amdgpu_buffer_rsrc_t ws_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(WANT_S ? p.Ws : p.Pi), 0, (uint32_t)((size_t)p.Hp * S * 4), 0x00020000);
 
@@ -212,8 +213,7 @@ __global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EG
         }
         // per register r: entry 16 t + 4 g + r (the edges this lane's data registers belong to).  The 16 entries of a tile share
         // their key node (the host pads every node's entries to whole tiles): one own row and one partial row per tile.
-        uint32_t ownoff[2];                        // byte offset of the tile's own row (+ hq)
-        uint32_t rowbase[2];                       // byte offset of the tile's partial row (+ hq); lane groups g > 0 hold no row of D
+        int ownoff[2];                             // byte offset of the tile's own row: wave-uniform, rides in the scalar offset
         float sv[2][4][ST];
         f16x4 gth[2], gtl[2], ind[2];
 #pragma unroll
@@ -223,14 +223,15 @@ __global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EG
             const int ev0 = e0 >= 0 ? e0 : 0;
             const int ig0 = ev0 / K;                                 // global node (b N + i)
             const int jg0 = p.idx ? (ig0 / N) * N + p.idx[ev0] : (ig0 / N) * N + (ev0 - ig0 * K);
-            ownoff[t] = (uint32_t)(((size_t)(p.by_dest ? jg0 : ig0) * p.ldp + hq) * 4);
-            rowbase[t] = g == 0 ? (uint32_t)((size_t)((q0 + 16 * t) >> 4) * row_bytes) + hq * 4 : spare_lane;
+            ownoff[t] = (int)((size_t)(p.by_dest ? jg0 : ig0) * p.ldp * 4);
             f32x4 gt = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int eid = e4[r];
                 const bool valid = eid >= 0;
-                ind[t][r] = (valid && hq == 0) ? (_Float16)1.f : (_Float16)0.f;      // row 0 of D = the tile's sum over its valid entries
+                // rows 0, 4, 8, 12 of D = the tile's sum over its valid entries: register 0 of every lane group holds it, and all
+                // four write the same value to the tile's partial row (no per-lane row select, no spare row)
+                ind[t][r] = (valid && (hq & 3) == 0) ? (_Float16)1.f : (_Float16)0.f;
                 if constexpr (WANT_S) {
 #pragma unroll
                     for (int c = 0; c < ST; ++c) sv[t][r][c] = (valid && c < S) ? p.scal[(size_t)eid * S + c] : 0.f;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EG
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb) ownpf[t][hb] = buf_load1f(own_rsrc, ownoff[t], (st0 * 32 + 16 * hb) * 4);
+            for (int hb = 0; hb < 2; ++hb) ownpf[t][hb] = buf_load1f(own_rsrc, hq4, ownoff[t] + (st0 * 32 + 16 * hb) * 4);
         // One step of 32 hidden columns (a lambda so that the unrolled loop below indexes the accumulator tiles with constants)
         auto step = [&](const int st) __attribute__((always_inline)) {
             const int hoff = (st0 + st) * 32;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EG
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
                     ow[t][hb] = ownpf[t][hb];
-                    ownpf[t][hb] = buf_load1f(own_rsrc, ownoff[t], (hnext + 16 * hb) * 4);
+                    ownpf[t][hb] = buf_load1f(own_rsrc, hq4, ownoff[t] + (hnext + 16 * hb) * 4);
                 }
             // park the neighbour lines of this step, pick them up transposed (same wave: DS operations execute in order)
 #pragma unroll
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EG
                     dP = __builtin_amdgcn_mfma_f32_16x16x16f16(ind[t], dh, dP, 0, 0, 0);
                     dP = __builtin_amdgcn_mfma_f32_16x16x16f16(ind[t], dl, dP, 0, 0, 0);
                     // (no branch around the store: the step stays one basic block and the scheduler interleaves the two tiles)
-                    buf_store1f(rows_rsrc, rowbase[t], (hoff + 16 * hb) * 4, dP[0] * rows_scale);
+                    buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)(q0 + 16 * t) >> 4) * row_bytes) + (hoff + 16 * hb) * 4, dP[0] * rows_scale);
                     if constexpr (WANT_W2) {
                         f16x4 ah, al;
 #pragma unroll
@@ -468,8 +469,8 @@ extern "C" int egnn_edge_bwd_pass_f32(const egnn_edge_bwd_args* args, void* stre
     if (a.B <= 0 || a.N <= 0 || a.K <= 0 || a.Hp <= 0 || (a.Hp % 32) != 0 || a.S < 1 || a.n_slabs < 1) return EGNN_E_SHAPE;
     if (a.L <= 0 || (a.L % 128) != 0 || a.ldp < a.Hp || (a.ldp % 4) != 0 || a.ld_rows < a.Hp) return EGNN_E_SHAPE;
     if (a.E != (int64_t)a.B * a.N * a.K || a.E >= ((int64_t)1 << 31) || a.L >= ((int64_t)1 << 31)) return EGNN_E_SHAPE;
-    if ((size_t)a.B * a.N * a.ldp * 4 >= ((size_t)1 << 32)) return EGNN_E_UNSUPPORTED;           // 32-bit buffer offsets into the P tables
-    if (((size_t)(a.L >> 4) + 1) * a.ld_rows * 4 >= ((size_t)1 << 32)) return EGNN_E_UNSUPPORTED;    // ... and into the partial rows
+    if ((size_t)a.B * a.N * a.ldp * 4 >= ((size_t)1 << 31)) return EGNN_E_UNSUPPORTED;           // 32-bit (signed scalar) buffer offsets into the P tables
+    if ((size_t)(a.L >> 4) * a.ld_rows * 4 >= ((size_t)1 << 31)) return EGNN_E_UNSUPPORTED;         // (scalar offsets are signed)    // ... and into the partial rows
     // built for S = 1 (the distance is the only per-edge scalar: every BASELINE config but c4): the by-source pass keeps 8 S
     // registers of scalars, 8 S of d/d s and 2 CH S of d/d W_s next to the d/d W_2 tiles.  More scalars take egnn_edge_bwd_dz_f32.
     if (a.S != 1 || a.wst_terms != 4) return EGNN_E_UNSUPPORTED;

@@ -9,10 +9,14 @@ import edge_tune
 
 if __name__ == "__main__":
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = "edge_fused"
     for spec in sys.argv[1:]:
+        if spec.startswith("src="):
+            src = spec[4:]
+            continue
         defs = dict(kv.split("=") for kv in spec.split(",") if kv)
         tag = "bwd_" + spec.replace("=", "").replace(",", "_")
-        lib = edge_tune.build(tag, defs, "edge_fused", tuning=True)
+        lib = edge_tune.build(tag, defs, src, tuning=src == "edge_fused")
         env = dict(os.environ, EGNN_HIP_LIB=lib)
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "train_step_probe.py"), "2"], env=env, capture_output=True, text=True, timeout=600)
         lines = r.stdout.strip().splitlines()
