@@ -6,16 +6,21 @@ Forward  = the HIP path (neighbour selection, fused edge pass, split-f16 GEMMs).
            forward edge kernel writes on the side when a graph is being recorded.
 Backward = `_backward_native` (fp32, coordinate dimension 3, m_dim <= 16):
              * the small tail behind u (second SiLU, gate, masks, coors_mlp, CoorsNorm, clamp, pooling, node_norm, node_mlp:
-               E x 16 / E x 64 / node-level tensors) is differentiated by autograd from u  ->  gU and those parameters' gradients;
-             * egnn_edge_bwd_dz_f32 (csrc/edge_fused.hip, MODE 2) recomputes the pre-activation z of the first SiLU exactly as
-               the forward does and writes a = SiLU(z) and dz = (W2^T gU) * SiLU'(z), the W2^T product on the matrix cores;
-             * reductions and plain library GEMMs over dz / a give d/d feats, d/d edge_mlp.{0,3}, d/d scalars (-> coors, edges).
+               E x 16 / E x 64 / node-level tensors) is differentiated by autograd from u  ->  gU and those parameters' gradients
+               (the weight gradients of the per-edge heads as split-K products, `_tn`);
+             * the E x H work -- z = P_i + P_j + W_s s, a = SiLU(z), dz = (W2^T gU) SiLU'(z) and their contractions -- on
+               egnn_edge_bwd_pass_f32 (csrc/edge_bwd.hip; `_edge_contract_fused`): one pass over the edges grouped by source node
+               (d/d P_i, d/d W_s, d/d scalars) and one over the edges sorted by destination (d/d P_j, d/d W_2), everything
+               recomputed and contracted in registers: nothing of size E x H reaches memory (8 GiB peak where the first native
+               backward needed 27).  More than one per-edge scalar (fourier features, edge features): `_edge_contract_dz`,
+               the first native backward -- egnn_edge_bwd_dz_f32 writes dz and a, reductions / library GEMMs read them;
+             * node-level fp32 library GEMMs give d/d feats and d/d edge_mlp.0 from the per-node sums.
            `_backward_recompute` (everything else, and the native path's reference in the tests): the whole layer re-evaluated
            a few graphs at a time as a differentiable chain of ATen ops over the neighbour list the HIP kernel selected,
            factorised like the forward, and differentiated by autograd.
-Gradients of feats / coors / edges / every parameter agree with the reference's autograd (tests/test_autograd.py).  d/d P_j is a
-fixed-order gather over the transposed neighbour list (egnn_rows_gather_sum_f32: no float atomics); the remaining ATen pieces
-are the per-node sums, the fp32 library GEMMs and the small tail.
+Gradients of feats / coors / edges / every parameter agree with the reference's autograd (tests/test_autograd.py).  Every sum
+over edges has a fixed order (partial rows + egnn_rows_gather_sum_f32, per-workgroup partials summed by index: no float
+atomics) -- the native backward is bit-reproducible.
 
 `layer_given_neighbors` is a restatement of egnn_pytorch.py:262-341 that takes the neighbour list as an input (the selection
 itself, :237-260, is not differentiable: topk indices and the `<= valid_radius` comparison carry no gradient upstream

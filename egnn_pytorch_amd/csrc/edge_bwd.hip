@@ -7,29 +7,34 @@
 //     d/d P_i[n] = sum of dz over the edges that leave n,      d/d P_j[n] = sum of dz over the edges that arrive at n,
 //     d/d W_2    = gU^T a,                                      d/d W_s    = dz^T s.
 // The first backward kernel (egnn_edge_bwd_dz_f32) wrote dz and a to HBM (35 GB at the north-star shape) for library
-// reductions to read back five times; this one recomputes z and contracts in registers.
+// reductions to read back five times: traffic-bound at 45 + 87 GB.  This one recomputes z and contracts in registers.
 //
 // Layout.  The forward kernel holds z as (hidden rows) x (edge columns) in the MFMA accumulator layout; contracting over
 // edges on the matrix cores needs the transpose -- edges along the K dimension of the B operand.  Swapping the operands of
 // every MFMA of the forward's first layer gives exactly that: with A = the per-edge fragment and B = the per-hidden-unit
 // fragment, D[m = edge][n = hidden unit] lands with lane (g, h) holding edges 4g .. 4g+3 of the tile for hidden unit h, and
 // those four registers ARE the B fragment [k = edge][n = hidden] of v_mfma_f32_16x16x16_f16.  Then
-//     d/d P partial = Ind x dz      (A = one-hot rows "edge e belongs to the tile's m-th node": the segmented sum over a node's
-//                                    edges for any K and for ragged in-degrees alike; the tile's rows go to a compact array of
-//                                    partial rows that egnn_rows_gather_sum_f32 adds up in fixed order -- no float atomics),
+//     d/d P partial = Ind x dz      (A = the tile's valid-entry flags: the sum over the 16 entries of a tile, which the host's
+//                                    list layout makes the entries of ONE node; a node's tiles are consecutive partial rows that
+//                                    egnn_rows_gather_sum_f32 adds up in fixed order -- no float atomics, any K, ragged in-degrees),
 //     d/d W_2 +=     gU^T x a       (A = this tile's gU transposed; accumulated in registers),
-// (dz and a as split-f16 pairs: the indicator is exact, gU is split as well -> fp32-class sums), while d/d W_s and d/d s are
-// plain FMAs on the values (S of them each).
+// dz and a as split-f16 pairs (the flags are exact, gU is split as well -> fp32-class sums; all three pre-scaled by powers of
+// two: the lo halves of values below ~0.25 would be fp16 subnormals and are lost on the way -- d/d W_2 came out at hi-only
+// accuracy, 2e-5, before the scaling), while d/d W_s and d/d s are plain FMAs on the values (S of them each).
 //
 // Persistence.  d/d W_2 and d/d W_s are sums over ALL edges per hidden column, so a workgroup owns CH x 32 hidden columns
-// (its W2^T / W_s fragments staged in LDS once) and streams a slab of the edge list through them: grid = slabs x column
-// chunks, the per-edge setup is redone per chunk (cheap next to 5 steps of SiLU work), and every (slab, wave) ends with one
-// small partial of d/d W_2 / d/d W_s that the host sums in fixed order.
+// (its W2^T / W_s fragments staged in LDS once) and streams a slab of the entry list through them: grid = slabs x column
+// chunks, the per-entry setup is redone per chunk (cheap next to 4 steps of SiLU work), and every (slab, wave) ends with one
+// small partial of d/d W_2 / d/d W_s that the host sums in fixed order.  Slabs are short (8 rounds of 128 entries) and the
+// block order keeps the workgroups of one graph and one column chunk side by side on an XCD: what they gather is the same
+// 512-byte pieces of that graph's rows (L2 hit rate 38 % -> forward-like with the order, 5.3 -> 4.4 ms per pass).
 //
-// Two passes over the edges: grouped by source node (d/d P_i, d/d W_2, d/d W_s, d/d s) and grouped by neighbour, i.e. over
-// the edge list sorted stably by destination (d/d P_j only).  z is rebuilt from fp32 P_i and P_j rows: the neighbour's rows as
-// whole 128-byte lines parked in wave-private LDS and picked up transposed, the node's own row (shared by the consecutive
-// entries of a group: L1 hits) by direct loads.
+// Two passes over the edges: grouped by source node (d/d P_i; carries d/d W_s and d/d s) and grouped by neighbour, i.e. over
+// the edge list sorted stably by destination (d/d P_j; carries d/d W_2) -- each all-edge contraction keeps its accumulators
+// in registers, and one pass carrying all of them drops from 3-4 to 2 workgroups per CU (measured: slower).  z is rebuilt
+// from fp32 P_i and P_j rows: the other endpoint's rows as whole 128-byte lines parked in wave-private LDS and picked up
+// transposed, the tile's own row (wave-uniform offset in the scalar operand) by one load per tile and half step -- both one
+// step ahead.
 #include "egnn_common.h"
 
 namespace {
@@ -102,8 +107,8 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo)
     }
 }
 
-// NM: first-layer MFMAs of the scalar term (egnn_edge_mfmas(S)); ST: register bound on S (per-edge scalars);
-// WANT_W: also d/d W_2, d/d W_s, d/d s (the by-source pass)
+// NM: first-layer MFMAs of the scalar term (egnn_edge_mfmas(S)); ST: register bound on S (per-edge scalars); WANT_W2: also
+// d/d W_2; WANT_S: also d/d W_s and d/d s; CH: steps of 32 hidden columns the workgroup owns
 template <int NM, int ST, bool WANT_W2, bool WANT_S, int CH>
 __global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EGNN_BWD_W2_BLOCKS : (WANT_S ? EGNN_BWD_S_BLOCKS : EGNN_BWD_DEST_BLOCKS))) void edge_bwd_kernel(const egnn_edge_bwd_args p)
 {

@@ -236,3 +236,46 @@ def test_native_backward_kernel_matches_the_aten_recompute(kw, n, flags):
         if a is not None:
             scale = max(1.0, float(r.abs().max()))
             np.testing.assert_allclose(a.numpy(), r.numpy(), atol=1e-4 * scale, rtol=0, err_msg=f"gradient #{pos}")
+
+
+def test_entry_list_pads_every_node_to_whole_tiles():
+    """autograd.entry_list (the list layout egnn_edge_bwd_pass_f32 reads, include/egnn_hip.h): each key's entries are consecutive,
+    in their given order, padded with -1 to whole 16-entry tiles; the list to a multiple of 128; seg = the tiles of each key."""
+    from egnn_pytorch_amd.autograd import entry_list
+    g = torch.Generator().manual_seed(3)
+    n_keys = 9
+    keys = torch.sort(torch.cat([torch.randint(0, n_keys, (70,), generator=g), torch.full((40,), 5)])).values
+    keys = keys[keys != 2]                                                 # a node nobody points to
+    eids = torch.randperm(keys.numel(), generator=g)
+    ent, seg = entry_list(eids, keys, n_keys)
+    assert ent.dtype == torch.int32 and ent.numel() % 128 == 0 and seg.tolist()[0] == 0
+    assert int((ent >= 0).sum()) == eids.numel() and int(seg[-1]) * 16 <= ent.numel()
+    for k in range(n_keys):
+        tile0, tile1 = int(seg[k]), int(seg[k + 1])
+        chunk = ent[tile0 * 16:tile1 * 16]
+        assert torch.equal(chunk[chunk >= 0], eids[keys == k].to(torch.int32))         # same entries, same order
+        assert tile1 - tile0 == (int((keys == k).sum()) + 15) // 16
+        valid = (chunk >= 0).int()
+        assert bool((valid[1:] <= valid[:-1]).all())                                   # padding only behind a node's entries
+    assert bool((ent[int(seg[-1]) * 16:] == -1).all())
+
+
+def test_split_k_transposed_product_equals_plain_product():
+    """autograd._tn (a^T b over tall operands; split-K batched GEMM on the GPU, plain on the CPU) and the per-edge heads routed
+    through it give the gradients of the plain modules."""
+    from egnn_pytorch_amd import autograd as A
+    g = torch.Generator().manual_seed(4)
+    a, b = torch.randn(4096, 24, generator=g), torch.randn(4096, 8, generator=g)
+    torch.testing.assert_close(A._tn(a, b), a.t() @ b)
+    head = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Dropout(0.0), torch.nn.SiLU(), torch.nn.Linear(64, 1)).double()
+    x = torch.randn(500, 16, dtype=torch.float64, generator=g, requires_grad=True)
+    y_ref = head(x)
+    gx_ref, *gp_ref = torch.autograd.grad(y_ref.square().sum(), [x] + list(head.parameters()))
+    y = x
+    for sub in head:
+        y = A._TallLinear.apply(y, sub.weight, sub.bias) if isinstance(sub, torch.nn.Linear) else sub(y)
+    gx, *gp = torch.autograd.grad(y.square().sum(), [x] + list(head.parameters()))
+    torch.testing.assert_close(y, y_ref)
+    torch.testing.assert_close(gx, gx_ref)
+    for u, v in zip(gp, gp_ref):
+        torch.testing.assert_close(u, v)
