@@ -39,6 +39,7 @@ _NATIVE_MODE = os.environ.get("EGNN_NATIVE_BACKWARD", "1")
 _NATIVE = _NATIVE_MODE != "0"
 # which pass of the fused backward carries d/d W_2: "dest" (default), "both" = the by-source pass carries everything (tuning knob)
 _FUSED_SPLIT = os.environ.get("EGNN_BWD_SPLIT", "dest")
+_FUSED_MAX_GRAPHS = 0                 # tests: force the chunking over graphs that very large batches need (0 = by size only)
 _NATIVE_BUDGET_BYTES = 24 << 30                      # dZ + SiLU(z), 2 x E x Hp fp32, per chunk of graphs
 
 # activations of the recompute per edge: a few E x H tensors (pre-activation, activation, gradients); 16 GB of the 288 GB
@@ -380,8 +381,11 @@ def _backward_native(ctx, g_node, g_coors):
     fused = _NATIVE_MODE != "dz" and s_in == 1           # (the by-source pass of egnn_edge_bwd_pass_f32 is built for S = 1)
     if fused:
         # nothing of size E x H: graphs are only chunked to keep the P table below 4 GB (32-bit buffer offsets) and E below 2^31
-        step = max(1, min(b, int(((1 << 32) - 1) // (n * 2 * hp * 4)), int(((1 << 31) - 1) // (n * k)),
-                          int(((1 << 32) - 1) // ((n * k // 16 + n + 16) * hp * 4))))         # (... and the partial rows)
+        # (the kernel addresses both with signed 32-bit scalar offsets)
+        step = max(1, min(b, int(((1 << 31) - 1) // (n * 2 * hp * 4)), int(((1 << 31) - 1) // (n * k)),
+                          int(((1 << 31) - 1) // ((n * k // 16 + n + 16) * hp * 4))))         # (... and the partial rows)
+        if _FUSED_MAX_GRAPHS > 0:
+            step = min(step, _FUSED_MAX_GRAPHS)
     else:
         per_graph = 2.0 * n * k * hp * 4
         step = max(1, min(b, int(_NATIVE_BUDGET_BYTES // per_graph)))

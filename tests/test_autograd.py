@@ -207,8 +207,8 @@ def test_inference_paths_record_nothing():
     (dict(dim=24, num_nearest_neighbors=48), 96, dict(mask=True)),                                         # multi-round node groups
 ])
 def test_native_backward_kernel_matches_the_aten_recompute(kw, n, flags):
-    """egnn_edge_bwd_dz_f32 path (E x H work on the HIP kernel, reductions / GEMMs around it) against the pure-ATen recompute
-    backward of the same Function: every gradient within 1e-4 of its scale.  (The recompute itself is pinned to the reference's
+    """The native backwards (E x H work on the HIP kernels, small tail and node-level GEMMs around them) against the pure-ATen
+    recompute backward of the same Function: every gradient within 1e-4 of its scale.  (The recompute itself is pinned to the reference's
     autograd in float64 on the CPU.)"""
     from egnn_pytorch_amd import EGNN, autograd
     torch.manual_seed(9)
@@ -221,21 +221,27 @@ def test_native_backward_kernel_matches_the_aten_recompute(kw, n, flags):
     feats, coors = torch.randn(b, n, kw["dim"], generator=g).cuda(), torch.randn(b, n, 3, generator=g).cuda()
     mask = (torch.arange(n)[None] < torch.tensor([[n], [n - 5], [n // 2 + 4]])).cuda() if flags.get("mask") else None
     edges = torch.randn(b, n, n, kw.get("edge_dim", 0), generator=g).cuda() if flags.get("edges") else None
-    results = []
-    for native in (True, False):
-        old = autograd._NATIVE
-        autograd._NATIVE = native
+    # (native, mode, graphs per chunk): the register-contraction backward (egnn_edge_bwd_pass_f32; where it applies: one per-edge
+    # scalar), the same with the batch cut into chunks (what batches beyond the kernels' 2 GB tables get), the dz-through-HBM
+    # version (egnn_edge_bwd_dz_f32), and the pure-ATen recompute they are all compared with
+    results = {}
+    for name, native, mode, max_graphs in (("fused", True, "1", 0), ("fused, chunked", True, "1", 2), ("dz", True, "dz", 0),
+                                           ("recompute", False, "1", 0)):
+        old = autograd._NATIVE, autograd._NATIVE_MODE, autograd._FUSED_MAX_GRAPHS
+        autograd._NATIVE, autograd._NATIVE_MODE, autograd._FUSED_MAX_GRAPHS = native, mode, max_graphs
         try:
             f, c = feats.clone().requires_grad_(True), coors.clone().requires_grad_(True)
             e = None if edges is None else edges.clone().requires_grad_(True)
-            results.append(_grads(layer, lambda: layer(f, c, e, mask), (f, c, e))[0])
+            results[name] = _grads(layer, lambda: layer(f, c, e, mask), (f, c, e))[0]
         finally:
-            autograd._NATIVE = old
-    for pos, (a, r) in enumerate(zip(*results)):
-        assert (a is None) == (r is None)
-        if a is not None:
-            scale = max(1.0, float(r.abs().max()))
-            np.testing.assert_allclose(a.numpy(), r.numpy(), atol=1e-4 * scale, rtol=0, err_msg=f"gradient #{pos}")
+            autograd._NATIVE, autograd._NATIVE_MODE, autograd._FUSED_MAX_GRAPHS = old
+    ref = results.pop("recompute")
+    for name, got in results.items():
+        for pos, (a, r) in enumerate(zip(got, ref)):
+            assert (a is None) == (r is None)
+            if a is not None:
+                scale = max(1.0, float(r.abs().max()))
+                np.testing.assert_allclose(a.numpy(), r.numpy(), atol=1e-4 * scale, rtol=0, err_msg=f"{name}: gradient #{pos}")
 
 
 def test_entry_list_pads_every_node_to_whole_tiles():
