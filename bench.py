@@ -176,6 +176,27 @@ def cpu_baseline(workload, kwargs, n, budget_s=25.0):
                        f"host: {os.cpu_count()} logical cores ({cpu}), torch threads {torch.get_num_threads()}")
 
 
+def train_step(layer, feats, coors, mask, edges=None, adj=None, steps=3):
+    """One training step of the same workload (forward under autograd + backward of a scalar loss of both outputs), after the
+    timed inference region: SURVEY.md §8f rank 2.  Reported next to the metric, never part of `value`."""
+    import time
+    f = feats.detach().clone().requires_grad_(True)
+    c = coors.detach().clone().requires_grad_(True)
+    fwd, bwd = [], []
+    torch.cuda.reset_peak_memory_stats()
+    for it in range(steps + 1):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        of, oc = layer(f, c, edges, mask=mask, adj_mat=adj)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        (of.square().mean() + oc.square().mean()).backward()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        if it:                                              # (the first step carries one-time allocations)
+            fwd.append(1e3 * (t1 - t0)); bwd.append(1e3 * (t2 - t1))
+        layer.zero_grad(); f.grad = None; c.grad = None
+    return {"forward_ms": round(min(fwd), 3), "backward_ms": round(min(bwd), 3), "steps": steps,
+            "peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "backward": "egnn_pytorch_amd.autograd (DESIGN.md section 10)"}
+
+
 def reference_gpu_eager(kwargs, b, n, device, steps=3):
     """Secondary baseline: the reference module run on the MI355X through PyTorch-ROCm eager, timed with
     events on the current stream.  Context only -- never `value`."""
@@ -238,6 +259,7 @@ def main():
                          "barrier / max-over-ranks timing, rank-0 JSON -- on CPU with this backend and a dummy step; no GPU work, "
                          "no numbers of any meaning")
     ap.add_argument("--ragged-mask", action="store_true", help="ragged masks (len ~ U{N/2..N}) instead of all-True")
+    ap.add_argument("--train-step", action="store_true", help="also time forward + backward of the same workload (not part of `value`)")
     ap.add_argument("--reference-eager", action="store_true",
                     help="also time the reference module on the MI355X through PyTorch eager (secondary baseline)")
     args = ap.parse_args()
@@ -386,6 +408,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload, kwargs, n)
         if args.reference_eager and world == 1:
             out["reference_gpu_eager"] = reference_gpu_eager(kwargs, b, n, device)
+        if args.train_step and world == 1 and not is_net:
+            out["train_step"] = train_step(layer, feats, coors, mask, edges, adj)
         print(json.dumps(out), flush=True)
 
     if dist is not None:

@@ -63,7 +63,7 @@ class EdgeBwdArgs(Structure):
         ("L", c_int64), ("E", c_int64),
         ("ent", c_void_p), ("Pi", c_void_p), ("Pj", c_void_p), ("ldp", c_int64),
         ("Wst", c_void_p), ("ws_inv_scale", c_float), ("idx", c_void_p), ("W2Th", c_void_p), ("gU", c_void_p),
-        ("gu_scale", c_float), ("inv_scale", c_float), ("scal", c_void_p), ("Ws", c_void_p),
+        ("gu_scale", c_float), ("inv_scale", c_float), ("scal", c_void_p), ("Ws", c_void_p), ("scal_scale", c_void_p),
         ("part_rows", c_void_p), ("ld_rows", c_int64),
         ("dW2_part", c_void_p), ("dWs_part", c_void_p), ("ds_part", c_void_p),
     ]

@@ -417,6 +417,11 @@ def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, w
         dws = empty(n_slabs * 16, s_in, hp, dtype=torch.float32, device=dev)
         ds = empty(n_chunks, e, s_in, dtype=torch.float32, device=dev)
         a.Ws, a.dWs_part, a.ds_part = ws_nat.data_ptr(), dws.data_ptr(), ds.data_ptr()
+        if s_in > 1:
+            # d/d W_s on the matrix cores: the scalars enter as split-fp16 fragments, each column brought into [1, 2) at its maximum
+            amax = scal.abs().amax(dim=0)
+            col_scale = torch.where(amax > 0, torch.exp2(-torch.floor(torch.log2(amax.clamp_min(1e-30)))), torch.ones_like(amax)).contiguous()
+            a.scal_scale = col_scale.data_ptr()
     with _timed("edge_bwd_by_dest" if by_dest else "edge_bwd_by_src"):
         rc = lib.egnn_edge_bwd_pass_f32(byref(a), _stream())
     _abi.check(rc, "egnn_edge_bwd_pass_f32")
@@ -424,7 +429,10 @@ def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, w
     if want_w2:
         out["w2"] = dw2.sum(dim=0)
     if ws_nat is not None:
-        out["ws"] = dws.sum(dim=0).t().contiguous()
+        if s_in > 1:                                          # one partial per wave (every 4th row of the array), times col_scale
+            out["ws"] = (dws.view(n_slabs * 4, 4, s_in, hp)[:, 0].sum(dim=0) / col_scale[:, None]).t().contiguous()
+        else:
+            out["ws"] = dws.sum(dim=0).t().contiguous()
         out["scal"] = ds.sum(dim=0)
     return out
 

@@ -12,7 +12,7 @@ Backward = `_backward_native` (fp32, coordinate dimension 3, m_dim <= 16):
                egnn_edge_bwd_pass_f32 (csrc/edge_bwd.hip; `_edge_contract_fused`): one pass over the edges grouped by source node
                (d/d P_i, d/d W_s, d/d scalars) and one over the edges sorted by destination (d/d P_j, d/d W_2), everything
                recomputed and contracted in registers: nothing of size E x H reaches memory (8 GiB peak where the first native
-               backward needed 27).  More than one per-edge scalar (fourier features, edge features): `_edge_contract_dz`,
+               backward needed 27).  More than five per-edge scalars (fourier_features >= 2): `_edge_contract_dz`,
                the first native backward -- egnn_edge_bwd_dz_f32 writes dz and a, reductions / library GEMMs read them;
              * node-level fp32 library GEMMs give d/d feats and d/d edge_mlp.0 from the per-node sums.
            `_backward_recompute` (everything else, and the native path's reference in the tests): the whole layer re-evaluated
@@ -326,7 +326,7 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
     ent, seg = entry_list(eids, eids // k, bc * n)
     # the contractions over all edges ride along: d/d W_s and d/d scalars with the first pass, d/d W_2 with the second (each keeps
     # its accumulators in registers; one pass carrying both drops from 3 to 2 workgroups per CU)
-    o = _ops.edge_bwd_pass(w, proj, i32, gu16, gu_scale, sc2, ent, bc, n, k, by_dest=False, ws_nat=w_s, want_w2=_FUSED_SPLIT == "both")
+    o = _ops.edge_bwd_pass(w, proj, i32, gu16, gu_scale, sc2, ent, bc, n, k, by_dest=False, ws_nat=w_s, want_w2=_FUSED_SPLIT == "both" and w["S"] == 1)
     g_ws, g_scal, g_w2 = o["ws"], o["scal"], o.get("w2")
     ident = torch.arange(o["rows"].shape[0], device=dev)
     gz_i = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n)
@@ -378,7 +378,7 @@ def _backward_native(ctx, g_node, g_coors):
     if g_coors is None:
         g_coors = torch.zeros_like(coors)
     u_all = ctx.u_pre.view(b, n, k, 16)
-    fused = _NATIVE_MODE != "dz" and s_in == 1           # (the by-source pass of egnn_edge_bwd_pass_f32 is built for S = 1)
+    fused = _NATIVE_MODE != "dz" and s_in <= 5           # (egnn_edge_bwd_pass_f32 is built for up to 5 per-edge scalars)
     if fused:
         # nothing of size E x H: graphs are only chunked to keep the P table below 4 GB (32-bit buffer offsets) and E below 2^31
         # (the kernel addresses both with signed 32-bit scalar offsets)

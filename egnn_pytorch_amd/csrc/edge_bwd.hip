@@ -117,7 +117,7 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo)
 // NM: first-layer MFMAs of the scalar term (egnn_edge_mfmas(S)); ST: register bound on S (per-edge scalars); WANT_W2: also
 // d/d W_2; WANT_S: also d/d W_s and d/d s; CH: steps of 32 hidden columns the workgroup owns
 template <int NM, int ST, bool WANT_W2, bool WANT_S, int CH>
-__global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EGNN_BWD_W2_BLOCKS : (WANT_S ? EGNN_BWD_S_BLOCKS : EGNN_BWD_DEST_BLOCKS))) void edge_bwd_kernel(const egnn_edge_bwd_args p)
+__global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WANT_S) && ST > 1)) ? 2 : (WANT_W2 ? EGNN_BWD_W2_BLOCKS : (WANT_S ? EGNN_BWD_S_BLOCKS : EGNN_BWD_DEST_BLOCKS))) void edge_bwd_kernel(const egnn_edge_bwd_args p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* w2t = reinterpret_cast<_Float16*>(smem);                                  // [CH][hb][hi|lo][64][4] halves
@@ -179,13 +179,20 @@ __global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EG
     const float* xr = xch + (4 * g) * XLD + hq;
 
     f32x4 dW2[WANT_W2 ? 2 * CH : 1];              // d/d W_2: rows c = 4g + r, column = chunk column 16 blk + hq
-    float dws[WANT_S ? 2 * CH : 1][ST];          // d/d W_s partial over this lane group's edges
+    // d/d W_s.  S = 1: per-lane FMAs against the entry's scalar (one register per column block).  S > 1: like d/d W_2, three
+    // MFMAs per tile with A = the tile's scalars transposed (split f16, columns pre-scaled by the host's powers of two) -- one
+    // accumulator tile per column block whatever S is, instead of S registers of scalars per entry and S per block.
+    constexpr bool MW = WANT_S && ST > 1;
+    float dws[(WANT_S && !MW) ? 2 * CH : 1][ST];  // d/d W_s partial over this lane group's edges
+    f32x4 dWsm[MW ? 2 * CH : 1];                  // rows c = 4g + r (scalar index), column = chunk column 16 blk + hq
 #pragma unroll
     for (int bl = 0; bl < (WANT_W2 ? 2 * CH : 1); ++bl) dW2[bl] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int bl = 0; bl < (WANT_S ? 2 * CH : 1); ++bl)
+    for (int bl = 0; bl < ((WANT_S && !MW) ? 2 * CH : 1); ++bl)
 #pragma unroll
         for (int c = 0; c < ST; ++c) dws[bl][c] = 0.f;
+#pragma unroll
+    for (int bl = 0; bl < (MW ? 2 * CH : 1); ++bl) dWsm[bl] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int64_t rounds_total = p.L / 128;
     const int64_t per_slab = (rounds_total + p.n_slabs - 1) / p.n_slabs;
@@ -226,7 +233,8 @@ __global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EG
         // per register r: entry 16 t + 4 g + r (the edges this lane's data registers belong to).  The 16 entries of a tile share
         // their key node (the host pads every node's entries to whole tiles): one own row and one partial row per tile.
         int ownoff[2];                             // byte offset of the tile's own row: wave-uniform, rides in the scalar offset
-        float sv[2][4][ST];
+        float sv[2][4][MW ? 1 : ST];
+        f16x4 sth[2], stl[2];                      // MW: the tile's scalars transposed, A fragment [m = scalar][k = entry]
         f16x4 gth[2], gtl[2], ind[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EG
             const int ig0 = ev0 / K;                                 // global node (b N + i)
             const int jg0 = p.idx ? (ig0 / N) * N + p.idx[ev0] : (ig0 / N) * N + (ev0 - ig0 * K);
             ownoff[t] = (int)((size_t)(p.by_dest ? jg0 : ig0) * p.ldp * 4);
-            f32x4 gt = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 gt = f32x4{0.f, 0.f, 0.f, 0.f}, st4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int eid = e4[r];
@@ -244,15 +252,19 @@ __global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EG
                 // rows 0, 4, 8, 12 of D = the tile's sum over its valid entries: register 0 of every lane group holds it, and all
                 // four write the same value to the tile's partial row (no per-lane row select, no spare row)
                 ind[t][r] = (valid && (hq & 3) == 0) ? (_Float16)1.f : (_Float16)0.f;
-                if constexpr (WANT_S) {
+                if constexpr (WANT_S && !MW) {
 #pragma unroll
                     for (int c = 0; c < ST; ++c) sv[t][r][c] = (valid && c < S) ? p.scal[(size_t)eid * S + c] : 0.f;
+                }
+                if constexpr (MW) {
+                    if (valid && hq < S) st4[r] = p.scal[(size_t)eid * S + hq] * p.scal_scale[hq];
                 }
                 if constexpr (WANT_W2) {
                     if (valid) gt[r] = p.gU[(size_t)eid * 16 + hq];
                 }
             }
             if constexpr (WANT_W2) split4(gt * (p.gu_scale * GT_UP), gth[t], gtl[t]);
+            if constexpr (MW) split4(st4 * GT_UP, sth[t], stl[t]);
         }
         // whole-line gathers of the other endpoint's rows: lane l fetches chunk l & 7 of entry 8 qq + (l >> 3)
         uint32_t goff[4];
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EG
 #pragma unroll
                             for (int c = 0; c < ST; ++c) {
                                 ps[t][r][c] = __builtin_fmaf(dz4[r], wsn[c], ps[t][r][c]);
-                                dws[2 * st + hb][c] = __builtin_fmaf(dz4[r], sv[t][r][c], dws[2 * st + hb][c]);
+                                if constexpr (!MW) dws[2 * st + hb][c] = __builtin_fmaf(dz4[r], sv[t][r][c], dws[2 * st + hb][c]);
                             }
                     }
                     // (hi, lo) halves: hi = RNE pair conversion, lo = product - hi as ONE v_fma_mix_f32 per value (the f16 operand read in place)
@@ -380,6 +392,13 @@ __global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EG
                     dP = __builtin_amdgcn_mfma_f32_16x16x16f16(ind[t], dl, dP, 0, 0, 0);
                     // (no branch around the store: the step stays one basic block and the scheduler interleaves the two tiles)
                     buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)(q0 + 16 * t) >> 4) * row_bytes) + (hoff + 16 * hb) * 4, dP[0] * rows_scale);
+                    if constexpr (MW) {
+                        f32x4 d = dWsm[2 * st + hb];
+                        d = __builtin_amdgcn_mfma_f32_16x16x16f16(sth[t], dh, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x16f16(sth[t], dl, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x16f16(stl[t], dh, d, 0, 0, 0);
+                        dWsm[2 * st + hb] = d;
+                    }
                     if constexpr (WANT_W2) {
                         f16x4 ah, al;
 #pragma unroll
@@ -438,10 +457,15 @@ __global__ __launch_bounds__(BW_THREADS, (WANT_W2 && WANT_S) ? 2 : (WANT_W2 ? EG
 #pragma unroll
                     for (int r = 0; r < 4; ++r) p.dW2_part[(w * 16 + 4 * g + r) * p.Hp + col] = dW2[bl][r] * w2_out_scale;
                 }
-                if constexpr (WANT_S) {
+                if constexpr (WANT_S && !MW) {
 #pragma unroll
                     for (int c = 0; c < ST; ++c)
                         if (c < S) p.dWs_part[((w * 4 + g) * S + c) * p.Hp + col] = dws[bl][c] * rows_scale;
+                }
+                if constexpr (MW) {                             // one partial per wave (rows = scalars); the host undoes scal_scale
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * g + r < S) p.dWs_part[((w * 4) * S + 4 * g + r) * p.Hp + col] = dWsm[bl][r] * (rows_scale * (1.0f / GT_UP));
                 }
             }
         }
@@ -461,7 +485,11 @@ int launch_v(const egnn_edge_bwd_args& a, hipStream_t s)
 template <int NM, int ST>
 int launch(const egnn_edge_bwd_args& a, hipStream_t s)
 {
-    if (a.dW2_part && a.dWs_part) return launch_v<NM, ST, true, true, CH_S>(a, s);
+    if (a.dW2_part && a.dWs_part) {
+        // (everything in one pass: built for S = 1 only; with more scalars its registers do not fit 2 workgroups per CU)
+        if constexpr (ST == 1) return launch_v<NM, ST, true, true, CH_S>(a, s);
+        else return EGNN_E_UNSUPPORTED;
+    }
     if (a.dW2_part) return launch_v<NM, ST, true, false, CH_W2>(a, s);
     if (a.dWs_part) return launch_v<NM, ST, false, true, CH_S>(a, s);
     return launch_v<NM, ST, false, false, CH_S>(a, s);
@@ -483,14 +511,15 @@ extern "C" int egnn_edge_bwd_pass_f32(const egnn_edge_bwd_args* args, void* stre
     if (a.E != (int64_t)a.B * a.N * a.K || a.E >= ((int64_t)1 << 31) || a.L >= ((int64_t)1 << 31)) return EGNN_E_SHAPE;
     if ((size_t)a.B * a.N * a.ldp * 4 >= ((size_t)1 << 31)) return EGNN_E_UNSUPPORTED;           // 32-bit (signed scalar) buffer offsets into the P tables
     if ((size_t)(a.L >> 4) * a.ld_rows * 4 >= ((size_t)1 << 31)) return EGNN_E_UNSUPPORTED;         // (scalar offsets are signed)    // ... and into the partial rows
-    // built for S = 1 (the distance is the only per-edge scalar: every BASELINE config but c4): the by-source pass keeps 8 S
-    // registers of scalars, 8 S of d/d s and 2 CH S of d/d W_s next to the d/d W_2 tiles.  More scalars take egnn_edge_bwd_dz_f32.
-    if (a.S != 1 || a.wst_terms != 4) return EGNN_E_UNSUPPORTED;
+    if (a.S > 5 || a.wst_terms != 4 * (a.S <= 1 ? 1 : (a.S <= 4 ? 3 : 4))) return EGNN_E_UNSUPPORTED;
+    if (a.dWs_part && a.S > 1 && !a.scal_scale) return EGNN_E_NULLPTR;
     if (!(a.ws_inv_scale > 0.f) || !(a.gu_scale > 0.f) || !(a.inv_scale > 0.f)) return EGNN_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(a.Pi) & 15) || (reinterpret_cast<uintptr_t>(a.Pj) & 15) || (reinterpret_cast<uintptr_t>(a.W2Th) & 15) ||
         (reinterpret_cast<uintptr_t>(a.gU) & 15) || (reinterpret_cast<uintptr_t>(a.ent) & 15) ||
         (reinterpret_cast<uintptr_t>(a.Wst) & 3))
         return EGNN_E_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return launch<1, 1>(a, s);
+    if (a.S == 1) return launch<1, 1>(a, s);
+    if (a.S <= 4) return launch<3, 4>(a, s);
+    return launch<4, 5>(a, s);
 }

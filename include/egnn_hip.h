@@ -256,11 +256,12 @@ int egnn_edge_bwd_dz_f32(const egnn_edge_args* args, void* stream);
  *     part_rows[q / 16, :]   = sum of dz over tile q / 16     (d/d P_i or d/d P_j after egnn_rows_gather_sum_f32 over each node's
  *                              consecutive tiles -- fixed order, no float atomics)
  *     dW2_part (n_slabs * 4, 16, Hp),  if not NULL:  partial sums of gU^T a  -> d loss / d edge_mlp.3.weight  = sum over dim 0
- *     dWs_part (n_slabs * 16, S, Hp) and ds_part (n_chunks, E, S), if not NULL (both or neither): partial sums of s^T dz
+ *     dWs_part (n_slabs * 16, S, Hp) -- S > 1: rows multiples of 4 only, times scal_scale[c] -- and ds_part (n_chunks, E, S),
+ *                              if not NULL (both or neither): partial sums of s^T dz
  *                              -> d loss / d (scalar columns of edge_mlp.0.weight), and dz W_s over each column chunk
  *                              -> d loss / d scalars = sum over dim 0   (n_chunks = ceil(Hp / 32 / egnn_edge_bwd_chunk_steps()))
  * The all-edge contractions can ride with either pass (each edge appears once in both lists).  Every element of the outputs is
- * written (no zero-fill needed).  Limits: S = 1 (the distance is the only per-edge scalar; EGNN_E_UNSUPPORTED otherwise --
+ * written (no zero-fill needed) except the unused rows of dWs_part at S > 1.  Limits: S <= 5 (EGNN_E_UNSUPPORTED beyond --
  * egnn_edge_bwd_dz_f32 covers those), m_dim <= 16, B*N*K < 2^31, the P table and the partial rows below 4 GB each.  All pointers
  * device memory. */
 typedef struct egnn_edge_bwd_args {
@@ -283,7 +284,8 @@ typedef struct egnn_edge_bwd_args {
     float gu_scale;             /* power of two applied to gU before its fp16 split */
     float inv_scale;            /* 1 / (gu_scale * scale of W2Th) */
     const float* scal;          /* (E, S) fp32 per-edge scalars [fourier..., dist, edges...] in natural units */
-    const float* Ws;            /* (Hp, S) fp32 scalar columns of edge_mlp.0.weight, rows >= H zero (by-source pass) */
+    const float* Ws;            /* (Hp, S) fp32 scalar columns of edge_mlp.0.weight, rows >= H zero (with dWs_part) */
+    const float* scal_scale;    /* (S) powers of two that bring each column of scal into [1, 2) at its maximum (with dWs_part, S > 1) */
     float* part_rows;           /* out: (L / 16 + 1, ld_rows) fp32, one row per tile, the last row scratch */
     int64_t ld_rows;
     float* dW2_part;            /* out or NULL */

@@ -323,17 +323,19 @@ def test_rows_gather_sum_fixed_order():
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), atol=1e-5)
 
 
-@pytest.mark.parametrize("b,n,k,dim,hub", [(2, 40, 8, 32, False), (1, 64, 32, 64, False), (3, 50, 5, 32, True), (1, 33, 16, 32, True)])
-def test_edge_bwd_pass_contractions_match_float64(b, n, k, dim, hub):
+@pytest.mark.parametrize("b,n,k,dim,hub,extra", [(2, 40, 8, 32, False, {}), (1, 64, 32, 64, False, {}), (3, 50, 5, 32, True, {}),
+                                                 (1, 33, 16, 32, True, {}), (2, 40, 16, 32, False, dict(edge_dim=4)),
+                                                 (1, 48, 8, 32, True, dict(fourier_features=1)), (1, 40, 8, 16, False, dict(edge_dim=1))])
+def test_edge_bwd_pass_contractions_match_float64(b, n, k, dim, hub, extra):
     """egnn_edge_bwd_pass_f32 (nothing of size E x H in memory: z, SiLU(z), dz recomputed and contracted in registers) and
     egnn_edge_bwd_dz_f32 (dz / SiLU(z) through HBM + library reductions) against the same contractions in float64:
     d/d P_i, d/d P_j (per node), d/d W_s, d/d scalars, d/d W_2.  K below / equal / above a 16-entry tile, and `hub` = a few nodes
     with very large in-degree (one key over many tiles) next to nodes nobody points to."""
     from egnn_pytorch_amd import EGNN, _weights, autograd
     g = torch.Generator().manual_seed(100 * n + k)
-    layer = EGNN(dim=dim, num_nearest_neighbors=k).cuda()
+    layer = EGNN(dim=dim, num_nearest_neighbors=k, **extra).cuda()
     w = layer.packed_weights()
-    h, hp, m = w["H"], w["Hp"], layer.m_dim
+    h, hp, m, s_in = w["H"], w["Hp"], layer.m_dim, w["S"]
     feats = torch.randn(b, n, dim, generator=g).cuda()
     idx = torch.randint(0, n, (b, n, k), generator=g)
     if hub:
@@ -342,7 +344,8 @@ def test_edge_bwd_pass_contractions_match_float64(b, n, k, dim, hub):
     idx32 = idx.to(torch.int32).cuda()
     e = b * n * k
     coors = (torch.randn(b, n, 3, generator=g) * 1.5).cuda()
-    scal = autograd.edge_scalars(layer, coors, None, idx32.long())[1].reshape(e, 1).contiguous()        # squared distances
+    edges = torch.randn(b, n, n, extra["edge_dim"], generator=g).cuda() if extra.get("edge_dim") else None
+    scal = autograd.edge_scalars(layer, coors, edges, idx32.long())[1].reshape(e, s_in).contiguous()    # [fourier, dist, edge feats]
     gu = torch.randn(e, m, generator=g) * 1e-3
     gu[torch.rand(e, generator=g) < 0.2] = 0.0                                  # masked edges carry no gradient
     gu16 = torch.zeros(e, 16)
@@ -351,15 +354,15 @@ def test_edge_bwd_pass_contractions_match_float64(b, n, k, dim, hub):
     gu_scale = _weights.pow2_scale(float(gu16.abs().max()))
     lin0, lin3 = layer.edge_mlp[0], layer.edge_mlp[3]
     w1 = lin0.weight.detach()
-    w_s = torch.zeros(hp, 1, device="cuda")
+    w_s = torch.zeros(hp, s_in, device="cuda")
     w_s[:h] = w1[:, 2 * dim:]
     f2d = feats.view(b * n, dim)
     outs = {}
     for name, fn in (("fused", autograd._edge_contract_fused), ("dz", autograd._edge_contract_dz)):
         with torch.no_grad():
-            outs[name] = fn(layer, w, f2d, coors, None, scal, idx32, gu16, gu_scale, w_s, b, n, k, k >= 6)
+            outs[name] = fn(layer, w, f2d, coors, edges, scal, idx32, gu16, gu_scale, w_s, b, n, k, k >= 6)
     with torch.no_grad():
-        again = autograd._edge_contract_fused(layer, w, f2d, coors, None, scal, idx32, gu16, gu_scale, w_s, b, n, k, k >= 6)
+        again = autograd._edge_contract_fused(layer, w, f2d, coors, edges, scal, idx32, gu16, gu_scale, w_s, b, n, k, k >= 6)
     assert all(torch.equal(x, y) for x, y in zip(outs["fused"], again))        # fixed summation order: bit-reproducible
     # float64 reference
     w1d, b1d, w2d = w1.double(), lin0.bias.detach().double(), lin3.weight.detach().double()
