@@ -370,6 +370,7 @@ def main():
                                      "mask": "ragged" if args.ragged_mask else "all-true"},
                           "kernel_ms_per_step": {k: round(v * (len(pt.summary()[k]) / 5), 4) for k, v in per_kernel.items()},
                           "layers": depth,
+                          **({"train_step": train_step(layer, feats, coors, mask, edges, adj)} if args.train_step and world == 1 and not is_net else {}),
                           **({} if args.no_cpu_baseline or world != 1 else {"cpu_baseline": cpu_baseline(args.workload, kwargs, n)})}),
               flush=True)
     elif rank == 0:
