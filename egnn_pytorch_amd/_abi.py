@@ -27,7 +27,7 @@ SYMBOLS = (
     "egnn_edge_fused_f32", "egnn_spatial_order_f32", "egnn_linear_hl_f32", "egnn_split_f16", "egnn_node_prep_hl",
     "egnn_packed_halves", "egnn_adj_expand_u8", "egnn_adj_expand_workspace_bytes", "egnn_edge_mfmas",
     "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32",
-    "egnn_edge_bwd_dz_f32", "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
+    "egnn_edge_bwd_dz_f32", "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_tail_bwd_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
     "egnn_induced_attn_f32", "egnn_token_attn_f32",
 )
 
@@ -66,6 +66,16 @@ class EdgeBwdArgs(Structure):
         ("gu_scale", c_float), ("inv_scale", c_float), ("scal", c_void_p), ("Ws", c_void_p), ("scal_scale", c_void_p),
         ("part_rows", c_void_p), ("ld_rows", c_int64),
         ("dW2_part", c_void_p), ("dWs_part", c_void_p), ("ds_part", c_void_p),
+    ]
+
+
+class EdgeTailArgs(Structure):
+    """Mirror of `struct egnn_edge_tail_args` (include/egnn_hip.h)."""
+    _fields_ = [
+        ("B", c_int32), ("N", c_int32), ("K", c_int32), ("norm_coors", c_int32), ("clamp", c_float), ("eps", c_float),
+        ("u", c_void_p), ("coors", c_void_p), ("idx", c_void_p), ("pair_mask", c_void_p), ("g_coors_out", c_void_p),
+        ("g_msum", c_void_p), ("W3", c_void_p), ("b3", c_void_p), ("W4", c_void_p), ("b4", c_void_p), ("scale", c_void_p),
+        ("gU", c_void_p), ("g_rel", c_void_p), ("g_hid", c_void_p), ("a3", c_void_p), ("g_w", c_void_p), ("g_scale", c_void_p),
     ]
 
 
@@ -197,6 +207,8 @@ def load():
     lib.egnn_edge_bwd_dz_f32.argtypes = [POINTER(EdgeArgs), c_void_p]
     lib.egnn_edge_bwd_pass_f32.restype = c_int
     lib.egnn_edge_bwd_pass_f32.argtypes = [POINTER(EdgeBwdArgs), c_void_p]
+    lib.egnn_edge_tail_bwd_f32.restype = c_int
+    lib.egnn_edge_tail_bwd_f32.argtypes = [POINTER(EdgeTailArgs), c_void_p]
     lib.egnn_edge_bwd_chunk_steps.restype = c_int
     lib.egnn_edge_bwd_chunk_steps.argtypes = []
     lib.egnn_induced_attn_f32.restype = c_int

@@ -376,6 +376,32 @@ def rows_gather_sum(rows, order, seg_ptr, n_out):
     return out
 
 
+def edge_tail_bwd(u16, coors, idx32, pair_mask, g_coors_out, g_msum16, w3p, b3p, w4p, b4, scale, eps, clamp, b, n, k):
+    """egnn_edge_tail_bwd_f32 (include/egnn_hip.h): the per-edge closed-form backward behind edge_mlp's second Linear.
+    Returns (gU (E, 16), g_rel (E, 4), g_hid (E, 64), a3 (E, 64), g_w (E,), g_scale (E,) or None)."""
+    dev = u16.device
+    e = b * n * k
+    f32 = dict(dtype=torch.float32, device=dev)
+    gu = empty(e, 16, **f32)
+    g_rel = empty(e, 4, **f32)
+    g_hid = empty(e, 64, **f32)
+    a3 = empty(e, 64, **f32)
+    g_w = empty(e, **f32)
+    g_scale = empty(e, **f32) if scale is not None else None
+    a = _abi.EdgeTailArgs()
+    a.B, a.N, a.K, a.norm_coors = b, n, k, int(scale is not None)
+    a.clamp = -1.0 if clamp is None else float(clamp)
+    a.eps = float(eps)
+    a.u, a.coors, a.idx, a.pair_mask = u16.data_ptr(), coors.data_ptr(), _ptr(idx32), _ptr(pair_mask)
+    a.g_coors_out, a.g_msum = g_coors_out.data_ptr(), g_msum16.data_ptr()
+    a.W3, a.b3, a.W4, a.b4, a.scale = w3p.data_ptr(), b3p.data_ptr(), w4p.data_ptr(), b4.data_ptr(), _ptr(scale)
+    a.gU, a.g_rel, a.g_hid, a.a3, a.g_w, a.g_scale = gu.data_ptr(), g_rel.data_ptr(), g_hid.data_ptr(), a3.data_ptr(), g_w.data_ptr(), _ptr(g_scale)
+    with _timed("edge_tail_bwd"):
+        rc = _abi.load().egnn_edge_tail_bwd_f32(byref(a), _stream())
+    _abi.check(rc, "egnn_edge_tail_bwd_f32")
+    return gu, g_rel, g_hid, a3, g_w, g_scale
+
+
 # rounds (of 128 entries) one workgroup of egnn_edge_bwd_pass_f32 streams through its column chunk: short enough that the
 # workgroups of one graph and one chunk (they share the gathered rows) are many and run side by side on an XCD
 ROUNDS_PER_SLAB = int(os.environ.get("EGNN_BWD_ROUNDS_PER_SLAB", "8"))

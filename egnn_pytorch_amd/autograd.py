@@ -39,6 +39,7 @@ _NATIVE_MODE = os.environ.get("EGNN_NATIVE_BACKWARD", "1")
 _NATIVE = _NATIVE_MODE != "0"
 # which pass of the fused backward carries d/d W_2: "dest" (default), "both" = the by-source pass carries everything (tuning knob)
 _FUSED_SPLIT = os.environ.get("EGNN_BWD_SPLIT", "dest")
+_TAIL_KERNEL = os.environ.get("EGNN_BWD_TAIL_KERNEL", "1") != "0"      # 0: the per-edge chain behind u through autograd
 _FUSED_MAX_GRAPHS = 0                 # tests: force the chunking over graphs that very large batches need (0 = by size only)
 _NATIVE_BUDGET_BYTES = 24 << 30                      # dZ + SiLU(z), 2 x E x Hp fp32, per chunk of graphs
 
@@ -165,6 +166,62 @@ def layer_tail(layer, feats, coors, u, rel, mask, idx, rank, valid_radius):
             m_i = m_ij.sum(dim=2)
         node_out = layer.node_mlp(torch.cat((layer.node_norm(feats), m_i), dim=-1)) + feats      # (:335-337)
     return node_out, coors_out
+
+
+def tail_edge_backward(layer, u, coors, idx, pair_mask, g_coors_out, g_msum):
+    """The per-edge part of the backward of `layer_tail` in closed form (what csrc/edge_tail.hip evaluates one edge per lane;
+    this torch version is its specification and the CPU tests' subject): given
+        u (B,N,K,m) the output of edge_mlp's second Linear, g_coors_out (B,N,3) = d loss / d coors_out and
+        g_msum (B,N,m) = d loss / d (sum over k of the pair-masked m_ij)  (sum pooling: d/d m_i; mean: that / count),
+    returns d loss / d u (B,N,K,m), d loss / d rel (B,N,K,3; rel = x_i - x_j, without the distance path), and what the parameter
+    gradients of coors_mlp / CoorsNorm are sums of: g_hid (E, 4m) = d/d (pre-activation of coors_mlp's SiLU), a3 (E, 4m) its
+    activation, g_w (E,) = d/d (coors_mlp's output), g_scale (E,) the per-edge terms of d/d coors_norm.scale.
+    Covers: no edge gate, coordinate dimension 3; masks, CoorsNorm, clamp as configured."""
+    b, n, k, m = u.shape
+    lin3, lin4 = layer.coors_mlp[0], layer.coors_mlp[3]
+    w3, b3, w4, b4 = lin3.weight, lin3.bias, lin4.weight[0], lin4.bias[0]
+    sg_u = torch.sigmoid(u)
+    mm = u * sg_u                                                               # m_ij = SiLU(u)
+    hid = mm @ w3.t() + b3
+    sg_h = torch.sigmoid(hid)
+    a3 = hid * sg_h
+    w = a3 @ w4 + b4                                                            # (B,N,K)
+    if idx is None:
+        rel = coors[:, :, None, :] - coors[:, None, :, :]
+    else:
+        bi = torch.arange(b, device=coors.device)[:, None, None]
+        rel = coors[:, :, None, :] - coors[bi, idx]
+    g_scale = None
+    if layer.norm_coors:
+        eps, scale = layer.coors_norm.eps, layer.coors_norm.scale
+        rn = rel.norm(dim=-1, keepdim=True)
+        den = rn.clamp(min=eps)
+        relp = rel / den * scale
+    else:
+        relp = rel
+    wm = w if pair_mask is None else w.masked_fill(~pair_mask, 0.0)
+    c = layer.coor_weights_clamp_value
+    wc = wm if c is None else wm.clamp(min=-c, max=c)
+    g = g_coors_out[:, :, None, :]                                              # broadcast over k
+    g_wc = (g * relp).sum(dim=-1)
+    g_relp = wc[..., None] * g
+    g_wm = g_wc if c is None else torch.where((wm >= -c) & (wm <= c), g_wc, torch.zeros_like(g_wc))
+    g_w = g_wm if pair_mask is None else g_wm.masked_fill(~pair_mask, 0.0)
+    g_a3 = g_w[..., None] * w4
+    g_hid = g_a3 * (sg_h * (1 + hid * (1 - sg_h)))
+    g_m = g_hid @ w3
+    gm_pool = g_msum[:, :, None, :].expand(b, n, k, m)
+    g_m = g_m + (gm_pool if pair_mask is None else gm_pool.masked_fill(~pair_mask[..., None], 0.0))
+    g_u = g_m * (sg_u * (1 + u * (1 - sg_u)))
+    if layer.norm_coors:
+        dot = (g_relp * rel).sum(dim=-1, keepdim=True)
+        g_scale = (dot / den).reshape(-1)
+        g_rel = g_relp * (scale / den) - torch.where(rn >= eps, dot * scale / (den * den) * (rel / rn.clamp(min=1e-30)), torch.zeros_like(rel))
+    else:
+        g_rel = g_relp
+    e = b * n * k
+    return dict(g_u=g_u, g_rel=g_rel, g_hid=g_hid.reshape(e, -1), a3=a3.reshape(e, -1), g_w=g_w.reshape(e), g_scale=g_scale,
+                m=mm.reshape(e, m))
 
 
 def layer_given_neighbors(layer, feats, coors, edges, mask, idx, rank, valid_radius, factorised=True):
@@ -395,6 +452,10 @@ def _backward_native(ctx, g_node, g_coors):
     w1p[:h] = lin0.weight.detach()
     w_i, w_j, w_s = w1p[:, :dim].contiguous(), w1p[:, dim:2 * dim].contiguous(), w1p[:, 2 * dim:].contiguous()
     pi_split = k >= 6
+    # the per-edge chain behind u in closed form on the device (egnn_edge_tail_bwd_f32) where it applies: the standard layer without
+    # the edge gate; otherwise that part goes through autograd as well
+    tail_kernel = (_TAIL_KERNEL and layer.edge_gate is None and layer.coors_mlp is not None and layer.node_mlp is not None
+                   and m <= 16 and layer.coors_mlp[0].weight.shape[0] <= 64)
     for lo in range(0, b, step):
         hi_ = min(b, lo + step)
         bc = hi_ - lo
@@ -404,33 +465,109 @@ def _backward_native(ctx, g_node, g_coors):
         i32 = None if idx32 is None else idx32[lo:hi_].contiguous()
         i64 = None if i32 is None else i32.long()
         r0 = None if rank is None else rank[lo:hi_]
-        # ---- 1. the small tail, through autograd
-        with torch.enable_grad():
-            f = f0.detach().requires_grad_(True)
-            c = c0.detach().requires_grad_(True)
-            e = None if e0 is None else e0.detach().requires_grad_(True)
-            u = u_all[lo:hi_, :, :, :m].detach().requires_grad_(True)
-            rel, scal = edge_scalars(layer, c, e, i64)
-            out_n, out_c = layer_tail(layer, f, c, u, rel, m0, i64, r0, ctx.valid_radius)
-            outs, gouts = [], []
-            for o, g in ((out_n, g_node[lo:hi_]), (out_c, g_coors[lo:hi_])):
-                if o.requires_grad:
-                    outs.append(o)
-                    gouts.append(g)
-            wrt = [u, f, c] + tail_params
-            tg = torch.autograd.grad(outs, wrt, gouts, allow_unused=True, retain_graph=True)
-        g_u = tg[0] if tg[0] is not None else torch.zeros_like(u)
-        if tg[1] is not None:
-            g_feats[lo:hi_] += tg[1]
-        if tg[2] is not None:
-            g_coors_in[lo:hi_] += tg[2]
-        for p, g in zip(tail_params, tg[3:]):
-            if g is not None:
-                grads_by_id[id(p)] += g
-        # ---- 2. the E x H work: d/d P_i, d/d P_j (per node), d/d W_s, d/d scalars, d/d W_2
         ec = bc * n * k
-        gu16 = torch.zeros(ec, 16, dtype=torch.float32, device=feats.device)
-        gu16[:, :m] = g_u.reshape(ec, m)
+        if tail_kernel:
+            # ---- 1. behind u: the node-level modules through autograd (node_norm, node_mlp, residual: from the pooled messages),
+            # the per-edge chain (second SiLU, masks, coors_mlp, CoorsNorm, clamp, coordinate update, pooling) in closed form on
+            # egnn_edge_tail_bwd_f32 -- `tail_edge_backward` is its specification
+            with torch.no_grad():
+                u16 = u_all[lo:hi_].contiguous()
+                pm = None
+                if m0 is not None:
+                    if i64 is None:
+                        pm = m0[:, :, None] & m0[:, None, :]
+                    else:
+                        bi = torch.arange(bc, device=feats.device)[:, None, None]
+                        pm = m0[:, :, None] & m0[bi, i64] & (r0 <= ctx.valid_radius)
+                mm = torch.nn.functional.silu(u16)                                           # (bc, n, k, 16), columns >= m are 0
+                mmask = mm if pm is None else mm.masked_fill(~pm[..., None], 0.0)
+                cnt = None
+                if layer.m_pool_method == "mean":
+                    if pm is not None:
+                        cnt = pm.sum(dim=-1, keepdim=True).to(mm.dtype)
+                        m_i = (mmask.sum(dim=2) / cnt.clamp(min=1e-8)).masked_fill(cnt == 0, 0.0)
+                    else:
+                        m_i = mmask.mean(dim=2)
+                else:
+                    m_i = mmask.sum(dim=2)
+                del mmask
+            with torch.enable_grad():
+                f = f0.detach().requires_grad_(True)
+                mi = m_i[..., :m].detach().requires_grad_(True)
+                c = c0.detach().requires_grad_(True)
+                e = None if e0 is None else e0.detach().requires_grad_(True)
+                rel, scal = edge_scalars(layer, c, e, i64)                                   # (only the scalars' graph is used below)
+                out_n = layer.node_mlp(torch.cat((layer.node_norm(f), mi), dim=-1)) + f
+                node_params = list(layer.node_norm.parameters()) + list(layer.node_mlp.parameters())
+                tg = torch.autograd.grad([out_n], [f, mi] + node_params, [g_node[lo:hi_]], allow_unused=True)
+            if tg[0] is not None:
+                g_feats[lo:hi_] += tg[0]
+            for p, g in zip(node_params, tg[2:]):
+                if g is not None:
+                    grads_by_id[id(p)] += g
+            with torch.no_grad():
+                g_msum = torch.zeros(bc, n, 16, dtype=torch.float32, device=feats.device)
+                if tg[1] is not None:
+                    g_mi = tg[1]
+                    if layer.m_pool_method == "mean":
+                        g_mi = (g_mi / cnt.clamp(min=1e-8)).masked_fill(cnt == 0, 0.0) if cnt is not None else g_mi / k
+                    g_msum[..., :m] = g_mi
+                lin_a, lin_b = layer.coors_mlp[0], layer.coors_mlp[3]
+                hid3 = lin_a.weight.shape[0]
+                w3p = torch.zeros(64, 16, dtype=torch.float32, device=feats.device)
+                w3p[:hid3, :m] = lin_a.weight.detach()
+                b3p = torch.zeros(64, dtype=torch.float32, device=feats.device)
+                b3p[:hid3] = lin_a.bias.detach()
+                w4p = torch.zeros(64, dtype=torch.float32, device=feats.device)
+                w4p[:hid3] = lin_b.weight.detach()[0]
+                norm = layer.norm_coors
+                gu16, g_rel, g_hid, a3, g_w, g_sc = _ops.edge_tail_bwd(
+                    u16, c0, i32, None if pm is None else pm.contiguous().view(torch.uint8), g_coors[lo:hi_].contiguous(), g_msum, w3p, b3p, w4p,
+                    lin_b.bias.detach().contiguous(), layer.coors_norm.scale.detach() if norm else None,
+                    layer.coors_norm.eps if norm else 0.0, layer.coor_weights_clamp_value, bc, n, k)
+                grads_by_id[id(lin_a.weight)] += _tn(g_hid, mm.view(ec, 16))[:hid3, :m]
+                grads_by_id[id(lin_a.bias)] += g_hid.sum(dim=0)[:hid3]
+                grads_by_id[id(lin_b.weight)] += _tn(g_w[:, None], a3)[:, :hid3]
+                grads_by_id[id(lin_b.bias)] += g_w.sum()[None]
+                if norm:
+                    grads_by_id[id(layer.coors_norm.scale)] += g_sc.sum()[None]
+                del g_hid, a3, mm
+                # coordinates: the residual, rel = x_i - x_j at the source (sum over a node's edges) and at the neighbour
+                g_coors_in[lo:hi_] += g_coors[lo:hi_] + g_rel.view(bc, n, k, 4).sum(dim=2)[..., :3]
+                if i64 is None:
+                    g_coors_in[lo:hi_] -= g_rel.view(bc, n, n, 4).sum(dim=1)[..., :3]
+                else:
+                    dest = (i64 + (torch.arange(bc, device=feats.device) * n)[:, None, None]).view(-1)
+                    dest_sorted, by_dest = torch.sort(dest, stable=True)
+                    seg = torch.searchsorted(dest_sorted, torch.arange(bc * n + 1, device=feats.device))
+                    g_coors_in[lo:hi_] -= _ops.rows_gather_sum(g_rel, by_dest, seg, bc * n).view(bc, n, 4)[..., :3]
+        else:
+            # ---- 1. the small tail, through autograd
+            with torch.enable_grad():
+                f = f0.detach().requires_grad_(True)
+                c = c0.detach().requires_grad_(True)
+                e = None if e0 is None else e0.detach().requires_grad_(True)
+                u = u_all[lo:hi_, :, :, :m].detach().requires_grad_(True)
+                rel, scal = edge_scalars(layer, c, e, i64)
+                out_n, out_c = layer_tail(layer, f, c, u, rel, m0, i64, r0, ctx.valid_radius)
+                outs, gouts = [], []
+                for o, g in ((out_n, g_node[lo:hi_]), (out_c, g_coors[lo:hi_])):
+                    if o.requires_grad:
+                        outs.append(o)
+                        gouts.append(g)
+                wrt = [u, f, c] + tail_params
+                tg = torch.autograd.grad(outs, wrt, gouts, allow_unused=True, retain_graph=True)
+            g_u = tg[0] if tg[0] is not None else torch.zeros_like(u)
+            if tg[1] is not None:
+                g_feats[lo:hi_] += tg[1]
+            if tg[2] is not None:
+                g_coors_in[lo:hi_] += tg[2]
+            for p, g in zip(tail_params, tg[3:]):
+                if g is not None:
+                    grads_by_id[id(p)] += g
+            gu16 = torch.zeros(ec, 16, dtype=torch.float32, device=feats.device)
+            gu16[:, :m] = g_u.reshape(ec, m)
+        # ---- 2. the E x H work: d/d P_i, d/d P_j (per node), d/d W_s, d/d scalars, d/d W_2
         amax = float(gu16.abs().max())
         gu_scale = _weights.pow2_scale(amax) if amax > 0 else 1.0
         with torch.no_grad():

@@ -1,0 +1,162 @@
+// egnn_edge_tail_bwd_f32 -- the per-edge part of the backward behind edge_mlp's second Linear, in closed form (gfx950).
+//
+// Reference semantics: autograd through egnn_pytorch.py:287 (second SiLU), :292-317 (pair mask, coors_mlp, CoorsNorm :67-77,
+// clamp, coordinate update) and :319-333 (message pooling), without the edge gate.  egnn_pytorch_amd/autograd.py::
+// tail_edge_backward is the specification (float64-equal to autograd of the restated layer, tests/test_autograd.py); this is
+// the same arithmetic, one edge per lane:
+//     m = SiLU(u),  hid = W3 m + b3,  a3 = SiLU(hid),  w = W4 a3 + b4,  rel' = CoorsNorm(x_i - x_j),  w_c = clamp(mask(w))
+//     g_w = mask(clamp'(g_coors_out[i] . rel')),   g_hid = g_w W4 SiLU'(hid),   g_u = (W3^T g_hid + mask(g_msum[i])) SiLU'(u),
+//     g_rel = CoorsNorm'(w_c g_coors_out[i])
+// Outputs per edge: g_u (what the E x H backward kernels take as gU), g_rel, and the two E x 64 arrays the parameter
+// gradients of coors_mlp are tall products of (g_hid, a3) plus g_w and the per-edge term of d/d CoorsNorm.scale.  In ATen this
+// chain is some thirty elementwise / reduction / small-GEMM passes over E x 16 and E x 64 tensors (6 ms at the north-star shape);
+// here one lane walks its edge's 64 hidden values with the weights broadcast from LDS.
+#include "egnn_common.h"
+
+namespace {
+
+constexpr int TM = 16;       // padded m_dim
+constexpr int TH = 64;       // padded hidden width of coors_mlp (4 m_dim)
+
+__global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail_args p)
+{
+    // weights in LDS (broadcast reads): as plain global loads they would sit in vector registers -- the compiler cannot prove
+    // them read-only next to the kernel's stores and does not use scalar loads
+    __shared__ __attribute__((aligned(16))) float sW3[TH * TM];
+    __shared__ float sb3[TH], sW4[TH];
+    for (int o = threadIdx.x; o < TH * TM; o += 256) sW3[o] = p.W3[o];
+    if (threadIdx.x < TH) { sb3[threadIdx.x] = p.b3[threadIdx.x]; sW4[threadIdx.x] = p.W4[threadIdx.x]; }
+    __syncthreads();
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t E = (int64_t)p.B * p.N * p.K;
+    if (e >= E) return;
+    const int K = p.K, N = p.N;
+    const int64_t ig = e / K;                                                  // global node (b N + i)
+    const int64_t jg = p.idx ? (ig / N) * N + p.idx[e] : (ig / N) * N + (e - ig * K);
+    const bool pm = p.pair_mask ? p.pair_mask[e] != 0 : true;
+
+    float u[TM], sgu[TM], m[TM];
+    {
+        const f32x4* up = reinterpret_cast<const f32x4*>(p.u + e * TM);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = up[q];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) u[4 * q + c] = v[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < TM; ++c) {
+        sgu[c] = egnn_sigmoid(u[c]);
+        m[c] = u[c] * sgu[c];
+    }
+    // coors_mlp forward (weights zero padded to 64 x 16 by the host: no run-time bounds).  The 64 hidden values are not kept:
+    // the backward loop below recomputes each (16 FMAs) instead of holding 64 registers across the scalar section.
+    float w = p.b4[0];
+#pragma unroll 2
+    for (int t = 0; t < TH; ++t) {
+        float h = sb3[t];
+#pragma unroll
+        for (int c = 0; c < TM; ++c) h = __builtin_fmaf(sW3[t * TM + c], m[c], h);
+        w = __builtin_fmaf(sW4[t], egnn_silu(h), w);
+    }
+    // relative coordinate, CoorsNorm
+    float rel[3], relp[3], g[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        rel[d] = p.coors[ig * 3 + d] - p.coors[jg * 3 + d];
+        g[d] = p.g_coors_out[ig * 3 + d];
+    }
+    float rn = 0.f, den = 1.f, scale = 1.f;
+    if (p.norm_coors) {
+        rn = sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]);
+        den = fmaxf(rn, p.eps);
+        scale = p.scale[0];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) relp[d] = rel[d] / den * scale;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) relp[d] = rel[d];
+    }
+    const float wm = pm ? w : 0.f;
+    const bool clamped = p.clamp >= 0.f && !(wm >= -p.clamp && wm <= p.clamp);
+    const float wc = p.clamp >= 0.f ? fminf(fmaxf(wm, -p.clamp), p.clamp) : wm;
+    const float g_wc = g[0] * relp[0] + g[1] * relp[1] + g[2] * relp[2];
+    const float g_w = (pm && !clamped) ? g_wc : 0.f;
+    float g_relp[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) g_relp[d] = wc * g[d];
+    f32x4 grel;
+    if (p.norm_coors) {
+        const float dot = g_relp[0] * rel[0] + g_relp[1] * rel[1] + g_relp[2] * rel[2];
+        if (p.g_scale) p.g_scale[e] = dot / den;
+        const float k1 = scale / den;
+        const float k2 = rn >= p.eps ? dot * scale / (den * den * fmaxf(rn, 1e-30f)) : 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) grel[d] = g_relp[d] * k1 - k2 * rel[d];
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) grel[d] = g_relp[d];
+    }
+    grel[3] = 0.f;
+    *reinterpret_cast<f32x4*>(p.g_rel + e * 4) = grel;
+    p.g_w[e] = g_w;
+
+    // coors_mlp backward; g_m accumulates W3^T g_hid
+    float gm[TM];
+#pragma unroll
+    for (int c = 0; c < TM; ++c) gm[c] = pm ? p.g_msum[ig * TM + c] : 0.f;
+    float* gh_out = p.g_hid + e * TH;
+    float* a3_out = p.a3 + e * TH;
+#pragma unroll 1
+    for (int t0 = 0; t0 < TH; t0 += 4) {
+        f32x4 ghv, a3v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = t0 + q;
+            float h = sb3[t];
+#pragma unroll
+            for (int c = 0; c < TM; ++c) h = __builtin_fmaf(sW3[t * TM + c], m[c], h);
+            const float sg = egnn_sigmoid(h);
+            a3v[q] = h * sg;
+            const float gh = g_w * sW4[t] * (sg * (1.0f + h * (1.0f - sg)));
+            ghv[q] = gh;
+#pragma unroll
+            for (int c = 0; c < TM; ++c) gm[c] = __builtin_fmaf(sW3[t * TM + c], gh, gm[c]);
+        }
+        *reinterpret_cast<f32x4*>(gh_out + t0) = ghv;
+        *reinterpret_cast<f32x4*>(a3_out + t0) = a3v;
+    }
+    f32x4* gup = reinterpret_cast<f32x4*>(p.gU + e * TM);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int cc = 4 * q + c;
+            v[c] = gm[cc] * (sgu[cc] * (1.0f + u[cc] * (1.0f - sgu[cc])));
+        }
+        gup[q] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int egnn_edge_tail_bwd_f32(const egnn_edge_tail_args* args, void* stream)
+{
+    if (!args) return EGNN_E_NULLPTR;
+    const egnn_edge_tail_args& a = *args;
+    if (!a.u || !a.coors || !a.g_coors_out || !a.g_msum || !a.W3 || !a.b3 || !a.W4 || !a.b4 || !a.gU || !a.g_rel || !a.g_hid || !a.a3 || !a.g_w)
+        return EGNN_E_NULLPTR;
+    if (a.norm_coors && (!a.scale || !a.g_scale)) return EGNN_E_NULLPTR;
+    if (a.B <= 0 || a.N <= 0 || a.K <= 0) return EGNN_E_SHAPE;
+    if (a.idx == nullptr && a.K != a.N) return EGNN_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(a.u) & 15) || (reinterpret_cast<uintptr_t>(a.gU) & 15) || (reinterpret_cast<uintptr_t>(a.g_rel) & 15) ||
+        (reinterpret_cast<uintptr_t>(a.g_hid) & 15) || (reinterpret_cast<uintptr_t>(a.a3) & 15))
+        return EGNN_E_ALIGN;
+    const int64_t E = (int64_t)a.B * a.N * a.K;
+    const int64_t blocks = (E + 255) / 256;
+    if (blocks >= ((int64_t)1 << 31)) return EGNN_E_SHAPE;
+    hipLaunchKernelGGL(edge_tail_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return egnn_launch_status();
+}

@@ -296,6 +296,39 @@ typedef struct egnn_edge_bwd_args {
 int egnn_edge_bwd_pass_f32(const egnn_edge_bwd_args* args, void* stream);
 int egnn_edge_bwd_chunk_steps(void);    /* hidden steps (of 32 columns) one workgroup owns: sizes ds_part */
 
+/* The per-edge part of the backward behind edge_mlp's second Linear in closed form (csrc/edge_tail.hip; autograd of
+ * egnn_pytorch.py:287 second SiLU, :292-317 pair mask / coors_mlp / CoorsNorm / clamp / coordinate update, :319-333 pooling; no edge
+ * gate, coordinate dimension 3).  One edge per lane: from u = the second Linear's output (E, 16), g_coors_out = d loss / d coors_out
+ * and g_msum = d loss / d (sum over k of the pair-masked messages; mean pooling: already divided by the count) it writes
+ * gU = d loss / d u (the input of egnn_edge_bwd_pass_f32), g_rel = d loss / d (x_i - x_j) without the distance path, and what the
+ * parameter gradients of coors_mlp are tall products of: g_hid (E, 64), a3 (E, 64), g_w (E), and the per-edge terms of
+ * d loss / d coors_norm.scale.  W3 / b3 / W4 zero padded to 64 x 16 / 64 / 64 by the caller. */
+typedef struct egnn_edge_tail_args {
+    int B, N, K;
+    int norm_coors;             /* CoorsNorm on (scale, eps below) */
+    float clamp;                /* coor_weights_clamp_value, < 0 = none */
+    float eps;                  /* CoorsNorm eps */
+    const float* u;             /* (E, 16) fp32, columns >= m_dim zero */
+    const float* coors;         /* (B*N, 3) */
+    const int32_t* idx;         /* (E) neighbour of each edge, NULL = dense (K == N) */
+    const uint8_t* pair_mask;   /* (E) mask_i & mask_j & (rank <= valid_radius), NULL = all pairs count */
+    const float* g_coors_out;   /* (B*N, 3) */
+    const float* g_msum;        /* (B*N, 16) zero padded */
+    const float* W3;            /* (64, 16) coors_mlp.0.weight zero padded */
+    const float* b3;            /* (64) */
+    const float* W4;            /* (64) coors_mlp.3.weight */
+    const float* b4;            /* (1) */
+    const float* scale;         /* (1) coors_norm.scale or NULL */
+    float* gU;                  /* out (E, 16) */
+    float* g_rel;               /* out (E, 4), last column 0 */
+    float* g_hid;               /* out (E, 64) */
+    float* a3;                  /* out (E, 64) */
+    float* g_w;                 /* out (E) */
+    float* g_scale;             /* out (E) or NULL */
+} egnn_edge_tail_args;
+
+int egnn_edge_tail_bwd_f32(const egnn_edge_tail_args* args, void* stream);
+
 /* Backward of the neighbour gather (egnn_pytorch.py:275): out[r, :] = sum of rows[order[p], :] for p in [seg_ptr[r], seg_ptr[r+1]),
  * in that order -- with `order` = the edges sorted (stably) by destination node this is d loss / d P_j from dZ, a fixed-order
  * read-only reduction (no float atomics: bit-reproducible).  rows (n_rows, ld) fp32, out (n_out, ldo) fp32, cols % 4 == 0,

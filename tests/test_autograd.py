@@ -285,3 +285,109 @@ def test_split_k_transposed_product_equals_plain_product():
     torch.testing.assert_close(gx, gx_ref)
     for u, v in zip(gp, gp_ref):
         torch.testing.assert_close(u, v)
+
+
+def _tail_case(kw, use_mask, dense, dtype, device, n=9, b=2):
+    """Inputs of the per-edge tail for one configuration + what autograd of `layer_tail` says (tests below)."""
+    from egnn_pytorch_amd import EGNN, autograd as A
+    torch.manual_seed(0)
+    layer = EGNN(**kw).to(device=device, dtype=dtype)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.mul_(40.0)
+    m = layer.m_dim
+    k = n if dense else kw["num_nearest_neighbors"]
+    g = torch.Generator().manual_seed(1)
+    rnd = lambda *shape: torch.randn(*shape, dtype=torch.float64, generator=g).to(device=device, dtype=dtype)
+    feats, coors = rnd(b, n, kw["dim"]), rnd(b, n, 3)
+    idx = None if dense else torch.randint(0, n, (b, n, k), generator=g).to(device)
+    rank = None if dense else torch.rand(b, n, k, generator=g, dtype=torch.float64).to(device=device, dtype=dtype)
+    radius = float("inf") if dense else 0.7
+    mask = (torch.arange(n)[None] < torch.tensor([n, n - 3, n // 2 + 1][:b])[:, None]).to(device) if use_mask else None
+    u = rnd(b, n, k, m).requires_grad_(True)
+    rel_leaf = A.edge_scalars(layer, coors, None, idx)[0].detach().requires_grad_(True)
+    out_n, out_c = A.layer_tail(layer, feats, coors, u, rel_leaf, mask, idx, rank, radius)
+    gn, gc = rnd(*out_n.shape), rnd(*out_c.shape)
+    names = [nme for nme, _ in layer.named_parameters() if nme.startswith(("coors_mlp", "coors_norm"))]
+    tparams = [p for nme, p in layer.named_parameters() if nme in names]
+    grads = torch.autograd.grad([out_n, out_c], [u, rel_leaf] + tparams, [gn, gc], allow_unused=True)
+    ref = dict(g_u=grads[0], g_rel=grads[1], **dict(zip(names, grads[2:])))
+    # what the closed form takes: the pair mask and d loss / d (masked sum over k of m_ij) from the node-level graph
+    pm = None
+    if mask is not None:
+        bi = torch.arange(b, device=device)[:, None, None]
+        pm = mask[:, :, None] & mask[:, None, :] if dense else mask[:, :, None] & mask[bi, idx] & (rank <= radius)
+    mm = torch.nn.functional.silu(u.detach())
+    mmask = mm if pm is None else mm.masked_fill(~pm[..., None], 0.0)
+    cnt = None
+    if layer.m_pool_method == "mean" and pm is not None:
+        cnt = pm.sum(-1, keepdim=True).to(dtype)
+        m_i = (mmask.sum(2) / cnt.clamp(min=1e-8)).masked_fill(cnt == 0, 0.0)
+    else:
+        m_i = mmask.mean(2) if layer.m_pool_method == "mean" else mmask.sum(2)
+    m_leaf = m_i.clone().requires_grad_(True)
+    g_mi = torch.autograd.grad(layer.node_mlp(torch.cat((layer.node_norm(feats), m_leaf), -1)) + feats, m_leaf, gn)[0]
+    if layer.m_pool_method == "mean":
+        g_msum = (g_mi / cnt.clamp(min=1e-8)).masked_fill(cnt == 0, 0.0) if cnt is not None else g_mi / k
+    else:
+        g_msum = g_mi
+    return layer, u.detach(), coors, idx, pm, gc, g_msum, ref
+
+
+TAIL_CASES = [(dict(dim=8, num_nearest_neighbors=5), False, False),
+              (dict(dim=8, num_nearest_neighbors=6, norm_coors=True, coor_weights_clamp_value=0.6), True, False),
+              (dict(dim=8, m_dim=8, m_pool_method="mean", norm_coors=True), True, True),
+              (dict(dim=8, num_nearest_neighbors=4, m_pool_method="mean", coor_weights_clamp_value=1.5), True, False)]
+
+
+def _tail_param_grads(r):
+    return {"coors_mlp.0.weight": r["g_hid"].t() @ r["m"], "coors_mlp.0.bias": r["g_hid"].sum(0),
+            "coors_mlp.3.weight": r["g_w"][None, :] @ r["a3"], "coors_mlp.3.bias": r["g_w"].sum()[None],
+            "coors_norm.scale": None if r["g_scale"] is None else r["g_scale"].sum()[None]}
+
+
+@pytest.mark.parametrize("kw,use_mask,dense", TAIL_CASES)
+def test_closed_form_tail_backward_equals_autograd(kw, use_mask, dense):
+    """autograd.tail_edge_backward -- the specification of egnn_edge_tail_bwd_f32: second SiLU, pair mask, coors_mlp, CoorsNorm,
+    clamp, coordinate update and pooling differentiated by hand -- against autograd of `layer_tail` in float64."""
+    from egnn_pytorch_amd import autograd as A
+    layer, u, coors, idx, pm, gc, g_msum, ref = _tail_case(kw, use_mask, dense, torch.float64, "cpu")
+    r = A.tail_edge_backward(layer, u, coors, idx, pm, gc, g_msum)
+    got = dict(g_u=r["g_u"], g_rel=r["g_rel"], **_tail_param_grads(r))
+    assert float(ref["coors_mlp.3.weight"].abs().max()) > 0                       # (the clamp leaves some weights active)
+    for key, want in ref.items():
+        torch.testing.assert_close(got[key].reshape(want.shape), want, rtol=1e-9, atol=1e-9 * max(1.0, float(want.abs().max())), msg=key)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,use_mask,dense", TAIL_CASES)
+def test_tail_kernel_matches_closed_form(kw, use_mask, dense):
+    """egnn_edge_tail_bwd_f32 (one edge per lane) against its torch specification evaluated in float64 on the same inputs."""
+    from egnn_pytorch_amd import _ops, autograd as A
+    layer, u, coors, idx, pm, gc, g_msum, _ = _tail_case(kw, use_mask, dense, torch.float32, "cuda", n=40, b=3)
+    b, n, k, m = u.shape
+    layer64 = __import__("copy").deepcopy(layer).double()
+    want = A.tail_edge_backward(layer64, u.double(), coors.double(), idx, pm, gc.double(), g_msum.double())
+    e = b * n * k
+    u16 = torch.zeros(b, n, k, 16, device="cuda"); u16[..., :m] = u
+    gm16 = torch.zeros(b, n, 16, device="cuda"); gm16[..., :m] = g_msum
+    la, lb = layer.coors_mlp[0], layer.coors_mlp[3]
+    hid3 = la.weight.shape[0]
+    w3p = torch.zeros(64, 16, device="cuda"); w3p[:hid3, :m] = la.weight.detach()
+    b3p = torch.zeros(64, device="cuda"); b3p[:hid3] = la.bias.detach()
+    w4p = torch.zeros(64, device="cuda"); w4p[:hid3] = lb.weight.detach()[0]
+    norm = layer.norm_coors
+    gu, g_rel, g_hid, a3, g_w, g_sc = _ops.edge_tail_bwd(
+        u16, coors.contiguous(), None if idx is None else idx.to(torch.int32).contiguous(), None if pm is None else pm.contiguous().view(torch.uint8),
+        gc.contiguous(), gm16, w3p, b3p, w4p, lb.bias.detach().contiguous(), layer.coors_norm.scale.detach() if norm else None,
+        layer.coors_norm.eps if norm else 0.0, layer.coor_weights_clamp_value, b, n, k)
+    got = dict(g_u=gu[:, :m], g_rel=g_rel[:, :3], g_hid=g_hid[:, :hid3], a3=a3[:, :hid3], g_w=g_w, g_scale=g_sc)
+    for key, t in got.items():
+        if t is None:
+            assert want[key] is None
+            continue
+        ref = want[key].reshape(t.shape)
+        scale = max(1e-30, float(ref.abs().max()))
+        err = float((t.double() - ref).abs().max())
+        assert err <= 2e-6 * scale, (key, err, scale)
+    assert float(gu[:, m:].abs().max() if m < 16 else 0.0) == 0.0 and float(g_rel[:, 3].abs().max()) == 0.0

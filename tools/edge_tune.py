@@ -29,7 +29,7 @@ print(json.dumps({k: round(min(v), 4) for k, v in s.items()}))
 def build(tag, defs, src="edge_fused", tuning=True):
     out = f"/tmp/egnn_{tag}"
     os.makedirs(out, exist_ok=True)
-    names = ("knn_select", "spatial_order", "adj_expand", "linear_hl", "node_ops", "edge_fused", "edge_fused_c", "edge_bwd", "layer_api", "segment_sum", "global_attn")
+    names = ("knn_select", "spatial_order", "adj_expand", "linear_hl", "node_ops", "edge_fused", "edge_fused_c", "edge_bwd", "edge_tail", "layer_api", "segment_sum", "global_attn")
     objs = [os.path.join(CSRC, "obj", f + ".o") for f in names if f != src]
     o = f"{out}/{src}.o"
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-Wno-inline-asm",
