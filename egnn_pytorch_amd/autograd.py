@@ -5,9 +5,11 @@ Forward  = the HIP path (neighbour selection, fused edge pass, split-f16 GEMMs).
            tensors are the inputs, the neighbour list and u (E x 16), the output of edge_mlp's second Linear, which the
            forward edge kernel writes on the side when a graph is being recorded.
 Backward = `_backward_native` (fp32, coordinate dimension 3, m_dim <= 16):
-             * the small tail behind u (second SiLU, gate, masks, coors_mlp, CoorsNorm, clamp, pooling, node_norm, node_mlp:
-               E x 16 / E x 64 / node-level tensors) is differentiated by autograd from u  ->  gU and those parameters' gradients
-               (the weight gradients of the per-edge heads as split-K products, `_tn`);
+             * behind u: the node-level modules (node_norm, node_mlp, residual) through autograd from the pooled messages, the
+               per-edge chain (second SiLU, masks, coors_mlp, CoorsNorm, clamp, coordinate update, pooling) in closed form on
+               egnn_edge_tail_bwd_f32 (csrc/edge_tail.hip; `tail_edge_backward` is its specification)  ->  gU, d/d (x_i - x_j) and
+               those parameters' gradients (weight gradients as split-K products, `_tn`).  With the edge gate (soft_edges) the
+               per-edge chain goes through autograd as well (`layer_tail`);
              * the E x H work -- z = P_i + P_j + W_s s, a = SiLU(z), dz = (W2^T gU) SiLU'(z) and their contractions -- on
                egnn_edge_bwd_pass_f32 (csrc/edge_bwd.hip; `_edge_contract_fused`): one pass over the edges grouped by source node
                (d/d P_i, d/d W_s, d/d scalars) and one over the edges sorted by destination (d/d P_j, d/d W_2), everything
@@ -92,8 +94,8 @@ class _TallLinear(torch.autograd.Function):
 
 
 def _per_edge(module, x):
-    """module(x) for the small per-edge heads (edge_gate, coors_mlp: Sequentials of Linear / Dropout / SiLU / Sigmoid) with the
-    Linears' weight gradients computed by `_tn`."""
+    """module(x) for Sequentials of Linear / Dropout / SiLU / Sigmoid applied to very many rows -- the per-edge heads (edge_gate,
+    coors_mlp) and the node-level node_mlp -- with the Linears' weight gradients computed by `_tn`."""
     if not x.is_cuda:
         return module(x)
     for sub in (module if isinstance(module, nn.Sequential) else [module]):
@@ -164,7 +166,7 @@ def layer_tail(layer, feats, coors, u, rel, mask, idx, rank, valid_radius):
                 m_i = m_ij.mean(dim=2)
         else:
             m_i = m_ij.sum(dim=2)
-        node_out = layer.node_mlp(torch.cat((layer.node_norm(feats), m_i), dim=-1)) + feats      # (:335-337)
+        node_out = _per_edge(layer.node_mlp, torch.cat((layer.node_norm(feats), m_i), dim=-1)) + feats      # (:335-337)
     return node_out, coors_out
 
 
@@ -306,7 +308,7 @@ def _edge_tables(layer, w, f2d, pi_split):
     return _ops.linear_hl(feats_hl, w["Wcat_split"], 2 * hp, w["bcat"], name="bwd_node_proj", split_cols=hp if pi_split else 0)
 
 
-def _edge_contract_dz(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split):
+def _edge_contract_dz(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_order=None):
     """egnn_edge_bwd_dz_f32 writes dz and a = SiLU(z) (2 x E x Hp fp32); reductions / library GEMMs over them.
     Returns d/d P_i (rows, Hp), d/d P_j (rows, Hp), d/d W_s (Hp, S), d/d scalars (E, S), d/d W_2 (16, Hp)."""
     from . import _abi, _ops
@@ -342,8 +344,10 @@ def _edge_contract_dz(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, 
     else:
         # scatter by neighbour as a fixed-order gather over the transposed neighbour list (edges sorted stably by
         # destination): no float atomics, bit-reproducible
-        dest = (i32.long() + (torch.arange(bc, device=dev) * n)[:, None, None]).view(-1)
-        dest_sorted, by_dest = torch.sort(dest, stable=True)
+        if dest_order is None:
+            dest = (i32.long() + (torch.arange(bc, device=dev) * n)[:, None, None]).view(-1)
+            dest_order = torch.sort(dest, stable=True)
+        dest_sorted, by_dest = dest_order
         seg = torch.searchsorted(dest_sorted, torch.arange(bc * n + 1, device=dev))
         gz_j = _ops.rows_gather_sum(dz, by_dest, seg, bc * n)
     g_ws = dz.t() @ sc2
@@ -372,7 +376,7 @@ def entry_list(eids, keys, n_keys):
     return ent, seg
 
 
-def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split):
+def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_order=None):
     """egnn_edge_bwd_pass_f32 (csrc/edge_bwd.hip) twice -- entries grouped by source node, then by neighbour: z, SiLU(z) and dz
     are recomputed and contracted in registers, nothing of size E x H reaches memory.  Same returns as _edge_contract_dz."""
     from . import _ops
@@ -388,11 +392,13 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
     ident = torch.arange(o["rows"].shape[0], device=dev)
     gz_i = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n)
     del o
-    if i32 is None:
-        dest = (torch.arange(k, device=dev)[None, None, :] + (torch.arange(bc, device=dev) * n)[:, None, None]).expand(bc, n, k).reshape(-1)
-    else:
-        dest = (i32.long() + (torch.arange(bc, device=dev) * n)[:, None, None]).view(-1)
-    dest_sorted, by_dest = torch.sort(dest, stable=True)
+    if dest_order is None:
+        if i32 is None:
+            dest = (torch.arange(k, device=dev)[None, None, :] + (torch.arange(bc, device=dev) * n)[:, None, None]).expand(bc, n, k).reshape(-1)
+        else:
+            dest = (i32.long() + (torch.arange(bc, device=dev) * n)[:, None, None]).view(-1)
+        dest_order = torch.sort(dest, stable=True)
+    dest_sorted, by_dest = dest_order
     ent, seg = entry_list(by_dest, dest_sorted, bc * n)
     o = _ops.edge_bwd_pass(w, proj, i32, gu16, gu_scale, sc2, ent, bc, n, k, by_dest=True, want_w2=g_w2 is None)
     if g_w2 is None:
@@ -466,6 +472,7 @@ def _backward_native(ctx, g_node, g_coors):
         i64 = None if i32 is None else i32.long()
         r0 = None if rank is None else rank[lo:hi_]
         ec = bc * n * k
+        dest_order = None
         if tail_kernel:
             # ---- 1. behind u: the node-level modules through autograd (node_norm, node_mlp, residual: from the pooled messages),
             # the per-edge chain (second SiLU, masks, coors_mlp, CoorsNorm, clamp, coordinate update, pooling) in closed form on
@@ -497,7 +504,7 @@ def _backward_native(ctx, g_node, g_coors):
                 c = c0.detach().requires_grad_(True)
                 e = None if e0 is None else e0.detach().requires_grad_(True)
                 rel, scal = edge_scalars(layer, c, e, i64)                                   # (only the scalars' graph is used below)
-                out_n = layer.node_mlp(torch.cat((layer.node_norm(f), mi), dim=-1)) + f
+                out_n = _per_edge(layer.node_mlp, torch.cat((layer.node_norm(f), mi), dim=-1)) + f      # (split-K weight gradients)
                 node_params = list(layer.node_norm.parameters()) + list(layer.node_mlp.parameters())
                 tg = torch.autograd.grad([out_n], [f, mi] + node_params, [g_node[lo:hi_]], allow_unused=True)
             if tg[0] is not None:
@@ -538,7 +545,8 @@ def _backward_native(ctx, g_node, g_coors):
                     g_coors_in[lo:hi_] -= g_rel.view(bc, n, n, 4).sum(dim=1)[..., :3]
                 else:
                     dest = (i64 + (torch.arange(bc, device=feats.device) * n)[:, None, None]).view(-1)
-                    dest_sorted, by_dest = torch.sort(dest, stable=True)
+                    dest_order = torch.sort(dest, stable=True)                                 # (shared with the E x H passes below)
+                    dest_sorted, by_dest = dest_order
                     seg = torch.searchsorted(dest_sorted, torch.arange(bc * n + 1, device=feats.device))
                     g_coors_in[lo:hi_] -= _ops.rows_gather_sum(g_rel, by_dest, seg, bc * n).view(bc, n, 4)[..., :3]
         else:
@@ -574,7 +582,7 @@ def _backward_native(ctx, g_node, g_coors):
             f2d = f0.view(bc * n, dim)
             sc2 = scal.detach().reshape(ec, s_in).contiguous()
             contract = _edge_contract_fused if fused else _edge_contract_dz
-            gz_i, gz_j, g_ws, g_scal, g_w2 = contract(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split)
+            gz_i, gz_j, g_ws, g_scal, g_w2 = contract(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_order)
             # ---- 3. node-level GEMMs
             g_feats[lo:hi_] += (gz_i @ w_i + gz_j @ w_j).view(bc, n, dim)
             gw1 = grads_by_id[id(lin0.weight)]
