@@ -99,6 +99,11 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
         for (int d = 0; d < 3; ++d) grel[d] = g_relp[d];
     }
     grel[3] = 0.f;
+    // A self pair (j == i: only_sparse_neighbors with the diagonal in the adjacency, dense all-pairs) has rel = x_i - x_i: its
+    // gradient reaches x_i once with each sign and cancels identically.  Written out as zero -- the two copies would otherwise
+    // travel through two different sums (per source, per neighbour) and, under CoorsNorm (|rel| < eps: a factor 1 / eps = 1e8),
+    // leave rounding noise of order one behind.
+    if (jg == ig) grel = f32x4{0.f, 0.f, 0.f, 0.f};
     *reinterpret_cast<f32x4*>(p.g_rel + e * 4) = grel;
     p.g_w[e] = g_w;
 
