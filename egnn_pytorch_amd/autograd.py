@@ -387,8 +387,10 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
     ent, seg = entry_list(eids, eids // k, bc * n)
     # the contractions over all edges ride along: d/d W_s and d/d scalars with the first pass, d/d W_2 with the second (each keeps
     # its accumulators in registers; one pass carrying both drops from 3 to 2 workgroups per CU)
-    o = _ops.edge_bwd_pass(w, proj, i32, gu16, gu_scale, sc2, ent, bc, n, k, by_dest=False, ws_nat=w_s, want_w2=_FUSED_SPLIT == "both" and w["S"] == 1)
-    g_ws, g_scal, g_w2 = o["ws"], o["scal"], o.get("w2")
+    s_first = _FUSED_SPLIT != "src"                          # ("src": d/d W_2 with the by-source pass, d/d W_s and d/d scalars with the other)
+    o = _ops.edge_bwd_pass(w, proj, i32, gu16, gu_scale, sc2, ent, bc, n, k, by_dest=False, ws_nat=w_s if s_first else None,
+                           want_w2=_FUSED_SPLIT == "src" or (_FUSED_SPLIT == "both" and w["S"] == 1))
+    g_ws, g_scal, g_w2 = o.get("ws"), o.get("scal"), o.get("w2")
     ident = torch.arange(o["rows"].shape[0], device=dev)
     gz_i = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n)
     del o
@@ -400,9 +402,11 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
         dest_order = torch.sort(dest, stable=True)
     dest_sorted, by_dest = dest_order
     ent, seg = entry_list(by_dest, dest_sorted, bc * n)
-    o = _ops.edge_bwd_pass(w, proj, i32, gu16, gu_scale, sc2, ent, bc, n, k, by_dest=True, want_w2=g_w2 is None)
+    o = _ops.edge_bwd_pass(w, proj, i32, gu16, gu_scale, sc2, ent, bc, n, k, by_dest=True, ws_nat=None if s_first else w_s, want_w2=g_w2 is None)
     if g_w2 is None:
         g_w2 = o["w2"]
+    if not s_first:
+        g_ws, g_scal = o["ws"], o["scal"]
     ident = torch.arange(o["rows"].shape[0], device=dev)
     gz_j = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n)
     return gz_i, gz_j, g_ws, g_scal, g_w2
