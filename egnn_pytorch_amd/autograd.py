@@ -507,7 +507,12 @@ def _backward_native(ctx, g_node, g_coors):
                 mi = m_i[..., :m].detach().requires_grad_(True)
                 c = c0.detach().requires_grad_(True)
                 e = None if e0 is None else e0.detach().requires_grad_(True)
-                rel, scal = edge_scalars(layer, c, e, i64)                                   # (only the scalars' graph is used below)
+                closed_dist = s_in == 1                       # the distance is the only per-edge scalar: its backward in closed form below
+                if closed_dist:
+                    with torch.no_grad():
+                        rel, scal = edge_scalars(layer, c0, None, i64)
+                else:
+                    rel, scal = edge_scalars(layer, c, e, i64)                               # (only the scalars' graph is used below)
                 out_n = _per_edge(layer.node_mlp, torch.cat((layer.node_norm(f), mi), dim=-1)) + f      # (split-K weight gradients)
                 node_params = list(layer.node_norm.parameters()) + list(layer.node_mlp.parameters())
                 tg = torch.autograd.grad([out_n], [f, mi] + node_params, [g_node[lo:hi_]], allow_unused=True)
@@ -543,17 +548,12 @@ def _backward_native(ctx, g_node, g_coors):
                 if norm:
                     grads_by_id[id(layer.coors_norm.scale)] += g_sc.sum()[None]
                 del g_hid, a3, mm
-                # coordinates: the residual, rel = x_i - x_j at the source (sum over a node's edges) and at the neighbour
-                g_coors_in[lo:hi_] += g_coors[lo:hi_] + g_rel.view(bc, n, k, 4).sum(dim=2)[..., :3]
-                if i64 is None:
-                    g_coors_in[lo:hi_] -= g_rel.view(bc, n, n, 4).sum(dim=1)[..., :3]
-                else:
+                g_coors_in[lo:hi_] += g_coors[lo:hi_]                              # (the residual; g_rel reaches the coordinates below)
+                if i64 is not None:
                     dest = (i64 + (torch.arange(bc, device=feats.device) * n)[:, None, None]).view(-1)
                     dest_order = torch.sort(dest, stable=True)                                 # (shared with the E x H passes below)
-                    dest_sorted, by_dest = dest_order
-                    seg = torch.searchsorted(dest_sorted, torch.arange(bc * n + 1, device=feats.device))
-                    g_coors_in[lo:hi_] -= _ops.rows_gather_sum(g_rel, by_dest, seg, bc * n).view(bc, n, 4)[..., :3]
         else:
+            closed_dist, g_rel = False, None
             # ---- 1. the small tail, through autograd
             with torch.enable_grad():
                 f = f0.detach().requires_grad_(True)
@@ -599,11 +599,26 @@ def _backward_native(ctx, g_node, g_coors):
             grads_by_id[id(lin3.bias)] += gu16[:, :m].sum(dim=0)
             del gz_i, gz_j
         # d loss / d scalars -> coordinates (through d = |x_i - x_j|^2 and the fourier terms) and edge features
-        sg = torch.autograd.grad([scal], [c] + ([e] if e is not None else []), [g_scal], allow_unused=True)
-        if sg[0] is not None:
-            g_coors_in[lo:hi_] += sg[0]
-        if e is not None and sg[1] is not None:
-            g_edges[lo:hi_] += sg[1]
+        if closed_dist:
+            with torch.no_grad():                                   # d = |rel|^2:  d loss / d rel += 2 g_d rel
+                g_rel[:, :3] += (2.0 * g_scal.reshape(ec, 1)) * rel.reshape(ec, 3)
+        else:
+            sg = torch.autograd.grad([scal], [c] + ([e] if e is not None else []), [g_scal], allow_unused=True)
+            if sg[0] is not None:
+                g_coors_in[lo:hi_] += sg[0]
+            if e is not None and sg[1] is not None:
+                g_edges[lo:hi_] += sg[1]
+        if g_rel is not None:
+            # rel = x_i - x_j reaches the coordinates at the source (sum over a node's edges) and, negated, at the neighbour
+            # (fixed-order gather over the edges sorted by destination)
+            with torch.no_grad():
+                g_coors_in[lo:hi_] += g_rel.view(bc, n, k, 4).sum(dim=2)[..., :3]
+                if i64 is None:
+                    g_coors_in[lo:hi_] -= g_rel.view(bc, n, n, 4).sum(dim=1)[..., :3]
+                else:
+                    dest_sorted, by_dest = dest_order
+                    seg = torch.searchsorted(dest_sorted, torch.arange(bc * n + 1, device=feats.device))
+                    g_coors_in[lo:hi_] -= _ops.rows_gather_sum(g_rel, by_dest, seg, bc * n).view(bc, n, 4)[..., :3]
     out_params = [grads_by_id[id(p)] if need[7 + i] else None for i, p in enumerate(params)]
     return (None, None, None, None, g_feats if need[4] else None, g_coors_in if need[5] else None,
             g_edges if (edges is not None and need[6]) else None, *out_params)
