@@ -358,11 +358,19 @@ def _edge_contract_dz(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, 
 
 def entry_list(eids, keys, n_keys):
     """The entry list of one egnn_edge_bwd_pass_f32 call (include/egnn_hip.h): edge ids `eids` (E,) ordered so that their keys
-    `keys` (E,) -- the node each entry is grouped by -- are non-decreasing.  Every node's entries are padded with -1 to whole
+    `keys` (E,) -- the node each entry is grouped by -- are non-decreasing (None: E / n_keys consecutive entries per node).  Every
+    node's entries are padded with -1 to whole
     16-entry tiles, the list to a multiple of 128.  Returns (ent int32 (L,), seg int64 (n_keys + 1,)): seg = the range of tiles
     (= partial rows) of each key."""
     dev = eids.device
     e = eids.numel()
+    if keys is None:                                          # every key has the same number of consecutive entries (by source: K)
+        per = e // n_keys
+        t = (per + 15) // 16
+        l = (n_keys * t * 16 + 127) // 128 * 128
+        ent = torch.full((max(l, 128),), -1, dtype=torch.int32, device=dev)
+        ent[:n_keys * t * 16].view(n_keys, t * 16)[:, :per] = eids.view(n_keys, per).to(torch.int32)
+        return ent, torch.arange(n_keys + 1, device=dev) * t
     deg = torch.bincount(keys, minlength=n_keys)
     tiles = (deg + 15) // 16
     seg = torch.zeros(n_keys + 1, dtype=torch.int64, device=dev)
@@ -383,8 +391,7 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
     dev = f2d.device
     ec = bc * n * k
     proj = _edge_tables(layer, w, f2d, False)
-    eids = torch.arange(ec, device=dev)
-    ent, seg = entry_list(eids, eids // k, bc * n)
+    ent, seg = entry_list(torch.arange(ec, device=dev), None, bc * n)
     # the contractions over all edges ride along: d/d W_s and d/d scalars with the first pass, d/d W_2 with the second (each keeps
     # its accumulators in registers; one pass carrying both drops from 3 to 2 workgroups per CU)
     s_first = _FUSED_SPLIT != "src"                          # ("src": d/d W_2 with the by-source pass, d/d W_s and d/d scalars with the other)

@@ -284,6 +284,12 @@ def test_entry_list_pads_every_node_to_whole_tiles():
         valid = (chunk >= 0).int()
         assert bool((valid[1:] <= valid[:-1]).all())                                   # padding only behind a node's entries
     assert bool((ent[int(seg[-1]) * 16:] == -1).all())
+    # uniform groups (the by-source list: K consecutive entries per node) without the keys
+    for per in (5, 16, 40):
+        e2 = torch.randperm(n_keys * per, generator=g)
+        a, sa = entry_list(e2, None, n_keys)
+        b_, sb = entry_list(e2, torch.arange(n_keys).repeat_interleave(per), n_keys)
+        assert torch.equal(a, b_) and torch.equal(sa, sb)
 
 
 def test_split_k_transposed_product_equals_plain_product():
