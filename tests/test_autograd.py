@@ -469,3 +469,116 @@ def test_backward_full_size_properties():
     scale = float(base[1].abs().max())
     assert float(((turned[1] - base[1] @ q) * valid).abs().max()) <= 2e-4 * scale
     assert float(((turned[0] - base[0]) * valid).abs().max()) <= 2e-4 * float(base[0].abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The host side of the native backward on the CPU: the three kernels replaced by torch emulations of their contracts
+# (include/egnn_hip.h), everything else -- entry lists, partial rows, fixed-order sums, chunking over graphs, node-level products,
+# parameter bookkeeping -- is the shipped code of autograd._backward_native.
+def _emulated_backward(layer, feats, coors, mask, idx, rank, radius, g_node, g_coors, max_graphs=0):
+    import types
+    from egnn_pytorch_amd import _ops, _weights, autograd as A
+    b, n, dim = feats.shape
+    k = idx.shape[-1]
+    m = layer.m_dim
+    w = layer.packed_weights()
+    hp, s_in = w["Hp"], w["S"]
+    lin0, lin3 = layer.edge_mlp[0], layer.edge_mlp[3]
+    w2n = torch.zeros(16, hp); w2n[:m, :w["H"]] = lin3.weight.detach()
+    nl2e = _weights.NEG_LOG2E
+
+    def tables(layer_, w_, f2d, pi_split):
+        return f2d @ w_["Wcat"].t() + w_["bcat"]                                     # fp32 P_i | P_j rows in the forward's units
+
+    def z_of(proj, idx32, scal, b_, n_, k_):
+        src = torch.arange(b_ * n_).repeat_interleave(k_)
+        dst = (idx32.long() + (torch.arange(b_) * n_)[:, None, None]).reshape(-1)
+        return (proj[src, :hp] + proj[dst, hp:] + scal @ w["Ws"]) / nl2e
+
+    def bwd_pass(w_, proj, idx32, gu16, gu_scale, scal, ent, b_, n_, k_, by_dest, ws_nat=None, want_w2=False, n_slabs=None):
+        z = z_of(proj, idx32, scal, b_, n_, k_)
+        sg = torch.sigmoid(z)
+        a = z * sg
+        dz = (gu16 @ w2n) * (sg * (1 + z * (1 - sg)))
+        tiles = ent.view(-1, 16).long()
+        rows = (dz[tiles.clamp(min=0)] * (tiles >= 0)[..., None]).sum(dim=1)        # one partial row per tile
+        out = {"rows": rows}
+        if want_w2:
+            out["w2"] = gu16.t() @ a
+        if ws_nat is not None:
+            out["ws"] = dz.t() @ scal
+            out["scal"] = dz @ ws_nat
+        return out
+
+    def gather_sum(rows, order, seg, n_out):
+        out = torch.zeros(n_out, rows.shape[1])
+        for r in range(n_out):
+            for p in range(int(seg[r]), int(seg[r + 1])):
+                out[r] = out[r] + rows[order[p]]
+        return out
+
+    def tail(u16, coors_, idx32, pair_mask, g_co, g_msum16, w3p, b3p, w4p, b4, scale, eps, clamp, b_, n_, k_):
+        r = A.tail_edge_backward(layer, u16[..., :m], coors_, None if idx32 is None else idx32.long(),
+                                 None if pair_mask is None else pair_mask.view(torch.bool).view(b_, n_, k_), g_co, g_msum16[..., :m])
+        e = b_ * n_ * k_
+        gu = torch.zeros(e, 16); gu[:, :m] = r["g_u"].reshape(e, m)
+        g_rel = torch.zeros(e, 4); g_rel[:, :3] = r["g_rel"].reshape(e, 3)
+        self_pair = (idx32.long() == torch.arange(n_)[None, :, None]).reshape(-1)
+        g_rel[self_pair] = 0.0
+        gh = torch.zeros(e, 64); gh[:, :r["g_hid"].shape[1]] = r["g_hid"]
+        a3 = torch.zeros(e, 64); a3[:, :r["a3"].shape[1]] = r["a3"]
+        return gu, g_rel, gh, a3, r["g_w"], r["g_scale"]
+
+    # u = the second Linear's output, as the forward kernel leaves it (E, 16)
+    with torch.no_grad():
+        _, scal = A.edge_scalars(layer, coors, None, idx.long())
+        proj = tables(layer, w, feats.reshape(b * n, dim), False)
+        z = z_of(proj, idx, scal.reshape(-1, s_in), b, n, k)
+        u = torch.zeros(b * n * k, 16)
+        u[:, :m] = torch.nn.functional.silu(z[:, :w["H"]]) @ lin3.weight.t() + lin3.bias
+    params = list(layer.parameters())
+    ctx = types.SimpleNamespace(layer=layer, u_pre=u, valid_radius=radius, has_edges=False, order=None,
+                                saved_tensors=(feats, coors, feats.new_empty(0), mask if mask is not None else feats.new_empty(0), idx, rank),
+                                flags=(mask is not None, True), needs_input_grad=(False, False, False, False, True, True, False) + (True,) * len(params))
+    saved = (_ops.edge_bwd_pass, _ops.rows_gather_sum, _ops.edge_tail_bwd, A._edge_tables, A._FUSED_MAX_GRAPHS)
+    _ops.edge_bwd_pass, _ops.rows_gather_sum, _ops.edge_tail_bwd, A._edge_tables, A._FUSED_MAX_GRAPHS = bwd_pass, gather_sum, tail, tables, max_graphs
+    try:
+        out = A._backward_native(ctx, g_node, g_coors)
+    finally:
+        _ops.edge_bwd_pass, _ops.rows_gather_sum, _ops.edge_tail_bwd, A._edge_tables, A._FUSED_MAX_GRAPHS = saved
+    return [out[4], out[5]] + list(out[7:])
+
+
+@pytest.mark.parametrize("kw,use_mask,max_graphs", [(dict(dim=8, num_nearest_neighbors=5), False, 0),
+                                                    (dict(dim=8, num_nearest_neighbors=6, norm_coors=True, coor_weights_clamp_value=0.6), True, 0),
+                                                    (dict(dim=8, num_nearest_neighbors=20, m_pool_method="mean", norm_feats=True), True, 2)])
+def test_native_backward_host_logic_with_emulated_kernels(kw, use_mask, max_graphs):
+    """autograd._backward_native on the CPU with its three kernels emulated in torch from their header contracts: what remains
+    under test is the host side -- entry lists, partial rows, fixed-order sums, chunking over graphs, the node-level products,
+    the parameter bookkeeping -- against autograd of the restated layer."""
+    from egnn_pytorch_amd import EGNN, autograd as A
+    torch.manual_seed(5)
+    layer = EGNN(**kw)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.mul_(40.0)
+    b, n = 3, 24
+    k = kw["num_nearest_neighbors"]
+    g = torch.Generator().manual_seed(6)
+    feats, coors = torch.randn(b, n, kw["dim"], generator=g), torch.randn(b, n, 3, generator=g)
+    idx = torch.randint(0, n, (b, n, k), generator=g).to(torch.int32)
+    idx[:, :, 0] = torch.arange(n)[None, :]                                          # the self pair, as the selection always has it
+    rank = torch.rand(b, n, k, generator=g)
+    mask = (torch.arange(n)[None] < torch.tensor([n, n - 5, n // 2])[:, None]) if use_mask else None
+    gn, gc = torch.randn(b, n, kw["dim"], generator=g), torch.randn(b, n, 3, generator=g)
+    got = _emulated_backward(layer, feats, coors, mask, idx, rank, 0.8, gn, gc, max_graphs)
+    l64 = __import__("copy").deepcopy(layer).double()
+    f, c = feats.double().requires_grad_(True), coors.double().requires_grad_(True)
+    node, co = A.layer_given_neighbors(l64, f, c, None, mask, idx.long(), rank.double(), 0.8)
+    want = torch.autograd.grad([node, co], [f, c] + list(l64.parameters()), [gn.double(), gc.double()], allow_unused=True)
+    for pos, (a, r) in enumerate(zip(got, want)):
+        if r is None:
+            assert a is None or float(a.abs().max()) == 0.0
+            continue
+        scale = max(1e-12, float(r.abs().max()))
+        assert float((a.double() - r).abs().max()) <= 2e-4 * scale, (pos, float((a.double() - r).abs().max()), scale)
