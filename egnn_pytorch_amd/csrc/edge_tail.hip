@@ -17,6 +17,7 @@ namespace {
 
 constexpr int TM = 16;       // padded m_dim
 constexpr int TH = 64;       // padded hidden width of coors_mlp (4 m_dim)
+constexpr int SLD = 36;      // floats per row of the store staging (144 B: the 16-byte writes of 16 lanes hit 64 distinct banks)
 
 __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail_args p)
 {
@@ -27,9 +28,14 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
     for (int o = threadIdx.x; o < TH * TM; o += 256) sW3[o] = p.W3[o];
     if (threadIdx.x < TH) { sb3[threadIdx.x] = p.b3[threadIdx.x]; sW4[threadIdx.x] = p.W4[threadIdx.x]; }
     __syncthreads();
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // the two E x 64 outputs leave through LDS: a lane produces 4 columns of ITS row per iteration (16 bytes at a 256-byte stride
+    // across the wave), staged per wave as [64 rows][32 columns] and written out as whole 128-byte lines, 8 rows per instruction
+    __shared__ __attribute__((aligned(16))) float stage[4][2][64][SLD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t E = (int64_t)p.B * p.N * p.K;
-    if (e >= E) return;
+    const int64_t e_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = e_raw < E;                                               // (lanes behind the last edge compute a copy of it and store nothing)
+    const int64_t e = live ? e_raw : E - 1;
     const int K = p.K, N = p.N;
     const int64_t ig = e / K;                                                  // global node (b N + i)
     const int64_t jg = p.idx ? (ig / N) * N + p.idx[e] : (ig / N) * N + (e - ig * K);
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
     f32x4 grel;
     if (p.norm_coors) {
         const float dot = g_relp[0] * rel[0] + g_relp[1] * rel[1] + g_relp[2] * rel[2];
-        if (p.g_scale) p.g_scale[e] = dot / den;
+        if (p.g_scale && live) p.g_scale[e] = dot / den;
         const float k1 = scale / den;
         const float k2 = rn >= p.eps ? dot * scale / (den * den * fmaxf(rn, 1e-30f)) : 0.f;
 #pragma unroll
@@ -104,15 +110,16 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
     // travel through two different sums (per source, per neighbour) and, under CoorsNorm (|rel| < eps: a factor 1 / eps = 1e8),
     // leave rounding noise of order one behind.
     if (jg == ig) grel = f32x4{0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(p.g_rel + e * 4) = grel;
-    p.g_w[e] = g_w;
+    if (live) {
+        *reinterpret_cast<f32x4*>(p.g_rel + e * 4) = grel;
+        p.g_w[e] = g_w;
+    }
 
     // coors_mlp backward; g_m accumulates W3^T g_hid
     float gm[TM];
 #pragma unroll
     for (int c = 0; c < TM; ++c) gm[c] = pm ? p.g_msum[ig * TM + c] : 0.f;
-    float* gh_out = p.g_hid + e * TH;
-    float* a3_out = p.a3 + e * TH;
+    const int64_t e_wave = (int64_t)blockIdx.x * 256 + wave * 64;              // first edge of this wave
 #pragma unroll 1
     for (int t0 = 0; t0 < TH; t0 += 4) {
         f32x4 ghv, a3v;
@@ -129,8 +136,25 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
 #pragma unroll
             for (int c = 0; c < TM; ++c) gm[c] = __builtin_fmaf(sW3[t * TM + c], gh, gm[c]);
         }
-        *reinterpret_cast<f32x4*>(gh_out + t0) = ghv;
-        *reinterpret_cast<f32x4*>(a3_out + t0) = a3v;
+        const int part = (t0 >> 2) & 7;                                          // 8 iterations fill 32 columns = one line per row
+        *reinterpret_cast<f32x4*>(&stage[wave][0][lane][4 * part]) = ghv;
+        *reinterpret_cast<f32x4*>(&stage[wave][1][lane][4 * part]) = a3v;
+        if (part == 7) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int col0 = t0 - 28;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = (lane >> 3) + 8 * j;
+                if (e_wave + row < E) {
+                    const size_t o = (size_t)(e_wave + row) * TH + col0 + 4 * (lane & 7);
+                    *reinterpret_cast<f32x4*>(p.g_hid + o) = *reinterpret_cast<const f32x4*>(&stage[wave][0][row][4 * (lane & 7)]);
+                    *reinterpret_cast<f32x4*>(p.a3 + o) = *reinterpret_cast<const f32x4*>(&stage[wave][1][row][4 * (lane & 7)]);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     f32x4* gup = reinterpret_cast<f32x4*>(p.gU + e * TM);
 #pragma unroll
@@ -141,7 +165,7 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
             const int cc = 4 * q + c;
             v[c] = gm[cc] * (sgu[cc] * (1.0f + u[cc] * (1.0f - sgu[cc])));
         }
-        gup[q] = v;
+        if (live) gup[q] = v;
     }
 }
 
