@@ -446,7 +446,8 @@ def _backward_native(ctx, g_node, g_coors):
     grads_by_id = {id(p): torch.zeros_like(p) for p in params}
     g_feats = torch.zeros_like(feats)
     g_coors_in = torch.zeros_like(coors)
-    g_edges = torch.zeros_like(edges) if edges is not None else None
+    want_ge = edges is not None and need[6]                 # (the (B,N,N,edge_dim) input: its gradient only if somebody asked for it)
+    g_edges = torch.zeros_like(edges) if want_ge else None
     if g_node is None:
         g_node = torch.zeros_like(feats)
     if g_coors is None:
@@ -513,7 +514,7 @@ def _backward_native(ctx, g_node, g_coors):
                 f = f0.detach().requires_grad_(True)
                 mi = m_i[..., :m].detach().requires_grad_(True)
                 c = c0.detach().requires_grad_(True)
-                e = None if e0 is None else e0.detach().requires_grad_(True)
+                e = None if e0 is None else e0.detach().requires_grad_(want_ge)
                 closed_dist = s_in == 1                       # the distance is the only per-edge scalar: its backward in closed form below
                 if closed_dist:
                     with torch.no_grad():
@@ -565,7 +566,7 @@ def _backward_native(ctx, g_node, g_coors):
             with torch.enable_grad():
                 f = f0.detach().requires_grad_(True)
                 c = c0.detach().requires_grad_(True)
-                e = None if e0 is None else e0.detach().requires_grad_(True)
+                e = None if e0 is None else e0.detach().requires_grad_(want_ge)
                 u = u_all[lo:hi_, :, :, :m].detach().requires_grad_(True)
                 rel, scal = edge_scalars(layer, c, e, i64)
                 out_n, out_c = layer_tail(layer, f, c, u, rel, m0, i64, r0, ctx.valid_radius)
@@ -610,10 +611,10 @@ def _backward_native(ctx, g_node, g_coors):
             with torch.no_grad():                                   # d = |rel|^2:  d loss / d rel += 2 g_d rel
                 g_rel[:, :3] += (2.0 * g_scal.reshape(ec, 1)) * rel.reshape(ec, 3)
         else:
-            sg = torch.autograd.grad([scal], [c] + ([e] if e is not None else []), [g_scal], allow_unused=True)
+            sg = torch.autograd.grad([scal], [c] + ([e] if want_ge else []), [g_scal], allow_unused=True)
             if sg[0] is not None:
                 g_coors_in[lo:hi_] += sg[0]
-            if e is not None and sg[1] is not None:
+            if want_ge and sg[1] is not None:
                 g_edges[lo:hi_] += sg[1]
         if g_rel is not None:
             # rel = x_i - x_j reaches the coordinates at the source (sum over a node's edges) and, negated, at the neighbour
@@ -628,7 +629,7 @@ def _backward_native(ctx, g_node, g_coors):
                     g_coors_in[lo:hi_] -= _ops.rows_gather_sum(g_rel, by_dest, seg, bc * n).view(bc, n, 4)[..., :3]
     out_params = [grads_by_id[id(p)] if need[7 + i] else None for i, p in enumerate(params)]
     return (None, None, None, None, g_feats if need[4] else None, g_coors_in if need[5] else None,
-            g_edges if (edges is not None and need[6]) else None, *out_params)
+            g_edges if want_ge else None, *out_params)
 
 
 def _backward_recompute(ctx, g_node, g_coors):
