@@ -420,16 +420,17 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
 
 
 def _backward_native(ctx, g_node, g_coors):
-    """The backward with the E x H work on the HIP kernel egnn_edge_bwd_dz_f32 (include/egnn_hip.h):
-       1. everything behind edge_mlp's second Linear (second SiLU, gate, masks, coors_mlp, CoorsNorm, clamp, pooling, node_norm,
-          node_mlp) is small -- E x 16 / E x 64 / node-level -- and is differentiated by autograd from u = ctx.u_pre, which
-          the forward kernel wrote: gives gU = d loss / d u and the gradients of those modules' parameters;
-       2. the kernel recomputes z (gathers + first-layer MFMAs, exactly the forward's) and writes a = SiLU(z) and
-          dz = (W2^T gU) * SiLU'(z);
-       3. what remains are reductions and plain GEMMs over dz and a:  d/d P_i = sum over a node's edges,  d/d P_j = scatter by
-          neighbour,  d/d W_i, W_j, b_1 from those and feats,  d/d W_s = dz^T s,  d/d s = dz W_s (-> coors, edges through
-          the scalars' own small graph),  d/d W_2 = gU^T a,  d/d b_2 = sum gU.
-    Graphs are processed in chunks so that dz and a (2 x E x Hp fp32) stay inside a fixed budget."""
+    """The backward on the HIP kernels (module docstring), per chunk of graphs:
+       1. behind u = ctx.u_pre (edge_mlp's second Linear, written by the forward kernel): node_norm / node_mlp / residual through
+          autograd from the pooled messages; the per-edge chain in closed form on egnn_edge_tail_bwd_f32 (with the edge gate:
+          through autograd, `layer_tail`)  ->  gU = d loss / d u, d loss / d (x_i - x_j), those modules' parameter gradients;
+       2. the E x H work on egnn_edge_bwd_pass_f32 (`_edge_contract_fused`: by source and by destination, everything recomputed
+          and contracted in registers) or, beyond 5 per-edge scalars, egnn_edge_bwd_dz_f32 + reductions (`_edge_contract_dz`)
+          ->  d/d P_i, d/d P_j per node, d/d W_s, d/d scalars, d/d W_2;
+       3. node-level products: d/d feats, d/d W_i, W_j, b_1 from the per-node sums and feats; d/d scalars -> coordinates (closed
+          form when the distance is the only scalar, the scalars' own small graph otherwise) and edge features.
+    Every sum over edges has a fixed order.  Chunks: the kernels' tables stay below 2 GB (signed 32-bit offsets); the dz version
+    keeps dz and a (2 x E x Hp fp32) inside a fixed budget."""
     from . import _abi, _ops, _weights
     layer = ctx.layer
     feats, coors, edges, mask, idx32, rank = _unpack(ctx)
