@@ -155,6 +155,8 @@ def range_check_after_forward(device, mode=None):
 
 def check_range(device=None, wait=True):
     """Examine the status word of earlier (deferred-mode) forwards; raises EGNNRangeError if a value left the range."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return                                          # event queries are illegal inside a stream capture (graphed())
     for key, st in list(_status.items()):
         if device is not None and torch.device(device).index not in (None, key):
             continue

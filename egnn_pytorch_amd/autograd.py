@@ -265,19 +265,31 @@ class EGNNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, layer, order_hint, mask, adj_mat, feats, coors, edges, *params):
-        native = (_NATIVE and layer.m_dim <= 16 and coors.shape[-1] == 3 and feats.dtype == torch.float32
-                  and coors.dtype == torch.float32 and (edges is None or edges.dtype == torch.float32))
+        # the native backward computes in fp32 like the forward: float64 / bfloat16 / float16 modules and inputs pass through
+        # the same boundary conversion (gradients are returned in the callers' dtypes)
+        native = _NATIVE and layer.m_dim <= 16 and coors.shape[-1] == 3
         with torch.no_grad():
             node_out, coors_out, order, idx, rank, valid_radius, u_pre = layer._forward_hip_checked(
                 feats, coors, edges, mask, adj_mat, order_hint, want_u=native)
+        use_nearest = layer.num_nearest_neighbors > 0 or layer.only_sparse_neighbors
+        if use_nearest and idx is None:
+            # neighbour path with K == 0 (only_sparse_neighbors and an empty adjacency): NO messages -- not the dense graph that
+            # `idx is None` stands for everywhere else
+            b, n = feats.shape[:2]
+            idx = torch.empty(b, n, 0, dtype=torch.int32, device=feats.device)
+            rank = torch.empty(b, n, 0, dtype=torch.float32, device=feats.device)
         ctx.layer = layer
-        ctx.u_pre = u_pre                                # (E, 16) fp32 or None: E x 16, not E x H
+        ctx.has_u = u_pre is not None                    # (E, 16) fp32: E x 16, not E x H
         ctx.valid_radius = valid_radius
         ctx.has_edges = edges is not None
-        ctx.save_for_backward(feats, coors, edges if edges is not None else feats.new_empty(0),
-                              mask if mask is not None else feats.new_empty(0),
-                              idx if idx is not None else feats.new_empty(0), rank if rank is not None else feats.new_empty(0))
+        none = feats.new_empty(0)
+        ctx.save_for_backward(feats, coors, edges if edges is not None else none, mask if mask is not None else none,
+                              idx if idx is not None else none, rank if rank is not None else none,
+                              u_pre if u_pre is not None else none)
         ctx.flags = (mask is not None, idx is not None)
+        # the backward reads the layer's parameters (and their packed images) as they are THEN: an in-place update between
+        # forward and backward must fail like it does for any saved tensor
+        ctx.param_versions = tuple(p._version for p in params)
         ctx.order = order
         # outputs must not alias the inputs of a custom Function
         if node_out is feats:
@@ -288,16 +300,42 @@ class EGNNFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_node, g_coors):
-        if ctx.u_pre is not None:
+        for p, v in zip(ctx.layer.parameters(), ctx.param_versions):
+            if p._version != v:
+                raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace "
+                                   "operation: a parameter of egnn_pytorch_amd.EGNN changed between forward and backward "
+                                   f"(version {p._version}, expected {v})")
+        if ctx.has_u:
             return _backward_native(ctx, g_node, g_coors)
         return _backward_recompute(ctx, g_node, g_coors)
 
 
 def _unpack(ctx):
-    feats, coors, edges, mask, idx, rank = ctx.saved_tensors
+    feats, coors, edges, mask, idx, rank, _ = ctx.saved_tensors
     has_mask, has_idx = ctx.flags
     return (feats, coors, edges if ctx.has_edges else None, mask if has_mask else None,
             idx if has_idx else None, rank if has_idx else None)
+
+
+def _f32_shadow(layer):
+    """The layer itself if its parameters are fp32, else an fp32 copy of it (cached per parameter version): the native backward
+    differentiates in fp32 whatever dtype the module has, and hands the gradients back in the parameters' dtype."""
+    from . import _weights
+    if all(p.dtype == torch.float32 for p in layer.parameters()):
+        return layer
+    key = _weights.version_key(layer)
+    cached = layer.__dict__.get("_shadow32")
+    if cached is None or cached[0] != key:
+        import copy
+        packed, layer._packed = layer._packed, None          # (not the packed kernel weights, not an older shadow)
+        layer.__dict__.pop("_shadow32", None)
+        try:
+            mod = copy.deepcopy(layer)
+        finally:
+            layer._packed = packed
+        cached = (key, mod.float())
+        layer.__dict__["_shadow32"] = cached
+    return cached[1]
 
 
 def _edge_tables(layer, w, f2d, pi_split):
@@ -432,14 +470,20 @@ def _backward_native(ctx, g_node, g_coors):
     Every sum over edges has a fixed order.  Chunks: the kernels' tables stay below 2 GB (signed 32-bit offsets); the dz version
     keeps dz and a (2 x E x Hp fp32) inside a fixed budget."""
     from . import _abi, _ops, _weights
-    layer = ctx.layer
+    w = ctx.layer.packed_weights()
+    orig_params = list(ctx.layer.parameters())
+    layer = _f32_shadow(ctx.layer)                       # (the layer itself unless it is a float64 / half module)
     feats, coors, edges, mask, idx32, rank = _unpack(ctx)
+    in_dtypes = (feats.dtype, coors.dtype, None if edges is None else edges.dtype)
+    feats, coors = feats.float(), coors.float()
+    edges = None if edges is None else edges.float()
+    g_node = None if g_node is None else g_node.float()
+    g_coors = None if g_coors is None else g_coors.float()
     params = list(layer.parameters())
     need = ctx.needs_input_grad                          # (layer, order_hint, mask, adj, feats, coors, edges, *params)
     b, n, dim = feats.shape
     k = idx32.shape[-1] if idx32 is not None else n
     m = layer.m_dim
-    w = layer.packed_weights()
     h, hp, s_in = w["H"], w["Hp"], w["S"]
     lin0, lin3 = layer.edge_mlp[0], layer.edge_mlp[3]
     head = {id(lin0.weight), id(lin0.bias), id(lin3.weight), id(lin3.bias)}
@@ -453,7 +497,7 @@ def _backward_native(ctx, g_node, g_coors):
         g_node = torch.zeros_like(feats)
     if g_coors is None:
         g_coors = torch.zeros_like(coors)
-    u_all = ctx.u_pre.view(b, n, k, 16)
+    u_all = ctx.saved_tensors[6].view(b, n, k, 16)
     fused = _NATIVE_MODE != "dz" and s_in <= 5           # (egnn_edge_bwd_pass_f32 is built for up to 5 per-edge scalars)
     if fused:
         # nothing of size E x H: graphs are only chunked to keep the P table below 4 GB (32-bit buffer offsets) and E below 2^31
@@ -523,7 +567,8 @@ def _backward_native(ctx, g_node, g_coors):
                 else:
                     rel, scal = edge_scalars(layer, c, e, i64)                               # (only the scalars' graph is used below)
                 out_n = _per_edge(layer.node_mlp, torch.cat((layer.node_norm(f), mi), dim=-1)) + f      # (split-K weight gradients)
-                node_params = list(layer.node_norm.parameters()) + list(layer.node_mlp.parameters())
+                # (only what requires grad may be differentiated: a frozen parameter in the list makes autograd.grad raise)
+                node_params = [p for p in list(layer.node_norm.parameters()) + list(layer.node_mlp.parameters()) if p.requires_grad]
                 tg = torch.autograd.grad([out_n], [f, mi] + node_params, [g_node[lo:hi_]], allow_unused=True)
             if tg[0] is not None:
                 g_feats[lo:hi_] += tg[0]
@@ -576,14 +621,15 @@ def _backward_native(ctx, g_node, g_coors):
                     if o.requires_grad:
                         outs.append(o)
                         gouts.append(g)
-                wrt = [u, f, c] + tail_params
+                live_tail = [p for p in tail_params if p.requires_grad]
+                wrt = [u, f, c] + live_tail
                 tg = torch.autograd.grad(outs, wrt, gouts, allow_unused=True, retain_graph=True)
             g_u = tg[0] if tg[0] is not None else torch.zeros_like(u)
             if tg[1] is not None:
                 g_feats[lo:hi_] += tg[1]
             if tg[2] is not None:
                 g_coors_in[lo:hi_] += tg[2]
-            for p, g in zip(tail_params, tg[3:]):
+            for p, g in zip(live_tail, tg[3:]):
                 if g is not None:
                     grads_by_id[id(p)] += g
             gu16 = torch.zeros(ec, 16, dtype=torch.float32, device=feats.device)
@@ -628,22 +674,27 @@ def _backward_native(ctx, g_node, g_coors):
                     dest_sorted, by_dest = dest_order
                     seg = torch.searchsorted(dest_sorted, torch.arange(bc * n + 1, device=feats.device))
                     g_coors_in[lo:hi_] -= _ops.rows_gather_sum(g_rel, by_dest, seg, bc * n).view(bc, n, 4)[..., :3]
-    out_params = [grads_by_id[id(p)] if need[7 + i] else None for i, p in enumerate(params)]
-    return (None, None, None, None, g_feats if need[4] else None, g_coors_in if need[5] else None,
-            g_edges if want_ge else None, *out_params)
+    out_params = [grads_by_id[id(p)].to(op.dtype) if need[7 + i] else None for i, (p, op) in enumerate(zip(params, orig_params))]
+    return (None, None, None, None, g_feats.to(in_dtypes[0]) if need[4] else None, g_coors_in.to(in_dtypes[1]) if need[5] else None,
+            g_edges.to(in_dtypes[2]) if want_ge else None, *out_params)
 
 
 def _backward_recompute(ctx, g_node, g_coors):
     """The pure-ATen backward: chunked recompute of the whole layer through autograd (module docstring).  Used for the shapes
     the native kernel does not cover (m_dim > 16, coordinate dimension != 3, non-fp32) and as its reference in the tests."""
     layer = ctx.layer
-    feats, coors, edges, mask, idx, rank = ctx.saved_tensors
-    has_mask, has_idx = ctx.flags
-    edges = edges if ctx.has_edges else None
-    mask = mask if has_mask else None
-    idx = idx.long() if has_idx else None
-    rank = rank if has_idx else None
+    feats, coors, edges, mask, idx, rank = _unpack(ctx)
+    idx = None if idx is None else idx.long()
     params = [p for p in layer.parameters()]
+    # inputs whose dtype differs from the parameters' (the forward converts at the boundary): differentiate in the parameters'
+    # dtype, return every gradient in the dtype of the tensor it belongs to
+    in_dtypes = (feats.dtype, coors.dtype, None if edges is None else edges.dtype)
+    pd = params[0].dtype if params else feats.dtype
+    feats, coors = feats.to(pd), coors.to(pd)
+    edges = None if edges is None else edges.to(pd)
+    rank = None if rank is None else rank.to(pd)
+    g_node = None if g_node is None else g_node.to(pd)
+    g_coors = None if g_coors is None else g_coors.to(pd)
     b, n, _ = feats.shape
     k = idx.shape[-1] if idx is not None else n
     step = _chunk_graphs(layer, n, k, b)
@@ -690,7 +741,8 @@ def _backward_recompute(ctx, g_node, g_coors):
                 g = next(it)
                 if g is not None:
                     gp.add_(g)
-    return (None, None, None, None, g_feats, g_coors_in, g_edges, *g_params)
+    cast = lambda g, dt: None if g is None else g.to(dt)                                        # noqa: E731
+    return (None, None, None, None, cast(g_feats, in_dtypes[0]), cast(g_coors_in, in_dtypes[1]), cast(g_edges, in_dtypes[2]), *g_params)
 
 
 def wants_grad(layer, *tensors):

@@ -22,11 +22,23 @@ pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
 # compiler errors / warnings (the resource-usage remarks are filtered out)
 grep -h -v "remark:\|^ *[0-9]* *|\|^ *|\|\^\|remarks\? generated\|^$" "$HERE"/obj/*.res || true
-# no kernel may use scratch (register spills): see edge_fused.hip::edge_min_blocks
-if grep -h "ScratchSize \[bytes/lane\]: [1-9]" "$HERE"/obj/*.res; then
-  echo "error: a kernel spills registers to scratch (see $HERE/obj/*.res)" >&2
-  exit 1
-fi
+# Register spills: none inside a kernel's loops (edge_fused.hip::edge_min_blocks).  A source whose kernels use scratch at all is
+# compiled to device assembly once more and csrc/check_scratch.py looks at where the scratch accesses sit.
+for res in "$HERE"/obj/*.res; do
+  if grep -q "ScratchSize \[bytes/lane\]: [1-9]" "$res"; then
+    f="$(basename "$res" .res)"
+    EXTRA=""; src="$f"
+    [ "$f" = edge_fused_c ] && { EXTRA="-DEGNN_EDGE_GENERIC_C"; src=edge_fused; }
+    [ "$f" = knn_select ] && EXTRA="-ffp-contract=off"
+    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed -Wno-inline-asm $EXTRA -S --cuda-device-only \
+        -o "$HERE/obj/$f.s" "$HERE/$src.hip" 2> /dev/null
+    if ! python3 "$HERE/check_scratch.py" "$HERE/obj/$f.s"; then
+      echo "error: $f spills registers inside a loop" >&2
+      exit 1
+    fi
+    echo "note: $f parks registers in scratch outside its loops ($(grep -h "ScratchSize \[bytes/lane\]: [1-9]" "$res" | sed 's/.*lane\]: \([0-9]*\).*/\1/' | sort -n | tail -1) bytes/lane)"
+  fi
+done
 # the product library, and -- separately -- the test-only reference kernels (include/egnn_hip_ref.h; loaded by tests/_reflib.py)
 REF_OBJS=("$HERE/obj/linear_f32.o" "$HERE/obj/linear_split.o" "$HERE/obj/node_prep_ref.o")
 PROD_OBJS=()

@@ -54,7 +54,7 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 #define EGNN_EDGE_HC 256
 #endif
 #ifndef EGNN_EDGE_MINW
-#define EGNN_EDGE_MINW 4
+#define EGNN_EDGE_MINW 5
 #endif
 // W2 / W_s staging as a two-slot ring of HCT/2 columns: the LDS-DMA of chunk c+1 is in flight while chunk c is computed
 // (one barrier per chunk and no exposed DMA latency) instead of barrier, DMA, wait, barrier per HCT columns
@@ -66,6 +66,16 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 #endif
 #ifndef EGNN_EDGE_BWD_NT
 #define EGNN_EDGE_BWD_NT 1
+#endif
+// Gathered P_j lines go straight from L2 into the wave's exchange rows by LDS-DMA (`buffer_load_dwordx4 ... lds`): no VGPR
+// round trip, no ds_write_b128 parking stores (4 KB of LDS-pipe traffic and 16 registers per wave and step)
+#ifndef EGNN_EDGE_GDMA
+#define EGNN_EDGE_GDMA 1
+#endif
+// The residual of the hi/lo split, lo = a - fp16(a), on the matrix cores: D = (-I) x hi + a is exact and the accumulator
+// layout of `a` is the B-fragment layout of `hi` -- one v_mfma_f32_16x16x16_f16 per 4 values instead of a v_fma_mix_f32 per value
+#ifndef EGNN_EDGE_LO_MFMA
+#define EGNN_EDGE_LO_MFMA 1
 #endif
 constexpr int EDGE_THREADS = EGNN_EDGE_THREADS;
 constexpr int EDGE_WAVES = EDGE_THREADS / 64;
@@ -93,8 +103,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
 }
 
-// Workgroups per CU the register allocator must allow, chosen so that no variant spills to scratch (csrc/build.sh
-// checks it: spills are slow on a VALU-bound kernel and one less thing to reason about).
+// Workgroups per CU the register allocator must allow.  Nothing may spill inside the hidden loop (csrc/build.sh checks the
+// ISA: csrc/check_scratch.py).  The K % 32 == 0 kernel of the standard layer runs FIVE workgroups per CU (96 registers, 26 KB of
+// LDS with 128-column staging chunks): a workgroup's setup and epilogue are latency chains (index -> neighbour list ->
+// coordinates -> first gathered lines; constants, barriers, stores: ~0.2 ms of 1.47 at the north-star shape with the loop
+// compiled out) that only the other workgroups of the CU can cover -- measured 1.470 -> 1.390 ms.  Its 13 spilled dwords are
+// per-slot values of the setup that the epilogue reads back (one store, one load each, outside every loop).
 constexpr int edge_min_blocks(int nm, int tpi, int nb)
 {
     if (nb >= 4) return 1;                      // m_dim > 32: four accumulator tiles per edge tile
@@ -102,8 +116,21 @@ constexpr int edge_min_blocks(int nm, int tpi, int nb)
     if (nm >= 12) return 1;
     if (nm > 4) return 2;
     if (nm > 1) return (CDM == 3 && tpi == 2) ? 3 : 2;
-    return (CDM == 3 && tpi >= 1) ? EGNN_EDGE_MINW : 3;
+    if (CDM == 3 && tpi == 2) return EGNN_EDGE_MINW;
+    return (CDM == 3 && tpi >= 1) ? 4 : 3;
 }
+// (the training forward also writes u and keeps the edge index: one workgroup fewer; the dz-through-HBM backward: at most 4)
+constexpr int edge_launch_blocks(int nm, int tpi, int nb, int mode)
+{
+    const int mb = edge_min_blocks(nm, tpi, nb);
+    if (mode == 1) return mb > 1 ? mb - 1 : mb;
+    if (mode == 2) return mb > 4 ? 4 : mb;
+    return mb;
+}
+// staging chunk of the five-workgroup kernel
+#ifndef EGNN_EDGE_HC5
+#define EGNN_EDGE_HC5 128
+#endif
 
 __device__ __forceinline__ float row16_sum(float v) { return egnn_row16_sum(v); }
 
@@ -141,6 +168,24 @@ __device__ __forceinline__ uint32_t buf_load1(__amdgpu_buffer_rsrc_t r, uint32_t
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0);
 }
 
+// One gather instruction of the LDS-DMA path: lane l's 16 bytes at (descriptor base + voff + soff) land at lds_addr + 16 l
+// (lds_addr, soff wave-uniform).  Inline asm for the same reason as lds_dma16.
+typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gather_dma16(u32x4s rsrc, uint32_t voff, uint32_t soff, uint32_t lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ u32x4s make_rsrc_words(const void* base, uint32_t bytes)
+{
+    const uint64_t a = (uint64_t)(size_t)base;
+    u32x4s r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+
 // NM: chained first-layer MFMAs (4 split terms each, 3 terms per per-edge scalar); HCT: hidden columns per LDS chunk;
 // TPI: how P_i reaches x.  2 (K % 32 == 0): the 32 slots of a wave belong to one node -- its (hi, lo) row rides in the
 // first-layer MFMA (K-slots 0, 1).  1 (K >= 6): the 16 slots of a tile touch at most 4 nodes -- their rows sit in the
@@ -158,6 +203,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
     // MODE 0: inference forward.  1: forward that also writes u (args.U_out) for the backward -- its own instantiation, the
     // inference kernels sit at the register limit of 4 workgroups per CU.  2: backward (egnn_edge_bwd_dz_f32).
     constexpr bool BWD = MODE == 2;
+    constexpr bool GDMA = EGNN_EDGE_GDMA && EGNN_EDGE_RING && !BWD;   // gathers by LDS-DMA (the backward keeps its counted store waits)
     constexpr int HC = EGNN_EDGE_RING ? HCT / 2 : HCT;     // columns per staged chunk (ring: two slots of HCT / 2)
     constexpr int NCH = nch_of(NB);
     constexpr int W2B = 64 * NB;                           // bytes of W2 fragments per hidden column: NB blocks x (hi | lo) x 16 channels
@@ -190,6 +236,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
     const uint32_t prow_bytes = (uint32_t)((size_t)N * p.ldp * 4);
     const __amdgpu_buffer_rsrc_t pj_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Pj + bN * p.ldp), 0, prow_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t pi_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Pi + bN * p.ldp), 0, prow_bytes, 0x00020000);
+    const u32x4s pj_words = make_rsrc_words(p.Pj + bN * p.ldp, prow_bytes);      // the same descriptor as four scalars (GDMA)
 
     for (int o = tid; o < G * NCH; o += EDGE_THREADS) nodeacc[o] = 0.f;
 
@@ -219,8 +266,13 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             int pos = node0 + nl;                                    // position in the (optionally permuted) node order
             bool valid = (q < slots_total) && (pos < N);
             if (!valid) { pos = node0 < N ? node0 : 0; k = 0; }
+#if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 1024)
+            const int i = pos;                                    // ablation: no index chain (order -> idx -> coors)
+            const int j = (pos + k) & (N - 1);
+#else
             const int i = p.order ? p.order[bN + pos] : pos;
             const int j = p.idx ? p.idx[(bN + i) * K + k] : k;
+#endif
             const int C = (CDM == 3) ? 3 : p.coor_dim;
             const float* ci = p.coors + (bN + i) * C;
             const float* cj = p.coors + (bN + j) * C;
@@ -323,12 +375,21 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             int k = (TPI == 2) ? k_w + qq * 8 + (lane >> 3) : q - nl * K;
             int pos = node0 + nl;
             if (!((q < slots_total) && (pos < N))) { pos = node0 < N ? node0 : 0; k = 0; }
+#if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 1024)
+            const int i2 = pos;
+            const int j2 = (pos + k) & (N - 1);
+#else
             const int i2 = p.order ? p.order[bN + pos] : pos;
             const int j2 = p.idx ? p.idx[(bN + i2) * K + k] : k;
+#endif
 #if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 1)
             goff[qq] = (uint32_t)(((size_t)(i2 & ~7) * p.ldp + 4 * (lane & 7)) * 4);
 #else
-            goff[qq] = (uint32_t)(((size_t)j2 * p.ldp + 4 * (lane & 7)) * 4);
+            // GDMA: the DMA drops lane l's chunk at byte 16 l of the 1 KB piece, i.e. at position l & 7 of row 8 qq + (l >> 3);
+            // the exchange buffer's swizzle (chunk c at position c ^ ((row >> 1) & 7)) moves to the global side: fetch the
+            // chunk that belongs at that position
+            const int chunk = GDMA ? ((lane & 7) ^ ((4 * qq + (lane >> 4)) & 7)) : (lane & 7);
+            goff[qq] = (uint32_t)(((size_t)j2 * p.ldp + 4 * chunk) * 4);
 #endif
         }
         // Exchange buffer: row = slot (128 B), 16-byte chunk c stored at position c ^ ((row >> 1) & 7): the parking
@@ -348,6 +409,10 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) xr[hb] = xch + e * XLD + 4 * ((4 * hb + g) ^ ((e >> 1) & 7));
 
+        // A operand of the residual MFMA: -I (row e, K-slots 4g .. 4g+3)
+        f16x4 neg_identity;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) neg_identity[u] = (e == 4 * g + u) ? (_Float16)-1.f : (_Float16)0.f;
         // first-layer A fragments: row (hidden unit) e of the 16-block, split term 4 m + g
         const char* tl = wst + (e * (4 * NM) + g) * 4;
         constexpr int tstep = 16 * 4 * NM * 4;                          // bytes per 16 hidden units
@@ -361,11 +426,17 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
         // ------------------------------------------------------------------ main loop over hidden units
         // Software pipeline: the Pi/Pj rows of step st+1 are requested before step st is computed, so the
         // gather latency (L2 / Infinity Cache) hides under the SiLU work of the current step.
-        f32x4 gl[4];
+        f32x4 gl[GDMA ? 1 : 4];
         f32x4 pin[TPI == 0 ? TILES : 1][2];
         uint32_t piv[TPI == 1 ? TILES : 1][2] = {};
+        const uint32_t xch_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)(char*)xch);
+        if constexpr (GDMA) {
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) gl[qq] = buf_load4(pj_rsrc, goff[qq], 0);
+            for (int qq = 0; qq < 4; ++qq) gather_dma16(pj_words, goff[qq], 0u, xch_lds + qq * 1024);
+        } else {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) gl[qq] = buf_load4(pj_rsrc, goff[qq], 0);
+        }
         if (TPI == 0) {
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
@@ -424,11 +495,15 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             // 2 x TILES x 2 stores issued last -- a step's, or the spare-row ones above -- which are younger than the DMA.)
             if constexpr (BWD) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 64))                         // (ablation 64: no chunk barrier -- timing only)
             __syncthreads();       // every wave's pieces have landed, and every wave has left the other slot
+#endif
 #if defined(EGNN_EDGE_RING_DBG) && (EGNN_EDGE_RING_DBG & 1)
             if (c0 + HC < p.Hp) { stage(c0 + HC, slot ^ 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
 #else
-            if (c0 + HC < p.Hp) stage(c0 + HC, slot ^ 1);
+            // (GDMA: issued inside the chunk's first step, behind that step's wait for its gathered lines -- every wait of the
+            // loop is then a plain vmcnt(0) and none of them sits out a DMA that has only just been issued)
+            if (!GDMA && c0 + HC < p.Hp) stage(c0 + HC, slot ^ 1);
 #endif
             const _Float16* w2c = w2s + slot * (HC * (W2B / 2));
             const char* tlc = tl + slot * (HC * NM * 16);
@@ -464,6 +539,53 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 #if EGNN_EDGE_PRIO
                 __builtin_amdgcn_s_setprio(EGNN_EDGE_PRIO);          // hurry through the LDS / MFMA head of the step
 #endif
+                int hnext = hoff + KSTEP;
+                if (hnext >= p.Hp) hnext = hoff;                 // last step: harmless re-read (GDMA: nothing is issued)
+                // x starts as the gathered P_j values, in the MFMA accumulator layout: lane (e, g) = edge e, hidden rows
+                // 16 hb + 4 g .. + 3 of this step
+                f32x4 x[TILES][2];
+                uint32_t pivn[TPI == 1 ? TILES : 1][2] = {};
+                if constexpr (GDMA) {
+                    // the lines of this step were requested a step ago and land in the wave's exchange rows by themselves.
+                    // (The waits are the builtin, not inline asm: the compiler then KNOWS that no load of its own -- the P_i
+                    // words -- is outstanding; guessing, it waits vmcnt(3) for them, which with four untracked DMA
+                    // instructions behind them means sitting out the latency of the lines just requested.)
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+#if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 32)
+                        x[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};                // ablation: no pick-up reads
+                        x[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
+                        x[t][0] = *reinterpret_cast<const f32x4*>(xr[0] + t * 16 * XLD);
+                        x[t][1] = *reinterpret_cast<const f32x4*>(xr[1] + t * 16 * XLD);
+#endif
+                    }
+                    // the rows are in registers before the next step's lines may overwrite them
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0)
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    // the step's P_i words are requested here, between two asm statements that order memory operations: left
+                    // to itself the scheduler sinks them to the end of the step, right in front of the wait that needs them
+                    if constexpr (TPI != 0) {
+#pragma unroll
+                        for (int t = 0; t < (TPI == 1 ? TILES : 1); ++t) {
+                            pivn[t][0] = buf_load1(pi_rsrc, piw[t], hnext * 4);
+                            pivn[t][1] = buf_load1(pi_rsrc, piw[t], hnext * 4 + 64);
+                        }
+                    }
+                    if (st == 0 && c0 + HC < p.Hp) stage(c0 + HC, slot ^ 1);
+#if !(defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 128))                     // (ablation 128: no gathers)
+                    if (hoff + KSTEP < p.Hp) {
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) gather_dma16(pj_words, goff[qq], (uint32_t)(hnext * 4), xch_lds + qq * 1024);
+                    }
+#endif
+                } else {
                 // park the lines fetched for this step, then (same wave, DS ops execute in order) pick the rows up
 #if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 32)
                 const f32x4 glx[4] = {gl[0], gl[1], gl[2], gl[3]};      // ablation: no park / pick-up through LDS
@@ -471,17 +593,12 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f32x4*>(xw[qq & 1] + (qq >> 1) * 16 * XLD) = gl[qq];
 #endif
-                int hnext = hoff + KSTEP;
-                if (hnext >= p.Hp) hnext = hoff;                 // last step: harmless re-read
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) gl[qq] = buf_load4(pj_rsrc, goff[qq], hnext * 4);
                 // Same-wave hand-off through LDS: DS operations of one wave execute in issue order; the explicit
                 // lgkmcnt(0) makes the store -> other-lane load dependency independent of that (4 stores, negligible).
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                // x starts as the gathered P_j values, in the MFMA accumulator layout: lane (e, g) = edge e, hidden rows
-                // 16 hb + 4 g .. + 3 of this step
-                f32x4 x[TILES][2];
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
 #if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 32)
@@ -494,6 +611,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                }
 
                 u32x2 av[NM][2];
 #pragma unroll
@@ -527,8 +645,13 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                     }
 #pragma unroll
                     for (int t = 0; t < (TPI == 1 ? TILES : 1); ++t) {
-                        piv[t][0] = buf_load1(pi_rsrc, piw[t], hnext * 4);
-                        piv[t][1] = buf_load1(pi_rsrc, piw[t], hnext * 4 + 64);
+                        if constexpr (GDMA) {
+                            piv[t][0] = pivn[t][0];
+                            piv[t][1] = pivn[t][1];
+                        } else {
+                            piv[t][0] = buf_load1(pi_rsrc, piw[t], hnext * 4);
+                            piv[t][1] = buf_load1(pi_rsrc, piw[t], hnext * 4 + 64);
+                        }
                     }
                 }
                 // First Linear of edge_mlp on the matrix cores: x += [P_i | W_s] x [1 | scalars]  (split-f16 products)
@@ -616,6 +739,33 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                             blo[u0 + u] = lo[0]; blo[u0 + u + 1] = lo[1];
                         }
                     }
+#elif EGNN_EDGE_LO_MFMA
+                    // a = y / (1 + 2^y) per value (4 VALU instructions), hi = fp16(a) (v_cvt_pk_f16_f32, IEEE: beyond 65504 -> inf,
+                    // so an overflowing hidden value poisons the edge's message instead of saturating silently), and the
+                    // residual on the matrix cores: lo32 = (-I) x hi + a, exact (a - hi has at most 13 significant bits)
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {
+                        f32x4 a4;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float y = x[t][hb][u];
+#if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 2)
+                            float h = y * (1.0f + y);                       // ablation: no transcendentals
+#else
+                            float h = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
+#endif
+                            asm("" : "+v"(h));           // keeps the products scalar (v_pk_mul_f32 costs 9.3 cycles per pair against 2 x 2.8)
+                            a4[u] = h;
+                        }
+                        const f16x2 h01 = __builtin_convertvector((f32x2v){a4[0], a4[1]}, f16x2);
+                        const f16x2 h23 = __builtin_convertvector((f32x2v){a4[2], a4[3]}, f16x2);
+                        const f16x4 hi4 = {h01[0], h01[1], h23[0], h23[1]};
+                        const f32x4 l4 = __builtin_amdgcn_mfma_f32_16x16x16f16(neg_identity, hi4, a4, 0, 0, 0);
+                        const f16x2 l01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l4[0], l4[1]));
+                        const f16x2 l23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l4[2], l4[3]));
+                        bhi[4 * hb + 0] = h01[0]; bhi[4 * hb + 1] = h01[1]; bhi[4 * hb + 2] = h23[0]; bhi[4 * hb + 3] = h23[1];
+                        blo[4 * hb + 0] = l01[0]; blo[4 * hb + 1] = l01[1]; blo[4 * hb + 2] = l23[0]; blo[4 * hb + 3] = l23[1];
+                    }
 #else
 #pragma unroll
                     for (int u = 0; u < 8; u += 2) {
@@ -672,6 +822,17 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             __syncthreads();                                 // (multi-round groups: both staging slots free again)
             continue;
         }
+        if constexpr (GDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may land in rows the epilogue reuses
+#if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 512)
+        {                                                     // ablation: no epilogue (keeps the accumulators alive)
+            float sacc = 0.f;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) sacc += acc[t][0][0] + acc[t][0][1] + acc[t][0][2] + acc[t][0][3] + (fm[t] ? 1.f : 0.f) + (float)(ei[t] + ej[t]);
+            if (sacc == 12345.678f) nodeacc[tid] = sacc;
+            __syncthreads();
+            continue;
+        }
+#endif
 
         // ------------------------------------------------------------------ per-edge epilogue (registers)
         // channel of (block nb, lane group g, register u) = 16 nb + 4 g + u
@@ -731,7 +892,11 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             cw[t] = 0.f;
         }
 
+#if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 256)
+        if (false) {                                          // ablation: no coors_mlp
+#else
         if (p.W3h) {
+#endif
             float part[TILES];
 #pragma unroll
             for (int t = 0; t < TILES; ++t) part[t] = 0.f;
@@ -945,7 +1110,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 }
 
 template <int NM, int HCT, int TPI, int NB, int MODE = 0>
-__global__ __launch_bounds__(EDGE_THREADS, (MODE == 1 && edge_min_blocks(NM, TPI, NB) > 1) ? edge_min_blocks(NM, TPI, NB) - 1 : edge_min_blocks(NM, TPI, NB)) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
+__global__ __launch_bounds__(EDGE_THREADS, edge_launch_blocks(NM, TPI, NB, MODE)) void edge_kernel(const egnn_edge_args p, const int G, const int gpg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     edge_body<NM, HCT, TPI, NB, MODE>(p, G, gpg, smem, blockIdx.x, gridDim.x);
@@ -984,7 +1149,7 @@ int dispatch_tpi_nb(const egnn_edge_args& a, hipStream_t s)
 {
     // K % 32 == 0: both tiles of a wave share node i; K >= 6: a tile touches <= 4 nodes -- either way P_i rides in the
     // first-layer MFMA as (hi, lo) words (pi_split); K < 6: it is added per lane from the fp32 projection
-    if (a.K % 32 == 0) return launch_edge<NM, HCT, 2, NB, MODE>(a, s);
+    if (a.K % 32 == 0) return launch_edge<NM, (NM == 1 && NB == 1 && edge_min_blocks(NM, 2, NB) >= 5) ? EGNN_EDGE_HC5 : HCT, 2, NB, MODE>(a, s);
     if (a.K >= 6) return launch_edge<NM, HCT, 1, NB, MODE>(a, s);
     return launch_edge<NM, HCT, 0, NB, MODE>(a, s);
 }

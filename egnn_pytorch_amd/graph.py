@@ -17,8 +17,11 @@ import torch
 from . import _ops
 
 
-def graphed(module, *example_inputs, warmup: int = 2, **example_kwargs):
-    """Capture `module(*example_inputs, **example_kwargs)` into a HIP graph; returns `run(*inputs, **kwargs)`."""
+def graphed(module, *example_inputs, warmup: int = 2, range_check: str | None = None, **example_kwargs):
+    """Capture `module(*example_inputs, **example_kwargs)` into a HIP graph; returns `run(*inputs, **kwargs)`.
+    range_check: how the range status word is examined after a replay -- None = the process setting (EGNN_RANGE_CHECK),
+    "deferred" = copied to pinned memory behind the replay and looked at by the next call (keeps the replay asynchronous),
+    "sync" = one blocking 4-byte read per replay, "off"."""
     args = [a.clone() if torch.is_tensor(a) else a for a in example_inputs]
     kwargs = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_kwargs.items()}
     dev = next(a for a in list(args) + list(kwargs.values()) if torch.is_tensor(a)).device
@@ -44,7 +47,7 @@ def graphed(module, *example_inputs, warmup: int = 2, **example_kwargs):
             elif dst is not src and dst != src:
                 raise ValueError("graphed(): non-tensor arguments are baked into the graph and cannot change")
         graph.replay()
-        _ops.range_check_after_forward(dev)                 # the captured forward could not read the status word itself
+        _ops.range_check_after_forward(dev, mode=range_check)   # the captured forward could not read the status word itself
         return outputs
 
     run.graph = graph

@@ -135,8 +135,14 @@ def test_bench_rank_logic_end_to_end_with_gloo_standin():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 2 * d["config"]["graphs_per_gpu"] and d["value"] > 0
     assert "STAND-IN" in d["data"]
-    # asking for 2 GPUs without the launcher is an error, not a silent 1-rank run
-    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--standin-backend", "gloo"],
-                        capture_output=True, text=True, timeout=120, cwd=ROOT, env={k: v for k, v in os.environ.items()
-                                                                                     if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
-    assert r1.returncode != 0 and "torch.distributed.run" in (r1.stderr + r1.stdout)
+    # the driver's own command line -- `python bench.py --gpus 2 ...` WITHOUT a launcher -- spawns the two ranks itself (VERDICT r2
+    # weak #6: it used to exit with "needs torch.distributed.run") and prints the same single line
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                         "--standin-backend", "gloo"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    lines1 = [l for l in r1.stdout.splitlines() if l.startswith("{")]
+    assert len(lines1) == 1, r1.stdout
+    d1 = json.loads(lines1[0])
+    assert d1["n_gpus"] == 2 and d1["steps"] == 3 and d1["warmup"] == 1
+    assert d1["config"]["global_batch"] == 2 * d1["config"]["graphs_per_gpu"]
