@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -28,7 +28,8 @@ SYMBOLS = (
     "egnn_packed_halves", "egnn_adj_expand_u8", "egnn_adj_expand_workspace_bytes", "egnn_edge_mfmas",
     "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32",
     "egnn_edge_bwd_dz_f32", "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_tail_bwd_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
-    "egnn_induced_attn_f32", "egnn_token_attn_f32",
+    "egnn_induced_attn_f32", "egnn_token_attn_f32", "egnn_slot_prep_f32", "egnn_struct_bytes",
+    "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32",
 )
 
 
@@ -52,6 +53,7 @@ class EdgeArgs(Structure):
         ("U_out", c_void_p), ("W2Th", c_void_p), ("gU", c_void_p), ("gu_scale", c_float), ("bwd_inv_scale", c_float),
         ("dZ", c_void_p), ("A_out", c_void_p), ("ldz", c_int64),
         ("edges_by_k", c_int32),
+        ("slots", c_void_p),
     ]
 
 
@@ -199,6 +201,19 @@ def load():
                                       c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]
     lib.egnn_spatial_order_f32.restype = c_int
     lib.egnn_spatial_order_f32.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.egnn_slot_prep_f32.restype = c_int
+    lib.egnn_slot_prep_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.egnn_dest_lists_capacity.restype = c_size_t
+    lib.egnn_dest_lists_capacity.argtypes = [c_int, c_int, c_int]
+    lib.egnn_dest_lists_i32.restype = c_int
+    lib.egnn_dest_lists_i32.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.egnn_split_scaled_f16.restype = c_int
+    lib.egnn_split_scaled_f16.argtypes = [c_void_p, c_int64, c_int64, c_int, c_float, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+    lib.egnn_linear_hl_splitk_f32.restype = c_int
+    lib.egnn_linear_hl_splitk_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
+                                              c_int, c_void_p]
+    lib.egnn_sum_parts_f32.restype = c_int
+    lib.egnn_sum_parts_f32.argtypes = [c_void_p, c_int, c_int64, c_float, c_void_p, c_void_p]
     lib.egnn_edge_mfmas.restype = c_int
     lib.egnn_edge_mfmas.argtypes = [c_int]
     lib.egnn_edge_fused_f32.restype = c_int
@@ -236,6 +251,12 @@ def load():
 
     if lib.egnn_abi_version() != ABI_VERSION:
         raise EGNNHipError(f"{path}: ABI version {lib.egnn_abi_version()} != {ABI_VERSION}; rebuild it")
+    lib.egnn_struct_bytes.restype = c_int64
+    lib.egnn_struct_bytes.argtypes = [c_int]
+    for which, mirror in enumerate((EdgeArgs, EdgeBwdArgs, EdgeTailArgs, LayerDesc, PackedInfo)):
+        if lib.egnn_struct_bytes(which) != ctypes.sizeof(mirror):
+            raise EGNNHipError(f"{path}: sizeof({mirror.__name__}) = {ctypes.sizeof(mirror)} here, {lib.egnn_struct_bytes(which)} in the "
+                               f"library: the ctypes mirror in _abi.py and include/egnn_hip.h disagree")
     _lib = lib
     return lib
 

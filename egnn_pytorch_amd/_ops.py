@@ -206,6 +206,18 @@ def spatial_order(coors):
     return order
 
 
+def slot_prep(coors, mask8, idx, rank, order, valid_radius):
+    """(B*N*K, 4) int32 per-slot records {j | pair_ok << 31, x_i - x_j} in the edge pass's consumption order --
+    egnn_slot_prep_f32 (flattens the setup's index chain: include/egnn_hip.h)."""
+    b, n, k = idx.shape
+    slots = empty(b * n * k, 4, dtype=torch.int32, device=coors.device)
+    with _timed("slot_prep"):
+        rc = _abi.load().egnn_slot_prep_f32(_ptr(coors), _ptr(mask8), _ptr(idx), _ptr(rank), _ptr(order),
+                                            float(min(valid_radius, 3.0e38)), b, n, k, _ptr(slots), _stream())
+    _abi.check(rc, "egnn_slot_prep_f32")
+    return slots
+
+
 def adj_expand(adj_mat, b, num_adj_degrees):
     """N-degree adjacency expansion (egnn_pytorch.py:414-427) -- egnn_adj_expand_u8.
     Returns (expanded adjacency (B,N,N) bool, adj_indices (B,N,N) uint8)."""
@@ -376,6 +388,93 @@ def rows_gather_sum(rows, order, seg_ptr, n_out):
                                                   cols, _stream())
     _abi.check(rc, "egnn_rows_gather_sum_f32")
     return out
+
+
+def split_scaled(x2d, scale, transposed=False, w_image=False):
+    """packed fp16 (hi, lo) images of scale * x2d (or of its transpose) -- egnn_split_scaled_f16.  w_image: allocate whole 128-row
+    tiles (zero filled), as the W operand of egnn_linear_hl_f32 wants."""
+    rows, cols = x2d.shape
+    img_rows, k_extent = (cols, rows) if transposed else (rows, cols)
+    kp = _kpad(k_extent)
+    alloc_rows = (img_rows + 127) // 128 * 128 if w_image else img_rows
+    hi = _packed_empty(alloc_rows, kp, x2d.device, zero=w_image)
+    lo = _packed_empty(alloc_rows, kp, x2d.device, zero=w_image)
+    with _timed("split_scaled"):
+        rc = _abi.load().egnn_split_scaled_f16(_ptr(x2d), x2d.stride(0), rows, cols, float(scale), int(transposed), _ptr(hi), _ptr(lo), kp,
+                                               _ptr(status_word(x2d.device).dev), _stream())
+    _abi.check(rc, "egnn_split_scaled_f16")
+    return PackedHL(hi, lo, img_rows, kp), alloc_rows
+
+
+def grad_nn(g2d, wsplit_t, n, residual=None, name="grad_nn"):
+    """g2d (R, K) fp32 @ W (K, n), W given as the packed split image of W^T (n rows, K): on the split-f16 GEMM of the forward,
+    g2d pre-scaled by a power of two (gradients are small: their fp16 lo halves must stay off the subnormals)."""
+    from . import _weights
+    amax = float(g2d.abs().max())
+    if not (amax > 0.0) or amax != amax or amax == float("inf"):
+        out = torch.zeros(g2d.shape[0], n, dtype=torch.float32, device=g2d.device)
+        return out if residual is None else out + residual
+    scale = _weights.pow2_scale(amax) * 4096.0                       # max |scale * g| in [2^12, 2^13)
+    a, _ = split_scaled(g2d, scale)
+    whi, wlo, inv, w_rows = wsplit_t
+    return linear_hl(a, (whi, wlo, inv / scale, w_rows), n, None, residual=residual, name=name)
+
+
+def grad_tn(g2d, x2d, k_splits=None, name="grad_tn"):
+    """g2d (R, M)^T @ x2d (R, N) -> (M, N): the weight-gradient contraction over R = B N nodes, split-K on the split-f16 GEMM."""
+    from . import _weights
+    r, m = g2d.shape
+    n = x2d.shape[1]
+    ag, ax = float(g2d.abs().max()), float(x2d.abs().max())
+    if not (ag > 0.0 and ax > 0.0) or ag != ag or ax != ax or ag == float("inf") or ax == float("inf"):
+        return torch.zeros(m, n, dtype=torch.float32, device=g2d.device)
+    sg, sx = _weights.pow2_scale(ag) * 4096.0, _weights.pow2_scale(ax) * 4096.0
+    a, _ = split_scaled(g2d, sg, transposed=True)                    # (m rows, K = r)
+    w, w_rows = split_scaled(x2d, sx, transposed=True, w_image=True)  # (n rows, K = r)
+    nkt = a.kp // 16
+    if k_splits is None:
+        tiles = ((m + 127) // 128) * ((n + 127) // 128)
+        k_splits = 1
+        while tiles * k_splits < 512 and nkt // (2 * k_splits) >= 64:
+            k_splits *= 2
+    mp = m
+    parts = empty(k_splits, mp, n, dtype=torch.float32, device=g2d.device)
+    with _timed(name):
+        rc = _abi.load().egnn_linear_hl_splitk_f32(_ptr(a.hi), _ptr(a.lo), _ptr(w.hi), _ptr(w.lo), 1.0, _ptr(parts), n, m, n, a.kp, w_rows,
+                                                   k_splits, _stream())
+    _abi.check(rc, "egnn_linear_hl_splitk_f32")
+    out = empty(m, n, dtype=torch.float32, device=g2d.device)
+    count = m * n
+    if count % 4 != 0:
+        return parts.sum(dim=0) / (sg * sx)
+    rc = _abi.load().egnn_sum_parts_f32(_ptr(parts), k_splits, count, 1.0 / (sg * sx), _ptr(out), _stream())
+    _abi.check(rc, "egnn_sum_parts_f32")
+    return out
+
+
+class DestLists:
+    """The edges sorted stably by destination (egnn_dest_lists_i32): `ent` / `tile_seg` = the padded entry list of
+    egnn_edge_bwd_pass_f32 (by_dest = 1), `order` / `seg` = the CSR form egnn_rows_gather_sum_f32 reads."""
+
+    def __init__(self, ent, tile_seg, order, seg):
+        self.ent, self.tile_seg, self.order, self.seg = ent, tile_seg, order, seg
+
+
+def dest_lists(idx32, b, n, k, device):
+    """idx32 (B,N,K) int32 or None (dense: destination = k).  One host read: the number of tiles (sizes the entry list)."""
+    lib = _abi.load()
+    cap = lib.egnn_dest_lists_capacity(b, n, k)
+    ent = torch.empty(cap, dtype=torch.int32, device=device)
+    tile_seg = torch.empty(b * n + 1, dtype=torch.int64, device=device)
+    order = torch.empty(b * n * k, dtype=torch.int64, device=device)
+    seg = torch.empty(b * n + 1, dtype=torch.int64, device=device)
+    scratch = torch.empty(b, dtype=torch.int64, device=device)
+    with _timed("dest_lists"):
+        rc = lib.egnn_dest_lists_i32(_ptr(idx32), b, n, k, _ptr(ent), cap, _ptr(tile_seg), _ptr(order), _ptr(seg), _ptr(scratch), _stream())
+    _abi.check(rc, "egnn_dest_lists_i32")
+    tiles = int(tile_seg[-1])
+    length = max(128, (tiles * 16 + 127) // 128 * 128)
+    return DestLists(ent[:length], tile_seg, order, seg)
 
 
 def edge_tail_bwd(u16, coors, idx32, pair_mask, g_coors_out, g_msum16, w3p, b3p, w4p, b4, scale, eps, clamp, b, n, k):

@@ -164,6 +164,12 @@ def pack(layer) -> dict:
 
     out = dict(H=h, Hp=hp, S=s, Wcat=wcat, Wcat_split=split_f16(wcat), bcat=bcat, Ws=ws, Wst=wst,
                ws_inv_scale=ws_inv_scale, W2h=w2h, w2_inv_scale=1.0 / w2_scale, b2=b2p)
+    # backward, d/d feats = dP_i W_i + dP_j W_j (natural units): the W operands of that GEMM are the transposes, (dim, Hp)
+    wit, wjt = z(dim, hp), z(dim, hp)
+    wit[:, :h] = w1[:, :dim].t()
+    wjt[:, :h] = w1[:, dim:2 * dim].t()
+    out["WiT_split"] = split_f16(wit)
+    out["WjT_split"] = split_f16(wjt)
     if nb == 1:
         # backward (egnn_edge_bwd_dz_f32): W2^T in natural units as A fragments of v_mfma_f32_16x16x16_f16,
         # [step][hb][hi|lo][lane = 16 g + r][u] = W2[4 g + u][32 step + 16 hb + r]

@@ -42,6 +42,7 @@ _NATIVE = _NATIVE_MODE != "0"
 # which pass of the fused backward carries d/d W_2: "dest" (default), "both" = the by-source pass carries everything (tuning knob)
 _FUSED_SPLIT = os.environ.get("EGNN_BWD_SPLIT", "dest")
 _TAIL_KERNEL = os.environ.get("EGNN_BWD_TAIL_KERNEL", "1") != "0"      # 0: the per-edge chain behind u through autograd
+_GRAD_GEMM = os.environ.get("EGNN_BWD_GRAD_GEMM", "1") != "0"          # 0: the node-level gradient products as fp32 library GEMMs
 _FUSED_MAX_GRAPHS = 0                 # tests: force the chunking over graphs that very large batches need (0 = by size only)
 _NATIVE_BUDGET_BYTES = 24 << 30                      # dZ + SiLU(z), 2 x E x Hp fp32, per chunk of graphs
 
@@ -346,7 +347,7 @@ def _edge_tables(layer, w, f2d, pi_split):
     return _ops.linear_hl(feats_hl, w["Wcat_split"], 2 * hp, w["bcat"], name="bwd_node_proj", split_cols=hp if pi_split else 0)
 
 
-def _edge_contract_dz(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_order=None):
+def _edge_contract_dz(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists=None):
     """egnn_edge_bwd_dz_f32 writes dz and a = SiLU(z) (2 x E x Hp fp32); reductions / library GEMMs over them.
     Returns d/d P_i (rows, Hp), d/d P_j (rows, Hp), d/d W_s (Hp, S), d/d scalars (E, S), d/d W_2 (16, Hp)."""
     from . import _abi, _ops
@@ -381,13 +382,10 @@ def _edge_contract_dz(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, 
         gz_j = dz4.sum(dim=1).view(bc * n, hp)                             # dense: neighbour k IS node j
     else:
         # scatter by neighbour as a fixed-order gather over the transposed neighbour list (edges sorted stably by
-        # destination): no float atomics, bit-reproducible
-        if dest_order is None:
-            dest = (i32.long() + (torch.arange(bc, device=dev) * n)[:, None, None]).view(-1)
-            dest_order = torch.sort(dest, stable=True)
-        dest_sorted, by_dest = dest_order
-        seg = torch.searchsorted(dest_sorted, torch.arange(bc * n + 1, device=dev))
-        gz_j = _ops.rows_gather_sum(dz, by_dest, seg, bc * n)
+        # destination, egnn_dest_lists_i32): no float atomics, bit-reproducible
+        if dest_lists is None:
+            dest_lists = _ops.dest_lists(i32, bc, n, k, dev)
+        gz_j = _ops.rows_gather_sum(dz, dest_lists.order, dest_lists.seg, bc * n)
     g_ws = dz.t() @ sc2
     g_scal = dz @ w_s
     g_w2 = gu16.t() @ act
@@ -422,7 +420,7 @@ def entry_list(eids, keys, n_keys):
     return ent, seg
 
 
-def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_order=None):
+def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists=None):
     """egnn_edge_bwd_pass_f32 (csrc/edge_bwd.hip) twice -- entries grouped by source node, then by neighbour: z, SiLU(z) and dz
     are recomputed and contracted in registers, nothing of size E x H reaches memory.  Same returns as _edge_contract_dz."""
     from . import _ops
@@ -439,14 +437,9 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
     ident = torch.arange(o["rows"].shape[0], device=dev)
     gz_i = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n)
     del o
-    if dest_order is None:
-        if i32 is None:
-            dest = (torch.arange(k, device=dev)[None, None, :] + (torch.arange(bc, device=dev) * n)[:, None, None]).expand(bc, n, k).reshape(-1)
-        else:
-            dest = (i32.long() + (torch.arange(bc, device=dev) * n)[:, None, None]).view(-1)
-        dest_order = torch.sort(dest, stable=True)
-    dest_sorted, by_dest = dest_order
-    ent, seg = entry_list(by_dest, dest_sorted, bc * n)
+    if dest_lists is None:
+        dest_lists = _ops.dest_lists(i32, bc, n, k, dev)                 # (dense: destination = k)
+    ent, seg = dest_lists.ent, dest_lists.tile_seg
     o = _ops.edge_bwd_pass(w, proj, i32, gu16, gu_scale, sc2, ent, bc, n, k, by_dest=True, ws_nat=None if s_first else w_s, want_w2=g_w2 is None)
     if g_w2 is None:
         g_w2 = o["w2"]
@@ -529,7 +522,7 @@ def _backward_native(ctx, g_node, g_coors):
         i64 = None if i32 is None else i32.long()
         r0 = None if rank is None else rank[lo:hi_]
         ec = bc * n * k
-        dest_order = None
+        dest_lists = None
         if tail_kernel:
             # ---- 1. behind u: the node-level modules through autograd (node_norm, node_mlp, residual: from the pooled messages),
             # the per-edge chain (second SiLU, masks, coors_mlp, CoorsNorm, clamp, coordinate update, pooling) in closed form on
@@ -604,8 +597,7 @@ def _backward_native(ctx, g_node, g_coors):
                 del g_hid, a3, mm
                 g_coors_in[lo:hi_] += g_coors[lo:hi_]                              # (the residual; g_rel reaches the coordinates below)
                 if i64 is not None:
-                    dest = (i64 + (torch.arange(bc, device=feats.device) * n)[:, None, None]).view(-1)
-                    dest_order = torch.sort(dest, stable=True)                                 # (shared with the E x H passes below)
+                    dest_lists = _ops.dest_lists(i32, bc, n, k, feats.device)                  # (shared with the E x H passes below)
         else:
             closed_dist, g_rel = False, None
             # ---- 1. the small tail, through autograd
@@ -641,12 +633,21 @@ def _backward_native(ctx, g_node, g_coors):
             f2d = f0.view(bc * n, dim)
             sc2 = scal.detach().reshape(ec, s_in).contiguous()
             contract = _edge_contract_fused if fused else _edge_contract_dz
-            gz_i, gz_j, g_ws, g_scal, g_w2 = contract(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_order)
-            # ---- 3. node-level GEMMs
-            g_feats[lo:hi_] += (gz_i @ w_i + gz_j @ w_j).view(bc, n, dim)
+            gz_i, gz_j, g_ws, g_scal, g_w2 = contract(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists)
+            # ---- 3. node-level products: d/d feats = dP_i W_i + dP_j W_j, d/d W_i = dP_i^T feats, d/d W_j = dP_j^T feats.  On the
+            # device: the forward's split-f16 matrix-core GEMM (operands pre-scaled by powers of two, the weight gradients split-K
+            # over the B N nodes with the parts summed in fixed order) -- the fp32 library GEMMs they replace ran at 60 - 130 TFLOP/s
             gw1 = grads_by_id[id(lin0.weight)]
-            gw1[:, :dim] += _tn(gz_i, f2d)[:h]
-            gw1[:, dim:2 * dim] += _tn(gz_j, f2d)[:h]
+            if f2d.is_cuda and _GRAD_GEMM:
+                t = _ops.grad_nn(gz_i, w["WiT_split"], dim, name="bwd_dfeats")
+                t = _ops.grad_nn(gz_j, w["WjT_split"], dim, residual=t, name="bwd_dfeats")
+                g_feats[lo:hi_] += t.view(bc, n, dim)
+                gw1[:, :dim] += _ops.grad_tn(gz_i, f2d, name="bwd_dw1")[:h]
+                gw1[:, dim:2 * dim] += _ops.grad_tn(gz_j, f2d, name="bwd_dw1")[:h]
+            else:
+                g_feats[lo:hi_] += (gz_i @ w_i + gz_j @ w_j).view(bc, n, dim)
+                gw1[:, :dim] += _tn(gz_i, f2d)[:h]
+                gw1[:, dim:2 * dim] += _tn(gz_j, f2d)[:h]
             gw1[:, 2 * dim:] += g_ws[:h]
             grads_by_id[id(lin0.bias)] += gz_i.sum(dim=0)[:h]
             g_scal = g_scal.view_as(scal)
@@ -671,9 +672,7 @@ def _backward_native(ctx, g_node, g_coors):
                 if i64 is None:
                     g_coors_in[lo:hi_] -= g_rel.view(bc, n, n, 4).sum(dim=1)[..., :3]
                 else:
-                    dest_sorted, by_dest = dest_order
-                    seg = torch.searchsorted(dest_sorted, torch.arange(bc * n + 1, device=feats.device))
-                    g_coors_in[lo:hi_] -= _ops.rows_gather_sum(g_rel, by_dest, seg, bc * n).view(bc, n, 4)[..., :3]
+                    g_coors_in[lo:hi_] -= _ops.rows_gather_sum(g_rel, dest_lists.order, dest_lists.seg, bc * n).view(bc, n, 4)[..., :3]
     out_params = [grads_by_id[id(p)].to(op.dtype) if need[7 + i] else None for i, (p, op) in enumerate(zip(params, orig_params))]
     return (None, None, None, None, g_feats.to(in_dtypes[0]) if need[4] else None, g_coors_in.to(in_dtypes[1]) if need[5] else None,
             g_edges.to(in_dtypes[2]) if want_ge else None, *out_params)

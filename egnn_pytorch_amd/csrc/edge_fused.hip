@@ -229,6 +229,10 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
     const int rounds = (slots_total + SLOTS_PER_ROUND - 1) / SLOTS_PER_ROUND;
     const bool has_mask = p.mask != nullptr;
     const bool has_rank = p.rank != nullptr && p.idx != nullptr;
+    // per-slot records of egnn_slot_prep_f32 (neighbour path, C = 3): {j | pair_ok << 31, x_i - x_j} in consumption order -- the
+    // setup then has no dependent loads (order -> idx -> coors -> mask / rank), just one coalesced 16-byte load per slot
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    const u32x4v* slot_rec = (CDM == 3 && !BWD && p.idx) ? static_cast<const u32x4v*>(p.slots) : nullptr;
     const size_t bN = (size_t)b * N;
     // Buffer resources over this graph's rows of P_j / P_i: the gathers are `buffer_load ... offen` with a 32-bit per-lane
     // byte offset (one address register per stream) and the hidden-unit offset of the step in the SCALAR offset operand --
@@ -271,12 +275,21 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             const int j = (pos + k) & (N - 1);
 #else
             const int i = p.order ? p.order[bN + pos] : pos;
-            const int j = p.idx ? p.idx[(bN + i) * K + k] : k;
+            u32x4v rec = u32x4v{0u, 0u, 0u, 0u};
+            if (slot_rec) rec = slot_rec[(bN + pos) * (size_t)K + k];
+            const int j = slot_rec ? (int)(rec[0] & 0x7fffffffu) : (p.idx ? p.idx[(bN + i) * K + k] : k);
 #endif
             const int C = (CDM == 3) ? 3 : p.coor_dim;
             const float* ci = p.coors + (bN + i) * C;
             const float* cj = p.coors + (bN + j) * C;
             float d;
+#if !(defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 1024))
+            if (slot_rec) {
+                // (by value: __builtin_bit_cast of a vector-element lvalue reads the vector's first bytes -- hipcc 7.2 -- i.e. element 0)
+                const uint32_t r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                d = egnn_sqdist_rel(__uint_as_float(r1), __uint_as_float(r2), __uint_as_float(r3));
+            } else
+#endif
             {
                 float rel0[CDM];
                 if (CDM == 3) {
@@ -343,6 +356,11 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             }
 
             bool em = valid;
+#if !(defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 1024))
+            if (slot_rec) {
+                em = em && (rec[0] >> 31) != 0u;                     // mask_i & mask_j & (rank <= radius), or 1 without a mask
+            } else
+#endif
             if (has_mask) {
                 em = em && p.mask[bN + i] && p.mask[bN + j];
                 if (has_rank) em = em && (p.rank[(bN + i) * K + k] <= p.valid_radius);
@@ -379,8 +397,13 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             const int i2 = pos;
             const int j2 = (pos + k) & (N - 1);
 #else
-            const int i2 = p.order ? p.order[bN + pos] : pos;
-            const int j2 = p.idx ? p.idx[(bN + i2) * K + k] : k;
+            int j2;
+            if (slot_rec) {
+                j2 = (int)(reinterpret_cast<const uint32_t*>(slot_rec + ((bN + pos) * (size_t)K + k))[0] & 0x7fffffffu);
+            } else {
+                const int i2 = p.order ? p.order[bN + pos] : pos;
+                j2 = p.idx ? p.idx[(bN + i2) * K + k] : k;
+            }
 #endif
 #if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 1)
             goff[qq] = (uint32_t)(((size_t)(i2 & ~7) * p.ldp + 4 * (lane & 7)) * 4);
@@ -809,9 +832,23 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 #else
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
+#if defined(EGNN_EDGE_L2_LEGACY) && EGNN_EDGE_L2_LEGACY
+                        // experiment: each K = 32 product as two legacy K = 16 MFMAs (the fragment halves are the two 16-row blocks)
+                        const f16x4 wh0 = {whi[nb][0], whi[nb][1], whi[nb][2], whi[nb][3]}, wh1 = {whi[nb][4], whi[nb][5], whi[nb][6], whi[nb][7]};
+                        const f16x4 wl0 = {wlo[nb][0], wlo[nb][1], wlo[nb][2], wlo[nb][3]}, wl1 = {wlo[nb][4], wlo[nb][5], wlo[nb][6], wlo[nb][7]};
+                        const f16x4 bh0 = {bhi[0], bhi[1], bhi[2], bhi[3]}, bh1 = {bhi[4], bhi[5], bhi[6], bhi[7]};
+                        const f16x4 bl0 = {blo[0], blo[1], blo[2], blo[3]}, bl1 = {blo[4], blo[5], blo[6], blo[7]};
+                        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh0, bh0, acc[t][nb], 0, 0, 0);
+                        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh1, bh1, acc[t][nb], 0, 0, 0);
+                        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl0, bh0, acc[t][nb], 0, 0, 0);
+                        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl1, bh1, acc[t][nb], 0, 0, 0);
+                        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh0, bl0, acc[t][nb], 0, 0, 0);
+                        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh1, bl1, acc[t][nb], 0, 0, 0);
+#else
                         acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[nb], bhi, acc[t][nb], 0, 0, 0);
                         acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[nb], bhi, acc[t][nb], 0, 0, 0);
                         acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[nb], blo, acc[t][nb], 0, 0, 0);
+#endif
                     }
 #endif
                 }
@@ -976,10 +1013,22 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             const int C = (CDM == 3) ? 3 : p.coor_dim;
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
-                const float* ci = p.coors + (bN + ei[t]) * C;
-                const float* cj = p.coors + (bN + ej[t]) * C;
+                if (CDM == 3 && slot_rec) {                              // (the record again: coalesced, L2)
+                    const int q = qwave + t * 16 + e;
+                    int nl = (TPI == 2) ? nl_w : q / K;
+                    int kk = (TPI == 2) ? k_w + t * 16 + e : q - nl * K;
+                    int pos = node0 + nl;
+                    if (!((q < slots_total) && (pos < N))) { pos = node0 < N ? node0 : 0; kk = 0; }
+                    const u32x4v rec = slot_rec[(bN + pos) * (size_t)K + kk];
+                    const uint32_t rw[3] = {rec[1], rec[2], rec[3]};     // (by value, see the setup)
 #pragma unroll
-                for (int c = 0; c < CDM; ++c) rel[t][c] = c < C ? ci[c] - cj[c] : 0.f;
+                    for (int c = 0; c < CDM; ++c) rel[t][c] = c < 3 ? __uint_as_float(rw[c < 3 ? c : 0]) : 0.f;
+                } else {
+                    const float* ci = p.coors + (bN + ei[t]) * C;
+                    const float* cj = p.coors + (bN + ej[t]) * C;
+#pragma unroll
+                    for (int c = 0; c < CDM; ++c) rel[t][c] = c < C ? ci[c] - cj[c] : 0.f;
+                }
             }
         }
         if (TPI == 2) {
@@ -1123,6 +1172,13 @@ int launch_edge(const egnn_edge_args& a, hipStream_t s)
     // nodes per workgroup: as many as fit one round of 128 slots -- or, when that would leave slots idle (K = 24: 120 of
     // 128, K = 48: 96), the smallest group whose slots fill whole rounds (K = 48: 8 nodes = 3 rounds), up to 16 nodes
     int G = SLOTS_PER_ROUND / a.K;
+#if defined(EGNN_EDGE_GMULT)
+    if (a.K % 32 == 0 && a.K <= SLOTS_PER_ROUND) G *= EGNN_EDGE_GMULT;          // experiment: several rounds per workgroup
+#else
+    // narrow layers (dim <= 256: at most 40 steps of the hidden loop): two rounds per workgroup -- the per-workgroup part of the
+    // fixed cost (launch, arguments, node sums and outputs) is a third of the pass there (c3: 0.533 -> 0.510 ms; north star +1 %)
+    if (a.K % 32 == 0 && a.K <= SLOTS_PER_ROUND && a.Hp <= 1280 && (int64_t)a.B * a.N / (2 * G) >= 4096) G *= 2;
+#endif
     if (G < 1) G = 1;
     if (G > GMAX) G = GMAX;
     if (a.K < SLOTS_PER_ROUND && (G * a.K) % SLOTS_PER_ROUND != 0)
@@ -1249,6 +1305,8 @@ int EGNN_EDGE_ENTRY(const egnn_edge_args* args, void* stream)
     if ((a.pi_split != 0) != (a.K >= 6)) return EGNN_E_SHAPE;          // P_i format must match the kernel variant
     if (a.edge_dim > 0 && !a.edges) return EGNN_E_NULLPTR;
     if (a.idx == nullptr && a.K != a.N) return EGNN_E_SHAPE;          // dense path: K == N
+    if (a.slots && (!a.idx || a.coor_dim != 3)) return EGNN_E_SHAPE;  // records exist for the neighbour path with 3-D coordinates
+    if (a.slots && (reinterpret_cast<uintptr_t>(a.slots) & 15)) return EGNN_E_ALIGN;
     if ((reinterpret_cast<uintptr_t>(a.Pi) & 15) || (reinterpret_cast<uintptr_t>(a.Pj) & 15) ||
         (reinterpret_cast<uintptr_t>(a.Wst) & 15) || (reinterpret_cast<uintptr_t>(a.W2h) & 15))
         return EGNN_E_ALIGN;

@@ -107,6 +107,16 @@ __device__ __forceinline__ float egnn_sqdist(float xi, float yi, float zi, float
     return sxy + sz;
 }
 
+// the same from the differences (egnn_slot_prep_f32 stores x_i - x_j): identical operations, identical bits
+__device__ __forceinline__ float egnn_sqdist_rel(float dx, float dy, float dz) {
+#pragma clang fp contract(off)
+    const float sx = dx * dx;
+    const float sy = dy * dy;
+    const float sz = dz * dz;
+    const float sxy = sx + sy;
+    return sxy + sz;
+}
+
 // General coordinate dimension C <= CDM (components >= C of a, b must be 0).  Summation order = what the reference's
 // `(rel_coors ** 2).sum(-1)` does on the CPU (measured, torch 2.10 fp32): left to
 // right for C in {1, 2, 3, 4, 8}; s0, s4, ..., s_{C-1}, s1, s2, s3 for C in {5, 6, 7}.  No FMA contraction.

@@ -244,7 +244,7 @@ extern "C" int egnn_pack_weights_host(const egnn_layer_desc* desc, const egnn_la
 namespace {
 
 struct Workspace {
-    size_t idx, rank, order, raw_hi, raw_lo, node_hi, node_lo, proj, hid_hi, hid_lo, bytes;
+    size_t idx, rank, order, slots, raw_hi, raw_lo, node_hi, node_lo, proj, hid_hi, hid_lo, bytes;
 };
 
 Workspace carve(const egnn_layer_desc* d, const Dims& x, int64_t B, int64_t N, int64_t K)
@@ -254,7 +254,7 @@ Workspace carve(const egnn_layer_desc* d, const Dims& x, int64_t B, int64_t N, i
     auto take = [&](size_t& field, size_t bytes) { field = off; off = align256(off + bytes); };
     const int64_t rows = B * N;
     const bool nearest = d->num_nearest_neighbors > 0 || d->only_sparse_neighbors;
-    if (nearest) { take(w.idx, (size_t)rows * K * 4); take(w.rank, (size_t)rows * K * 4); }
+    if (nearest) { take(w.idx, (size_t)rows * K * 4); take(w.rank, (size_t)rows * K * 4); take(w.slots, (size_t)rows * K * 16); }
     take(w.order, (size_t)rows * 4);
     take(w.raw_hi, (size_t)egnn_packed_halves(rows, x.kp_dim) * 2);
     take(w.raw_lo, (size_t)egnn_packed_halves(rows, x.kp_dim) * 2);
@@ -358,6 +358,11 @@ extern "C" int egnn_layer_forward_f32(const egnn_layer_desc* desc, const egnn_pa
             int32_t* order = reinterpret_cast<int32_t*>(ws + w.order);
             EGNN_TRY(egnn_spatial_order_f32(coors, B, N, order, stream));
             a.order = order;
+        }
+        if (idx && coor_dim == 3) {                                             // the setup's index chain, flattened (egnn_slot_prep_f32)
+            EGNN_TRY(egnn_slot_prep_f32(coors, mask, idx, rank, a.order, valid_radius < 3.0e38f ? valid_radius : 3.0e38f, B, N, K,
+                                        ws + w.slots, stream));
+            a.slots = ws + w.slots;
         }
         a.valid_radius = valid_radius < 3.0e38f ? valid_radius : 3.0e38f;
         a.clamp = desc->coor_weights_clamp_value < 0.f ? -1.f : desc->coor_weights_clamp_value;

@@ -56,7 +56,8 @@ __device__ __forceinline__ void linear_hl_body(
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
     const float* __restrict__ bias, const float* __restrict__ R, int64_t ldr,
     float* __restrict__ C, int64_t ldc, _Float16* __restrict__ Chi, _Float16* __restrict__ Clo, int nkt_out,
-    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, int32_t* __restrict__ status, char* smem, const int bid)
+    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, int32_t* __restrict__ status, char* smem, const int bid,
+    const int kt0 = 0, const int kt_count = -1)
 {
     using C_ = Cfg<CFG>;
     constexpr int BM = C_::BM, BN = C_::BN, TI = C_::TI, TJ = C_::TJ, STAGES = C_::STAGES;
@@ -147,10 +148,11 @@ __device__ __forceinline__ void linear_hl_body(
     const int a_base = (wm * TI * 32) * ROWB + foff;
     const int b_base = 2 * AARR + (wn * TJ * 32) * ROWB + foff;
 
-    const int nk = nkt;
+    // (split-K launches -- egnn_linear_hl_splitk_f32 -- give every workgroup a range [kt0, kt0 + kt_count) of the K-tiles)
+    const int nk = kt_count < 0 ? nkt : kt_count;
     // prologue: tiles 0 .. S-2 in flight (dummies past the end keep the vmcnt bookkeeping uniform)
 #pragma unroll
-    for (int t = 0; t < STAGES - 1; ++t) stage(t < nk ? t : nk - 1, t);
+    for (int t = 0; t < STAGES - 1; ++t) stage(kt0 + (t < nk ? t : nk - 1), t);
 
     int slot = 0;                                                      // ring slot of tile kt
     for (int kt = 0; kt < nk; ++kt) {
@@ -163,7 +165,7 @@ __device__ __forceinline__ void linear_hl_body(
         const int nt = kt + STAGES - 1;
         int nslot = slot - 1;
         if (nslot < 0) nslot += STAGES;                                // (kt + S - 1) % S
-        const int nsrc = nt < nk ? nt : nk - 1;                        // past the end: harmless re-fetch of the last tile
+        const int nsrc = kt0 + (nt < nk ? nt : nk - 1);                // past the end: harmless re-fetch of the last tile
 #if !(defined(EGNN_HL_ILV) && EGNN_HL_ILV)
         {
 #if defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 4)
@@ -287,6 +289,31 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
                                       out_scale, split_cols, status, smem, blockIdx.x);
 }
 
+// Split-K: blockIdx.y = part; the part's partial product goes to its own (M, ldc) slab (summed afterwards in fixed order)
+template <int CFG>
+__global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl_splitk_kernel(
+    const _Float16* __restrict__ Ahi, const _Float16* __restrict__ Alo, const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
+    float* __restrict__ Cpart, int64_t ldc, int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int tiles_per_part)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int part = blockIdx.y;
+    const int nkt = Kp / BK;
+    const int kt0 = part * tiles_per_part;
+    int cnt = nkt - kt0;
+    if (cnt > tiles_per_part) cnt = tiles_per_part;
+    linear_hl_body<CFG, 0, false>(Ahi, Alo, Whi, Wlo, nullptr, nullptr, 0, Cpart + (size_t)part * M * ldc, ldc, nullptr, nullptr, 0,
+                                  M, N, Kp, ntm, ntn, out_scale, 0, nullptr, smem, blockIdx.x, kt0, cnt);
+}
+
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ parts, int nparts, int64_t count, float scale, float* __restrict__ out)
+{
+    for (int64_t o = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; o < count; o += (int64_t)gridDim.x * 1024) {
+        f32x4 acc = *reinterpret_cast<const f32x4*>(parts + o);
+        for (int p = 1; p < nparts; ++p) acc += *reinterpret_cast<const f32x4*>(parts + (size_t)p * count + o);     // fixed order
+        *reinterpret_cast<f32x4*>(out + o) = acc * scale;
+    }
+}
+
 template <int CFG, int ACT, bool HAS_RES>
 int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, const _Float16* Wlo,
                   const float* bias, const float* R, int64_t ldr, float* C, int64_t ldc, _Float16* Chi, _Float16* Clo,
@@ -359,6 +386,39 @@ extern "C" int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void
     if (act == 2) return launch_hl<2, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
     if (residual) return launch_hl<1, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
     return launch_hl<1, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
+}
+
+extern "C" int egnn_linear_hl_splitk_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo, float w_inv_scale,
+                                         float* C_parts, int64_t ldc, int64_t M, int N, int Kp, int w_rows, int k_splits, void* stream)
+{
+    if (!A_hi || !A_lo || !W_hi || !W_lo || !C_parts) return EGNN_E_NULLPTR;
+    if (M <= 0 || N <= 0 || Kp <= 0 || (Kp % 32) != 0 || ldc < N || k_splits < 1) return EGNN_E_SHAPE;
+    if (w_rows < (N + 127) / 128 * 128 || !(w_inv_scale > 0.f)) return EGNN_E_SHAPE;
+    const int nkt = Kp / BK;
+    const int per = (nkt + k_splits - 1) / k_splits;
+    if ((int64_t)per * (k_splits - 1) >= nkt) return EGNN_E_SHAPE;                 // every part must own at least one K-tile
+    using C_ = Cfg<0>;
+    const int64_t ntm = (M + C_::BM - 1) / C_::BM, ntn = (N + C_::BN - 1) / C_::BN;
+    if (ntm * ntn > 0x7fffffffLL || k_splits > 65535) return EGNN_E_UNSUPPORTED;
+    const size_t lds = (size_t)C_::STAGES * (2 * C_::BM + 2 * C_::BN) * ROWB;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_hl_splitk_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((linear_hl_splitk_kernel<0>), dim3((unsigned)(ntm * ntn), (unsigned)k_splits), dim3(C_::WM * C_::WN * 64), lds,
+                       static_cast<hipStream_t>(stream), static_cast<const _Float16*>(A_hi), static_cast<const _Float16*>(A_lo),
+                       static_cast<const _Float16*>(W_hi), static_cast<const _Float16*>(W_lo), C_parts, ldc, M, N, Kp, (int)ntm, (int)ntn,
+                       w_inv_scale, per);
+    return egnn_launch_status();
+}
+
+extern "C" int egnn_sum_parts_f32(const float* parts, int nparts, int64_t count, float scale, float* out, void* stream)
+{
+    if (!parts || !out) return EGNN_E_NULLPTR;
+    if (nparts < 1 || count <= 0 || (count % 4) != 0) return EGNN_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(parts) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return EGNN_E_ALIGN;
+    int64_t blocks = (count / 4 + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), parts, nparts, count, scale, out);
+    return egnn_launch_status();
 }
 
 extern "C" int64_t egnn_packed_halves(int64_t rows, int Kp) { return (rows + 31) / 32 * 32 * (int64_t)Kp; }

@@ -118,7 +118,78 @@ __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restri
     }
 }
 
+// X (rows, cols) fp32 -> packed (hi, lo) images of scale * X (transposed = 0) or of (scale * X)^T (transposed = 1: the image has
+// `cols` rows and K = rows) -- the operands of the backward's node-level gradient GEMMs (egnn_split_scaled_f16).
+// One workgroup = 64 X-rows x 32 X-columns through LDS; every thread emits one 16-byte chunk (8 consecutive K values of one
+// image row) per image, so that the workgroup's stores fill whole 1 KB (row block, K-tile) pieces.
+__global__ __launch_bounds__(256) void split_scaled_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int cols, float scale,
+                                                           int transposed, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int nkt,
+                                                           int64_t img_rows_p, int32_t* __restrict__ status)
+{
+    typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+    __shared__ float tile[64][33];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * 64;
+    const int c0 = blockIdx.x * 32;
+    for (int o = tid; o < 64 * 32; o += 256) {
+        const int r = o >> 5, c = o & 31;
+        float v = 0.f;
+        if (r0 + r < rows && c0 + c < cols) v = X[(r0 + r) * ldx + c0 + c] * scale;
+        tile[r][c] = v;
+    }
+    __syncthreads();
+    float x[8];
+    int64_t out_row;
+    int out_k;
+    if (transposed) {                         // image row = X column c0 + (tid & 31), K = X rows r0 + 8 q .. + 7
+        const int c = tid & 31, q = tid >> 5;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = tile[8 * q + u][c];
+        out_row = c0 + c;
+        out_k = (int)(r0 + 8 * q);
+    } else {                                  // image row = X row r0 + (tid >> 2), K = X columns c0 + 8 (tid & 3) .. + 7
+        const int r = tid >> 2, q = tid & 3;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = tile[r][8 * q + u];
+        out_row = r0 + r;
+        out_k = c0 + 8 * q;
+    }
+    bool beyond = false;
+    f16x8v h8, l8;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        beyond = beyond || egnn_beyond_f16(x[u]);
+        const _Float16 h = (_Float16)x[u];
+        h8[u] = h;
+        l8[u] = (_Float16)(x[u] - (float)h);
+    }
+    egnn_flag_range(status, beyond, EGNN_RANGE_A_OPERAND);
+    if (out_k < nkt * 16 && out_row < img_rows_p) {       // (inside the padded image: rows / K beyond the matrix are written as zeros)
+        const size_t o = egnn_pk_off(out_row, out_k, nkt);
+        *reinterpret_cast<f16x8v*>(hi + o) = h8;
+        *reinterpret_cast<f16x8v*>(lo + o) = l8;
+    }
+}
+
 }  // namespace
+
+extern "C" int egnn_split_scaled_f16(const float* X, int64_t ldx, int64_t rows, int cols, float scale, int transposed, void* hi, void* lo,
+                                     int Kp, int32_t* status, void* stream)
+{
+    if (!X || !hi || !lo) return EGNN_E_NULLPTR;
+    const int64_t k_extent = transposed ? rows : cols;                  // the K dimension of the image
+    const int64_t img_rows = transposed ? cols : rows;
+    if (rows <= 0 || cols <= 0 || ldx < cols || Kp < k_extent || (Kp % 32) != 0 || !(scale > 0.f)) return EGNN_E_SHAPE;
+    // the grid covers the padded image exactly: image rows up to a multiple of 32, K up to Kp (tiles of 64 x 32 or 32 x 64 of X)
+    const int64_t rows_cover = transposed ? Kp : (img_rows + 31) / 32 * 32;
+    const int64_t cols_cover = transposed ? (img_rows + 31) / 32 * 32 : Kp;
+    const int64_t gy = (rows_cover + 63) / 64, gx = (cols_cover + 31) / 32;
+    if (gy > 65535 * 16LL || gx > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
+    if (gy > 65535) return EGNN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(split_scaled_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, static_cast<hipStream_t>(stream), X, ldx, rows, cols,
+                       scale, transposed, static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), Kp / 16, (img_rows + 31) / 32 * 32, status);
+    return egnn_launch_status();
+}
 
 // internal: shared by egnn_node_prep_hl and egnn_split_f16
 int egnn_pack_rows_launch(const float* X, int64_t ldx, const float* m_i, const float* gamma, const float* beta, float eps,
@@ -149,6 +220,18 @@ extern "C" int egnn_node_prep_hl(const float* feats, const float* m_i, const flo
 }
 
 extern "C" int egnn_abi_version(void) { return EGNN_ABI_VERSION; }
+
+extern "C" int64_t egnn_struct_bytes(int which)
+{
+    switch (which) {
+    case 0: return (int64_t)sizeof(egnn_edge_args);
+    case 1: return (int64_t)sizeof(egnn_edge_bwd_args);
+    case 2: return (int64_t)sizeof(egnn_edge_tail_args);
+    case 3: return (int64_t)sizeof(egnn_layer_desc);
+    case 4: return (int64_t)sizeof(egnn_packed_info);
+    default: return -1;
+    }
+}
 
 extern "C" const char* egnn_error_string(int code)
 {

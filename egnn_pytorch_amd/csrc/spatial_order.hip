@@ -81,7 +81,50 @@ __global__ __launch_bounds__(256) void spatial_order_kernel(const float* __restr
     for (int i = tid; i < N; i += 256) order[(size_t)b * N + i] = (int32_t)(uint32_t)(keys[i] & 0xffffffffull);
 }
 
+// One thread per edge slot, in the edge pass's consumption order: the dependent loads of its setup done once, coalesced.
+__global__ __launch_bounds__(256) void slot_prep_kernel(const float* __restrict__ coors, const uint8_t* __restrict__ mask,
+                                                        const int32_t* __restrict__ idx, const float* __restrict__ rank,
+                                                        const int32_t* __restrict__ order, float valid_radius, int N, int K,
+                                                        int64_t total, uint4* __restrict__ slots)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total) return;
+    const int64_t node = q / K;                              // b * N + pos
+    const int k = (int)(q - node * K);
+    const int64_t bN = node / N * N;
+    const int i = order ? order[node] : (int)(node - bN);
+    const int64_t e = (bN + i) * K + k;
+    const int j = idx[e];
+    const float* ci = coors + (bN + i) * 3;
+    const float* cj = coors + (bN + j) * 3;
+    bool ok = true;
+    if (mask) {
+        ok = mask[bN + i] && mask[bN + j];
+        if (rank) ok = ok && (rank[e] <= valid_radius);
+    }
+    uint4 r;
+    r.x = (uint32_t)j | (ok ? 0x80000000u : 0u);
+    r.y = __float_as_uint(ci[0] - cj[0]);
+    r.z = __float_as_uint(ci[1] - cj[1]);
+    r.w = __float_as_uint(ci[2] - cj[2]);
+    slots[q] = r;
+}
+
 }  // namespace
+
+extern "C" int egnn_slot_prep_f32(const float* coors, const uint8_t* mask, const int32_t* idx, const float* rank, const int32_t* order,
+                                  float valid_radius, int B, int N, int K, void* slots, void* stream)
+{
+    if (!coors || !idx || !slots) return EGNN_E_NULLPTR;
+    if (B <= 0 || N <= 0 || K <= 0) return EGNN_E_SHAPE;
+    if (reinterpret_cast<uintptr_t>(slots) & 15) return EGNN_E_ALIGN;
+    const int64_t total = (int64_t)B * N * K;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(slot_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), coors, mask, idx, rank,
+                       order, valid_radius, N, K, total, static_cast<uint4*>(slots));
+    return egnn_launch_status();
+}
 
 extern "C" int egnn_spatial_order_f32(const float* coors, int B, int N, int32_t* order_out, void* stream)
 {

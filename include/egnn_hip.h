@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 20
+#define EGNN_ABI_VERSION 21
 
 enum {
     EGNN_OK = 0,
@@ -53,6 +53,10 @@ enum {
 };
 
 int egnn_abi_version(void);
+/* sizeof of the argument structs as this library was compiled -- 0: egnn_edge_args, 1: egnn_edge_bwd_args, 2: egnn_edge_tail_args,
+ * 3: egnn_layer_desc, 4: the packed-weights info struct; -1 otherwise -- so that a binding that mirrors them (ctypes, cgo, JNI) can verify its
+ * layout at load time instead of corrupting a call. */
+int64_t egnn_struct_bytes(int which);
 const char* egnn_error_string(int code);
 
 /* Padded hidden width the projection / edge kernels use for H = 2*edge_input_dim:
@@ -87,6 +91,30 @@ int egnn_adj_max_degree_u8(const uint8_t* adj, int64_t rows, int N, int32_t* out
 /* Scheduling aid for egnn_edge_fused_f32 (no reference counterpart): per-graph Morton (Z-order) permutation of
  * the nodes, order_out (B,N) int32.  N <= 4096. */
 int egnn_spatial_order_f32(const float* coors, int B, int N, int32_t* order_out, void* stream);
+
+/* The transposed neighbour list of the backward (autograd of the gather at egnn_pytorch.py:275): the edge ids (b, i, k) -> b N K + i K + k
+ * sorted stably by destination node b N + idx[b,i,k] (idx NULL: dense, destination = k, K = N), in two forms:
+ *     csr_order (B N K) int64 with csr_seg (B N + 1): the edges that arrive at node n are csr_order[csr_seg[n] .. csr_seg[n+1])  (the
+ *         `order` / `seg_ptr` of egnn_rows_gather_sum_f32)
+ *     ent (capacity) int32 with tile_seg (B N + 1): the same, every node's entries padded with -1 to whole 16-entry tiles -- node n owns
+ *         tiles [tile_seg[n], tile_seg[n+1]) -- and -1 behind the last tile: the entry list of egnn_edge_bwd_pass_f32 (by_dest = 1),
+ *         of which the caller uses the first (tile_seg[B N] * 16 rounded up to 128) entries
+ * ent_capacity >= egnn_dest_lists_capacity(B, N, K) entries; tiles_per_graph: (B) int64 scratch.  Counting sort per graph (the
+ * destinations of one source row are distinct), two launches, deterministic.  Limits: B N K < 2^31, N <= ~8000. */
+size_t egnn_dest_lists_capacity(int B, int N, int K);
+int egnn_dest_lists_i32(const int32_t* idx, int B, int N, int K, int32_t* ent, size_t ent_capacity, int64_t* tile_seg,
+                        int64_t* csr_order, int64_t* csr_seg, int64_t* tiles_per_graph, void* stream);
+
+/* Flattens the index chain of the edge pass's setup (no reference counterpart; coordinate dimension 3, neighbour path).  A
+ * workgroup of egnn_edge_fused_f32 starts with dependent loads -- order -> neighbour list -> coordinates -> mask / rank -- that
+ * only the other workgroups of its CU can cover (~0.2 ms of 1.47 at the north-star shape).  This pass does
+ * them once per edge slot, in the order the edge pass consumes the slots (position pos of `order`, neighbour k), and leaves one
+ * 16-byte record per slot:
+ *     slots[(b*N + pos)*K + k] = { j | (pair_ok << 31),  x_i - x_j  (3 floats, the reference's :232 subtraction bit for bit) }
+ * with i = order ? order[b,pos] : pos, j = idx[b,i,k], pair_ok = mask ? mask[b,i] && mask[b,j] && (rank ? rank[b,i,k] <= valid_radius : 1) : 1
+ * (:292-300).  The edge pass then needs one coalesced load per slot (egnn_edge_args.slots).  slots: B*N*K records of 4 dwords. */
+int egnn_slot_prep_f32(const float* coors, const uint8_t* mask, const int32_t* idx, const float* rank, const int32_t* order,
+                       float valid_radius, int B, int N, int K, void* slots, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * EGNN_Network front-end: N-degree adjacency expansion, egnn_pytorch.py:414-427.
@@ -135,6 +163,20 @@ int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void* W_hi, con
                        float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
                        float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
                        int w_rows, int act, int split_cols, int32_t* status, void* stream);
+
+/* The backward's node-level gradient products (autograd of egnn_pytorch.py:287, 336: d/d feats = dP W, d/d W = dP^T feats) on the same
+ * split-f16 matrix-core GEMM as the forward.
+ * egnn_split_scaled_f16: X (rows, cols) fp32 -> packed (hi, lo) images of scale * X (transposed = 0: `rows` image rows, K = cols) or of
+ *     its transpose (transposed = 1: `cols` image rows, K = rows); scale > 0 (a power of two that lifts small gradients off fp16's
+ *     subnormals); image rows padded to a multiple of 32 and K to Kp with zeros (both written).
+ * egnn_linear_hl_splitk_f32: C_parts[p] (M, ldc) = w_inv_scale * A[:, K range p] W[:, K range p]^T for p < k_splits -- a contraction
+ *     that is deep (K = B N nodes) and has a small output fills the chip only when K is cut; parts are summed in fixed order by
+ * egnn_sum_parts_f32: out[o] = scale * sum_p parts[p][o], o < count (count % 4 == 0). */
+int egnn_split_scaled_f16(const float* X, int64_t ldx, int64_t rows, int cols, float scale, int transposed, void* hi, void* lo, int Kp,
+                          int32_t* status, void* stream);
+int egnn_linear_hl_splitk_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo, float w_inv_scale, float* C_parts,
+                              int64_t ldc, int64_t M, int N, int Kp, int w_rows, int k_splits, void* stream);
+int egnn_sum_parts_f32(const float* parts, int nparts, int64_t count, float scale, float* out, void* stream);
 
 /* X (rows, cols) fp32 row-major -> packed (rows, Kp) images hi = fp16(x), lo = fp16(x - hi); pads zero; Kp % 32 == 0,
  * Kp >= cols.  |X| >= 65504 (finite) sets EGNN_RANGE_A_OPERAND in *status (optional) and turns into inf / NaN. */
@@ -223,6 +265,8 @@ typedef struct egnn_edge_args {
     int64_t ldz;                /* >= Hp, multiple of 4 */
     int32_t edges_by_k;         /* 0: `edges` is (B,N,N,edge_dim), read at [b,i,j];  1: `edges` is (B,N,K,edge_dim), the features of the
                                    selected pairs in neighbour-list order (egnn_edge_features_gather_f32), read at [b,i,k] */
+    const void* slots;          /* optional (idx != NULL, coor_dim == 3): the records of egnn_slot_prep_f32 for the SAME idx / rank / mask /
+                                   order / valid_radius -- the setup reads them instead of walking order -> idx -> coors -> mask */
 } egnn_edge_args;
 
 int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream);

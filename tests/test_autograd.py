@@ -471,6 +471,63 @@ def test_backward_full_size_properties():
     assert float(((turned[0] - base[0]) * valid).abs().max()) <= 2e-4 * float(base[0].abs().max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw,b,n", [
+    ("north_star", dict(dim=512, num_nearest_neighbors=32), 4, 1024),
+    ("c3_layer", dict(dim=128, num_nearest_neighbors=32, norm_feats=True), 4, 1024),
+    ("c5_layer", dict(dim=256, num_nearest_neighbors=32, norm_feats=True, norm_coors=True), 2, 1024),
+    ("c4_layer", dict(dim=512, edge_dim=4, only_sparse_neighbors=True), 2, 256),
+])
+def test_backward_at_baseline_widths_matches_the_reference_autograd(ref, name, kw, b, n):
+    """the backward pinned at the BASELINE widths.  Gradients of feats, coors and EVERY parameter of
+    the north-star layer (dim 512: Hp = 2080 = 17 persistent column chunks, split-K partials), the c3 layer (dim 128), the c5
+    layer (dim 256, CoorsNorm) and the c4 layer (dim 512, 4 edge features, adjacency) through the HIP forward + native backward,
+    against the REFERENCE module's own autograd run on the MI355X in float64 (oracle/_ref .cuda().double(): float64 so that the
+    comparison measures our fp32-class arithmetic, not the eager fp32 run's own rounding -- with CoorsNorm the self pair's
+    1e8-sized cancelling terms leave O(1) noise in any fp32 autograd), xavier-scale weights, ragged masks: 1e-4 of each
+    gradient's scale."""
+    import zlib
+    from egnn_pytorch_amd import EGNN
+    torch.manual_seed(zlib.crc32(name.encode()))
+    rlayer = ref.EGNN(**kw)
+    for mod in rlayer.modules():
+        if isinstance(mod, torch.nn.Linear):
+            torch.nn.init.xavier_normal_(mod.weight)
+    layer = EGNN(**kw)
+    layer.load_state_dict(rlayer.state_dict(), strict=True)
+    layer = layer.cuda()
+    rlayer = rlayer.double().cuda()
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) + 1)
+    feats, coors = torch.randn(b, n, kw["dim"], generator=g).cuda(), torch.randn(b, n, 3, generator=g).cuda()
+    lens = torch.randint(3 * n // 4, n + 1, (b,), generator=g)
+    mask = (torch.arange(n)[None] < lens[:, None]).cuda()
+    edges = adj = None
+    if kw.get("edge_dim"):
+        edges = torch.randn(b, n, n, kw["edge_dim"], generator=g).cuda()
+    if kw.get("only_sparse_neighbors"):
+        i = torch.arange(n)
+        adj = ((i[:, None] - i[None, :]).abs() <= 1).cuda()                      # the README chain (diagonal included): K = 3
+    mk = lambda t, dt: None if t is None else t.clone().to(dt).requires_grad_(True)
+    f1, c1, e1 = mk(feats, torch.float32), mk(coors, torch.float32), mk(edges, torch.float32)
+    f2, c2, e2 = mk(feats, torch.float64), mk(coors, torch.float64), mk(edges, torch.float64)
+    got, s1 = _grads(layer, lambda: layer(f1, c1, e1, mask, adj), (f1, c1, e1))
+    want, s2 = _grads(rlayer, lambda: rlayer(f2, c2, e2, mask, adj), (f2, c2, e2))
+    assert s1 == s2
+    names = ["feats", "coors"] + (["edges"] if edges is not None else []) + [k for k, _ in layer.named_parameters()]
+    worst = {}
+    for nm, gg, ww in zip(names, got, want):
+        assert (gg is None) == (ww is None), nm
+        if gg is None:
+            continue
+        scale = float(ww.abs().max())
+        assert scale > 0, nm                                                      # (a vanishing gradient would make the test vacuous)
+        worst[nm] = float((gg.double() - ww).abs().max()) / scale
+    if os.environ.get("EGNN_TEST_VERBOSE"):
+        print(name, {k: f"{v:.1e}" for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if not v <= 1e-4}
+    assert not bad, (name, bad)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # The host side of the native backward on the CPU: the three kernels replaced by torch emulations of their contracts
 # (include/egnn_hip.h), everything else -- entry lists, partial rows, fixed-order sums, chunking over graphs, node-level products,
@@ -541,12 +598,21 @@ def _emulated_backward(layer, feats, coors, mask, idx, rank, radius, g_node, g_c
                                 saved_tensors=(feats, coors, feats.new_empty(0), mask if mask is not None else feats.new_empty(0), idx, rank, u),
                                 flags=(mask is not None, True),
                                 needs_input_grad=(False, False, False, False, True, True, False) + tuple(p.requires_grad for p in params))
-    saved = (_ops.edge_bwd_pass, _ops.rows_gather_sum, _ops.edge_tail_bwd, A._edge_tables, A._FUSED_MAX_GRAPHS)
-    _ops.edge_bwd_pass, _ops.rows_gather_sum, _ops.edge_tail_bwd, A._edge_tables, A._FUSED_MAX_GRAPHS = bwd_pass, gather_sum, tail, tables, max_graphs
+    def dest_lists(idx32, b_, n_, k_, device):
+        """egnn_dest_lists_i32's contract (include/egnn_hip.h) from a stable sort"""
+        dest = (idx32.long() + (torch.arange(b_) * n_)[:, None, None]).reshape(-1)
+        dest_sorted, by_dest = torch.sort(dest, stable=True)
+        ent, tile_seg = A.entry_list(by_dest, dest_sorted, b_ * n_)
+        seg = torch.searchsorted(dest_sorted, torch.arange(b_ * n_ + 1))
+        return _ops.DestLists(ent, tile_seg, by_dest, seg)
+
+    saved = (_ops.edge_bwd_pass, _ops.rows_gather_sum, _ops.edge_tail_bwd, A._edge_tables, A._FUSED_MAX_GRAPHS, _ops.dest_lists)
+    _ops.edge_bwd_pass, _ops.rows_gather_sum, _ops.edge_tail_bwd, A._edge_tables, A._FUSED_MAX_GRAPHS, _ops.dest_lists = \
+        bwd_pass, gather_sum, tail, tables, max_graphs, dest_lists
     try:
         out = A._backward_native(ctx, g_node, g_coors)
     finally:
-        _ops.edge_bwd_pass, _ops.rows_gather_sum, _ops.edge_tail_bwd, A._edge_tables, A._FUSED_MAX_GRAPHS = saved
+        _ops.edge_bwd_pass, _ops.rows_gather_sum, _ops.edge_tail_bwd, A._edge_tables, A._FUSED_MAX_GRAPHS, _ops.dest_lists = saved
     return [out[4], out[5]] + list(out[7:])
 
 
