@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -30,6 +30,7 @@ SYMBOLS = (
     "egnn_edge_bwd_dz_f32", "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_tail_bwd_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
     "egnn_induced_attn_f32", "egnn_token_attn_f32", "egnn_slot_prep_f32", "egnn_struct_bytes",
     "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32",
+    "egnn_linear_hl_drop_f32",
 )
 
 
@@ -54,6 +55,7 @@ class EdgeArgs(Structure):
         ("dZ", c_void_p), ("A_out", c_void_p), ("ldz", c_int64),
         ("edges_by_k", c_int32),
         ("slots", c_void_p),
+        ("drop_thr", ctypes.c_uint32), ("drop_seed", ctypes.c_uint32), ("drop_inv_keep", c_float),
     ]
 
 
@@ -194,6 +196,10 @@ def load():
     lib.egnn_linear_hl_f32.restype = c_int
     lib.egnn_linear_hl_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p,
                                        c_int64, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.egnn_linear_hl_drop_f32.restype = c_int
+    lib.egnn_linear_hl_drop_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p,
+                                            c_int64, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int,
+                                            ctypes.c_uint32, ctypes.c_uint32, c_float, c_void_p, c_void_p]
     lib.egnn_split_f16.restype = c_int
     lib.egnn_split_f16.argtypes = [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.egnn_node_prep_hl.restype = c_int

@@ -286,7 +286,7 @@ def split_f16(x2d):
 
 
 def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32=True, out_hl=False, name="linear",
-              split_cols=0):
+              split_cols=0, drop=None):
     """act(A @ W.T + bias) (+ residual) with pre-split packed fp16 (hi, lo) operands -- egnn_linear_hl_f32.
     Returns fp32 C, or a PackedHL (padded to 32 columns for the next GEMM) when out_hl, or both.
     split_cols: columns [0, split_cols) of C hold (fp16 hi, fp16 lo) words instead of fp32 values."""
@@ -306,10 +306,19 @@ def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32
         assert residual.shape == (m, n) and residual.is_contiguous()
         ldr = n
     with _timed(name):
-        rc = _abi.load().egnn_linear_hl_f32(_ptr(a.hi), _ptr(a.lo), _ptr(whi), _ptr(wlo), float(inv), _ptr(bias),
-                                            _ptr(residual), ldr, _ptr(c), n, _ptr(out.hi) if out else None,
-                                            _ptr(out.lo) if out else None, kp_out, m, n, kp, w_rows, act, int(split_cols),
-                                            _ptr(status_word(dev).dev), _stream())
+        if drop is None:
+            rc = _abi.load().egnn_linear_hl_f32(_ptr(a.hi), _ptr(a.lo), _ptr(whi), _ptr(wlo), float(inv), _ptr(bias),
+                                                _ptr(residual), ldr, _ptr(c), n, _ptr(out.hi) if out else None,
+                                                _ptr(out.lo) if out else None, kp_out, m, n, kp, w_rows, act, int(split_cols),
+                                                _ptr(status_word(dev).dev), _stream())
+        else:                                               # (p, seed): nn.Dropout between the Linear and its activation
+            from . import _dropout
+            p_drop, seed = drop
+            rc = _abi.load().egnn_linear_hl_drop_f32(_ptr(a.hi), _ptr(a.lo), _ptr(whi), _ptr(wlo), float(inv), _ptr(bias),
+                                                     _ptr(residual), ldr, _ptr(c), n, _ptr(out.hi) if out else None,
+                                                     _ptr(out.lo) if out else None, kp_out, m, n, kp, w_rows, act, int(split_cols),
+                                                     _dropout.threshold(p_drop), int(seed), 1.0 / (1.0 - p_drop),
+                                                     _ptr(status_word(dev).dev), _stream())
     _abi.check(rc, "egnn_linear_hl_f32")
     if out_f32 and out_hl:
         return c, out

@@ -125,9 +125,28 @@ def edge_scalars(layer, coors, edges, idx):
     return rel, scal
 
 
-def layer_tail(layer, feats, coors, u, rel, mask, idx, rank, valid_radius):
+def _mlp_drop(module, x, drop, site, rows):
+    """A Linear -> Dropout -> SiLU -> Linear [-> SiLU] Sequential with its dropout given by the kernels' hash mask
+    (drop = (p, seed); rows = the mask row of every leading index of x) instead of the module's own nn.Dropout."""
+    from . import _dropout
+    mods = list(module)
+    h = _TallLinear.apply(x, mods[0].weight, mods[0].bias) if x.is_cuda else mods[0](x)
+    h = _dropout.apply(h, drop[1], site, rows, drop[0])
+    for sub in mods[2:]:
+        h = _TallLinear.apply(h, sub.weight, sub.bias) if (isinstance(sub, nn.Linear) and h.is_cuda) else sub(h)
+    return h
+
+
+def _edge_rows(b, n, k, device, graph_offset):
+    """global edge ids (b N K + i K + k) of a chunk of graphs that starts at graph `graph_offset`: (b, n, k) int64"""
+    return (torch.arange(b * n * k, device=device) + graph_offset * n * k).view(b, n, k)
+
+
+def layer_tail(layer, feats, coors, u, rel, mask, idx, rank, valid_radius, drop=None, graph_offset=0):
     """Everything of EGNN.forward behind the second Linear of edge_mlp (:183-341): u (B,N,K,m_dim) = edge_mlp[3](...) ->
-    second SiLU, gate, masks, coors_mlp / CoorsNorm / clamp / coordinate update, pooling, node_norm + node_mlp + residual."""
+    second SiLU, gate, masks, coors_mlp / CoorsNorm / clamp / coordinate update, pooling, node_norm + node_mlp + residual.
+    drop = (p, seed): training-mode dropout with the kernels' hash masks (egnn_pytorch_amd/_dropout.py)."""
+    from . import _dropout
     b = feats.shape[0]
     m_ij = layer.edge_mlp[4](u)
     if layer.edge_gate is not None:
@@ -143,7 +162,11 @@ def layer_tail(layer, feats, coors, u, rel, mask, idx, rank, valid_radius):
 
     coors_out = coors
     if layer.coors_mlp is not None:
-        w = _per_edge(layer.coors_mlp, m_ij).squeeze(-1)                          # (:303-304)
+        if drop is not None:
+            w = _mlp_drop(layer.coors_mlp, m_ij, drop, _dropout.SITE_COORS,
+                          _edge_rows(b, m_ij.shape[1], m_ij.shape[2], m_ij.device, graph_offset)).squeeze(-1)
+        else:
+            w = _per_edge(layer.coors_mlp, m_ij).squeeze(-1)                      # (:303-304)
         if layer.norm_coors:                                                      # CoorsNorm (:67-77)
             norm = rel.norm(dim=-1, keepdim=True)
             rel = rel / norm.clamp(min=layer.coors_norm.eps) * layer.coors_norm.scale
@@ -167,7 +190,13 @@ def layer_tail(layer, feats, coors, u, rel, mask, idx, rank, valid_radius):
                 m_i = m_ij.mean(dim=2)
         else:
             m_i = m_ij.sum(dim=2)
-        node_out = _per_edge(layer.node_mlp, torch.cat((layer.node_norm(feats), m_i), dim=-1)) + feats      # (:335-337)
+        node_in = torch.cat((layer.node_norm(feats), m_i), dim=-1)
+        if drop is not None:
+            n_ = feats.shape[1]
+            rows = (torch.arange(b * n_, device=feats.device) + graph_offset * n_).view(b, n_)
+            node_out = _mlp_drop(layer.node_mlp, node_in, drop, _dropout.SITE_NODE, rows) + feats
+        else:
+            node_out = _per_edge(layer.node_mlp, node_in) + feats                 # (:335-337)
     return node_out, coors_out
 
 
@@ -227,7 +256,7 @@ def tail_edge_backward(layer, u, coors, idx, pair_mask, g_coors_out, g_msum):
                 m=mm.reshape(e, m))
 
 
-def layer_given_neighbors(layer, feats, coors, edges, mask, idx, rank, valid_radius, factorised=True):
+def layer_given_neighbors(layer, feats, coors, edges, mask, idx, rank, valid_radius, factorised=True, drop=None, graph_offset=0):
     """EGNN.forward (egnn_pytorch.py:262-341) for given neighbours.
     idx (B,N,K) int64 / rank (B,N,K): the selection of :258 (None, None = dense all-pairs, K = N).
     Differentiable in feats, coors, edges and the parameters of `layer`.
@@ -250,9 +279,15 @@ def layer_given_neighbors(layer, feats, coors, edges, mask, idx, rank, valid_rad
         feats_i = feats[:, :, None, :].expand_as(feats_j)
         z = lin(torch.cat((feats_i, feats_j, scal), dim=-1))                      # (:287, first Linear)
     u = z
-    for mod in list(layer.edge_mlp)[1:4]:                                         # dropout | Identity, SiLU, Linear
-        u = mod(u)
-    return layer_tail(layer, feats, coors, u, rel, mask, idx, rank, valid_radius)
+    if drop is not None:                                                          # (p, seed): the kernels' hash mask instead of nn.Dropout
+        from . import _dropout
+        u = _dropout.apply(u, drop[1], _dropout.SITE_EDGE, _edge_rows(b, u.shape[1], u.shape[2], u.device, graph_offset), drop[0])
+        for mod in list(layer.edge_mlp)[2:4]:                                     # SiLU, Linear
+            u = mod(u)
+    else:
+        for mod in list(layer.edge_mlp)[1:4]:                                     # dropout | Identity, SiLU, Linear
+            u = mod(u)
+    return layer_tail(layer, feats, coors, u, rel, mask, idx, rank, valid_radius, drop, graph_offset)
 
 
 def _chunk_graphs(layer, n, k, batch):
@@ -268,10 +303,17 @@ class EGNNFunction(torch.autograd.Function):
     def forward(ctx, layer, order_hint, mask, adj_mat, feats, coors, edges, *params):
         # the native backward computes in fp32 like the forward: float64 / bfloat16 / float16 modules and inputs pass through
         # the same boundary conversion (gradients are returned in the callers' dtypes)
-        native = _NATIVE and layer.m_dim <= 16 and coors.shape[-1] == 3
+        # training-mode dropout: the forward kernels draw their masks from a hash of (seed, site, row, unit); the backward re-evaluates
+        # the layer with the same masks (egnn_pytorch_amd/_dropout.py) on the recompute path
+        drop = None
+        if layer.dropout_active():
+            from . import _dropout
+            drop = (layer.dropout_p, _dropout.draw_seed())
+        native = _NATIVE and layer.m_dim <= 16 and coors.shape[-1] == 3 and drop is None
         with torch.no_grad():
             node_out, coors_out, order, idx, rank, valid_radius, u_pre = layer._forward_hip_checked(
-                feats, coors, edges, mask, adj_mat, order_hint, want_u=native)
+                feats, coors, edges, mask, adj_mat, order_hint, want_u=native, drop_seed=None if drop is None else drop[1])
+        ctx.drop = drop
         use_nearest = layer.num_nearest_neighbors > 0 or layer.only_sparse_neighbors
         if use_nearest and idx is None:
             # neighbour path with K == 0 (only_sparse_neighbors and an empty adjacency): NO messages -- not the dense graph that
@@ -714,7 +756,7 @@ def _backward_recompute(ctx, g_node, g_coors):
             e = None if edges is None else edges[lo:hi].detach().requires_grad_(bool(need[6]))
             out_n, out_c = layer_given_neighbors(layer, f, c, e, None if mask is None else mask[lo:hi],
                                                  None if idx is None else idx[lo:hi], None if rank is None else rank[lo:hi],
-                                                 ctx.valid_radius)
+                                                 ctx.valid_radius, drop=getattr(ctx, "drop", None), graph_offset=lo)
             wrt = [t for t in (f, c, e) if t is not None and t.requires_grad] + [p for p, g in zip(params, g_params) if g is not None]
             outs, gouts = [], []
             for o, g in ((out_n, g_node[lo:hi]), (out_c, g_coors[lo:hi])):

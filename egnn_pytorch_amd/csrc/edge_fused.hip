@@ -123,7 +123,7 @@ constexpr int edge_min_blocks(int nm, int tpi, int nb)
 constexpr int edge_launch_blocks(int nm, int tpi, int nb, int mode)
 {
     const int mb = edge_min_blocks(nm, tpi, nb);
-    if (mode == 1) return mb > 1 ? mb - 1 : mb;
+    if (mode == 1 || mode == 3) return mb > 1 ? mb - 1 : mb;
     if (mode == 2) return mb > 4 ? 4 : mb;
     return mb;
 }
@@ -203,6 +203,8 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
     // MODE 0: inference forward.  1: forward that also writes u (args.U_out) for the backward -- its own instantiation, the
     // inference kernels sit at the register limit of 4 workgroups per CU.  2: backward (egnn_edge_bwd_dz_f32).
     constexpr bool BWD = MODE == 2;
+    constexpr bool DROP = MODE == 3;                         // training-mode dropout (args.drop_thr); writes u like MODE 1 if asked
+    constexpr bool WRITE_U = MODE == 1 || MODE == 3;
     constexpr bool GDMA = EGNN_EDGE_GDMA && EGNN_EDGE_RING && !BWD;   // gathers by LDS-DMA (the backward keeps its counted store waits)
     constexpr int HC = EGNN_EDGE_RING ? HCT / 2 : HCT;     // columns per staged chunk (ring: two slots of HCT / 2)
     constexpr int NCH = nch_of(NB);
@@ -253,6 +255,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
         int ei[TILES], ej[TILES];                            // node / neighbour of this lane's edge: x_i - x_j is recomputed in the
                                                              // epilogue instead of living in 2 x CDM registers across the hidden loop
         bool fm[TILES];                                      // edge contributes (valid slot and unmasked)
+        uint32_t ekey[DROP ? TILES : 1] = {};                // DROP: mask row key of this lane's edge (+ the lane's unit offset)
         int64_t erow[TILES];                                 // BWD: global edge index (b, i, k) of this lane's edge; padding slots
                                                              // write to the spare row B*N*K of dZ / A_out
         f16x4 guhi[TILES], gulo[TILES];                      // BWD: d loss / d u of this lane's edge (B fragments)
@@ -302,6 +305,8 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 }
             }
             ei[t] = i; ej[t] = j;
+            if constexpr (DROP)                                   // the edge's mask row (csrc/egnn_common.h), + this lane's 4 g of the unit index
+                ekey[t] = egnn_drop_base(p.drop_seed, EGNN_DROP_SITE_EDGE, (uint32_t)((bN + i) * (size_t)K + k)) + (uint32_t)(4 * g) * 0x85EBCA77u;
             if (BWD) erow[t] = valid ? (int64_t)((bN + i) * (size_t)K + k) : (int64_t)((size_t)p.B * N * K);
             if (BWD) {
                 // B fragment of the W2^T product: channels 4g .. 4g+3 of this edge's d loss / d u, as a split-f16 pair
@@ -771,7 +776,13 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                         f32x4 a4;
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const float y = x[t][hb][u];
+                            float y = x[t][hb][u];
+                            if constexpr (DROP) {
+                                // nn.Dropout behind edge_mlp's first Linear (:180): unit hoff + 16 hb + 4 g + u of this lane's edge.
+                                // (y = -log2(e) z: scaling commutes; a dropped unit gives SiLU(0) = 0 like the reference's)
+                                const uint32_t hsh = egnn_drop_hash(ekey[t], (uint32_t)(hoff + 16 * hb + u));
+                                y = hsh >= p.drop_thr ? y * p.drop_inv_keep : 0.f;
+                            }
 #if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 2)
                             float h = y * (1.0f + y);                       // ablation: no transcendentals
 #else
@@ -905,7 +916,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 part += gwr[nb][0] * m[nb][0] + gwr[nb][1] * m[nb][1] + gwr[nb][2] * m[nb][2] + gwr[nb][3] * m[nb][3];
             }
             egnn_flag_range(p.status, bad && fm[t], EGNN_RANGE_HIDDEN);
-            if constexpr (MODE == 1) {                       // u = W2 SiLU(x) + b2: what the backward differentiates from
+            if (WRITE_U && (MODE == 1 || p.U_out)) {         // u = W2 SiLU(x) + b2: what the backward differentiates from
                 // (the slot -> (node, k) decode of the setup again: keeping the edge index live through the hidden loop costs
                 // four registers the TPI = 1 variant does not have)
                 const int q = qwave + t * 16 + e;
@@ -991,7 +1002,12 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                     const f32x4 a2 = a2t[t];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        part[t] += w4[u] * egnn_silu(a2[u] * p.w3_inv_scale + b3[u]);
+                        float hpre = a2[u] * p.w3_inv_scale + b3[u];
+                        if constexpr (DROP) {                            // nn.Dropout behind coors_mlp's first Linear (:205), unit 16 blk + 4 g + u
+                            const uint32_t base = ekey[t] + (EGNN_DROP_SITE_COORS - EGNN_DROP_SITE_EDGE) * 0x27D4EB2Fu;
+                            hpre = egnn_drop_hash(base, (uint32_t)(16 * blk + u)) >= p.drop_thr ? hpre * p.drop_inv_keep : 0.f;
+                        }
+                        part[t] += w4[u] * egnn_silu(hpre);
                     }
                 }
             }
@@ -1224,7 +1240,10 @@ template <int NM, int HCT>
 int dispatch_tpi(const egnn_edge_args& a, hipStream_t s)
 {
 #ifndef EGNN_EDGE_GENERIC_C
+    if (a.drop_thr) return a.m_dim <= 16 ? dispatch_tpi_nb<NM, HCT, 1, 3>(a, s) : EGNN_E_UNSUPPORTED;   // training-mode dropout
     if (a.m_dim <= 16 && a.U_out) return dispatch_tpi_nb<NM, HCT, 1, 1>(a, s);      // forward under autograd: also writes u
+#else
+    if (a.drop_thr) return EGNN_E_UNSUPPORTED;
 #endif
     if (a.m_dim <= 16) return dispatch_tpi_nb<NM, HCT, 1>(a, s);
 #ifndef EGNN_EDGE_TUNING_BUILD
@@ -1306,6 +1325,7 @@ int EGNN_EDGE_ENTRY(const egnn_edge_args* args, void* stream)
     if (a.edge_dim > 0 && !a.edges) return EGNN_E_NULLPTR;
     if (a.idx == nullptr && a.K != a.N) return EGNN_E_SHAPE;          // dense path: K == N
     if (a.slots && (!a.idx || a.coor_dim != 3)) return EGNN_E_SHAPE;  // records exist for the neighbour path with 3-D coordinates
+    if (a.drop_thr && !(a.drop_inv_keep >= 1.f)) return EGNN_E_SHAPE;
     if (a.slots && (reinterpret_cast<uintptr_t>(a.slots) & 15)) return EGNN_E_ALIGN;
     if ((reinterpret_cast<uintptr_t>(a.Pi) & 15) || (reinterpret_cast<uintptr_t>(a.Pj) & 15) ||
         (reinterpret_cast<uintptr_t>(a.Wst) & 15) || (reinterpret_cast<uintptr_t>(a.W2h) & 15))

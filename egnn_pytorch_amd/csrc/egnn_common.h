@@ -90,6 +90,29 @@ __device__ __forceinline__ float egnn_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
+// Training-mode dropout (egnn_pytorch.py:176: ONE nn.Dropout shared by edge_mlp, node_mlp and coors_mlp, each time behind the
+// first Linear).  The E x H activations of edge_mlp never exist in memory, so neither can a mask: the keep decision of element
+// (row, col) of a site is a counter-based hash of (seed, site, row, col) -- the same function in the forward kernels and in
+// whatever differentiates them (egnn_pytorch_amd/_dropout.py is its torch twin).  row = edge id b N K + i K + k (sites 0, 1) or
+// node id b N + i (site 2); col = the unit's index in the reference's hidden dimension.  keep <=> hash >= thr, thr = p 2^32.
+#define EGNN_DROP_SITE_EDGE 0u
+#define EGNN_DROP_SITE_COORS 1u
+#define EGNN_DROP_SITE_NODE 2u
+__host__ __device__ __forceinline__ uint32_t egnn_drop_base(uint32_t seed, uint32_t site, uint32_t row)
+{
+    return row * 0x9E3779B1u + seed + site * 0x27D4EB2Fu;
+}
+__host__ __device__ __forceinline__ uint32_t egnn_drop_hash(uint32_t base, uint32_t col)
+{
+    uint32_t x = base + col * 0x85EBCA77u;
+    x ^= x >> 15;
+    x *= 0x2C1B3C6Du;
+    x ^= x >> 12;
+    x *= 0x297A2D39u;
+    x ^= x >> 15;
+    return x;
+}
+
 // squared distance exactly as the reference's CPU path produces it:
 // ((dx*dx + dy*dy) + dz*dz), each operation rounded separately -- no FMA contraction.
 __device__ __forceinline__ float egnn_sqdist(float xi, float yi, float zi, float xj, float yj, float zj,

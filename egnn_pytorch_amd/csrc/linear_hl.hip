@@ -25,6 +25,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+// training-mode dropout between the Linear and its activation (egnn_linear_hl_drop_f32); thr = 0: off
+struct DropArgs { uint32_t thr, seed; float inv_keep; };
+
 constexpr int BK = 16;                       // one v_mfma_f32_32x32x16_f16 step per K-tile
 constexpr int ROWB = BK * 2;                 // bytes per LDS row (32)
 constexpr int GROUP_M = 8;
@@ -57,7 +60,7 @@ __device__ __forceinline__ void linear_hl_body(
     const float* __restrict__ bias, const float* __restrict__ R, int64_t ldr,
     float* __restrict__ C, int64_t ldc, _Float16* __restrict__ Chi, _Float16* __restrict__ Clo, int nkt_out,
     int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, int32_t* __restrict__ status, char* smem, const int bid,
-    const int kt0 = 0, const int kt_count = -1)
+    const int kt0 = 0, const int kt_count = -1, const DropArgs drop = DropArgs{0u, 0u, 1.f})
 {
     using C_ = Cfg<CFG>;
     constexpr int BM = C_::BM, BN = C_::BN, TI = C_::TI, TJ = C_::TJ, STAGES = C_::STAGES;
@@ -247,6 +250,8 @@ __device__ __forceinline__ void linear_hl_body(
                 const int64_t gm = m0 + wm * (TI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
                 if (gm >= M) continue;
                 float x = acc[i][j][r] * out_scale + bv;
+                if (drop.thr)                                       // nn.Dropout behind the Linear (egnn_pytorch.py:196-201)
+                    x = egnn_drop_hash(egnn_drop_base(drop.seed, EGNN_DROP_SITE_NODE, (uint32_t)gm), (uint32_t)gn) >= drop.thr ? x * drop.inv_keep : 0.f;
                 if (ACT == 1) x = egnn_silu(x);
                 if (ACT == 2) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));     // exact GELU (nn.GELU default, :130)
                 if (HAS_RES) x += R[gm * ldr + gn];
@@ -282,11 +287,11 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
     const float* __restrict__ bias, const float* __restrict__ R, int64_t ldr,
     float* __restrict__ C, int64_t ldc, _Float16* __restrict__ Chi, _Float16* __restrict__ Clo, int nkt_out,
-    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, int32_t* __restrict__ status)
+    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, int32_t* __restrict__ status, const DropArgs drop)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // STAGES x BUF
     linear_hl_body<CFG, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, ntm, ntn,
-                                      out_scale, split_cols, status, smem, blockIdx.x);
+                                      out_scale, split_cols, status, smem, blockIdx.x, 0, -1, drop);
 }
 
 // Split-K: blockIdx.y = part; the part's partial product goes to its own (M, ldc) slab (summed afterwards in fixed order)
@@ -317,7 +322,8 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
 template <int CFG, int ACT, bool HAS_RES>
 int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, const _Float16* Wlo,
                   const float* bias, const float* R, int64_t ldr, float* C, int64_t ldc, _Float16* Chi, _Float16* Clo,
-                  int nkt_out, int64_t M, int N, int Kp, float out_scale, int split_cols, int32_t* status, hipStream_t s)
+                  int nkt_out, int64_t M, int N, int Kp, float out_scale, int split_cols, int32_t* status, hipStream_t s,
+                  const DropArgs drop = DropArgs{0u, 0u, 1.f})
 {
     using C_ = Cfg<CFG>;
     const int64_t ntm = (M + C_::BM - 1) / C_::BM;
@@ -328,7 +334,7 @@ int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((linear_hl_kernel<CFG, ACT, HAS_RES>), dim3((unsigned)(ntm * ntn)), dim3(C_::WM * C_::WN * 64), lds, s,
-                       Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale, split_cols, status);
+                       Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale, split_cols, status, drop);
     return egnn_launch_status();
 }
 
@@ -342,22 +348,23 @@ int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi,
 template <int ACT, bool HAS_RES>
 int launch_hl(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, const _Float16* Wlo,
               const float* bias, const float* R, int64_t ldr, float* C, int64_t ldc, _Float16* Chi, _Float16* Clo,
-              int nkt_out, int64_t M, int N, int Kp, float out_scale, int w_rows, int split_cols, int32_t* status, hipStream_t s)
+              int nkt_out, int64_t M, int N, int Kp, float out_scale, int w_rows, int split_cols, int32_t* status, hipStream_t s,
+              const DropArgs drop = DropArgs{0u, 0u, 1.f})
 {
     // Large problems (enough 256 x 128 tiles to fill the chip twice) use the larger tile; small ones the 128 x 128 tile.
     constexpr int BIG = EGNN_HL_CFG;
     const int64_t tbig = ((M + Cfg<BIG>::BM - 1) / Cfg<BIG>::BM) * ((N + Cfg<BIG>::BN - 1) / Cfg<BIG>::BN);
     if (BIG != 0 && tbig >= 512 && w_rows >= (N + Cfg<BIG>::BN - 1) / Cfg<BIG>::BN * Cfg<BIG>::BN)
-        return launch_hl_cfg<BIG, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, split_cols, status, s);
-    return launch_hl_cfg<0, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, split_cols, status, s);
+        return launch_hl_cfg<BIG, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, split_cols, status, s, drop);
+    return launch_hl_cfg<0, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, split_cols, status, s, drop);
 }
 
 }  // namespace
 
-extern "C" int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo,
-                                  float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
-                                  float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
-                                  int w_rows, int act, int split_cols, int32_t* status, void* stream)
+static int linear_hl_entry(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo,
+                           float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
+                           float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
+                           int w_rows, int act, int split_cols, int32_t* status, void* stream, const DropArgs drop)
 {
     if (!A_hi || !A_lo || !W_hi || !W_lo) return EGNN_E_NULLPTR;
     if (!C && !C_hi) return EGNN_E_NULLPTR;
@@ -380,12 +387,33 @@ extern "C" int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void
     _Float16 *ch = static_cast<_Float16*>(C_hi), *cl = static_cast<_Float16*>(C_lo);
     const int nkt_out = Kp_out / 16;
     if (act == 0) {
-        if (residual) return launch_hl<0, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
-        return launch_hl<0, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
+        if (residual) return launch_hl<0, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s, drop);
+        return launch_hl<0, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s, drop);
     }
-    if (act == 2) return launch_hl<2, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
-    if (residual) return launch_hl<1, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
-    return launch_hl<1, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s);
+    if (act == 2) return launch_hl<2, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s, drop);
+    if (residual) return launch_hl<1, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s, drop);
+    return launch_hl<1, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s, drop);
+}
+
+extern "C" int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo,
+                                  float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
+                                  float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
+                                  int w_rows, int act, int split_cols, int32_t* status, void* stream)
+{
+    return linear_hl_entry(A_hi, A_lo, W_hi, W_lo, w_inv_scale, bias, residual, ldr, C, ldc, C_hi, C_lo, Kp_out, M, N, Kp, w_rows, act,
+                           split_cols, status, stream, DropArgs{0u, 0u, 1.f});
+}
+
+extern "C" int egnn_linear_hl_drop_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo,
+                                       float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
+                                       float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
+                                       int w_rows, int act, int split_cols, uint32_t drop_thr, uint32_t drop_seed, float drop_inv_keep,
+                                       int32_t* status, void* stream)
+{
+    if (drop_thr && !(drop_inv_keep >= 1.f)) return EGNN_E_SHAPE;
+    if (M > 0xffffffffLL) return EGNN_E_UNSUPPORTED;                          // the mask's row counter is 32 bits
+    return linear_hl_entry(A_hi, A_lo, W_hi, W_lo, w_inv_scale, bias, residual, ldr, C, ldc, C_hi, C_lo, Kp_out, M, N, Kp, w_rows, act,
+                           split_cols, status, stream, DropArgs{drop_thr, drop_seed, drop_inv_keep});
 }
 
 extern "C" int egnn_linear_hl_splitk_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo, float w_inv_scale,

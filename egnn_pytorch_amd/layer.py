@@ -18,7 +18,7 @@ import warnings
 import torch
 from torch import nn
 
-from . import _abi, _ops, _weights, autograd as _autograd
+from . import _abi, _dropout, _ops, _weights, autograd as _autograd
 from .attention import GlobalLinearAttention
 
 _SPATIAL_ORDER = os.environ.get("EGNN_SPATIAL_ORDER", "1") != "0"     # scheduling knob only; results do not depend on it
@@ -132,9 +132,9 @@ class EGNN(nn.Module):
             raise NotImplementedError("the gfx950 path supports coordinate dimensions 1..8")
         if feats.shape[-1] != self.dim:
             raise ValueError(f"feats last dim {feats.shape[-1]} != dim {self.dim}")
-        if self.training and self.dropout_p > 0:
-            raise NotImplementedError("dropout in training mode is not supported by the gfx950 forward (the fused edge pass "
-                                      "has no dropout mask); use dropout=0 or call .eval()")
+        if self.training and self.dropout_p > 0 and (coors.shape[-1] != 3 or self.m_dim > 16):
+            raise NotImplementedError("training-mode dropout on the gfx950 path needs 3-D coordinates and m_dim <= 16 "
+                                      "(the dropout instantiation of the fused edge pass); use dropout=0 or call .eval()")
         if (edges is not None) != (self.edge_dim > 0):
             raise ValueError("`edges` must be passed if and only if edge_dim > 0")
         b, n = feats.shape[:2]
@@ -165,12 +165,16 @@ class EGNN(nn.Module):
                 node_out, coors_out, order = self._forward_with_hint(feats, coors, edges, mask, adj_mat, order_hint)[:3]
         return node_out, coors_out, order
 
-    def _forward_hip_checked(self, feats, coors, edges, mask, adj_mat, order_hint, want_u=False):
+    def _forward_hip_checked(self, feats, coors, edges, mask, adj_mat, order_hint, want_u=False, drop_seed=None):
         """(node_out, coors_out, order, idx, rank, valid_radius, u) -- what autograd.EGNNFunction.forward needs; u = the
         (B*N*K, 16) pre-activation of edge_mlp's second SiLU when `want_u` (the native backward differentiates from it)."""
-        return self._forward_with_hint(feats, coors, edges, mask, adj_mat, order_hint, want_u=want_u)
+        return self._forward_with_hint(feats, coors, edges, mask, adj_mat, order_hint, want_u=want_u, drop_seed=drop_seed)
 
-    def _forward_with_hint(self, feats, coors, edges, mask, adj_mat, order_hint, want_u=False):
+    def dropout_active(self):
+        """training mode with dropout > 0: every forward draws a fresh mask seed (egnn_pytorch_amd/_dropout.py)"""
+        return self.training and self.dropout_p > 0
+
+    def _forward_with_hint(self, feats, coors, edges, mask, adj_mat, order_hint, want_u=False, drop_seed=None):
         """forward + the scheduling permutation it used (EGNN_Network hands layer 0's on to the next layers)."""
         self._check_inputs(feats, coors, edges, mask, adj_mat)
         _abi.load()
@@ -178,14 +182,16 @@ class EGNN(nn.Module):
         if f_dtype == torch.float64 or c_dtype == torch.float64:
             _warn_float64_once()
         with torch.cuda.device(feats.device):
+            if self.dropout_active() and drop_seed is None:
+                drop_seed = _dropout.draw_seed()
             out = self._forward_hip(feats.float(), coors.float(),
                                     edges if (edges is None or isinstance(edges, EdgeLookup)) else edges.float(), mask, adj_mat, order_hint,
-                                    want_u=want_u)
+                                    want_u=want_u, drop=(self.dropout_p, drop_seed) if self.dropout_active() else None)
         if f_dtype != torch.float32 or c_dtype != torch.float32:
             out = (out[0].to(f_dtype), out[1].to(c_dtype)) + tuple(out[2:])
         return out
 
-    def _forward_hip(self, feats, coors, edges, mask, adj_mat, order_hint=None, want_u=False):
+    def _forward_hip(self, feats, coors, edges, mask, adj_mat, order_hint=None, want_u=False, drop=None):
         b, n, dim = feats.shape
         w = self.packed_weights()
         feats = feats.contiguous()
@@ -304,6 +310,8 @@ class EGNN(nn.Module):
             a.pool_mean = int(self.m_pool_method == "mean")
             if self.node_mlp is not None:
                 a.node_hi, a.node_lo, a.node_kp = node_in.hi.data_ptr(), node_in.lo.data_ptr(), node_in.kp
+            if drop is not None:                                  # training-mode dropout: the mask is a hash, see _dropout.py
+                a.drop_thr, a.drop_seed, a.drop_inv_keep = _dropout.threshold(drop[0]), int(drop[1]), 1.0 / (1.0 - drop[0])
             if want_u and self.m_dim <= 16:
                 u_pre = _ops.empty(b * n * k, 16, dtype=torch.float32, device=feats.device)
                 a.U_out = u_pre.data_ptr()
@@ -315,7 +323,7 @@ class EGNN(nn.Module):
         # ---- node update (egnn_pytorch.py:335-337)
         if self.node_mlp is not None:
             hid = _ops.linear_hl(node_in, w["W5_split"], 2 * dim, w["b5"], act=1, out_f32=False, out_hl=True,
-                                 name="node_mlp0")
+                                 name="node_mlp0", drop=drop)
             node_out = _ops.linear_hl(hid, w["W6_split"], dim, w["b6"], residual=feats2d, name="node_mlp1").view(b, n, dim)
         return node_out, coors_out, order, idx, rank, valid_radius, u_pre
 

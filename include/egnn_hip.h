@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 21
+#define EGNN_ABI_VERSION 22
 
 enum {
     EGNN_OK = 0,
@@ -163,6 +163,14 @@ int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void* W_hi, con
                        float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
                        float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
                        int w_rows, int act, int split_cols, int32_t* status, void* stream);
+/* The same with training-mode dropout between the Linear and the activation (node_mlp, egnn_pytorch.py:196-201): element (row, col) of
+ * A W^T + bias is kept iff the hash of [seed, site = node, row, col] (csrc/egnn_common.h) is >= drop_thr and multiplied by drop_inv_keep,
+ * else zeroed. */
+int egnn_linear_hl_drop_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo,
+                            float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
+                            float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
+                            int w_rows, int act, int split_cols, uint32_t drop_thr, uint32_t drop_seed, float drop_inv_keep,
+                            int32_t* status, void* stream);
 
 /* The backward's node-level gradient products (autograd of egnn_pytorch.py:287, 336: d/d feats = dP W, d/d W = dP^T feats) on the same
  * split-f16 matrix-core GEMM as the forward.
@@ -267,6 +275,12 @@ typedef struct egnn_edge_args {
                                    selected pairs in neighbour-list order (egnn_edge_features_gather_f32), read at [b,i,k] */
     const void* slots;          /* optional (idx != NULL, coor_dim == 3): the records of egnn_slot_prep_f32 for the SAME idx / rank / mask /
                                    order / valid_radius -- the setup reads them instead of walking order -> idx -> coors -> mask */
+    /* training-mode dropout (egnn_pytorch.py:176, 178-184, 203-208; drop_thr = 0: off).  Element (edge, unit) of the pre-activation of
+     * edge_mlp's and of coors_mlp's first SiLU is kept iff the counter-based hash of [seed, site, edge id, unit] is >= drop_thr (csrc/egnn_common.h;
+     * the torch twin is egnn_pytorch_amd/_dropout.py) and multiplied by drop_inv_keep = 1 / (1 - p), else zeroed.  coor_dim 3, m_dim <= 16. */
+    uint32_t drop_thr;          /* round(p * 2^32), p in (0, 1) */
+    uint32_t drop_seed;
+    float drop_inv_keep;
 } egnn_edge_args;
 
 int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream);

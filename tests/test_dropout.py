@@ -1,0 +1,170 @@
+"""Training-mode dropout (egnn_pytorch.py:176: one nn.Dropout shared by edge_mlp, node_mlp and coors_mlp, each time behind the
+first Linear) on the gfx950 path -- VERDICT r2 missing #3.  The masks are a counter-based hash (csrc/egnn_common.h) whose torch
+twin is egnn_pytorch_amd/_dropout.py: no two dropout implementations share a random stream, so parity with the reference is
+(a) identical semantics -- Bernoulli(1 - p) keep, 1 / (1 - p) rescale, behind the first Linear of each MLP, fresh per call,
+training mode only -- checked against a float64 restatement that applies the SAME masks, and (b) the mask's statistics."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+
+def _py_hash(seed, site, row, col):
+    m = 0xFFFFFFFF
+    x = (row * 0x9E3779B1 + seed + site * 0x27D4EB2F + col * 0x85EBCA77) & m
+    x ^= x >> 15
+    x = (x * 0x2C1B3C6D) & m
+    x ^= x >> 12
+    x = (x * 0x297A2D39) & m
+    x ^= x >> 15
+    return x
+
+
+def test_hash_twin_equals_the_c_definition_and_is_bernoulli():
+    from egnn_pytorch_amd import _dropout as D
+    rows = torch.tensor([0, 1, 5, 2 ** 31 - 5, 123456789, 4294967295])
+    cols = torch.tensor([0, 1, 2049, 63])
+    h = D.hash32(12345, 2, rows, cols)
+    for i in range(rows.numel()):
+        for j in range(cols.numel()):
+            assert int(h[i, j]) == _py_hash(12345, 2, int(rows[i]), int(cols[j]))
+    for p in (0.1, 0.5, 0.9):
+        keep = D.keep_mask(99, D.SITE_EDGE, torch.arange(3000), torch.arange(700), p).float()
+        assert abs(float(keep.mean()) - (1 - p)) < 2e-3
+        assert abs(float(keep.mean(dim=0).std())) < 0.03 and abs(float(keep.mean(dim=1).std())) < 0.05      # no dead rows / columns
+        # neighbouring rows / columns are uncorrelated
+        a, b = keep[:-1] - (1 - p), keep[1:] - (1 - p)
+        assert abs(float((a * b).mean())) < 2e-3
+        a, b = keep[:, :-1] - (1 - p), keep[:, 1:] - (1 - p)
+        assert abs(float((a * b).mean())) < 2e-3
+    assert not torch.equal(D.keep_mask(1, 0, torch.arange(100), torch.arange(64), 0.5), D.keep_mask(2, 0, torch.arange(100), torch.arange(64), 0.5))
+    assert not torch.equal(D.keep_mask(1, 0, torch.arange(100), torch.arange(64), 0.5), D.keep_mask(1, 1, torch.arange(100), torch.arange(64), 0.5))
+
+
+def test_restatement_with_masks_reduces_to_the_plain_layer_at_tiny_p():
+    """CPU: layer_given_neighbors(drop=(p, seed)) keeps everything for p -> 0 and then equals the eval layer (times 1 / (1 - p) ~ 1)."""
+    from egnn_pytorch_amd import EGNN, autograd as A
+    torch.manual_seed(0)
+    layer = EGNN(dim=8, num_nearest_neighbors=4, dropout=0.5).double()
+    with torch.no_grad():
+        for prm in layer.parameters():
+            prm.mul_(40.0)
+    g = torch.Generator().manual_seed(1)
+    feats, coors = torch.randn(2, 10, 8, generator=g).double(), torch.randn(2, 10, 3, generator=g).double()
+    idx = torch.randint(0, 10, (2, 10, 4), generator=g)
+    rank = torch.rand(2, 10, 4, generator=g).double()
+    layer.eval()
+    with torch.no_grad():
+        plain = A.layer_given_neighbors(layer, feats, coors, None, None, idx, rank, 1e9)
+        tiny = A.layer_given_neighbors(layer, feats, coors, None, None, idx, rank, 1e9, drop=(1e-12, 5))
+        half = A.layer_given_neighbors(layer, feats, coors, None, None, idx, rank, 1e9, drop=(0.5, 5))
+        half2 = A.layer_given_neighbors(layer, feats, coors, None, None, idx, rank, 1e9, drop=(0.5, 5))
+        # a chunk that starts at graph 1 sees the same masks as graph 1 inside the full batch
+        part = A.layer_given_neighbors(layer, feats[1:], coors[1:], None, None, idx[1:], rank[1:], 1e9, drop=(0.5, 5), graph_offset=1)
+    assert torch.allclose(plain[0], tiny[0], atol=1e-9) and torch.allclose(plain[1], tiny[1], atol=1e-9)
+    assert not torch.allclose(plain[0], half[0], atol=1e-3)
+    assert torch.equal(half[0], half2[0])
+    assert torch.allclose(part[0], half[0][1:], atol=1e-12) and torch.allclose(part[1], half[1][1:], atol=1e-12)
+
+
+CASES = [
+    (dict(dim=64, num_nearest_neighbors=32, dropout=0.25, norm_feats=True), 96, True),            # one node per wave
+    (dict(dim=32, num_nearest_neighbors=8, dropout=0.1, norm_coors=True, soft_edges=True), 40, True),   # four nodes per tile
+    (dict(dim=32, dropout=0.5, m_pool_method="mean"), 20, False),                                 # dense all-pairs
+    (dict(dim=24, num_nearest_neighbors=5, dropout=0.3, m_dim=8, coor_weights_clamp_value=1.0), 30, True),   # P_i on the VALU
+    (dict(dim=32, num_nearest_neighbors=16, dropout=0.2, edge_dim=3, fourier_features=1), 48, True),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,n,use_mask", CASES)
+def test_training_mode_forward_applies_exactly_the_hash_masks(kw, n, use_mask):
+    """HIP forward in training mode with a given seed == the float64 restatement of the layer with the SAME masks at the three
+    dropout sites (1e-4, like every parity test): pins where the masks sit, their row / unit indexing and the rescaling."""
+    from egnn_pytorch_amd import EGNN, autograd as A
+    torch.manual_seed(11)
+    layer = EGNN(**kw)
+    with torch.no_grad():
+        for prm in layer.parameters():
+            prm.mul_(40.0)
+    layer = layer.cuda().train()
+    g = torch.Generator().manual_seed(3)
+    b = 3
+    feats, coors = torch.randn(b, n, kw["dim"], generator=g).cuda(), torch.randn(b, n, 3, generator=g).cuda()
+    mask = (torch.arange(n)[None] < torch.tensor([[n], [n - 3], [n // 2 + 2]])).cuda() if use_mask else None
+    edges = torch.randn(b, n, n, kw["edge_dim"], generator=g).cuda() if kw.get("edge_dim") else None
+    seed = 424242
+    with torch.no_grad():
+        node, co, _, idx, rank, radius, _ = layer._forward_hip_checked(feats, coors, edges, mask, None, None, drop_seed=seed)
+        node2, co2 = layer._forward_hip_checked(feats, coors, edges, mask, None, None, drop_seed=seed)[:2]
+        node3 = layer._forward_hip_checked(feats, coors, edges, mask, None, None, drop_seed=seed + 1)[0]
+    assert torch.equal(node, node2) and torch.equal(co, co2)                      # same seed: same masks
+    assert not torch.allclose(node, node3, atol=1e-3)                             # another seed: other masks
+    l64 = copy.deepcopy(layer).double()
+    with torch.no_grad():
+        want = A.layer_given_neighbors(l64, feats.double(), coors.double(), None if edges is None else edges.double(), mask,
+                                       None if idx is None else idx.long(), None if rank is None else rank.double(), radius,
+                                       drop=(kw["dropout"], seed))
+    np.testing.assert_allclose(node.cpu().numpy(), want[0].cpu().numpy(), atol=1e-4, rtol=0)
+    np.testing.assert_allclose(co.cpu().numpy(), want[1].cpu().numpy(), atol=1e-4, rtol=0)
+    # eval mode: no dropout, no seed drawn
+    layer.eval()
+    st = torch.random.get_rng_state()
+    with torch.no_grad():
+        e1 = layer(feats, coors, edges, mask)
+    assert torch.equal(st, torch.random.get_rng_state())
+    with torch.no_grad():
+        plain = A.layer_given_neighbors(l64.eval(), feats.double(), coors.double(), None if edges is None else edges.double(), mask,
+                                        None if idx is None else idx.long(), None if rank is None else rank.double(), radius)
+    np.testing.assert_allclose(e1[0].cpu().numpy(), plain[0].cpu().numpy(), atol=1e-4, rtol=0)
+
+
+@pytest.mark.gpu
+def test_training_mode_backward_differentiates_the_masked_layer():
+    """loss.backward() through the drop-in layer in training mode: every gradient equals float64 autograd of the restatement with
+    the masks of THAT forward call (the seed comes from torch's CPU generator: torch.manual_seed reproduces it)."""
+    from egnn_pytorch_amd import EGNN, _dropout, autograd as A
+    torch.manual_seed(21)
+    kw = dict(dim=32, num_nearest_neighbors=8, dropout=0.2, norm_feats=True)
+    layer = EGNN(**kw)
+    with torch.no_grad():
+        for prm in layer.parameters():
+            prm.mul_(40.0)
+    layer = layer.cuda().train()
+    g = torch.Generator().manual_seed(4)
+    b, n = 2, 40
+    feats, coors = torch.randn(b, n, 32, generator=g).cuda(), torch.randn(b, n, 3, generator=g).cuda()
+    rn, rc = torch.randn(b, n, 32, generator=g).cuda(), torch.randn(b, n, 3, generator=g).cuda()
+    torch.manual_seed(77)
+    seed = _dropout.draw_seed()
+    torch.manual_seed(77)
+    f, c = feats.clone().requires_grad_(True), coors.clone().requires_grad_(True)
+    node, co = layer(f, c)
+    got = torch.autograd.grad((node * rn).sum() + (co * rc).sum(), [f, c] + list(layer.parameters()), allow_unused=True)
+    with torch.no_grad():
+        idx, rank, radius = layer._forward_hip_checked(feats, coors, None, None, None, None, drop_seed=seed)[3:6]
+    l64 = copy.deepcopy(layer).double()
+    f2, c2 = feats.double().requires_grad_(True), coors.double().requires_grad_(True)
+    n2, co2 = A.layer_given_neighbors(l64, f2, c2, None, None, idx.long(), rank.double(), radius, drop=(0.2, seed))
+    np.testing.assert_allclose(node.detach().cpu().numpy(), n2.detach().cpu().numpy(), atol=1e-4, rtol=0)
+    want = torch.autograd.grad((n2 * rn.double()).sum() + (co2 * rc.double()).sum(), [f2, c2] + list(l64.parameters()), allow_unused=True)
+    for a, r in zip(got, want):
+        assert (a is None) == (r is None)
+        if a is not None:
+            assert float((a.double() - r).abs().max()) <= 1e-4 * max(1.0, float(r.abs().max()))
+    # two training-mode calls draw different masks
+    with torch.no_grad():
+        a1, a2 = layer(feats, coors)[0], layer(feats, coors)[0]
+    assert not torch.allclose(a1, a2, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_dropout_configurations_outside_the_kernel_still_raise():
+    from egnn_pytorch_amd import EGNN
+    f, c5 = torch.randn(1, 12, 16).cuda(), torch.randn(1, 12, 5).cuda()
+    with pytest.raises(NotImplementedError):
+        EGNN(dim=16, dropout=0.1).cuda().train()(f, c5)
+    with pytest.raises(NotImplementedError):
+        EGNN(dim=16, dropout=0.1, m_dim=32).cuda().train()(f, torch.randn(1, 12, 3).cuda())
+    EGNN(dim=16, dropout=0.1, m_dim=32).cuda().eval()(f, torch.randn(1, 12, 3).cuda())      # eval: dropout is the identity
