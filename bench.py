@@ -70,6 +70,8 @@ def model_counts(kwargs, b, n):
         "node_prep": dict(bound="hbm", bytes=4 * bn * dim + 4 * bn * dim + 4 * bn * (dim + m), flops=10.0 * bn * dim),
         "split_f16": dict(bound="hbm", bytes=4 * 2 * bn * dim, flops=2.0 * bn * dim),
         "spatial_order": dict(bound="hbm", bytes=16 * bn, flops=0.0),
+        # per-slot records for the edge pass's setup: reads the neighbour list, rank and two coordinate rows, writes 16 bytes per slot
+        "slot_prep": dict(bound="hbm", bytes=e * (4 + 4 + 16) + 24 * bn, flops=6.0 * e),
         # fused select: compulsory traffic is tiny; the comparable figure is one fp32 rank per ordered pair
         "knn_select": dict(bound="hbm", bytes=4 * b * n * n, flops=8.0 * b * n * n),
     }, dict(E=e, K=k, H=h, Hp=hp)

@@ -1,0 +1,24 @@
+#!/bin/bash
+# The round's measurement run on the GPU box (from the repo root):   bash tools/measure.sh <tag>
+#   * full GPU test suite + smoke()
+#   * the default bench line with the reference timed on the host cores, on the MI355X through PyTorch eager, and one training step
+#   * ragged masks and the other BASELINE.json configs at full size
+#   * tools/profile.sh: rocprofv3 kernel trace + stats of the default command and one PMC pass per counter group
+# Everything lands under gpurun_out/prof_<tag>/; the summaries to keep are copied into profiles/<tag>/ afterwards.
+TAG="${1:-r03_final}"
+REPO="$(pwd)"
+OUT="$REPO/gpurun_out/prof_$TAG"
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -W ignore::UserWarning > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python bench.py --reference-eager --train-step > $OUT/bench_line.json 2> $OUT/bench_line.err; echo "bench rc=$?"
+python -c "
+import json; d=json.load(open('$OUT/bench_line.json')); print(d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'], d['cpu_baseline']['value'], d.get('reference_gpu_eager', {}).get('value'), d.get('train_step'))"
+python bench.py --ragged-mask --no-cpu-baseline > $OUT/bench_ragged_mask.json 2>> $OUT/bench_line.err
+for w in c2_dense c3_network c4_sparse c5_shard; do
+  python bench.py --workload $w > $OUT/bench_$w.json 2>> $OUT/bench_line.err; head -c 160 $OUT/bench_$w.json; echo
+done
+python bench.py --workload c4_sparse --no-cpu-baseline --train-step > $OUT/bench_train_step_c4_sparse.json 2>> $OUT/bench_line.err
+bash tools/profile.sh $TAG 2>&1 | tail -70
+rm -f $OUT/trace/*kernel_trace.csv $OUT/trace/*/*kernel_trace.csv $OUT/pmc*/*/*kernel_trace.csv $OUT/pmc*/*kernel_trace.csv 2>/dev/null
