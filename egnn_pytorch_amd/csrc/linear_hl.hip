@@ -53,7 +53,7 @@ template <> struct Cfg<2> { static constexpr int BM = 256, BN = 256, WM = 2, WN 
 //     issue the DMAs of tile kt+S-1 into that slot
 //     fragments of tile kt -> 3 x TI x TJ MFMAs
 // (Device function of the block index: see edge_fused.hip::edge_body.)
-template <int CFG, int ACT, bool HAS_RES>
+template <int CFG, int ACT, bool HAS_RES, bool DROP = false>
 __device__ __forceinline__ void linear_hl_body(
     const _Float16* __restrict__ Ahi, const _Float16* __restrict__ Alo,
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
@@ -250,7 +250,7 @@ __device__ __forceinline__ void linear_hl_body(
                 const int64_t gm = m0 + wm * (TI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
                 if (gm >= M) continue;
                 float x = acc[i][j][r] * out_scale + bv;
-                if (drop.thr)                                       // nn.Dropout behind the Linear (egnn_pytorch.py:196-201)
+                if constexpr (DROP)                                 // nn.Dropout behind the Linear (egnn_pytorch.py:196-201); its own
                     x = egnn_drop_hash(egnn_drop_base(drop.seed, EGNN_DROP_SITE_NODE, (uint32_t)gm), (uint32_t)gn) >= drop.thr ? x * drop.inv_keep : 0.f;
                 if (ACT == 1) x = egnn_silu(x);
                 if (ACT == 2) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));     // exact GELU (nn.GELU default, :130)
@@ -281,7 +281,7 @@ __device__ __forceinline__ void linear_hl_body(
     }
 }
 
-template <int CFG, int ACT, bool HAS_RES>
+template <int CFG, int ACT, bool HAS_RES, bool DROP = false>
 __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl_kernel(
     const _Float16* __restrict__ Ahi, const _Float16* __restrict__ Alo,
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
@@ -290,8 +290,8 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
     int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, int32_t* __restrict__ status, const DropArgs drop)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // STAGES x BUF
-    linear_hl_body<CFG, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, ntm, ntn,
-                                      out_scale, split_cols, status, smem, blockIdx.x, 0, -1, drop);
+    linear_hl_body<CFG, ACT, HAS_RES, DROP>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, ntm, ntn,
+                                            out_scale, split_cols, status, smem, blockIdx.x, 0, -1, drop);
 }
 
 // Split-K: blockIdx.y = part; the part's partial product goes to its own (M, ldc) slab (summed afterwards in fixed order)
@@ -330,6 +330,20 @@ int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi,
     const int64_t ntn = (N + C_::BN - 1) / C_::BN;
     if (ntm * ntn > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
     const size_t lds = (size_t)C_::STAGES * (2 * C_::BM + 2 * C_::BN) * ROWB;
+    // (the dropout epilogue -- a hash per output element -- is its own instantiation: as a run-time branch in the common kernel it cost
+    // the residual GEMM 18 % (0.25 -> 0.30 ms) through register pressure alone)
+    if constexpr (ACT == 1 && !HAS_RES) {
+        if (drop.thr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_hl_kernel<CFG, ACT, HAS_RES, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((linear_hl_kernel<CFG, ACT, HAS_RES, true>), dim3((unsigned)(ntm * ntn)), dim3(C_::WM * C_::WN * 64), lds, s,
+                               Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale, split_cols, status, drop);
+            return egnn_launch_status();
+        }
+    } else if (drop.thr) {
+        return EGNN_E_UNSUPPORTED;                       // dropout sits behind node_mlp's first Linear only (SiLU, no residual)
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_hl_kernel<CFG, ACT, HAS_RES>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
