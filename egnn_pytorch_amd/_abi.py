@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -29,7 +29,7 @@ SYMBOLS = (
     "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32",
     "egnn_edge_bwd_dz_f32", "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_tail_bwd_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
     "egnn_induced_attn_f32", "egnn_token_attn_f32", "egnn_slot_prep_f32", "egnn_struct_bytes",
-    "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32",
+    "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32",
     "egnn_linear_hl_drop_f32",
 )
 
@@ -80,6 +80,7 @@ class EdgeTailArgs(Structure):
         ("u", c_void_p), ("coors", c_void_p), ("idx", c_void_p), ("pair_mask", c_void_p), ("g_coors_out", c_void_p),
         ("g_msum", c_void_p), ("W3", c_void_p), ("b3", c_void_p), ("W4", c_void_p), ("b4", c_void_p), ("scale", c_void_p),
         ("gU", c_void_p), ("g_rel", c_void_p), ("g_hid", c_void_p), ("a3", c_void_p), ("g_w", c_void_p), ("g_scale", c_void_p),
+        ("gate_w", c_void_p), ("gate_b", c_void_p), ("g_gate", c_void_p),
     ]
 
 
@@ -220,6 +221,10 @@ def load():
                                               c_int, c_void_p]
     lib.egnn_sum_parts_f32.restype = c_int
     lib.egnn_sum_parts_f32.argtypes = [c_void_p, c_int, c_int64, c_float, c_void_p, c_void_p]
+    lib.egnn_absmax_f32.restype = c_int
+    lib.egnn_absmax_f32.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
+    lib.egnn_unsplit_words_f32.restype = c_int
+    lib.egnn_unsplit_words_f32.argtypes = [c_void_p, c_int64, c_int64, c_int, c_void_p]
     lib.egnn_edge_mfmas.restype = c_int
     lib.egnn_edge_mfmas.argtypes = [c_int]
     lib.egnn_edge_fused_f32.restype = c_int

@@ -415,11 +415,43 @@ def split_scaled(x2d, scale, transposed=False, w_image=False):
     return PackedHL(hi, lo, img_rows, kp), alloc_rows
 
 
-def grad_nn(g2d, wsplit_t, n, residual=None, name="grad_nn"):
-    """g2d (R, K) fp32 @ W (K, n), W given as the packed split image of W^T (n rows, K): on the split-f16 GEMM of the forward,
-    g2d pre-scaled by a power of two (gradients are small: their fp16 lo halves must stay off the subnormals)."""
+def absmax(x):
+    """max |x| as a Python float (one host read) -- egnn_absmax_f32: one pass over x where `x.abs().max()` makes two and a copy.
+    What the power-of-two scales of the gradient GEMMs and of the edge backward are chosen from.  (Host tensors -- the CPU tests of
+    the backward's host logic -- go through torch.)"""
+    if not x.is_cuda:
+        return float(x.abs().max())
+    x = x if x.is_contiguous() else x.contiguous()
+    out = torch.empty(1, dtype=torch.int32, device=x.device)
+    with _timed("absmax"):
+        rc = _abi.load().egnn_absmax_f32(_ptr(x), x.numel(), _ptr(out), _stream())
+    _abi.check(rc, "egnn_absmax_f32")
+    return float(out.view(torch.float32).item())
+
+
+def unsplit_words_(table, cols):
+    """egnn_unsplit_words_f32: columns [0, cols) of the fp32 table hold (fp16 hi, fp16 lo) words -> hi + lo, in place."""
+    with _timed("unsplit_words"):
+        rc = _abi.load().egnn_unsplit_words_f32(_ptr(table), table.stride(0), table.shape[0], cols, _stream())
+    _abi.check(rc, "egnn_unsplit_words_f32")
+    return table
+
+
+def grad_scale(amax):
+    """The power of two that brings max |x| into [2^12, 2^13) (fp16 hi halves well inside the range, lo halves off the subnormals);
+    None for 0 / NaN / inf: the caller returns zeros (or lets the NaN through)."""
     from . import _weights
-    amax = float(g2d.abs().max())
+    if not (amax > 0.0) or amax != amax or amax == float("inf"):
+        return None
+    return _weights.pow2_scale(amax) * 4096.0
+
+
+def grad_nn(g2d, wsplit_t, n, residual=None, name="grad_nn", amax=None):
+    """g2d (R, K) fp32 @ W (K, n), W given as the packed split image of W^T (n rows, K): on the split-f16 GEMM of the forward,
+    g2d pre-scaled by a power of two (gradients are small: their fp16 lo halves must stay off the subnormals).  amax: max |g2d| if
+    the caller has it already."""
+    from . import _weights
+    amax = absmax(g2d) if amax is None else amax
     if not (amax > 0.0) or amax != amax or amax == float("inf"):
         out = torch.zeros(g2d.shape[0], n, dtype=torch.float32, device=g2d.device)
         return out if residual is None else out + residual
@@ -429,17 +461,28 @@ def grad_nn(g2d, wsplit_t, n, residual=None, name="grad_nn"):
     return linear_hl(a, (whi, wlo, inv / scale, w_rows), n, None, residual=residual, name=name)
 
 
-def grad_tn(g2d, x2d, k_splits=None, name="grad_tn"):
-    """g2d (R, M)^T @ x2d (R, N) -> (M, N): the weight-gradient contraction over R = B N nodes, split-K on the split-f16 GEMM."""
-    from . import _weights
+def grad_tn_operand(x2d):
+    """The right-hand operand of grad_tn, prepared once for several products with the same x2d: (packed image of (s x2d)^T, rows, s)
+    or None when x2d is all zero / not finite."""
+    sx = grad_scale(absmax(x2d))
+    if sx is None:
+        return None
+    w, w_rows = split_scaled(x2d, sx, transposed=True, w_image=True)  # (n rows, K = r)
+    return w, w_rows, sx
+
+
+def grad_tn(g2d, x2d, k_splits=None, name="grad_tn", amax=None, x_operand=None):
+    """g2d (R, M)^T @ x2d (R, N) -> (M, N): the weight-gradient contraction over R = B N nodes, split-K on the split-f16 GEMM.
+    amax: max |g2d| if known; x_operand: grad_tn_operand(x2d) if several products share x2d."""
     r, m = g2d.shape
     n = x2d.shape[1]
-    ag, ax = float(g2d.abs().max()), float(x2d.abs().max())
-    if not (ag > 0.0 and ax > 0.0) or ag != ag or ax != ax or ag == float("inf") or ax == float("inf"):
+    sg = grad_scale(absmax(g2d) if amax is None else amax)
+    if x_operand is None:
+        x_operand = grad_tn_operand(x2d)
+    if sg is None or x_operand is None:
         return torch.zeros(m, n, dtype=torch.float32, device=g2d.device)
-    sg, sx = _weights.pow2_scale(ag) * 4096.0, _weights.pow2_scale(ax) * 4096.0
+    w, w_rows, sx = x_operand
     a, _ = split_scaled(g2d, sg, transposed=True)                    # (m rows, K = r)
-    w, w_rows = split_scaled(x2d, sx, transposed=True, w_image=True)  # (n rows, K = r)
     nkt = a.kp // 16
     if k_splits is None:
         tiles = ((m + 127) // 128) * ((n + 127) // 128)
@@ -486,9 +529,10 @@ def dest_lists(idx32, b, n, k, device):
     return DestLists(ent[:length], tile_seg, order, seg)
 
 
-def edge_tail_bwd(u16, coors, idx32, pair_mask, g_coors_out, g_msum16, w3p, b3p, w4p, b4, scale, eps, clamp, b, n, k):
+def edge_tail_bwd(u16, coors, idx32, pair_mask, g_coors_out, g_msum16, w3p, b3p, w4p, b4, scale, eps, clamp, b, n, k, gate=None):
     """egnn_edge_tail_bwd_f32 (include/egnn_hip.h): the per-edge closed-form backward behind edge_mlp's second Linear.
-    Returns (gU (E, 16), g_rel (E, 4), g_hid (E, 64), a3 (E, 64), g_w (E,), g_scale (E,) or None)."""
+    Returns (gU (E, 16), g_rel (E, 4), g_hid (E, 64), a3 (E, 64), g_w (E,), g_scale (E,) or None); with gate = (gate_w (16) zero
+    padded, gate_b (1)) -- soft_edges -- a seventh element g_gate (E,) = d loss / d (gate pre-activation)."""
     dev = u16.device
     e = b * n * k
     f32 = dict(dtype=torch.float32, device=dev)
@@ -506,9 +550,15 @@ def edge_tail_bwd(u16, coors, idx32, pair_mask, g_coors_out, g_msum16, w3p, b3p,
     a.g_coors_out, a.g_msum = g_coors_out.data_ptr(), g_msum16.data_ptr()
     a.W3, a.b3, a.W4, a.b4, a.scale = w3p.data_ptr(), b3p.data_ptr(), w4p.data_ptr(), b4.data_ptr(), _ptr(scale)
     a.gU, a.g_rel, a.g_hid, a.a3, a.g_w, a.g_scale = gu.data_ptr(), g_rel.data_ptr(), g_hid.data_ptr(), a3.data_ptr(), g_w.data_ptr(), _ptr(g_scale)
+    g_gate = None
+    if gate is not None:
+        g_gate = empty(e, **f32)
+        a.gate_w, a.gate_b, a.g_gate = gate[0].data_ptr(), gate[1].data_ptr(), g_gate.data_ptr()
     with _timed("edge_tail_bwd"):
         rc = _abi.load().egnn_edge_tail_bwd_f32(byref(a), _stream())
     _abi.check(rc, "egnn_edge_tail_bwd_f32")
+    if gate is not None:
+        return gu, g_rel, g_hid, a3, g_w, g_scale, g_gate
     return gu, g_rel, g_hid, a3, g_w, g_scale
 
 

@@ -43,6 +43,7 @@ _NATIVE = _NATIVE_MODE != "0"
 _FUSED_SPLIT = os.environ.get("EGNN_BWD_SPLIT", "dest")
 _TAIL_KERNEL = os.environ.get("EGNN_BWD_TAIL_KERNEL", "1") != "0"      # 0: the per-edge chain behind u through autograd
 _GRAD_GEMM = os.environ.get("EGNN_BWD_GRAD_GEMM", "1") != "0"          # 0: the node-level gradient products as fp32 library GEMMs
+_KEEP_PROJ = os.environ.get("EGNN_BWD_KEEP_PROJ", "1") != "0"          # 0: the backward recomputes the P_i | P_j table (B N x 2 Hp fp32 less to keep)
 _FUSED_MAX_GRAPHS = 0                 # tests: force the chunking over graphs that very large batches need (0 = by size only)
 _NATIVE_BUDGET_BYTES = 24 << 30                      # dZ + SiLU(z), 2 x E x Hp fp32, per chunk of graphs
 
@@ -207,13 +208,21 @@ def tail_edge_backward(layer, u, coors, idx, pair_mask, g_coors_out, g_msum):
         g_msum (B,N,m) = d loss / d (sum over k of the pair-masked m_ij)  (sum pooling: d/d m_i; mean: that / count),
     returns d loss / d u (B,N,K,m), d loss / d rel (B,N,K,3; rel = x_i - x_j, without the distance path), and what the parameter
     gradients of coors_mlp / CoorsNorm are sums of: g_hid (E, 4m) = d/d (pre-activation of coors_mlp's SiLU), a3 (E, 4m) its
-    activation, g_w (E,) = d/d (coors_mlp's output), g_scale (E,) the per-edge terms of d/d coors_norm.scale.
-    Covers: no edge gate, coordinate dimension 3; masks, CoorsNorm, clamp as configured."""
+    activation, g_w (E,) = d/d (coors_mlp's output), g_scale (E,) the per-edge terms of d/d coors_norm.scale; with the edge gate
+    (soft_edges, :289-290) also g_gate (E,) = d/d (the gate's pre-activation) and m0 = SiLU(u) next to the gated m.
+    Covers: coordinate dimension 3; edge gate, masks, CoorsNorm, clamp as configured."""
     b, n, k, m = u.shape
     lin3, lin4 = layer.coors_mlp[0], layer.coors_mlp[3]
     w3, b3, w4, b4 = lin3.weight, lin3.bias, lin4.weight[0], lin4.bias[0]
     sg_u = torch.sigmoid(u)
-    mm = u * sg_u                                                               # m_ij = SiLU(u)
+    m0 = u * sg_u                                                               # SiLU(u)
+    gate = layer.edge_gate is not None
+    if gate:
+        gw, gb = layer.edge_gate[0].weight[0], layer.edge_gate[0].bias[0]
+        gt = torch.sigmoid(m0 @ gw + gb)[..., None]
+        mm = m0 * gt                                                            # m_ij = SiLU(u) * sigmoid(gate(SiLU(u)))
+    else:
+        mm = m0
     hid = mm @ w3.t() + b3
     sg_h = torch.sigmoid(hid)
     a3 = hid * sg_h
@@ -244,6 +253,11 @@ def tail_edge_backward(layer, u, coors, idx, pair_mask, g_coors_out, g_msum):
     g_m = g_hid @ w3
     gm_pool = g_msum[:, :, None, :].expand(b, n, k, m)
     g_m = g_m + (gm_pool if pair_mask is None else gm_pool.masked_fill(~pair_mask[..., None], 0.0))
+    g_gate = None
+    if gate:
+        g_s = (g_m * m0).sum(dim=-1, keepdim=True) * gt * (1 - gt)
+        g_m = g_m * gt + g_s * gw
+        g_gate = g_s.reshape(-1)
     g_u = g_m * (sg_u * (1 + u * (1 - sg_u)))
     if layer.norm_coors:
         dot = (g_relp * rel).sum(dim=-1, keepdim=True)
@@ -253,7 +267,7 @@ def tail_edge_backward(layer, u, coors, idx, pair_mask, g_coors_out, g_msum):
         g_rel = g_relp
     e = b * n * k
     return dict(g_u=g_u, g_rel=g_rel, g_hid=g_hid.reshape(e, -1), a3=a3.reshape(e, -1), g_w=g_w.reshape(e), g_scale=g_scale,
-                m=mm.reshape(e, m))
+                m=mm.reshape(e, m), m0=m0.reshape(e, m), g_gate=g_gate)
 
 
 def layer_given_neighbors(layer, feats, coors, edges, mask, idx, rank, valid_radius, factorised=True, drop=None, graph_offset=0):
@@ -311,7 +325,7 @@ class EGNNFunction(torch.autograd.Function):
             drop = (layer.dropout_p, _dropout.draw_seed())
         native = _NATIVE and layer.m_dim <= 16 and coors.shape[-1] == 3 and drop is None
         with torch.no_grad():
-            node_out, coors_out, order, idx, rank, valid_radius, u_pre = layer._forward_hip_checked(
+            node_out, coors_out, order, idx, rank, valid_radius, u_pre, proj = layer._forward_hip_checked(
                 feats, coors, edges, mask, adj_mat, order_hint, want_u=native, drop_seed=None if drop is None else drop[1])
         ctx.drop = drop
         use_nearest = layer.num_nearest_neighbors > 0 or layer.only_sparse_neighbors
@@ -328,7 +342,11 @@ class EGNNFunction(torch.autograd.Function):
         none = feats.new_empty(0)
         ctx.save_for_backward(feats, coors, edges if edges is not None else none, mask if mask is not None else none,
                               idx if idx is not None else none, rank if rank is not None else none,
-                              u_pre if u_pre is not None else none)
+                              u_pre if u_pre is not None else none,
+                              proj[0] if (proj is not None and _KEEP_PROJ) else none)
+        # the projection table as the forward's edge pass read it: P_i as (fp16 hi, fp16 lo) words when pi_split -- the backward turns
+        # them into fp32 in place, once (a second backward over a retained graph finds them decoded)
+        ctx.proj_words = bool(proj is not None and proj[1])
         ctx.flags = (mask is not None, idx is not None)
         # the backward reads the layer's parameters (and their packed images) as they are THEN: an in-place update between
         # forward and backward must fail like it does for any saved tensor
@@ -354,7 +372,7 @@ class EGNNFunction(torch.autograd.Function):
 
 
 def _unpack(ctx):
-    feats, coors, edges, mask, idx, rank, _ = ctx.saved_tensors
+    feats, coors, edges, mask, idx, rank = ctx.saved_tensors[:6]
     has_mask, has_idx = ctx.flags
     return (feats, coors, edges if ctx.has_edges else None, mask if has_mask else None,
             idx if has_idx else None, rank if has_idx else None)
@@ -389,7 +407,7 @@ def _edge_tables(layer, w, f2d, pi_split):
     return _ops.linear_hl(feats_hl, w["Wcat_split"], 2 * hp, w["bcat"], name="bwd_node_proj", split_cols=hp if pi_split else 0)
 
 
-def _edge_contract_dz(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists=None):
+def _edge_contract_dz(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists=None, proj=None):
     """egnn_edge_bwd_dz_f32 writes dz and a = SiLU(z) (2 x E x Hp fp32); reductions / library GEMMs over them.
     Returns d/d P_i (rows, Hp), d/d P_j (rows, Hp), d/d W_s (Hp, S), d/d scalars (E, S), d/d W_2 (16, Hp)."""
     from . import _abi, _ops
@@ -462,13 +480,14 @@ def entry_list(eids, keys, n_keys):
     return ent, seg
 
 
-def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists=None):
+def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists=None, proj=None):
     """egnn_edge_bwd_pass_f32 (csrc/edge_bwd.hip) twice -- entries grouped by source node, then by neighbour: z, SiLU(z) and dz
     are recomputed and contracted in registers, nothing of size E x H reaches memory.  Same returns as _edge_contract_dz."""
     from . import _ops
     dev = f2d.device
     ec = bc * n * k
-    proj = _edge_tables(layer, w, f2d, False)
+    if proj is None:
+        proj = _edge_tables(layer, w, f2d, False)
     ent, seg = entry_list(torch.arange(ec, device=dev), None, bc * n)
     # the contractions over all edges ride along: d/d W_s and d/d scalars with the first pass, d/d W_2 with the second (each keeps
     # its accumulators in registers; one pass carrying both drops from 3 to 2 workgroups per CU)
@@ -495,8 +514,8 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
 def _backward_native(ctx, g_node, g_coors):
     """The backward on the HIP kernels (module docstring), per chunk of graphs:
        1. behind u = ctx.u_pre (edge_mlp's second Linear, written by the forward kernel): node_norm / node_mlp / residual through
-          autograd from the pooled messages; the per-edge chain in closed form on egnn_edge_tail_bwd_f32 (with the edge gate:
-          through autograd, `layer_tail`)  ->  gU = d loss / d u, d loss / d (x_i - x_j), those modules' parameter gradients;
+          autograd from the pooled messages; the per-edge chain in closed form on egnn_edge_tail_bwd_f32 (m_dim > 16 or a wider
+          coors_mlp: through autograd, `layer_tail`)  ->  gU = d loss / d u, d loss / d (x_i - x_j), those modules' parameter gradients;
        2. the E x H work on egnn_edge_bwd_pass_f32 (`_edge_contract_fused`: by source and by destination, everything recomputed
           and contracted in registers) or, beyond 5 per-edge scalars, egnn_edge_bwd_dz_f32 + reductions (`_edge_contract_dz`)
           ->  d/d P_i, d/d P_j per node, d/d W_s, d/d scalars, d/d W_2;
@@ -534,6 +553,12 @@ def _backward_native(ctx, g_node, g_coors):
         g_coors = torch.zeros_like(coors)
     u_all = ctx.saved_tensors[6].view(b, n, k, 16)
     fused = _NATIVE_MODE != "dz" and s_in <= 5           # (egnn_edge_bwd_pass_f32 is built for up to 5 per-edge scalars)
+    proj_all = None
+    if len(ctx.saved_tensors) > 7 and ctx.saved_tensors[7].numel() and fused:
+        proj_all = ctx.saved_tensors[7]                                   # (B N, 2 Hp): what the forward's edge pass read
+        if ctx.proj_words:
+            _ops.unsplit_words_(proj_all, hp)
+            ctx.proj_words = False
     if fused:
         # nothing of size E x H: graphs are only chunked to keep the P table below 4 GB (32-bit buffer offsets) and E below 2^31
         # (the kernel addresses both with signed 32-bit scalar offsets)
@@ -550,9 +575,9 @@ def _backward_native(ctx, g_node, g_coors):
     w1p[:h] = lin0.weight.detach()
     w_i, w_j, w_s = w1p[:, :dim].contiguous(), w1p[:, dim:2 * dim].contiguous(), w1p[:, 2 * dim:].contiguous()
     pi_split = k >= 6
-    # the per-edge chain behind u in closed form on the device (egnn_edge_tail_bwd_f32) where it applies: the standard layer without
-    # the edge gate; otherwise that part goes through autograd as well
-    tail_kernel = (_TAIL_KERNEL and layer.edge_gate is None and layer.coors_mlp is not None and layer.node_mlp is not None
+    # the per-edge chain behind u in closed form on the device (egnn_edge_tail_bwd_f32) where it applies (m_dim <= 16, coors_mlp
+    # hidden width <= 64); otherwise that part goes through autograd as well
+    tail_kernel = (_TAIL_KERNEL and layer.coors_mlp is not None and layer.node_mlp is not None
                    and m <= 16 and layer.coors_mlp[0].weight.shape[0] <= 64)
     for lo in range(0, b, step):
         hi_ = min(b, lo + step)
@@ -579,6 +604,13 @@ def _backward_native(ctx, g_node, g_coors):
                         bi = torch.arange(bc, device=feats.device)[:, None, None]
                         pm = m0[:, :, None] & m0[bi, i64] & (r0 <= ctx.valid_radius)
                 mm = torch.nn.functional.silu(u16)                                           # (bc, n, k, 16), columns >= m are 0
+                gate, mm_pre = None, None
+                if layer.edge_gate is not None:                                              # soft_edges (:289-290)
+                    gw16 = torch.zeros(16, dtype=torch.float32, device=feats.device)
+                    gw16[:m] = layer.edge_gate[0].weight.detach()[0]
+                    gate = (gw16, layer.edge_gate[0].bias.detach().contiguous())
+                    mm_pre = mm
+                    mm = mm_pre * torch.sigmoid(mm_pre @ gw16 + gate[1])[..., None]
                 mmask = mm if pm is None else mm.masked_fill(~pm[..., None], 0.0)
                 cnt = None
                 if layer.m_pool_method == "mean":
@@ -626,10 +658,16 @@ def _backward_native(ctx, g_node, g_coors):
                 w4p = torch.zeros(64, dtype=torch.float32, device=feats.device)
                 w4p[:hid3] = lin_b.weight.detach()[0]
                 norm = layer.norm_coors
-                gu16, g_rel, g_hid, a3, g_w, g_sc = _ops.edge_tail_bwd(
+                tail_out = _ops.edge_tail_bwd(
                     u16, c0, i32, None if pm is None else pm.contiguous().view(torch.uint8), g_coors[lo:hi_].contiguous(), g_msum, w3p, b3p, w4p,
                     lin_b.bias.detach().contiguous(), layer.coors_norm.scale.detach() if norm else None,
-                    layer.coors_norm.eps if norm else 0.0, layer.coor_weights_clamp_value, bc, n, k)
+                    layer.coors_norm.eps if norm else 0.0, layer.coor_weights_clamp_value, bc, n, k, gate=gate)
+                gu16, g_rel, g_hid, a3, g_w, g_sc = tail_out[:6]
+                if gate is not None:
+                    g_gate = tail_out[6]
+                    grads_by_id[id(layer.edge_gate[0].weight)] += _tn(g_gate[:, None], mm_pre.view(ec, 16))[:, :m]
+                    grads_by_id[id(layer.edge_gate[0].bias)] += g_gate.sum()[None]
+                    del mm_pre, g_gate
                 grads_by_id[id(lin_a.weight)] += _tn(g_hid, mm.view(ec, 16))[:hid3, :m]
                 grads_by_id[id(lin_a.bias)] += g_hid.sum(dim=0)[:hid3]
                 grads_by_id[id(lin_b.weight)] += _tn(g_w[:, None], a3)[:, :hid3]
@@ -669,23 +707,27 @@ def _backward_native(ctx, g_node, g_coors):
             gu16 = torch.zeros(ec, 16, dtype=torch.float32, device=feats.device)
             gu16[:, :m] = g_u.reshape(ec, m)
         # ---- 2. the E x H work: d/d P_i, d/d P_j (per node), d/d W_s, d/d scalars, d/d W_2
-        amax = float(gu16.abs().max())
+        amax = _ops.absmax(gu16)
         gu_scale = _weights.pow2_scale(amax) if amax > 0 else 1.0
         with torch.no_grad():
             f2d = f0.view(bc * n, dim)
             sc2 = scal.detach().reshape(ec, s_in).contiguous()
             contract = _edge_contract_fused if fused else _edge_contract_dz
-            gz_i, gz_j, g_ws, g_scal, g_w2 = contract(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists)
+            proj = None if proj_all is None else proj_all[lo * n:hi_ * n]
+            gz_i, gz_j, g_ws, g_scal, g_w2 = contract(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists, proj)
             # ---- 3. node-level products: d/d feats = dP_i W_i + dP_j W_j, d/d W_i = dP_i^T feats, d/d W_j = dP_j^T feats.  On the
             # device: the forward's split-f16 matrix-core GEMM (operands pre-scaled by powers of two, the weight gradients split-K
             # over the B N nodes with the parts summed in fixed order) -- the fp32 library GEMMs they replace ran at 60 - 130 TFLOP/s
             gw1 = grads_by_id[id(lin0.weight)]
             if f2d.is_cuda and _GRAD_GEMM:
-                t = _ops.grad_nn(gz_i, w["WiT_split"], dim, name="bwd_dfeats")
-                t = _ops.grad_nn(gz_j, w["WjT_split"], dim, residual=t, name="bwd_dfeats")
+                a_i, a_j = _ops.absmax(gz_i), _ops.absmax(gz_j)             # (one read each; both products of a matrix share it)
+                t = _ops.grad_nn(gz_i, w["WiT_split"], dim, name="bwd_dfeats", amax=a_i)
+                t = _ops.grad_nn(gz_j, w["WjT_split"], dim, residual=t, name="bwd_dfeats", amax=a_j)
                 g_feats[lo:hi_] += t.view(bc, n, dim)
-                gw1[:, :dim] += _ops.grad_tn(gz_i, f2d, name="bwd_dw1")[:h]
-                gw1[:, dim:2 * dim] += _ops.grad_tn(gz_j, f2d, name="bwd_dw1")[:h]
+                f_op = _ops.grad_tn_operand(f2d)                               # (feats^T, split once for both weight gradients)
+                gw1[:, :dim] += _ops.grad_tn(gz_i, f2d, name="bwd_dw1", amax=a_i, x_operand=f_op)[:h]
+                gw1[:, dim:2 * dim] += _ops.grad_tn(gz_j, f2d, name="bwd_dw1", amax=a_j, x_operand=f_op)[:h]
+                del f_op
             else:
                 g_feats[lo:hi_] += (gz_i @ w_i + gz_j @ w_j).view(bc, n, dim)
                 gw1[:, :dim] += _tn(gz_i, f2d)[:h]

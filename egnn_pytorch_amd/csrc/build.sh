@@ -20,6 +20,13 @@ done
 ( "$HIPCC" $FLAGS -DEGNN_EDGE_GENERIC_C -c "$HERE/edge_fused.hip" -o "$HERE/obj/edge_fused_c.o" 2> "$HERE/obj/edge_fused_c.res" ) &
 pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
+for res in "$HERE"/obj/*.res; do
+  if [ ! -f "${res%.res}.o" ]; then
+    echo "error: $(basename "$res" .res).hip does not compile" >&2
+    grep -h -v "remark:" "$res" | head -40 >&2
+    exit 1
+  fi
+done
 # compiler errors / warnings (the resource-usage remarks are filtered out)
 grep -h -v "remark:\|^ *[0-9]* *|\|^ *|\|\^\|remarks\? generated\|^$" "$HERE"/obj/*.res || true
 # Register spills: none inside a kernel's loops (edge_fused.hip::edge_min_blocks).  A source whose kernels use scratch at all is

@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
     // weights in LDS (broadcast reads): as plain global loads they would sit in vector registers -- the compiler cannot prove
     // them read-only next to the kernel's stores and does not use scalar loads
     __shared__ __attribute__((aligned(16))) float sW3[TH * TM];
-    __shared__ float sb3[TH], sW4[TH];
+    __shared__ float sb3[TH], sW4[TH], sgw[TM];
+    if (threadIdx.x < TM) sgw[threadIdx.x] = p.gate_w ? p.gate_w[threadIdx.x] : 0.f;
     for (int o = threadIdx.x; o < TH * TM; o += 256) sW3[o] = p.W3[o];
     if (threadIdx.x < TH) { sb3[threadIdx.x] = p.b3[threadIdx.x]; sW4[threadIdx.x] = p.W4[threadIdx.x]; }
     __syncthreads();
@@ -55,6 +56,17 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
     for (int c = 0; c < TM; ++c) {
         sgu[c] = egnn_sigmoid(u[c]);
         m[c] = u[c] * sgu[c];
+    }
+    // edge gate (soft_edges, :289-290): m_ij = m0 * gt, gt = sigmoid(gate_w . m0 + gate_b); m0 is rebuilt from u in the backward
+    float gt = 1.f, gtc = 0.f;                    // gate and 1 - gate (as sigmoid(-s): no cancellation where the gate saturates)
+    if (p.gate_w) {
+        float sgate = p.gate_b[0];
+#pragma unroll
+        for (int c = 0; c < TM; ++c) sgate = __builtin_fmaf(sgw[c], m[c], sgate);
+        gt = egnn_sigmoid(sgate);
+        gtc = egnn_sigmoid(-sgate);
+#pragma unroll
+        for (int c = 0; c < TM; ++c) m[c] *= gt;
     }
     // coors_mlp forward (weights zero padded to 64 x 16 by the host: no run-time bounds).  The 64 hidden values are not kept:
     // the backward loop below recomputes each (16 FMAs) instead of holding 64 registers across the scalar section.
@@ -156,6 +168,16 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if (p.gate_w) {
+        // through the gate: m = m0 gt  =>  d/d m0 = gm gt + (gm . m0) gt (1 - gt) gate_w,   d/d (gate pre-activation) = (gm . m0) gt (1 - gt)
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < TM; ++c) dot = __builtin_fmaf(gm[c], u[c] * sgu[c], dot);
+        const float gs = dot * gt * gtc;
+#pragma unroll
+        for (int c = 0; c < TM; ++c) gm[c] = __builtin_fmaf(gs, sgw[c], gm[c] * gt);
+        if (live) p.g_gate[e] = gs;
+    }
     f32x4* gup = reinterpret_cast<f32x4*>(p.gU + e * TM);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -178,6 +200,7 @@ extern "C" int egnn_edge_tail_bwd_f32(const egnn_edge_tail_args* args, void* str
     if (!a.u || !a.coors || !a.g_coors_out || !a.g_msum || !a.W3 || !a.b3 || !a.W4 || !a.b4 || !a.gU || !a.g_rel || !a.g_hid || !a.a3 || !a.g_w)
         return EGNN_E_NULLPTR;
     if (a.norm_coors && (!a.scale || !a.g_scale)) return EGNN_E_NULLPTR;
+    if (a.gate_w && (!a.gate_b || !a.g_gate)) return EGNN_E_NULLPTR;
     if (a.B <= 0 || a.N <= 0 || a.K <= 0) return EGNN_E_SHAPE;
     if (a.idx == nullptr && a.K != a.N) return EGNN_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(a.u) & 15) || (reinterpret_cast<uintptr_t>(a.gU) & 15) || (reinterpret_cast<uintptr_t>(a.g_rel) & 15) ||

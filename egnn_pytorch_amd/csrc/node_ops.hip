@@ -171,7 +171,80 @@ __global__ __launch_bounds__(256) void split_scaled_kernel(const float* __restri
     }
 }
 
+// max |x| over a flat array as the bit pattern of the float (non-negative floats order like unsigned integers; a NaN's pattern
+// is above infinity's, so it wins and the host sees it): integer atomicMax -- the result does not depend on the order
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ X, int64_t count, uint32_t* __restrict__ out_bits)
+{
+    const int64_t quads = count >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    uint32_t m = 0u;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += stride) {
+        const uint4 v = reinterpret_cast<const uint4*>(X)[q];
+        const uint32_t a = v.x & 0x7fffffffu, b = v.y & 0x7fffffffu, c = v.z & 0x7fffffffu, d = v.w & 0x7fffffffu;
+        const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+        const uint32_t t = ab > cd ? ab : cd;
+        m = m > t ? m : t;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
+        const uint32_t t = __float_as_uint(X[(quads << 2) + threadIdx.x]) & 0x7fffffffu;
+        m = m > t ? m : t;
+    }
+    __shared__ uint32_t block_max;
+    if (threadIdx.x == 0) block_max = 0u;
+    __syncthreads();
+    if (m) atomicMax(&block_max, m);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_max) atomicMax(out_bits, block_max);
+}
+
+// columns [0, cols) of X hold (fp16 hi, fp16 lo) words (egnn_linear_hl_f32 with split_cols): rewritten in place as the fp32 values
+// hi + lo.  One thread per four words.
+__global__ __launch_bounds__(256) void unsplit_words_kernel(float* __restrict__ X, int64_t ldx, int64_t rows, int cols)
+{
+    typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+    const int qpr = cols >> 2;                                          // quads per row
+    const int64_t total = rows * qpr;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t r = o / qpr;
+        const int c = (int)(o - r * qpr) * 4;
+        uint4* p = reinterpret_cast<uint4*>(X + r * ldx + c);
+        const uint4 v = *p;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        f32x4 f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f16x2v h = __builtin_bit_cast(f16x2v, w[u]);
+            f[u] = (float)h[0] + (float)h[1];
+        }
+        *reinterpret_cast<f32x4*>(p) = f;
+    }
+}
+
 }  // namespace
+
+extern "C" int egnn_unsplit_words_f32(float* X, int64_t ldx, int64_t rows, int cols, void* stream)
+{
+    if (!X) return EGNN_E_NULLPTR;
+    if (rows <= 0 || cols <= 0 || (cols % 4) != 0 || ldx < cols || (ldx % 4) != 0) return EGNN_E_SHAPE;
+    if (reinterpret_cast<uintptr_t>(X) & 15) return EGNN_E_ALIGN;
+    int64_t blocks = (rows * (cols >> 2) + 256 * 4 - 1) / (256 * 4);
+    blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+    hipLaunchKernelGGL(unsplit_words_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), X, ldx, rows, cols);
+    return egnn_launch_status();
+}
+
+extern "C" int egnn_absmax_f32(const float* X, int64_t count, uint32_t* out_bits, void* stream)
+{
+    if (!X || !out_bits) return EGNN_E_NULLPTR;
+    if (count <= 0) return EGNN_E_SHAPE;
+    if (reinterpret_cast<uintptr_t>(X) & 15) return EGNN_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(out_bits, 0, sizeof(uint32_t), s) != hipSuccess) return (int)hipGetLastError();
+    int64_t blocks = ((count >> 2) + 256 * 8 - 1) / (256 * 8);           // ~8 quads per thread
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, count, out_bits);
+    return egnn_launch_status();
+}
 
 extern "C" int egnn_split_scaled_f16(const float* X, int64_t ldx, int64_t rows, int cols, float scale, int transposed, void* hi, void* lo,
                                      int Kp, int32_t* status, void* stream)

@@ -166,8 +166,9 @@ class EGNN(nn.Module):
         return node_out, coors_out, order
 
     def _forward_hip_checked(self, feats, coors, edges, mask, adj_mat, order_hint, want_u=False, drop_seed=None):
-        """(node_out, coors_out, order, idx, rank, valid_radius, u) -- what autograd.EGNNFunction.forward needs; u = the
-        (B*N*K, 16) pre-activation of edge_mlp's second SiLU when `want_u` (the native backward differentiates from it)."""
+        """(node_out, coors_out, order, idx, rank, valid_radius, u, proj) -- what autograd.EGNNFunction.forward needs; u = the
+        (B*N*K, 16) pre-activation of edge_mlp's second SiLU when `want_u` (the native backward differentiates from it), proj =
+        ((B*N, 2 Hp) projection table P_i | P_j, pi_split) the edge pass read (kept for the backward instead of a second GEMM)."""
         return self._forward_with_hint(feats, coors, edges, mask, adj_mat, order_hint, want_u=want_u, drop_seed=drop_seed)
 
     def dropout_active(self):
@@ -256,7 +257,7 @@ class EGNN(nn.Module):
         side_join = use_nearest and k > 0 and _SIDE_STREAM and _ops._timer is None
 
         node_out, coors_out = feats, coors
-        node_in = u_pre = None
+        node_in = u_pre = proj_kept = None
         if k > 0:
             # ---- node-level projections P = feats [W_i ; W_j]^T + [b1 ; 0]
             # (K >= 6: the edge pass feeds P_i to its first-layer MFMA as (fp16 hi, fp16 lo) words)
@@ -316,6 +317,8 @@ class EGNN(nn.Module):
                 u_pre = _ops.empty(b * n * k, 16, dtype=torch.float32, device=feats.device)
                 a.U_out = u_pre.data_ptr()
             _ops.edge_fused(a, feats.device)
+            if u_pre is not None:
+                proj_kept = (proj, pi_split)
             del proj
         elif self.node_mlp is not None:                                   # K == 0: no messages, m_i = 0
             node_in = _ops.node_prep_hl(feats2d, None, w.get("gamma"), w.get("beta"), w.get("ln_eps", 1e-5), self.m_dim)
@@ -325,7 +328,7 @@ class EGNN(nn.Module):
             hid = _ops.linear_hl(node_in, w["W5_split"], 2 * dim, w["b5"], act=1, out_f32=False, out_hl=True,
                                  name="node_mlp0", drop=drop)
             node_out = _ops.linear_hl(hid, w["W6_split"], dim, w["b6"], residual=feats2d, name="node_mlp1").view(b, n, dim)
-        return node_out, coors_out, order, idx, rank, valid_radius, u_pre
+        return node_out, coors_out, order, idx, rank, valid_radius, u_pre, proj_kept
 
 
 _FP64_WARNED = False

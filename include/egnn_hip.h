@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 22
+#define EGNN_ABI_VERSION 23
 
 enum {
     EGNN_OK = 0,
@@ -179,12 +179,19 @@ int egnn_linear_hl_drop_f32(const void* A_hi, const void* A_lo, const void* W_hi
  *     subnormals); image rows padded to a multiple of 32 and K to Kp with zeros (both written).
  * egnn_linear_hl_splitk_f32: C_parts[p] (M, ldc) = w_inv_scale * A[:, K range p] W[:, K range p]^T for p < k_splits -- a contraction
  *     that is deep (K = B N nodes) and has a small output fills the chip only when K is cut; parts are summed in fixed order by
- * egnn_sum_parts_f32: out[o] = scale * sum_p parts[p][o], o < count (count % 4 == 0). */
+ * egnn_sum_parts_f32: out[o] = scale * sum_p parts[p][o], o < count (count % 4 == 0).
+ * egnn_absmax_f32: *out_bits = the bit pattern of max |X[o]|, o < count (what the power-of-two scales are chosen from; a NaN anywhere
+ *     comes back as a NaN pattern); X 16-byte aligned; one pass, integer atomicMax (order independent). */
 int egnn_split_scaled_f16(const float* X, int64_t ldx, int64_t rows, int cols, float scale, int transposed, void* hi, void* lo, int Kp,
                           int32_t* status, void* stream);
 int egnn_linear_hl_splitk_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo, float w_inv_scale, float* C_parts,
                               int64_t ldc, int64_t M, int N, int Kp, int w_rows, int k_splits, void* stream);
 int egnn_sum_parts_f32(const float* parts, int nparts, int64_t count, float scale, float* out, void* stream);
+int egnn_absmax_f32(const float* X, int64_t count, uint32_t* out_bits, void* stream);
+/* The P_i half of the forward's projection table (egnn_linear_hl_f32 with split_cols: columns [0, cols) are [fp16 hi, fp16 lo] words) turned
+ * into the fp32 values hi + lo IN PLACE, for the backward kernels, which read both halves as fp32: the table the forward used is kept
+ * for the backward instead of being recomputed.  cols % 4 == 0, ldx % 4 == 0, X 16-byte aligned. */
+int egnn_unsplit_words_f32(float* X, int64_t ldx, int64_t rows, int cols, void* stream);
 
 /* X (rows, cols) fp32 row-major -> packed (rows, Kp) images hi = fp16(x), lo = fp16(x - hi); pads zero; Kp % 32 == 0,
  * Kp >= cols.  |X| >= 65504 (finite) sets EGNN_RANGE_A_OPERAND in *status (optional) and turns into inf / NaN. */
@@ -355,8 +362,8 @@ int egnn_edge_bwd_pass_f32(const egnn_edge_bwd_args* args, void* stream);
 int egnn_edge_bwd_chunk_steps(void);    /* hidden steps (of 32 columns) one workgroup owns: sizes ds_part */
 
 /* The per-edge part of the backward behind edge_mlp's second Linear in closed form (csrc/edge_tail.hip; autograd of
- * egnn_pytorch.py:287 second SiLU, :292-317 pair mask / coors_mlp / CoorsNorm / clamp / coordinate update, :319-333 pooling; no edge
- * gate, coordinate dimension 3).  One edge per lane: from u = the second Linear's output (E, 16), g_coors_out = d loss / d coors_out
+ * egnn_pytorch.py:287 second SiLU, :289-290 edge gate (soft_edges), :292-317 pair mask / coors_mlp / CoorsNorm / clamp / coordinate
+ * update, :319-333 pooling; coordinate dimension 3).  One edge per lane: from u = the second Linear's output (E, 16), g_coors_out = d loss / d coors_out
  * and g_msum = d loss / d (sum over k of the pair-masked messages; mean pooling: already divided by the count) it writes
  * gU = d loss / d u (the input of egnn_edge_bwd_pass_f32), g_rel = d loss / d (x_i - x_j) without the distance path, and what the
  * parameter gradients of coors_mlp are tall products of: g_hid (E, 64), a3 (E, 64), g_w (E), and the per-edge terms of
@@ -383,6 +390,9 @@ typedef struct egnn_edge_tail_args {
     float* a3;                  /* out (E, 64) */
     float* g_w;                 /* out (E) */
     float* g_scale;             /* out (E) or NULL */
+    const float* gate_w;        /* (16) edge_gate.0.weight zero padded, or NULL (soft_edges=False): m_ij = SiLU(u) sigmoid(gate_w . SiLU(u) + gate_b) */
+    const float* gate_b;        /* (1) */
+    float* g_gate;              /* out (E): d loss / d (gate pre-activation) -- d/d gate_w = sum_e g_gate[e] SiLU(u_e), d/d gate_b = sum_e g_gate[e] */
 } egnn_edge_tail_args;
 
 int egnn_edge_tail_bwd_f32(const egnn_edge_tail_args* args, void* stream);

@@ -248,7 +248,7 @@ def test_native_backward_kernel_matches_the_aten_recompute(kw, n, flags):
         # in the coordinate gradient.  The native paths are compared with float64 autograd over the same neighbour list instead.
         import copy
         with torch.no_grad():
-            _, _, _, idx, rank, radius, _ = layer._forward_hip_checked(feats, coors, edges, mask, adj, None)
+            idx, rank, radius = layer._forward_hip_checked(feats, coors, edges, mask, adj, None)[3:6]
         l64 = copy.deepcopy(layer).double()
         f, c = feats.double().requires_grad_(True), coors.double().requires_grad_(True)
         e = None if edges is None else edges.double().requires_grad_(True)
@@ -319,8 +319,8 @@ def _tail_case(kw, use_mask, dense, dtype, device, n=9, b=2):
     torch.manual_seed(0)
     layer = EGNN(**kw).to(device=device, dtype=dtype)
     with torch.no_grad():
-        for p in layer.parameters():
-            p.mul_(40.0)
+        for nme, p in layer.named_parameters():
+            p.mul_(8.0 if nme.startswith("edge_gate") else 40.0)      # (the gate: large enough to matter, not saturated everywhere)
     m = layer.m_dim
     k = n if dense else kw["num_nearest_neighbors"]
     g = torch.Generator().manual_seed(1)
@@ -334,7 +334,7 @@ def _tail_case(kw, use_mask, dense, dtype, device, n=9, b=2):
     rel_leaf = A.edge_scalars(layer, coors, None, idx)[0].detach().requires_grad_(True)
     out_n, out_c = A.layer_tail(layer, feats, coors, u, rel_leaf, mask, idx, rank, radius)
     gn, gc = rnd(*out_n.shape), rnd(*out_c.shape)
-    names = [nme for nme, _ in layer.named_parameters() if nme.startswith(("coors_mlp", "coors_norm"))]
+    names = [nme for nme, _ in layer.named_parameters() if nme.startswith(("coors_mlp", "coors_norm", "edge_gate"))]
     tparams = [p for nme, p in layer.named_parameters() if nme in names]
     grads = torch.autograd.grad([out_n, out_c], [u, rel_leaf] + tparams, [gn, gc], allow_unused=True)
     ref = dict(g_u=grads[0], g_rel=grads[1], **dict(zip(names, grads[2:])))
@@ -344,6 +344,8 @@ def _tail_case(kw, use_mask, dense, dtype, device, n=9, b=2):
         bi = torch.arange(b, device=device)[:, None, None]
         pm = mask[:, :, None] & mask[:, None, :] if dense else mask[:, :, None] & mask[bi, idx] & (rank <= radius)
     mm = torch.nn.functional.silu(u.detach())
+    if layer.edge_gate is not None:
+        mm = mm * layer.edge_gate(mm).detach()
     mmask = mm if pm is None else mm.masked_fill(~pm[..., None], 0.0)
     cnt = None
     if layer.m_pool_method == "mean" and pm is not None:
@@ -363,13 +365,17 @@ def _tail_case(kw, use_mask, dense, dtype, device, n=9, b=2):
 TAIL_CASES = [(dict(dim=8, num_nearest_neighbors=5), False, False),
               (dict(dim=8, num_nearest_neighbors=6, norm_coors=True, coor_weights_clamp_value=0.6), True, False),
               (dict(dim=8, m_dim=8, m_pool_method="mean", norm_coors=True), True, True),
-              (dict(dim=8, num_nearest_neighbors=4, m_pool_method="mean", coor_weights_clamp_value=1.5), True, False)]
+              (dict(dim=8, num_nearest_neighbors=4, m_pool_method="mean", coor_weights_clamp_value=1.5), True, False),
+              (dict(dim=8, num_nearest_neighbors=5, soft_edges=True, norm_coors=True), True, False),
+              (dict(dim=8, m_dim=12, soft_edges=True, m_pool_method="mean"), False, True)]
 
 
 def _tail_param_grads(r):
     return {"coors_mlp.0.weight": r["g_hid"].t() @ r["m"], "coors_mlp.0.bias": r["g_hid"].sum(0),
             "coors_mlp.3.weight": r["g_w"][None, :] @ r["a3"], "coors_mlp.3.bias": r["g_w"].sum()[None],
-            "coors_norm.scale": None if r["g_scale"] is None else r["g_scale"].sum()[None]}
+            "coors_norm.scale": None if r["g_scale"] is None else r["g_scale"].sum()[None],
+            "edge_gate.0.weight": None if r["g_gate"] is None else r["g_gate"][None, :] @ r["m0"],
+            "edge_gate.0.bias": None if r["g_gate"] is None else r["g_gate"].sum()[None]}
 
 
 @pytest.mark.parametrize("kw,use_mask,dense", TAIL_CASES)
@@ -403,11 +409,18 @@ def test_tail_kernel_matches_closed_form(kw, use_mask, dense):
     b3p = torch.zeros(64, device="cuda"); b3p[:hid3] = la.bias.detach()
     w4p = torch.zeros(64, device="cuda"); w4p[:hid3] = lb.weight.detach()[0]
     norm = layer.norm_coors
-    gu, g_rel, g_hid, a3, g_w, g_sc = _ops.edge_tail_bwd(
+    gate = None
+    if layer.edge_gate is not None:
+        gw16 = torch.zeros(16, device="cuda"); gw16[:m] = layer.edge_gate[0].weight.detach()[0]
+        gate = (gw16, layer.edge_gate[0].bias.detach().contiguous())
+    out = _ops.edge_tail_bwd(
         u16, coors.contiguous(), None if idx is None else idx.to(torch.int32).contiguous(), None if pm is None else pm.contiguous().view(torch.uint8),
         gc.contiguous(), gm16, w3p, b3p, w4p, lb.bias.detach().contiguous(), layer.coors_norm.scale.detach() if norm else None,
-        layer.coors_norm.eps if norm else 0.0, layer.coor_weights_clamp_value, b, n, k)
+        layer.coors_norm.eps if norm else 0.0, layer.coor_weights_clamp_value, b, n, k, gate=gate)
+    gu, g_rel, g_hid, a3, g_w, g_sc = out[:6]
     got = dict(g_u=gu[:, :m], g_rel=g_rel[:, :3], g_hid=g_hid[:, :hid3], a3=a3[:, :hid3], g_w=g_w, g_scale=g_sc)
+    if gate is not None:
+        got["g_gate"] = out[6]
     # (self pairs: the kernel writes their d/d rel as zero -- the two signed copies cancel identically at x_i)
     j = torch.arange(n, device="cuda")[None, None, :].expand(b, n, n) if idx is None else idx
     self_pair = (j == torch.arange(n, device="cuda")[None, :, None])
@@ -574,7 +587,7 @@ def _emulated_backward(layer, feats, coors, mask, idx, rank, radius, g_node, g_c
                 out[r] = out[r] + rows[order[p]]
         return out
 
-    def tail(u16, coors_, idx32, pair_mask, g_co, g_msum16, w3p, b3p, w4p, b4, scale, eps, clamp, b_, n_, k_):
+    def tail(u16, coors_, idx32, pair_mask, g_co, g_msum16, w3p, b3p, w4p, b4, scale, eps, clamp, b_, n_, k_, gate=None):
         r = A.tail_edge_backward(A._f32_shadow(layer), u16[..., :m], coors_, None if idx32 is None else idx32.long(),
                                  None if pair_mask is None else pair_mask.view(torch.bool).view(b_, n_, k_), g_co, g_msum16[..., :m])
         e = b_ * n_ * k_
@@ -584,6 +597,8 @@ def _emulated_backward(layer, feats, coors, mask, idx, rank, radius, g_node, g_c
         g_rel[self_pair] = 0.0
         gh = torch.zeros(e, 64); gh[:, :r["g_hid"].shape[1]] = r["g_hid"]
         a3 = torch.zeros(e, 64); a3[:, :r["a3"].shape[1]] = r["a3"]
+        if gate is not None:
+            return gu, g_rel, gh, a3, r["g_w"], r["g_scale"], r["g_gate"]
         return gu, g_rel, gh, a3, r["g_w"], r["g_scale"]
 
     # u = the second Linear's output, as the forward kernel leaves it (E, 16)
@@ -618,7 +633,8 @@ def _emulated_backward(layer, feats, coors, mask, idx, rank, radius, g_node, g_c
 
 @pytest.mark.parametrize("kw,use_mask,max_graphs", [(dict(dim=8, num_nearest_neighbors=5), False, 0),
                                                     (dict(dim=8, num_nearest_neighbors=6, norm_coors=True, coor_weights_clamp_value=0.6), True, 0),
-                                                    (dict(dim=8, num_nearest_neighbors=20, m_pool_method="mean", norm_feats=True), True, 2)])
+                                                    (dict(dim=8, num_nearest_neighbors=20, m_pool_method="mean", norm_feats=True), True, 2),
+                                                    (dict(dim=8, num_nearest_neighbors=7, soft_edges=True, m_dim=12), True, 0)])
 def test_native_backward_host_logic_with_emulated_kernels(kw, use_mask, max_graphs):
     """autograd._backward_native on the CPU with its three kernels emulated in torch from their header contracts: what remains
     under test is the host side -- entry lists, partial rows, fixed-order sums, chunking over graphs, the node-level products,

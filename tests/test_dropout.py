@@ -96,7 +96,7 @@ def test_training_mode_forward_applies_exactly_the_hash_masks(kw, n, use_mask):
     edges = torch.randn(b, n, n, kw["edge_dim"], generator=g).cuda() if kw.get("edge_dim") else None
     seed = 424242
     with torch.no_grad():
-        node, co, _, idx, rank, radius, _ = layer._forward_hip_checked(feats, coors, edges, mask, None, None, drop_seed=seed)
+        node, co, _, idx, rank, radius = layer._forward_hip_checked(feats, coors, edges, mask, None, None, drop_seed=seed)[:6]
         node2, co2 = layer._forward_hip_checked(feats, coors, edges, mask, None, None, drop_seed=seed)[:2]
         node3 = layer._forward_hip_checked(feats, coors, edges, mask, None, None, drop_seed=seed + 1)[0]
     assert torch.equal(node, node2) and torch.equal(co, co2)                      # same seed: same masks

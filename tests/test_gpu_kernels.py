@@ -501,3 +501,46 @@ def test_gradient_gemms_match_float64(r, m, n):
         assert float((alt.double() - want_tn).abs().max()) <= 3e-6 * float(want_tn.abs().max())
     zero = _ops.grad_tn(torch.zeros_like(grad), x)
     assert float(zero.abs().max()) == 0.0
+    # the shared pieces (one absmax per matrix, feats^T split once) give the same bits as the stand-alone calls
+    op = _ops.grad_tn_operand(x)
+    assert torch.equal(_ops.grad_tn(grad, x, amax=_ops.absmax(grad), x_operand=op), got_tn)
+    assert torch.equal(_ops.grad_nn(grad, _weights.split_f16(w.t().contiguous()), n, amax=_ops.absmax(grad)), got_nn)
+
+
+@pytest.mark.parametrize("count", [1, 3, 4, 1000, 4099, 1 << 22, (1 << 22) + 2])
+def test_absmax_is_exact(count):
+    """egnn_absmax_f32 against torch: the exact maximum of |x| (integer atomicMax on the bit patterns), tails that are not a multiple
+    of four, negative extremes, zeros, and a NaN anywhere comes back as NaN."""
+    from egnn_pytorch_amd import _ops
+    g = torch.Generator().manual_seed(count)
+    x = (torch.randn(count, generator=g) * torch.logspace(-8, 3, count)).cuda()
+    assert _ops.absmax(x) == float(x.abs().max())
+    x[count // 2] = -1.0e9
+    assert _ops.absmax(x) == 1.0e9
+    x[count - 1] = -3.0e9                                                       # (the tail element)
+    assert _ops.absmax(x) == float(torch.tensor(3.0e9, dtype=torch.float32))
+    assert _ops.absmax(torch.zeros(count, device="cuda")) == 0.0
+    x[count // 3] = float("nan")
+    v = _ops.absmax(x)
+    assert v != v
+
+
+def test_unsplit_words_recovers_the_forward_projection():
+    """egnn_unsplit_words_f32: the P_i half of the projection table as the forward's edge pass reads it ((fp16 hi, fp16 lo) words,
+    egnn_linear_hl_f32 with split_cols) decoded in place equals hi + lo exactly; the P_j half is untouched; and the decoded table
+    equals the all-fp32 table of the same GEMM to the split's resolution."""
+    from egnn_pytorch_amd import EGNN, _ops
+    torch.manual_seed(3)
+    layer = EGNN(dim=64, num_nearest_neighbors=8).cuda()
+    w = layer.packed_weights()
+    hp = w["Hp"]
+    f2d = torch.randn(200, 64, device="cuda")
+    words = _ops.linear_hl(_ops.split_f16(f2d), w["Wcat_split"], 2 * hp, w["bcat"], split_cols=hp)
+    full = _ops.linear_hl(_ops.split_f16(f2d), w["Wcat_split"], 2 * hp, w["bcat"], split_cols=0)
+    halves = words[:, :hp].contiguous().view(torch.float16).view(200, hp, 2).float()
+    want = halves[..., 0] + halves[..., 1]
+    pj = words[:, hp:].clone()
+    _ops.unsplit_words_(words, hp)
+    assert torch.equal(words[:, :hp], want)
+    assert torch.equal(words[:, hp:], pj)
+    assert float((words - full).abs().max()) <= 2.0 ** -20 * float(full.abs().max())

@@ -1,13 +1,14 @@
 """A/B of compile-time variants of one kernel source, split in two halves so that no GPU-box time goes into compiling:
 
    python tools/variants.py build [src=edge_fused] [full=1] "EDGE_GDMA=0,EDGE_LO_MFMA=0" "EDGE_GDMA=1" ...      (dev container)
-   python tools/variants.py run [shapes=ns,c3] [reps=10]                                              (MI355X, via gpurun)
+   python tools/variants.py run [shapes=ns,c3] [reps=10] [probe=train]                                (MI355X, via gpurun)
 
 `build` compiles <src>.hip once per variant (-DEGNN_<K>=<V>; the tuning build of the edge pass unless full=1), links it with
 the other objects of csrc/obj into build_variants/<tag>/libegnn_hip.so (git-ignored; travels with the gpurun snapshot) and
 records the list in build_variants/index.json.  `run` times every kernel of a layer forward with each library
 (EGNN_HIP_LIB, HIP events on the launch stream, min over reps) and prints a digest of the outputs: variants that are meant
-to be bit-identical (LDS-DMA gathers, the residual on the matrix cores) must show the same digest."""
+to be bit-identical (LDS-DMA gathers, the residual on the matrix cores) must show the same digest.  probe=train: one training
+step of the north-star layer instead (tools/train_step_probe.py: forward / backward wall time and every kernel of the step)."""
 import hashlib
 import json
 import os
@@ -88,7 +89,7 @@ def build(src, spec, full):
 def main():
     mode = sys.argv[1]
     args = sys.argv[2:]
-    keys = ("src", "full", "shapes", "reps", "only")
+    keys = ("src", "full", "shapes", "reps", "only", "probe")
     opts = dict(a.split("=", 1) for a in args if a.split("=")[0] in keys)
     specs = [a for a in args if a.split("=")[0] not in keys]
     if mode == "build":
@@ -103,6 +104,13 @@ def main():
             tags = [t for t in tags if any(o in t for o in opts["only"].split("+"))]
         shapes = opts.get("shapes", "ns").split(",")
         reps = int(opts.get("reps", "10"))
+        if opts.get("probe") == "train":
+            for tag in tags:
+                env = dict(os.environ, EGNN_HIP_LIB=os.path.join(VDIR, tag, "libegnn_hip.so"), EGNN_RANGE_CHECK="off")
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_step_probe.py"), "2"], env=env, capture_output=True, text=True, timeout=600)
+                lines = r.stdout.strip().splitlines()
+                print(f"{tag}\n   {lines[-2] if len(lines) > 1 else r.stderr[-600:]}\n   {lines[-1] if lines else ''}", flush=True)
+            return
         for shape in shapes:
             for tag in tags:
                 env = dict(os.environ, EGNN_HIP_LIB=os.path.join(VDIR, tag, "libegnn_hip.so"), EGNN_RANGE_CHECK="off")
