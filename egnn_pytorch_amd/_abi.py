@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -27,9 +27,9 @@ SYMBOLS = (
     "egnn_edge_fused_f32", "egnn_spatial_order_f32", "egnn_linear_hl_f32", "egnn_split_f16", "egnn_node_prep_hl",
     "egnn_packed_halves", "egnn_adj_expand_u8", "egnn_adj_expand_workspace_bytes", "egnn_edge_mfmas",
     "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32",
-    "egnn_edge_bwd_dz_f32", "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_tail_bwd_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
+    "egnn_edge_bwd_dz_f32", "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_bwd_work_bytes", "egnn_edge_tail_bwd_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
     "egnn_induced_attn_f32", "egnn_token_attn_f32", "egnn_slot_prep_f32", "egnn_struct_bytes",
-    "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32",
+    "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32", "egnn_split_scaled_both_f16", "egnn_silu_bwd_f32",
     "egnn_linear_hl_drop_f32",
 )
 
@@ -70,6 +70,7 @@ class EdgeBwdArgs(Structure):
         ("gu_scale", c_float), ("inv_scale", c_float), ("scal", c_void_p), ("Ws", c_void_p), ("scal_scale", c_void_p),
         ("part_rows", c_void_p), ("ld_rows", c_int64),
         ("dW2_part", c_void_p), ("dWs_part", c_void_p), ("ds_part", c_void_p),
+        ("row_pairs", c_int32), ("work", c_void_p), ("work_bytes", c_int64),
     ]
 
 
@@ -223,6 +224,11 @@ def load():
     lib.egnn_sum_parts_f32.argtypes = [c_void_p, c_int, c_int64, c_float, c_void_p, c_void_p]
     lib.egnn_absmax_f32.restype = c_int
     lib.egnn_absmax_f32.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
+    lib.egnn_split_scaled_both_f16.restype = c_int
+    lib.egnn_split_scaled_both_f16.argtypes = [c_void_p, c_int64, c_int64, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                               c_void_p, c_void_p]
+    lib.egnn_silu_bwd_f32.restype = c_int
+    lib.egnn_silu_bwd_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
     lib.egnn_unsplit_words_f32.restype = c_int
     lib.egnn_unsplit_words_f32.argtypes = [c_void_p, c_int64, c_int64, c_int, c_void_p]
     lib.egnn_edge_mfmas.restype = c_int
@@ -237,6 +243,8 @@ def load():
     lib.egnn_edge_tail_bwd_f32.argtypes = [POINTER(EdgeTailArgs), c_void_p]
     lib.egnn_edge_bwd_chunk_steps.restype = c_int
     lib.egnn_edge_bwd_chunk_steps.argtypes = []
+    lib.egnn_edge_bwd_work_bytes.restype = c_size_t
+    lib.egnn_edge_bwd_work_bytes.argtypes = [c_int64, c_int, c_int, c_int]
     lib.egnn_induced_attn_f32.restype = c_int
     lib.egnn_induced_attn_f32.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                           c_void_p]

@@ -415,6 +415,40 @@ def split_scaled(x2d, scale, transposed=False, w_image=False):
     return PackedHL(hi, lo, img_rows, kp), alloc_rows
 
 
+def split_scaled_both(x2d, scale):
+    """(plain image, transposed image) of scale * x2d from one read -- egnn_split_scaled_both_f16."""
+    rows, cols = x2d.shape
+    kp, kpt = _kpad(cols), _kpad(rows)
+    hi, lo = _packed_empty(rows, kp, x2d.device), _packed_empty(rows, kp, x2d.device)
+    hit, lot = _packed_empty(cols, kpt, x2d.device), _packed_empty(cols, kpt, x2d.device)
+    with _timed("split_scaled"):
+        rc = _abi.load().egnn_split_scaled_both_f16(_ptr(x2d), x2d.stride(0), rows, cols, float(scale), _ptr(hi), _ptr(lo), kp,
+                                                    _ptr(hit), _ptr(lot), kpt, _ptr(status_word(x2d.device).dev), _stream())
+    _abi.check(rc, "egnn_split_scaled_both_f16")
+    return PackedHL(hi, lo, rows, kp), PackedHL(hit, lot, cols, kpt)
+
+
+def silu_bwd_(z, g):
+    """z <- SiLU(z), g <- g * SiLU'(z), in place, one pass (egnn_silu_bwd_f32).  Returns (z, g)."""
+    with _timed("silu_bwd"):
+        rc = _abi.load().egnn_silu_bwd_f32(_ptr(z), _ptr(g), _ptr(z), _ptr(g), z.numel(), _stream())
+    _abi.check(rc, "egnn_silu_bwd_f32")
+    return z, g
+
+
+class GradOperand:
+    """A gradient matrix g (R, M) prepared once for its two products: .plain = image of s g (the A operand of g @ W), .t = image of
+    (s g)^T (the A operand of g^T @ x), .scale = s (a power of two, grad_scale); .zero: g is all zero / not finite."""
+
+    def __init__(self, g2d, amax=None):
+        self.shape = g2d.shape
+        self.scale = grad_scale(absmax(g2d) if amax is None else amax)
+        self.zero = self.scale is None
+        self.plain = self.t = None
+        if not self.zero:
+            self.plain, self.t = split_scaled_both(g2d, self.scale)
+
+
 def absmax(x):
     """max |x| as a Python float (one host read) -- egnn_absmax_f32: one pass over x where `x.abs().max()` makes two and a copy.
     What the power-of-two scales of the gradient GEMMs and of the edge backward are chosen from.  (Host tensors -- the CPU tests of
@@ -449,14 +483,16 @@ def grad_scale(amax):
 def grad_nn(g2d, wsplit_t, n, residual=None, name="grad_nn", amax=None):
     """g2d (R, K) fp32 @ W (K, n), W given as the packed split image of W^T (n rows, K): on the split-f16 GEMM of the forward,
     g2d pre-scaled by a power of two (gradients are small: their fp16 lo halves must stay off the subnormals).  amax: max |g2d| if
-    the caller has it already."""
-    from . import _weights
-    amax = absmax(g2d) if amax is None else amax
-    if not (amax > 0.0) or amax != amax or amax == float("inf"):
-        out = torch.zeros(g2d.shape[0], n, dtype=torch.float32, device=g2d.device)
+    the caller has it already; g2d may be a GradOperand (both of its products share one split)."""
+    if isinstance(g2d, GradOperand):
+        op = g2d
+        scale, a, rows, dev = op.scale, op.plain, op.shape[0], (residual.device if residual is not None else wsplit_t[0].device)
+    else:
+        scale, rows, dev = grad_scale(absmax(g2d) if amax is None else amax), g2d.shape[0], g2d.device
+        a = None if scale is None else split_scaled(g2d, scale)[0]      # max |scale * g| in [2^12, 2^13)
+    if scale is None:
+        out = torch.zeros(rows, n, dtype=torch.float32, device=dev)
         return out if residual is None else out + residual
-    scale = _weights.pow2_scale(amax) * 4096.0                       # max |scale * g| in [2^12, 2^13)
-    a, _ = split_scaled(g2d, scale)
     whi, wlo, inv, w_rows = wsplit_t
     return linear_hl(a, (whi, wlo, inv / scale, w_rows), n, None, residual=residual, name=name)
 
@@ -474,15 +510,16 @@ def grad_tn_operand(x2d):
 def grad_tn(g2d, x2d, k_splits=None, name="grad_tn", amax=None, x_operand=None):
     """g2d (R, M)^T @ x2d (R, N) -> (M, N): the weight-gradient contraction over R = B N nodes, split-K on the split-f16 GEMM.
     amax: max |g2d| if known; x_operand: grad_tn_operand(x2d) if several products share x2d."""
-    r, m = g2d.shape
+    op = g2d if isinstance(g2d, GradOperand) else None
+    r, m = (op.shape if op is not None else g2d.shape)
     n = x2d.shape[1]
-    sg = grad_scale(absmax(g2d) if amax is None else amax)
+    sg = op.scale if op is not None else grad_scale(absmax(g2d) if amax is None else amax)
     if x_operand is None:
         x_operand = grad_tn_operand(x2d)
     if sg is None or x_operand is None:
-        return torch.zeros(m, n, dtype=torch.float32, device=g2d.device)
+        return torch.zeros(m, n, dtype=torch.float32, device=x2d.device)
     w, w_rows, sx = x_operand
-    a, _ = split_scaled(g2d, sg, transposed=True)                    # (m rows, K = r)
+    a = op.t if op is not None else split_scaled(g2d, sg, transposed=True)[0]                    # (m rows, K = r)
     nkt = a.kp // 16
     if k_splits is None:
         tiles = ((m + 127) // 128) * ((n + 127) // 128)
@@ -490,12 +527,12 @@ def grad_tn(g2d, x2d, k_splits=None, name="grad_tn", amax=None, x_operand=None):
         while tiles * k_splits < 512 and nkt // (2 * k_splits) >= 64:
             k_splits *= 2
     mp = m
-    parts = empty(k_splits, mp, n, dtype=torch.float32, device=g2d.device)
+    parts = empty(k_splits, mp, n, dtype=torch.float32, device=x2d.device)
     with _timed(name):
         rc = _abi.load().egnn_linear_hl_splitk_f32(_ptr(a.hi), _ptr(a.lo), _ptr(w.hi), _ptr(w.lo), 1.0, _ptr(parts), n, m, n, a.kp, w_rows,
                                                    k_splits, _stream())
     _abi.check(rc, "egnn_linear_hl_splitk_f32")
-    out = empty(m, n, dtype=torch.float32, device=g2d.device)
+    out = empty(m, n, dtype=torch.float32, device=x2d.device)
     count = m * n
     if count % 4 != 0:
         return parts.sum(dim=0) / (sg * sx)
@@ -567,11 +604,11 @@ def edge_tail_bwd(u16, coors, idx32, pair_mask, g_coors_out, g_msum16, w3p, b3p,
 ROUNDS_PER_SLAB = int(os.environ.get("EGNN_BWD_ROUNDS_PER_SLAB", "8"))
 
 
-def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, ws_nat=None, want_w2=False, n_slabs=None):
+def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, ws_nat=None, want_w2=False, n_slabs=None, row_pairs=False):
     """One pass of egnn_edge_bwd_pass_f32 (include/egnn_hip.h) over the entry list ent (autograd.entry_list).  proj = (B*N, 2 Hp)
     fp32 P_i | P_j rows.  Returns a dict: rows (L / 16, Hp) partial rows, one per tile; with want_w2: w2 = d/d W_2 (16, Hp); with ws_nat (the
     natural-units scalar weights (Hp, S)): ws = d/d W_s (Hp, S) and scal = d/d scalars (E, S) -- the partial arrays of the
-    kernel already summed (fixed order)."""
+    kernel already summed (fixed order).  row_pairs (by source, 16 < K <= 32, with ws_nat): rows = one row per node (L / 32, Hp)."""
     lib = _abi.load()
     hp, s_in = w["Hp"], w["S"]
     dev = proj.device
@@ -579,7 +616,7 @@ def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, w
     l = ent.numel()
     if n_slabs is None:
         n_slabs = max(1, (l // 128 + ROUNDS_PER_SLAB - 1) // ROUNDS_PER_SLAB)
-    n_rows = l // 16
+    n_rows = l // 32 if row_pairs else l // 16
     rows = empty(n_rows + 1, hp, dtype=torch.float32, device=dev)
     a = _abi.EdgeBwdArgs()
     a.B, a.N, a.K, a.Hp, a.S, a.by_dest, a.n_slabs = b, n, k, hp, s_in, int(by_dest), n_slabs
@@ -593,6 +630,7 @@ def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, w
     a.inv_scale = 1.0 / (gu_scale * w["w2t_scale"])
     a.scal = scal.data_ptr()
     a.part_rows, a.ld_rows = rows.data_ptr(), hp
+    a.row_pairs = int(row_pairs)
     if want_w2:
         dw2 = empty(n_slabs * 4, 16, hp, dtype=torch.float32, device=dev)
         a.dW2_part = dw2.data_ptr()
@@ -608,6 +646,9 @@ def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, w
             amax = scal.abs().amax(dim=0)
             col_scale = torch.where(amax > 0, torch.exp2(-torch.floor(torch.log2(amax.clamp_min(1e-30)))), torch.ones_like(amax)).contiguous()
             a.scal_scale = col_scale.data_ptr()
+    wb = lib.egnn_edge_bwd_work_bytes(l, s_in, int(want_w2), int(ws_nat is not None))
+    work = empty(max(wb, 16), dtype=torch.uint8, device=dev)
+    a.work, a.work_bytes = work.data_ptr(), wb
     with _timed("edge_bwd_by_dest" if by_dest else "edge_bwd_by_src"):
         rc = lib.egnn_edge_bwd_pass_f32(byref(a), _stream())
     _abi.check(rc, "egnn_edge_bwd_pass_f32")

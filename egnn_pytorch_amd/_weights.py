@@ -212,6 +212,9 @@ def pack(layer) -> dict:
                    b6=layer.node_mlp[3].bias.detach().float().contiguous())
         out["W5_split"] = split_f16(out["W5"])
         out["W6_split"] = split_f16(out["W6"])
+        # backward: d/d (node_mlp input) = g W5, d/d (hidden) = g W6 -- the W operands are the transposes
+        out["W5T_split"] = split_f16(out["W5"].t().contiguous())
+        out["W6T_split"] = split_f16(out["W6"].t().contiguous())
         if layer.norm_feats:
             out.update(gamma=layer.node_norm.weight.detach().float().contiguous(),
                        beta=layer.node_norm.bias.detach().float().contiguous(),

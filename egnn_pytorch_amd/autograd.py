@@ -492,11 +492,17 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
     # the contractions over all edges ride along: d/d W_s and d/d scalars with the first pass, d/d W_2 with the second (each keeps
     # its accumulators in registers; one pass carrying both drops from 3 to 2 workgroups per CU)
     s_first = _FUSED_SPLIT != "src"                          # ("src": d/d W_2 with the by-source pass, d/d W_s and d/d scalars with the other)
+    want_w2_first = _FUSED_SPLIT == "src" or (_FUSED_SPLIT == "both" and w["S"] == 1)
+    # by source every node has ceil(K / 16) tiles: two (16 < K <= 32) are summed inside the kernel, one IS the node's row -- no gather-sum
+    pairs = 16 < k <= 32 and s_first and not want_w2_first
     o = _ops.edge_bwd_pass(w, proj, i32, gu16, gu_scale, sc2, ent, bc, n, k, by_dest=False, ws_nat=w_s if s_first else None,
-                           want_w2=_FUSED_SPLIT == "src" or (_FUSED_SPLIT == "both" and w["S"] == 1))
+                           want_w2=want_w2_first, row_pairs=pairs)
     g_ws, g_scal, g_w2 = o.get("ws"), o.get("scal"), o.get("w2")
-    ident = torch.arange(o["rows"].shape[0], device=dev)
-    gz_i = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n)
+    if pairs or k <= 16:
+        gz_i = o["rows"][:bc * n]
+    else:
+        ident = torch.arange(o["rows"].shape[0], device=dev)
+        gz_i = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n)
     del o
     if dest_lists is None:
         dest_lists = _ops.dest_lists(i32, bc, n, k, dev)                 # (dense: destination = k)
@@ -509,6 +515,54 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
     ident = torch.arange(o["rows"].shape[0], device=dev)
     gz_j = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n)
     return gz_i, gz_j, g_ws, g_scal, g_w2
+
+
+def _node_mlp_backward(layer, w, f, m_i, g_out, grads_by_id):
+    """Backward of the node update out = node_mlp(cat(node_norm(f), m_i)) + f (egnn_pytorch.py:335-337) on the split-f16 GEMMs:
+    the hidden pre-activation recomputed by the forward's GEMM, then per Linear one NN product (d/d input) and one split-K TN product
+    (d/d weight) that share one (plain, transposed) split of the incoming gradient; SiLU and its derivative in one pass
+    (egnn_silu_bwd_f32).  node_norm (LayerNorm or Identity, element-wise per node) stays with autograd.  f: (bc, n, dim) leaf that
+    requires grad; m_i (bc, n, m); g_out (bc, n, dim).  Adds the parameter gradients into grads_by_id; returns (d/d f, d/d m_i)."""
+    from . import _ops
+    bc, n, dim = f.shape
+    m = m_i.shape[-1]
+    rows = bc * n
+    lin5, lin6 = layer.node_mlp[0], layer.node_mlp[3]
+    with torch.enable_grad():
+        ln = layer.node_norm(f)
+    with torch.no_grad():
+        in32 = torch.cat((ln.detach(), m_i), dim=-1).view(rows, dim + m)
+        g2d = g_out.reshape(rows, dim).contiguous()
+        z1 = _ops.linear_hl(_ops.split_f16(in32), w["W5_split"], 2 * dim, w["b5"], name="bwd_node_mlp")        # (rows, 2 dim) pre-activation
+        go = _ops.GradOperand(g2d)
+        g_a1 = _ops.grad_nn(go, w["W6T_split"], 2 * dim, name="bwd_node_mlp")
+        if z1.numel() % 4 == 0:
+            a1, g_z1 = _ops.silu_bwd_(z1, g_a1)
+        else:
+            sg = torch.sigmoid(z1)
+            a1, g_z1 = z1 * sg, g_a1 * (sg * (1 + z1 * (1 - sg)))
+        if lin6.weight.requires_grad:
+            grads_by_id[id(lin6.weight)] += _ops.grad_tn(go, a1, name="bwd_node_mlp_w")
+        if lin6.bias.requires_grad:
+            grads_by_id[id(lin6.bias)] += g2d.sum(dim=0)
+        del go, a1
+        gz = _ops.GradOperand(g_z1)
+        g_in = _ops.grad_nn(gz, w["W5T_split"], dim + m, name="bwd_node_mlp")
+        if lin5.weight.requires_grad:
+            grads_by_id[id(lin5.weight)] += _ops.grad_tn(gz, in32, name="bwd_node_mlp_w")
+        if lin5.bias.requires_grad:
+            grads_by_id[id(lin5.bias)] += g_z1.sum(dim=0)
+        del gz, g_z1
+        g_ln = g_in[:, :dim].reshape(bc, n, dim)
+        g_mi = g_in[:, dim:].reshape(bc, n, m)
+    if ln is f:                                                   # node_norm = Identity
+        return g_ln + g_out, g_mi
+    ln_params = [p for p in layer.node_norm.parameters() if p.requires_grad]
+    tg = torch.autograd.grad([ln], [f] + ln_params, [g_ln], allow_unused=True)
+    for p, g in zip(ln_params, tg[1:]):
+        if g is not None:
+            grads_by_id[id(p)] += g
+    return (tg[0] if tg[0] is not None else torch.zeros_like(g_out)) + g_out, g_mi
 
 
 def _backward_native(ctx, g_node, g_coors):
@@ -624,7 +678,6 @@ def _backward_native(ctx, g_node, g_coors):
                 del mmask
             with torch.enable_grad():
                 f = f0.detach().requires_grad_(True)
-                mi = m_i[..., :m].detach().requires_grad_(True)
                 c = c0.detach().requires_grad_(True)
                 e = None if e0 is None else e0.detach().requires_grad_(want_ge)
                 closed_dist = s_in == 1                       # the distance is the only per-edge scalar: its backward in closed form below
@@ -633,19 +686,25 @@ def _backward_native(ctx, g_node, g_coors):
                         rel, scal = edge_scalars(layer, c0, None, i64)
                 else:
                     rel, scal = edge_scalars(layer, c, e, i64)                               # (only the scalars' graph is used below)
-                out_n = _per_edge(layer.node_mlp, torch.cat((layer.node_norm(f), mi), dim=-1)) + f      # (split-K weight gradients)
-                # (only what requires grad may be differentiated: a frozen parameter in the list makes autograd.grad raise)
-                node_params = [p for p in list(layer.node_norm.parameters()) + list(layer.node_mlp.parameters()) if p.requires_grad]
-                tg = torch.autograd.grad([out_n], [f, mi] + node_params, [g_node[lo:hi_]], allow_unused=True)
-            if tg[0] is not None:
-                g_feats[lo:hi_] += tg[0]
-            for p, g in zip(node_params, tg[2:]):
-                if g is not None:
-                    grads_by_id[id(p)] += g
+            if f0.is_cuda and _GRAD_GEMM:
+                g_f, g_mi = _node_mlp_backward(layer, w, f, m_i[..., :m], g_node[lo:hi_], grads_by_id)
+                g_feats[lo:hi_] += g_f
+            else:
+                with torch.enable_grad():
+                    mi = m_i[..., :m].detach().requires_grad_(True)
+                    out_n = _per_edge(layer.node_mlp, torch.cat((layer.node_norm(f), mi), dim=-1)) + f      # (split-K weight gradients)
+                    # (only what requires grad may be differentiated: a frozen parameter in the list makes autograd.grad raise)
+                    node_params = [p for p in list(layer.node_norm.parameters()) + list(layer.node_mlp.parameters()) if p.requires_grad]
+                    tg = torch.autograd.grad([out_n], [f, mi] + node_params, [g_node[lo:hi_]], allow_unused=True)
+                if tg[0] is not None:
+                    g_feats[lo:hi_] += tg[0]
+                for p, g in zip(node_params, tg[2:]):
+                    if g is not None:
+                        grads_by_id[id(p)] += g
+                g_mi = tg[1]
             with torch.no_grad():
                 g_msum = torch.zeros(bc, n, 16, dtype=torch.float32, device=feats.device)
-                if tg[1] is not None:
-                    g_mi = tg[1]
+                if g_mi is not None:
                     if layer.m_pool_method == "mean":
                         g_mi = (g_mi / cnt.clamp(min=1e-8)).masked_fill(cnt == 0, 0.0) if cnt is not None else g_mi / k
                     g_msum[..., :m] = g_mi
@@ -720,14 +779,15 @@ def _backward_native(ctx, g_node, g_coors):
             # over the B N nodes with the parts summed in fixed order) -- the fp32 library GEMMs they replace ran at 60 - 130 TFLOP/s
             gw1 = grads_by_id[id(lin0.weight)]
             if f2d.is_cuda and _GRAD_GEMM:
-                a_i, a_j = _ops.absmax(gz_i), _ops.absmax(gz_j)             # (one read each; both products of a matrix share it)
-                t = _ops.grad_nn(gz_i, w["WiT_split"], dim, name="bwd_dfeats", amax=a_i)
-                t = _ops.grad_nn(gz_j, w["WjT_split"], dim, residual=t, name="bwd_dfeats", amax=a_j)
+                # (each matrix: one absmax, one read for its plain and transposed images; feats^T split once for both weight gradients)
+                op_i, op_j = _ops.GradOperand(gz_i), _ops.GradOperand(gz_j)
+                t = _ops.grad_nn(op_i, w["WiT_split"], dim, name="bwd_dfeats")
+                t = _ops.grad_nn(op_j, w["WjT_split"], dim, residual=t, name="bwd_dfeats")
                 g_feats[lo:hi_] += t.view(bc, n, dim)
-                f_op = _ops.grad_tn_operand(f2d)                               # (feats^T, split once for both weight gradients)
-                gw1[:, :dim] += _ops.grad_tn(gz_i, f2d, name="bwd_dw1", amax=a_i, x_operand=f_op)[:h]
-                gw1[:, dim:2 * dim] += _ops.grad_tn(gz_j, f2d, name="bwd_dw1", amax=a_j, x_operand=f_op)[:h]
-                del f_op
+                f_op = _ops.grad_tn_operand(f2d)
+                gw1[:, :dim] += _ops.grad_tn(op_i, f2d, name="bwd_dw1", x_operand=f_op)[:h]
+                gw1[:, dim:2 * dim] += _ops.grad_tn(op_j, f2d, name="bwd_dw1", x_operand=f_op)[:h]
+                del f_op, op_i, op_j
             else:
                 g_feats[lo:hi_] += (gz_i @ w_i + gz_j @ w_j).view(bc, n, dim)
                 gw1[:, :dim] += _tn(gz_i, f2d)[:h]

@@ -56,7 +56,7 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 #define EGNN_BWD_S_BLOCKS 4
 #endif
 #ifndef EGNN_BWD_CHUNK_STEPS
-#define EGNN_BWD_CHUNK_STEPS 4
+#define EGNN_BWD_CHUNK_STEPS 8
 #endif
 #ifndef EGNN_BWD_GROUP_SLABS
 #define EGNN_BWD_GROUP_SLABS 32
@@ -66,7 +66,7 @@ constexpr int BW_THREADS = 256;
 constexpr int BW_WAVES = 4;
 constexpr int CH_S = EGNN_BWD_CHUNK_STEPS;   // steps of 32 hidden columns a workgroup owns (the variant that writes ds_part: sizes it)
 #ifndef EGNN_BWD_CH_W2
-#define EGNN_BWD_CH_W2 4
+#define EGNN_BWD_CH_W2 6
 #endif
 constexpr int CH_W2 = EGNN_BWD_CH_W2;                     // ... of the variant with the d/d W_2 tiles only: one step fewer keeps it at 3 workgroups per CU
 constexpr int XLD = 36;                      // floats per exchange row: 144 B -> rows 4 apart sit 16 banks apart (transposed pick-up)
@@ -114,10 +114,115 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo)
     }
 }
 
+// Per-entry records of one pass, in list order (edge_bwd_prep_kernel).  A workgroup owns a chunk of hidden columns, so every
+// 128-entry round is set up once per column chunk (4 - 8 times per pass at the north-star width): index arithmetic (two integer
+// divisions per entry), the fp16 splits of gU and of the scalars' first-layer terms used to be redone each time -- a third of the
+// pass's VALU instructions.  Now they are computed once per pass and the round's setup is a handful of loads.
+struct BwdPrep {
+    uint2* gu_frag;         // [L][8]: fp16 hi (4 x uint2: channels 0-15) | lo of gU x gu_scale x DZ_UP -- the A fragments [m = entry][k = channel]
+    uint2* gt_frag;         // [L/16][2][16][4]: per tile hi | lo of (gU x gu_scale x GT_UP)^T -- the A fragments [m = channel][k = entry]; or NULL
+    uint32_t* sq;           // [L][4 NM]: the scalars' split terms as the first layer's (fp16, fp16) words, per (m, g)
+    int32_t* oth;           // [L]: row (b N + node) of the entry's other endpoint, -1 = padding
+    int32_t* own;           // [L/16]: row of the tile's key node
+    float* scal_l;          // [L]: the entry's scalar (S == 1, with d/d W_s), or NULL
+};
+
+__host__ __device__ inline size_t prep_bytes(int64_t L, int NM, bool w2, bool s1)
+{
+    return (size_t)L * 64 + (w2 ? (size_t)L * 64 : 0) + (size_t)L * 16 * NM + (size_t)L * 4 + (size_t)(L / 16) * 4 + (s1 ? (size_t)L * 4 : 0);
+}
+
+inline BwdPrep prep_carve(void* work, int64_t L, int NM, bool w2, bool s1)
+{
+    char* c = static_cast<char*>(work);
+    BwdPrep w;
+    w.gu_frag = reinterpret_cast<uint2*>(c); c += (size_t)L * 64;
+    w.gt_frag = w2 ? reinterpret_cast<uint2*>(c) : nullptr; c += w2 ? (size_t)L * 64 : 0;
+    w.sq = reinterpret_cast<uint32_t*>(c); c += (size_t)L * 16 * NM;
+    w.oth = reinterpret_cast<int32_t*>(c); c += (size_t)L * 4;
+    w.scal_l = s1 ? reinterpret_cast<float*>(c) : nullptr; c += s1 ? (size_t)L * 4 : 0;
+    w.own = reinterpret_cast<int32_t*>(c);
+    return w;
+}
+
+template <int NM>
+__global__ __launch_bounds__(256) void edge_bwd_prep_kernel(const egnn_edge_bwd_args p, const BwdPrep w)
+{
+    __shared__ _Float16 th[256][18], tl[256][18];           // (gU x GT_UP) halves of the workgroup's 16 tiles, for the transposed table
+    const int tid = threadIdx.x;
+    const int64_t q = (int64_t)blockIdx.x * 256 + tid;
+    const bool inside = q < p.L;
+    const int eid = inside ? p.ent[q] : -1;
+    const bool valid = eid >= 0;
+    const int ev = valid ? eid : 0;
+    const int ig = ev / p.K;                                 // global node (b N + i)
+    const int jg = (ig / p.N) * p.N + (p.idx ? p.idx[ev] : ev - ig * p.K);
+    f32x4 gv[4];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) gv[c4] = valid ? *reinterpret_cast<const f32x4*>(p.gU + (size_t)eid * 16 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (inside) {
+        w.oth[q] = valid ? (p.by_dest ? ig : jg) : -1;
+        if ((q & 15) == 0) w.own[q >> 4] = p.by_dest ? jg : ig;             // (padding sits behind a node's entries; whole padding tiles: row 0)
+        if (w.scal_l) w.scal_l[q] = valid ? p.scal[(size_t)eid * p.S] : 0.f;
+        f16x4 hi[4], lo[4];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) split4(gv[c4] * (p.gu_scale * DZ_UP), hi[c4], lo[c4]);
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            w.gu_frag[q * 8 + c4] = __builtin_bit_cast(uint2, hi[c4]);
+            w.gu_frag[q * 8 + 4 + c4] = __builtin_bit_cast(uint2, lo[c4]);
+        }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            uint32_t wd[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // split term tau = 4 m + g of scalar tau / 3, exactly the forward's (csrc/edge_fused.hip, _weights.py::scalar_table)
+                const int tau = 4 * m + g;
+                const int sidx = tau / 3, kind = tau - 3 * sidx;
+                wd[g] = 0u;
+                if (sidx < p.S && valid) {
+                    float val = p.scal[(size_t)eid * p.S + sidx] * p.ws_inv_scale;
+                    if (fabsf(val) >= 6.0e7f) val = __builtin_nanf("");
+                    const _Float16 s1 = (_Float16)(val * (1.0f / 1024.0f));
+                    const float r = val - (float)s1 * 1024.0f;
+                    const _Float16 rh = (_Float16)r;
+                    const _Float16 rl = (_Float16)(r - (float)rh);
+                    wd[g] = kind == 0 ? pack_h2(s1, s1) : (kind == 1 ? pack_h2(rh, rh) : pack_h2(rl, (_Float16)0.f));
+                }
+            }
+            *reinterpret_cast<uint4*>(w.sq + (q * NM + m) * 4) = uint4{wd[0], wd[1], wd[2], wd[3]};
+        }
+    }
+    if (w.gt_frag) {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            f16x4 h, l;
+            split4(gv[c4] * (p.gu_scale * GT_UP), h, l);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { th[tid][4 * c4 + u] = h[u]; tl[tid][4 * c4 + u] = l[u]; }
+        }
+        __syncthreads();
+        // 16 tiles x (hi | lo) x 16 channels x 2 half-rows of 8 entries = 1024 chunks of 16 bytes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x = tid + 256 * i;
+            const int tile_l = x >> 6, half = (x >> 5) & 1, c = (x >> 1) & 15, eh = x & 1;
+            const int64_t tile = (int64_t)blockIdx.x * 16 + tile_l;
+            typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+            f16x8v v;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = half ? tl[tile_l * 16 + 8 * eh + u][c] : th[tile_l * 16 + 8 * eh + u][c];
+            if (tile < (p.L >> 4)) *reinterpret_cast<f16x8v*>(w.gt_frag + ((tile * 2 + half) * 16 + c) * 4 + 2 * eh) = v;
+        }
+    }
+}
+
 // NM: first-layer MFMAs of the scalar term (egnn_edge_mfmas(S)); ST: register bound on S (per-edge scalars); WANT_W2: also
 // d/d W_2; WANT_S: also d/d W_s and d/d s; CH: steps of 32 hidden columns the workgroup owns
-template <int NM, int ST, bool WANT_W2, bool WANT_S, int CH>
-__global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WANT_S) && ST > 1)) ? 2 : (WANT_W2 ? EGNN_BWD_W2_BLOCKS : (WANT_S ? EGNN_BWD_S_BLOCKS : EGNN_BWD_DEST_BLOCKS))) void edge_bwd_kernel(const egnn_edge_bwd_args p)
+// PAIR: the two tiles of a round belong to one node (by source, 16 < K <= 32): one partial row per round = the node's row
+template <int NM, int ST, bool WANT_W2, bool WANT_S, int CH, bool PAIR = false>
+__global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WANT_S) && ST > 1)) ? 2 : (WANT_W2 ? EGNN_BWD_W2_BLOCKS : (WANT_S ? EGNN_BWD_S_BLOCKS : EGNN_BWD_DEST_BLOCKS))) void edge_bwd_kernel(const egnn_edge_bwd_args p, const BwdPrep w)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* w2t = reinterpret_cast<_Float16*>(smem);                                  // [CH][hb][hi|lo][64][4] halves
@@ -129,7 +234,7 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hq = lane & 15;                    // n index of the MFMA layouts: hidden unit (data), edge / row (A fragments)
     const int g = lane >> 4;
-    const int S = p.S, K = p.K, N = p.N;
+    const int S = p.S, N = p.N;
     const float rows_scale = p.inv_scale * (1.0f / DZ_UP);      // everything derived from dz leaves in natural units
     const float w2_out_scale = 1.0f / (p.gu_scale * GT_UP * A_UP);
 
@@ -203,32 +308,16 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
         const int q0 = (int)round * 128 + wave * 32;            // (L < 2^31: 32-bit entry indices keep the list addresses in scalar base + offset form)
         // ---------------------------------------------------------------- per-entry setup
         // A fragments indexed by edge (m = hq): gU (channels 4g .. 4g+3) and the scalar terms of the first layer
+        // (all of it read from the pass's per-entry records, edge_bwd_prep_kernel)
         f16x4 guhi[2], gulo[2];
         u32x2 bq[2][NM];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int eid = p.ent[q0 + 16 * t + hq];
-            const bool valid = eid >= 0;
-            f32x4 gu = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (valid) gu = *reinterpret_cast<const f32x4*>(p.gU + (size_t)eid * 16 + 4 * g);
-            split4(gu * (p.gu_scale * DZ_UP), guhi[t], gulo[t]);
+            const int q = q0 + 16 * t + hq;
+            guhi[t] = __builtin_bit_cast(f16x4, w.gu_frag[(size_t)q * 8 + g]);
+            gulo[t] = __builtin_bit_cast(f16x4, w.gu_frag[(size_t)q * 8 + 4 + g]);
 #pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                // split term tau = 4 m + g of scalar tau / 3, exactly the forward's (csrc/edge_fused.hip, _weights.py::scalar_table)
-                const int tau = 4 * m + g;
-                const int sidx = tau / 3, kind = tau - 3 * sidx;
-                u32x2 bw = u32x2{0u, 0u};
-                if (sidx < S && valid) {
-                    float val = p.scal[(size_t)eid * S + sidx] * p.ws_inv_scale;
-                    if (fabsf(val) >= 6.0e7f) val = __builtin_nanf("");
-                    const _Float16 s1 = (_Float16)(val * (1.0f / 1024.0f));
-                    const float r = val - (float)s1 * 1024.0f;
-                    const _Float16 rh = (_Float16)r;
-                    const _Float16 rl = (_Float16)(r - (float)rh);
-                    bw[1] = kind == 0 ? pack_h2(s1, s1) : (kind == 1 ? pack_h2(rh, rh) : pack_h2(rl, (_Float16)0.f));
-                }
-                bq[t][m] = bw;
-            }
+            for (int m = 0; m < NM; ++m) bq[t][m] = u32x2{0u, w.sq[((size_t)q * NM + m) * 4 + g]};
         }
         // per register r: entry 16 t + 4 g + r (the edges this lane's data registers belong to).  The 16 entries of a tile share
         // their key node (the host pads every node's entries to whole tiles): one own row and one partial row per tile.
@@ -239,12 +328,14 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const i32x4 e4 = *reinterpret_cast<const i32x4*>(p.ent + q0 + 16 * t + 4 * g);
-            const int e0 = __builtin_amdgcn_readfirstlane(p.ent[q0 + 16 * t]);      // (padding sits behind a node's entries)
-            const int ev0 = e0 >= 0 ? e0 : 0;
-            const int ig0 = ev0 / K;                                 // global node (b N + i)
-            const int jg0 = p.idx ? (ig0 / N) * N + p.idx[ev0] : (ig0 / N) * N + (ev0 - ig0 * K);
-            ownoff[t] = (int)((size_t)(p.by_dest ? jg0 : ig0) * p.ldp * 4);
-            f32x4 gt = f32x4{0.f, 0.f, 0.f, 0.f}, st4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int tile = (q0 >> 4) + t;
+            ownoff[t] = (int)((size_t)__builtin_amdgcn_readfirstlane(w.own[tile]) * p.ldp * 4);
+            f32x4 st4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (WANT_S && !MW) {                            // (ST == 1: the entries' scalar, zero for padding)
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(w.scal_l + q0 + 16 * t + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sv[t][r][0] = s4[r];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int eid = e4[r];
@@ -252,29 +343,22 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
                 // rows 0, 4, 8, 12 of D = the tile's sum over its valid entries: register 0 of every lane group holds it, and all
                 // four write the same value to the tile's partial row (no per-lane row select, no spare row)
                 ind[t][r] = (valid && (hq & 3) == 0) ? (_Float16)1.f : (_Float16)0.f;
-                if constexpr (WANT_S && !MW) {
-#pragma unroll
-                    for (int c = 0; c < ST; ++c) sv[t][r][c] = (valid && c < S) ? p.scal[(size_t)eid * S + c] : 0.f;
-                }
                 if constexpr (MW) {
                     if (valid && hq < S) st4[r] = p.scal[(size_t)eid * S + hq] * p.scal_scale[hq];
                 }
-                if constexpr (WANT_W2) {
-                    if (valid) gt[r] = p.gU[(size_t)eid * 16 + hq];
-                }
             }
-            if constexpr (WANT_W2) split4(gt * (p.gu_scale * GT_UP), gth[t], gtl[t]);
+            if constexpr (WANT_W2) {
+                gth[t] = __builtin_bit_cast(f16x4, w.gt_frag[((size_t)tile * 2 * 16 + hq) * 4 + g]);
+                gtl[t] = __builtin_bit_cast(f16x4, w.gt_frag[((size_t)tile * 2 * 16 + 16 + hq) * 4 + g]);
+            }
             if constexpr (MW) split4(st4 * GT_UP, sth[t], stl[t]);
         }
         // whole-line gathers of the other endpoint's rows: lane l fetches chunk l & 7 of entry 8 qq + (l >> 3)
         uint32_t goff[4];
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            const int eid = p.ent[q0 + 8 * qq + (lane >> 3)];
-            const int ev = eid >= 0 ? eid : 0;
-            const int ig = ev / K;
-            const int jg = p.idx ? (ig / N) * N + p.idx[ev] : (ig / N) * N + (ev - ig * K);
-            const int othrow = eid >= 0 ? (p.by_dest ? ig : jg) : 0;
+            const int o = w.oth[q0 + 8 * qq + (lane >> 3)];
+            const int othrow = o >= 0 ? o : 0;
             goff[qq] = (uint32_t)(((size_t)othrow * p.ldp + 4 * (lane & 7)) * 4);
         }
 
@@ -342,6 +426,7 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
 #pragma unroll
                     for (int c = 0; c < ST; ++c) wsn[c] = c < S ? buf_load1f(ws_rsrc, (uint32_t)((hq * S + c) * 4), (hoff + 16 * hb) * S * 4) : 0.f;
                 }
+                f32x4 dPc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     f32x4 ga = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -387,11 +472,16 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
                         dl[r] = lo[0]; dl[r + 1] = lo[1];
                     }
                     // sum over each node's edges of the tile: rows = the tile's local nodes
-                    f32x4 dP = f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 dP = (PAIR && t == 1) ? dPc : f32x4{0.f, 0.f, 0.f, 0.f};
                     dP = __builtin_amdgcn_mfma_f32_16x16x16f16(ind[t], dh, dP, 0, 0, 0);
                     dP = __builtin_amdgcn_mfma_f32_16x16x16f16(ind[t], dl, dP, 0, 0, 0);
                     // (no branch around the store: the step stays one basic block and the scheduler interleaves the two tiles)
-                    buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)(q0 + 16 * t) >> 4) * row_bytes) + (hoff + 16 * hb) * 4, dP[0] * rows_scale);
+                    if constexpr (PAIR) {
+                        if (t == 0) dPc = dP;
+                        else buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)q0 >> 5) * row_bytes) + (hoff + 16 * hb) * 4, dP[0] * rows_scale);
+                    } else {
+                        buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)(q0 + 16 * t) >> 4) * row_bytes) + (hoff + 16 * hb) * 4, dP[0] * rows_scale);
+                    }
                     if constexpr (MW) {
                         f32x4 d = dWsm[2 * st + hb];
                         d = __builtin_amdgcn_mfma_f32_16x16x16f16(sth[t], dh, d, 0, 0, 0);
@@ -472,13 +562,19 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
     }
 }
 
-template <int NM, int ST, bool W2, bool SS, int CH>
+template <int NM, int ST, bool W2, bool SS, int CH, bool PAIR = false>
 int launch_v(const egnn_edge_bwd_args& a, hipStream_t s)
 {
+    if (a.row_pairs && !PAIR) return EGNN_E_UNSUPPORTED;
     const int n_chunks = (a.Hp / 32 + CH - 1) / CH;
     const size_t lds = (size_t)CH * 2048 + (size_t)CH * 32 * 4 * NM * 4 + (size_t)BW_WAVES * 32 * XLD * 4;
     const dim3 grid((unsigned)((a.n_slabs + GS - 1) / GS * GS * n_chunks));
-    hipLaunchKernelGGL((edge_bwd_kernel<NM, ST, W2, SS, CH>), grid, dim3(BW_THREADS), lds, s, a);
+    // the pass's per-entry records first (list order; read once per column chunk by the kernel below)
+    constexpr bool S1 = SS && ST == 1;
+    if (!a.work || a.work_bytes < (int64_t)prep_bytes(a.L, NM, W2, S1)) return EGNN_E_SHAPE;
+    const BwdPrep w = prep_carve(a.work, a.L, NM, W2, S1);
+    hipLaunchKernelGGL((edge_bwd_prep_kernel<NM>), dim3((unsigned)((a.L + 255) / 256)), dim3(256), 0, s, a, w);
+    hipLaunchKernelGGL((edge_bwd_kernel<NM, ST, W2, SS, CH, PAIR>), grid, dim3(BW_THREADS), lds, s, a, w);
     return egnn_launch_status();
 }
 
@@ -491,7 +587,7 @@ int launch(const egnn_edge_bwd_args& a, hipStream_t s)
         else return EGNN_E_UNSUPPORTED;
     }
     if (a.dW2_part) return launch_v<NM, ST, true, false, CH_W2>(a, s);
-    if (a.dWs_part) return launch_v<NM, ST, false, true, CH_S>(a, s);
+    if (a.dWs_part) return a.row_pairs ? launch_v<NM, ST, false, true, CH_S, true>(a, s) : launch_v<NM, ST, false, true, CH_S>(a, s);
     return launch_v<NM, ST, false, false, CH_S>(a, s);
 }
 
@@ -499,13 +595,21 @@ int launch(const egnn_edge_bwd_args& a, hipStream_t s)
 
 extern "C" int egnn_edge_bwd_chunk_steps(void) { return CH_S; }
 
+extern "C" size_t egnn_edge_bwd_work_bytes(int64_t L, int S, int want_w2, int want_s)
+{
+    if (L <= 0 || S < 1 || S > 5) return 0;
+    const int nm = S <= 1 ? 1 : (S <= 4 ? 3 : 4);
+    return prep_bytes(L, nm, want_w2 != 0, want_s != 0 && S == 1);
+}
+
 extern "C" int egnn_edge_bwd_pass_f32(const egnn_edge_bwd_args* args, void* stream)
 {
     if (!args) return EGNN_E_NULLPTR;
     const egnn_edge_bwd_args& a = *args;
-    if (!a.ent || !a.Pi || !a.Pj || !a.Wst || !a.W2Th || !a.gU || !a.scal || !a.part_rows) return EGNN_E_NULLPTR;
+    if (!a.ent || !a.Pi || !a.Pj || !a.Wst || !a.W2Th || !a.gU || !a.scal || !a.part_rows || !a.work) return EGNN_E_NULLPTR;
     if ((a.dWs_part == nullptr) != (a.ds_part == nullptr)) return EGNN_E_NULLPTR;
     if (a.dWs_part && !a.Ws) return EGNN_E_NULLPTR;
+    if (a.row_pairs && (a.by_dest || a.K <= 16 || a.K > 32 || a.L != (((int64_t)a.B * a.N * 32 + 127) / 128) * 128)) return EGNN_E_SHAPE;
     if (a.B <= 0 || a.N <= 0 || a.K <= 0 || a.Hp <= 0 || (a.Hp % 32) != 0 || a.S < 1 || a.n_slabs < 1) return EGNN_E_SHAPE;
     if (a.L <= 0 || (a.L % 128) != 0 || a.ldp < a.Hp || (a.ldp % 4) != 0 || a.ld_rows < a.Hp) return EGNN_E_SHAPE;
     if (a.E != (int64_t)a.B * a.N * a.K || a.E >= ((int64_t)1 << 31) || a.L >= ((int64_t)1 << 31)) return EGNN_E_SHAPE;
@@ -516,7 +620,7 @@ extern "C" int egnn_edge_bwd_pass_f32(const egnn_edge_bwd_args* args, void* stre
     if (!(a.ws_inv_scale > 0.f) || !(a.gu_scale > 0.f) || !(a.inv_scale > 0.f)) return EGNN_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(a.Pi) & 15) || (reinterpret_cast<uintptr_t>(a.Pj) & 15) || (reinterpret_cast<uintptr_t>(a.W2Th) & 15) ||
         (reinterpret_cast<uintptr_t>(a.gU) & 15) || (reinterpret_cast<uintptr_t>(a.ent) & 15) ||
-        (reinterpret_cast<uintptr_t>(a.Wst) & 3))
+        (reinterpret_cast<uintptr_t>(a.Wst) & 3) || (reinterpret_cast<uintptr_t>(a.work) & 15))
         return EGNN_E_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.S == 1) return launch<1, 1>(a, s);

@@ -122,9 +122,11 @@ __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restri
 // `cols` rows and K = rows) -- the operands of the backward's node-level gradient GEMMs (egnn_split_scaled_f16).
 // One workgroup = 64 X-rows x 32 X-columns through LDS; every thread emits one 16-byte chunk (8 consecutive K values of one
 // image row) per image, so that the workgroup's stores fill whole 1 KB (row block, K-tile) pieces.
+// transposed = 2: both images from one read of X (hi / lo = the plain image, hiT / loT = the transposed one).
 __global__ __launch_bounds__(256) void split_scaled_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int cols, float scale,
                                                            int transposed, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int nkt,
-                                                           int64_t img_rows_p, int32_t* __restrict__ status)
+                                                           int64_t img_rows_p, _Float16* __restrict__ hiT, _Float16* __restrict__ loT, int nktT,
+                                                           int64_t img_rows_pT, int32_t* __restrict__ status)
 {
     typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
     __shared__ float tile[64][33];
@@ -138,10 +140,16 @@ __global__ __launch_bounds__(256) void split_scaled_kernel(const float* __restri
         tile[r][c] = v;
     }
     __syncthreads();
+    for (int pass = 0; pass < (transposed == 2 ? 2 : 1); ++pass) {
+    const bool tr = transposed == 2 ? pass == 1 : transposed != 0;
+    _Float16* ohi = (transposed == 2 && pass == 1) ? hiT : hi;
+    _Float16* olo = (transposed == 2 && pass == 1) ? loT : lo;
+    const int onkt = (transposed == 2 && pass == 1) ? nktT : nkt;
+    const int64_t orows = (transposed == 2 && pass == 1) ? img_rows_pT : img_rows_p;
     float x[8];
     int64_t out_row;
     int out_k;
-    if (transposed) {                         // image row = X column c0 + (tid & 31), K = X rows r0 + 8 q .. + 7
+    if (tr) {                                 // image row = X column c0 + (tid & 31), K = X rows r0 + 8 q .. + 7
         const int c = tid & 31, q = tid >> 5;
 #pragma unroll
         for (int u = 0; u < 8; ++u) x[u] = tile[8 * q + u][c];
@@ -164,10 +172,29 @@ __global__ __launch_bounds__(256) void split_scaled_kernel(const float* __restri
         l8[u] = (_Float16)(x[u] - (float)h);
     }
     egnn_flag_range(status, beyond, EGNN_RANGE_A_OPERAND);
-    if (out_k < nkt * 16 && out_row < img_rows_p) {       // (inside the padded image: rows / K beyond the matrix are written as zeros)
-        const size_t o = egnn_pk_off(out_row, out_k, nkt);
-        *reinterpret_cast<f16x8v*>(hi + o) = h8;
-        *reinterpret_cast<f16x8v*>(lo + o) = l8;
+    if (out_k < onkt * 16 && out_row < orows) {           // (inside the padded image: rows / K beyond the matrix are written as zeros)
+        const size_t o = egnn_pk_off(out_row, out_k, onkt);
+        *reinterpret_cast<f16x8v*>(ohi + o) = h8;
+        *reinterpret_cast<f16x8v*>(olo + o) = l8;
+    }
+    }
+}
+
+// a = SiLU(z) and gz = g SiLU'(z) in one pass (the backward of node_mlp's activation, egnn_pytorch.py:196-201); a_out may be z, gz_out may be g
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const float* z, const float* g, float* a_out, float* gz_out, int64_t quads)
+{
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (int64_t)gridDim.x * 256) {
+        const f32x4 zv = reinterpret_cast<const f32x4*>(z)[q];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[q];
+        f32x4 av, dv;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float sg = 1.0f / (1.0f + __expf(-zv[u]));
+            av[u] = zv[u] * sg;
+            dv[u] = gv[u] * (sg * (1.0f + zv[u] * (1.0f - sg)));
+        }
+        reinterpret_cast<f32x4*>(a_out)[q] = av;
+        reinterpret_cast<f32x4*>(gz_out)[q] = dv;
     }
 }
 
@@ -260,7 +287,36 @@ extern "C" int egnn_split_scaled_f16(const float* X, int64_t ldx, int64_t rows, 
     if (gy > 65535 * 16LL || gx > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
     if (gy > 65535) return EGNN_E_UNSUPPORTED;
     hipLaunchKernelGGL(split_scaled_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, static_cast<hipStream_t>(stream), X, ldx, rows, cols,
-                       scale, transposed, static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), Kp / 16, (img_rows + 31) / 32 * 32, status);
+                       scale, transposed, static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), Kp / 16, (img_rows + 31) / 32 * 32,
+                       static_cast<_Float16*>(nullptr), static_cast<_Float16*>(nullptr), 0, (int64_t)0, status);
+    return egnn_launch_status();
+}
+
+extern "C" int egnn_split_scaled_both_f16(const float* X, int64_t ldx, int64_t rows, int cols, float scale, void* hi, void* lo, int Kp,
+                                          void* hiT, void* loT, int KpT, int32_t* status, void* stream)
+{
+    if (!X || !hi || !lo || !hiT || !loT) return EGNN_E_NULLPTR;
+    if (rows <= 0 || cols <= 0 || ldx < cols || Kp < cols || (Kp % 32) != 0 || KpT < rows || (KpT % 32) != 0 || !(scale > 0.f)) return EGNN_E_SHAPE;
+    // the grid covers both padded images: X rows up to max(rows | 32, KpT), X columns up to max(Kp, cols | 32)
+    const int64_t rows32 = (rows + 31) / 32 * 32, cols32 = ((int64_t)cols + 31) / 32 * 32;
+    const int64_t rows_cover = rows32 > KpT ? rows32 : KpT, cols_cover = Kp > cols32 ? Kp : cols32;
+    const int64_t gy = (rows_cover + 63) / 64, gx = (cols_cover + 31) / 32;
+    if (gy > 65535 || gx > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(split_scaled_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, static_cast<hipStream_t>(stream), X, ldx, rows, cols,
+                       scale, 2, static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), Kp / 16, rows32,
+                       static_cast<_Float16*>(hiT), static_cast<_Float16*>(loT), KpT / 16, cols32, status);
+    return egnn_launch_status();
+}
+
+extern "C" int egnn_silu_bwd_f32(const float* z, const float* g, float* a_out, float* gz_out, int64_t count, void* stream)
+{
+    if (!z || !g || !a_out || !gz_out) return EGNN_E_NULLPTR;
+    if (count <= 0 || (count % 4) != 0) return EGNN_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(a_out) | reinterpret_cast<uintptr_t>(gz_out)) & 15)
+        return EGNN_E_ALIGN;
+    int64_t blocks = (count / 4 + 256 * 4 - 1) / (256 * 4);
+    blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), z, g, a_out, gz_out, count / 4);
     return egnn_launch_status();
 }
 

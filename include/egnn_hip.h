@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 23
+#define EGNN_ABI_VERSION 24
 
 enum {
     EGNN_OK = 0,
@@ -184,6 +184,13 @@ int egnn_linear_hl_drop_f32(const void* A_hi, const void* A_lo, const void* W_hi
  *     comes back as a NaN pattern); X 16-byte aligned; one pass, integer atomicMax (order independent). */
 int egnn_split_scaled_f16(const float* X, int64_t ldx, int64_t rows, int cols, float scale, int transposed, void* hi, void* lo, int Kp,
                           int32_t* status, void* stream);
+/* both images of egnn_split_scaled_f16 from one read of X: hi / lo (`rows` image rows, K = cols padded to Kp) and hiT / loT (`cols` image
+ * rows, K = rows padded to KpT) -- a gradient matrix enters one NN product (d/d input) and one TN product (d/d weight). */
+int egnn_split_scaled_both_f16(const float* X, int64_t ldx, int64_t rows, int cols, float scale, void* hi, void* lo, int Kp,
+                               void* hiT, void* loT, int KpT, int32_t* status, void* stream);
+/* backward of an MLP's SiLU (node_mlp, egnn_pytorch.py:196-201) in one pass: a_out = SiLU(z), gz_out = g * SiLU'(z); count % 4 == 0,
+ * 16-byte aligned; a_out may be z and gz_out may be g (element-wise). */
+int egnn_silu_bwd_f32(const float* z, const float* g, float* a_out, float* gz_out, int64_t count, void* stream);
 int egnn_linear_hl_splitk_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo, float w_inv_scale, float* C_parts,
                               int64_t ldc, int64_t M, int N, int Kp, int w_rows, int k_splits, void* stream);
 int egnn_sum_parts_f32(const float* parts, int nparts, int64_t count, float scale, float* out, void* stream);
@@ -319,7 +326,7 @@ int egnn_edge_bwd_dz_f32(const egnn_edge_args* args, void* stream);
  * L is a multiple of 128 (whole tiles of -1 at the end).  The pass recomputes z = P_i[i] + P_j[j] + W_s s per edge, a = SiLU(z),
  * dz = (W2^T gU) SiLU'(z), and contracts them in registers:
  *     part_rows[q / 16, :]   = sum of dz over tile q / 16     (d/d P_i or d/d P_j after egnn_rows_gather_sum_f32 over each node's
- *                              consecutive tiles -- fixed order, no float atomics)
+ *                              consecutive tiles -- fixed order, no float atomics; row_pairs: one row per node directly)
  *     dW2_part (n_slabs * 4, 16, Hp),  if not NULL:  partial sums of gU^T a  -> d loss / d edge_mlp.3.weight  = sum over dim 0
  *     dWs_part (n_slabs * 16, S, Hp) -- S > 1: rows multiples of 4 only, times scal_scale[c] -- and ds_part (n_chunks, E, S),
  *                              if not NULL (both or neither): partial sums of s^T dz
@@ -356,10 +363,16 @@ typedef struct egnn_edge_bwd_args {
     float* dW2_part;            /* out or NULL */
     float* dWs_part;            /* out or NULL (with ds_part) */
     float* ds_part;             /* out or NULL (with dWs_part) */
+    int row_pairs;              /* 1 (by source with d/d W_s, 16 < K <= 32, the list = 32 entries per node): the two tiles of a node are summed */
+                                /*   in the kernel -- part_rows (L / 32 + 1, ld_rows) holds one row per NODE and no gather-sum is needed */
+    void* work;                 /* scratch, 16-byte aligned: the pass's per-entry records (other endpoint's row, fp16 fragments of gU and of */
+    int64_t work_bytes;         /*   the scalars' first-layer terms, in list order), written by a first launch, read once per column chunk */
 } egnn_edge_bwd_args;
 
 int egnn_edge_bwd_pass_f32(const egnn_edge_bwd_args* args, void* stream);
 int egnn_edge_bwd_chunk_steps(void);    /* hidden steps (of 32 columns) one workgroup owns: sizes ds_part */
+/* bytes of egnn_edge_bwd_args.work for a list of L entries; want_w2 / want_s = dW2_part / dWs_part not NULL; 0 = outside the limits */
+size_t egnn_edge_bwd_work_bytes(int64_t L, int S, int want_w2, int want_s);
 
 /* The per-edge part of the backward behind edge_mlp's second Linear in closed form (csrc/edge_tail.hip; autograd of
  * egnn_pytorch.py:287 second SiLU, :289-290 edge gate (soft_edges), :292-317 pair mask / coors_mlp / CoorsNorm / clamp / coordinate

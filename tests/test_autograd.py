@@ -565,13 +565,15 @@ def _emulated_backward(layer, feats, coors, mask, idx, rank, radius, g_node, g_c
         dst = (idx32.long() + (torch.arange(b_) * n_)[:, None, None]).reshape(-1)
         return (proj[src, :hp] + proj[dst, hp:] + scal @ w["Ws"]) / nl2e
 
-    def bwd_pass(w_, proj, idx32, gu16, gu_scale, scal, ent, b_, n_, k_, by_dest, ws_nat=None, want_w2=False, n_slabs=None):
+    def bwd_pass(w_, proj, idx32, gu16, gu_scale, scal, ent, b_, n_, k_, by_dest, ws_nat=None, want_w2=False, n_slabs=None, row_pairs=False):
         z = z_of(proj, idx32, scal, b_, n_, k_)
         sg = torch.sigmoid(z)
         a = z * sg
         dz = (gu16 @ w2n) * (sg * (1 + z * (1 - sg)))
         tiles = ent.view(-1, 16).long()
         rows = (dz[tiles.clamp(min=0)] * (tiles >= 0)[..., None]).sum(dim=1)        # one partial row per tile
+        if row_pairs:                                                               # ... per node: its two tiles summed in the kernel
+            rows = rows.view(-1, 2, rows.shape[1]).sum(dim=1)
         out = {"rows": rows}
         if want_w2:
             out["w2"] = gu16.t() @ a

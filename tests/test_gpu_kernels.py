@@ -328,7 +328,9 @@ def test_rows_gather_sum_fixed_order():
                                                  (1, 48, 8, 32, True, dict(fourier_features=1)), (1, 40, 8, 16, False, dict(edge_dim=1)),
                                                  # the BASELINE widths: 17 / 9 / 5 persistent column chunks of 128 (Hp = 2080 / 1056 / 544)
                                                  (1, 96, 32, 512, False, {}), (1, 80, 32, 256, True, {}), (2, 64, 32, 128, False, {}),
-                                                 (1, 64, 16, 512, True, dict(edge_dim=4))])
+                                                 (1, 64, 16, 512, True, dict(edge_dim=4)),
+                                                 # two tiles per source node with padding in the second (summed in the kernel), three tiles (gather-sum)
+                                                 (1, 40, 24, 32, False, {}), (2, 50, 40, 32, True, {}), (1, 40, 20, 32, False, dict(edge_dim=2))])
 def test_edge_bwd_pass_contractions_match_float64(b, n, k, dim, hub, extra):
     """egnn_edge_bwd_pass_f32 (nothing of size E x H in memory: z, SiLU(z), dz recomputed and contracted in registers) and
     egnn_edge_bwd_dz_f32 (dz / SiLU(z) through HBM + library reductions) against the same contractions in float64:
@@ -544,3 +546,33 @@ def test_unsplit_words_recovers_the_forward_projection():
     assert torch.equal(words[:, :hp], want)
     assert torch.equal(words[:, hp:], pj)
     assert float((words - full).abs().max()) <= 2.0 ** -20 * float(full.abs().max())
+
+
+@pytest.mark.parametrize("rows,cols", [(1000, 96), (4096, 2080), (70, 24), (129, 33)])
+def test_split_scaled_both_equals_the_two_single_splits(rows, cols):
+    """egnn_split_scaled_both_f16 (one read of X) writes exactly the images of the two stand-alone egnn_split_scaled_f16 calls."""
+    from egnn_pytorch_amd import _ops
+    g = torch.Generator().manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, generator=g) * 1e-6).cuda()
+    scale = _ops.grad_scale(_ops.absmax(x))
+    plain, tr = _ops.split_scaled_both(x, scale)
+    p1 = _ops.split_scaled(x, scale)[0]
+    t1 = _ops.split_scaled(x, scale, transposed=True)[0]
+    for a, b in ((plain, p1), (tr, t1)):
+        assert a.kp == b.kp and a.rows == b.rows
+        assert torch.equal(a.hi, b.hi) and torch.equal(a.lo, b.lo)
+
+
+def test_silu_bwd_matches_autograd():
+    """egnn_silu_bwd_f32: a = SiLU(z) and gz = g SiLU'(z) in place, against torch autograd in float64."""
+    from egnn_pytorch_amd import _ops
+    g = torch.Generator().manual_seed(4)
+    z = (torch.randn(513, 64, generator=g) * 4).cuda()
+    gr = torch.randn(513, 64, generator=g).cuda()
+    with torch.enable_grad():
+        z64 = z.double().requires_grad_(True)
+        a64 = torch.nn.functional.silu(z64)
+        want = torch.autograd.grad(a64, z64, gr.double())[0]
+    a, gz = _ops.silu_bwd_(z.clone(), gr.clone())
+    assert float((a.double() - a64.detach()).abs().max()) <= 2e-6 * float(a64.abs().max())
+    assert float((gz.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
