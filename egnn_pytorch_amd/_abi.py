@@ -27,7 +27,7 @@ SYMBOLS = (
     "egnn_edge_fused_f32", "egnn_spatial_order_f32", "egnn_linear_hl_f32", "egnn_split_f16", "egnn_node_prep_hl",
     "egnn_packed_halves", "egnn_adj_expand_u8", "egnn_adj_expand_workspace_bytes", "egnn_edge_mfmas",
     "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32",
-    "egnn_edge_bwd_dz_f32", "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_bwd_work_bytes", "egnn_edge_tail_bwd_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
+    "egnn_edge_bwd_dz_f32", "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_bwd_work_bytes", "egnn_edge_tail_bwd_f32", "egnn_edge_tail_part_floats", "egnn_edge_pool_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
     "egnn_induced_attn_f32", "egnn_token_attn_f32", "egnn_slot_prep_f32", "egnn_struct_bytes",
     "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32", "egnn_split_scaled_both_f16", "egnn_silu_bwd_f32",
     "egnn_linear_hl_drop_f32",
@@ -82,6 +82,7 @@ class EdgeTailArgs(Structure):
         ("g_msum", c_void_p), ("W3", c_void_p), ("b3", c_void_p), ("W4", c_void_p), ("b4", c_void_p), ("scale", c_void_p),
         ("gU", c_void_p), ("g_rel", c_void_p), ("g_hid", c_void_p), ("a3", c_void_p), ("g_w", c_void_p), ("g_scale", c_void_p),
         ("gate_w", c_void_p), ("gate_b", c_void_p), ("g_gate", c_void_p),
+        ("part", c_void_p), ("rel_out", c_void_p), ("dist_out", c_void_p),
     ]
 
 
@@ -241,6 +242,10 @@ def load():
     lib.egnn_edge_bwd_pass_f32.argtypes = [POINTER(EdgeBwdArgs), c_void_p]
     lib.egnn_edge_tail_bwd_f32.restype = c_int
     lib.egnn_edge_tail_bwd_f32.argtypes = [POINTER(EdgeTailArgs), c_void_p]
+    lib.egnn_edge_tail_part_floats.restype = c_int
+    lib.egnn_edge_tail_part_floats.argtypes = []
+    lib.egnn_edge_pool_f32.restype = c_int
+    lib.egnn_edge_pool_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.egnn_edge_bwd_chunk_steps.restype = c_int
     lib.egnn_edge_bwd_chunk_steps.argtypes = []
     lib.egnn_edge_bwd_work_bytes.restype = c_size_t

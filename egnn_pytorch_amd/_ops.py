@@ -566,15 +566,72 @@ def dest_lists(idx32, b, n, k, device):
     return DestLists(ent[:length], tile_seg, order, seg)
 
 
-def edge_tail_bwd(u16, coors, idx32, pair_mask, g_coors_out, g_msum16, w3p, b3p, w4p, b4, scale, eps, clamp, b, n, k, gate=None):
+def sum_rows(part):
+    """Column sums of a (rows, count) fp32 array with many rows, in a fixed order, on egnn_sum_parts_f32 (which walks its parts one
+    after the other per output element: made for a handful of split-K parts): first the rows p G + g over p for each of G groups
+    (the array read as (rows / G) parts of G * count elements), then the G group sums."""
+    rows, count = part.shape
+    lib = _abi.load()
+    g = 1
+    while g < 256 and rows % (2 * g) == 0 and rows // (2 * g) >= 1:
+        g *= 2
+    out = empty(count, dtype=torch.float32, device=part.device)
+    with _timed("sum_rows"):
+        if g > 1 and rows // g > 1:
+            mid = empty(g, count, dtype=torch.float32, device=part.device)
+            _abi.check(lib.egnn_sum_parts_f32(_ptr(part), rows // g, g * count, 1.0, _ptr(mid), _stream()), "egnn_sum_parts_f32")
+            part, rows = mid, g
+        _abi.check(lib.egnn_sum_parts_f32(_ptr(part), rows, count, 1.0, _ptr(out), _stream()), "egnn_sum_parts_f32")
+    return out
+
+
+def edge_pool(u16, gate, pair_mask, b, n, k):
+    """egnn_edge_pool_f32: (B, N, 16) sum over k of pair_mask * SiLU(u) * gate -- the pooled messages the backward's node-level part
+    starts from.  gate = (gate_w (16) zero padded, gate_b (1)) or None; pair_mask (E) uint8 or None."""
+    out = empty(b, n, 16, dtype=torch.float32, device=u16.device)
+    with _timed("edge_pool"):
+        rc = _abi.load().egnn_edge_pool_f32(_ptr(u16), _ptr(gate[0]) if gate is not None else None, _ptr(gate[1]) if gate is not None else None,
+                                            _ptr(pair_mask), b, n, k, _ptr(out), _stream())
+    _abi.check(rc, "egnn_edge_pool_f32")
+    return out
+
+
+def edge_tail_bwd(u16, coors, idx32, pair_mask, g_coors_out, g_msum16, w3p, b3p, w4p, b4, scale, eps, clamp, b, n, k, gate=None,
+                  reduce=False, want_rel=False):
     """egnn_edge_tail_bwd_f32 (include/egnn_hip.h): the per-edge closed-form backward behind edge_mlp's second Linear.
     Returns (gU (E, 16), g_rel (E, 4), g_hid (E, 64), a3 (E, 64), g_w (E,), g_scale (E,) or None); with gate = (gate_w (16) zero
-    padded, gate_b (1)) -- soft_edges -- a seventh element g_gate (E,) = d loss / d (gate pre-activation)."""
+    padded, gate_b (1)) -- soft_edges -- a seventh element g_gate (E,) = d loss / d (gate pre-activation).
+    reduce: the kernel sums the parameter gradients' per-edge terms itself -- returns (gU, g_rel, sums (1192,), rel (E, 4) or None,
+    dist (E,) or None): sums = [d/d W3 (64 x 16) | d/d b3 (64) | d/d W4 (64) | column sums of gU (16) | d/d gate_w (16) | d/d b4 |
+    d/d CoorsNorm.scale | d/d gate_b | 0...]; want_rel: also x_i - x_j and |x_i - x_j|^2 per edge."""
     dev = u16.device
     e = b * n * k
     f32 = dict(dtype=torch.float32, device=dev)
     gu = empty(e, 16, **f32)
     g_rel = empty(e, 4, **f32)
+    if reduce:
+        lib = _abi.load()
+        pf = lib.egnn_edge_tail_part_floats()
+        n_waves = (e + 255) // 256 * 4
+        part = empty(n_waves, pf, **f32)
+        a = _abi.EdgeTailArgs()
+        a.B, a.N, a.K, a.norm_coors = b, n, k, int(scale is not None)
+        a.clamp = -1.0 if clamp is None else float(clamp)
+        a.eps = float(eps)
+        a.u, a.coors, a.idx, a.pair_mask = u16.data_ptr(), coors.data_ptr(), _ptr(idx32), _ptr(pair_mask)
+        a.g_coors_out, a.g_msum = g_coors_out.data_ptr(), g_msum16.data_ptr()
+        a.W3, a.b3, a.W4, a.b4, a.scale = w3p.data_ptr(), b3p.data_ptr(), w4p.data_ptr(), b4.data_ptr(), _ptr(scale)
+        a.gU, a.g_rel, a.part = gu.data_ptr(), g_rel.data_ptr(), part.data_ptr()
+        if gate is not None:
+            a.gate_w, a.gate_b = gate[0].data_ptr(), gate[1].data_ptr()
+        rel = dist = None
+        if want_rel:
+            rel, dist = empty(e, 4, **f32), empty(e, **f32)
+            a.rel_out, a.dist_out = rel.data_ptr(), dist.data_ptr()
+        with _timed("edge_tail_bwd"):
+            rc = lib.egnn_edge_tail_bwd_f32(byref(a), _stream())
+        _abi.check(rc, "egnn_edge_tail_bwd_f32")
+        return gu, g_rel, sum_rows(part), rel, dist
     g_hid = empty(e, 64, **f32)
     a3 = empty(e, 64, **f32)
     g_w = empty(e, **f32)
@@ -632,13 +689,13 @@ def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, w
     a.part_rows, a.ld_rows = rows.data_ptr(), hp
     a.row_pairs = int(row_pairs)
     if want_w2:
-        dw2 = empty(n_slabs * 4, 16, hp, dtype=torch.float32, device=dev)
+        dw2 = empty(n_slabs, 16, hp, dtype=torch.float32, device=dev)
         a.dW2_part = dw2.data_ptr()
     if ws_nat is not None:
         ch = lib.egnn_edge_bwd_chunk_steps()
         n_chunks = (hp // 32 + ch - 1) // ch
         ws_nat = ws_nat.contiguous()
-        dws = empty(n_slabs * 16, s_in, hp, dtype=torch.float32, device=dev)
+        dws = empty(n_slabs * 16 if s_in > 1 else n_slabs, s_in, hp, dtype=torch.float32, device=dev)
         ds = empty(n_chunks, e, s_in, dtype=torch.float32, device=dev)
         a.Ws, a.dWs_part, a.ds_part = ws_nat.data_ptr(), dws.data_ptr(), ds.data_ptr()
         if s_in > 1:

@@ -43,6 +43,7 @@ _NATIVE = _NATIVE_MODE != "0"
 _FUSED_SPLIT = os.environ.get("EGNN_BWD_SPLIT", "dest")
 _TAIL_KERNEL = os.environ.get("EGNN_BWD_TAIL_KERNEL", "1") != "0"      # 0: the per-edge chain behind u through autograd
 _GRAD_GEMM = os.environ.get("EGNN_BWD_GRAD_GEMM", "1") != "0"          # 0: the node-level gradient products as fp32 library GEMMs
+_TAIL_REDUCE = os.environ.get("EGNN_BWD_TAIL_REDUCE", "1") != "0"      # 0: the tail kernel writes its E x 64 factors out for library reductions
 _KEEP_PROJ = os.environ.get("EGNN_BWD_KEEP_PROJ", "1") != "0"          # 0: the backward recomputes the P_i | P_j table (B N x 2 Hp fp32 less to keep)
 _FUSED_MAX_GRAPHS = 0                 # tests: force the chunking over graphs that very large batches need (0 = by size only)
 _NATIVE_BUDGET_BYTES = 24 << 30                      # dZ + SiLU(z), 2 x E x Hp fp32, per chunk of graphs
@@ -657,33 +658,40 @@ def _backward_native(ctx, g_node, g_coors):
                     else:
                         bi = torch.arange(bc, device=feats.device)[:, None, None]
                         pm = m0[:, :, None] & m0[bi, i64] & (r0 <= ctx.valid_radius)
-                mm = torch.nn.functional.silu(u16)                                           # (bc, n, k, 16), columns >= m are 0
-                gate, mm_pre = None, None
+                reduce = f0.is_cuda and _TAIL_REDUCE       # (the kernels pool the messages and sum the parameter gradients' terms themselves)
+                pm8 = None if pm is None else pm.contiguous().view(torch.uint8)
+                gate, mm_pre, mm = None, None, None
                 if layer.edge_gate is not None:                                              # soft_edges (:289-290)
                     gw16 = torch.zeros(16, dtype=torch.float32, device=feats.device)
                     gw16[:m] = layer.edge_gate[0].weight.detach()[0]
                     gate = (gw16, layer.edge_gate[0].bias.detach().contiguous())
-                    mm_pre = mm
-                    mm = mm_pre * torch.sigmoid(mm_pre @ gw16 + gate[1])[..., None]
-                mmask = mm if pm is None else mm.masked_fill(~pm[..., None], 0.0)
+                if reduce:
+                    m_sum = _ops.edge_pool(u16, gate, pm8, bc, n, k)
+                else:
+                    mm = torch.nn.functional.silu(u16)                                       # (bc, n, k, 16), columns >= m are 0
+                    if gate is not None:
+                        mm_pre = mm
+                        mm = mm_pre * torch.sigmoid(mm_pre @ gate[0] + gate[1])[..., None]
+                    m_sum = (mm if pm is None else mm.masked_fill(~pm[..., None], 0.0)).sum(dim=2)
                 cnt = None
                 if layer.m_pool_method == "mean":
                     if pm is not None:
-                        cnt = pm.sum(dim=-1, keepdim=True).to(mm.dtype)
-                        m_i = (mmask.sum(dim=2) / cnt.clamp(min=1e-8)).masked_fill(cnt == 0, 0.0)
+                        cnt = pm.sum(dim=-1, keepdim=True).to(m_sum.dtype)
+                        m_i = (m_sum / cnt.clamp(min=1e-8)).masked_fill(cnt == 0, 0.0)
                     else:
-                        m_i = mmask.mean(dim=2)
+                        m_i = m_sum / k
                 else:
-                    m_i = mmask.sum(dim=2)
-                del mmask
+                    m_i = m_sum
+                del m_sum
             with torch.enable_grad():
                 f = f0.detach().requires_grad_(True)
                 c = c0.detach().requires_grad_(True)
                 e = None if e0 is None else e0.detach().requires_grad_(want_ge)
                 closed_dist = s_in == 1                       # the distance is the only per-edge scalar: its backward in closed form below
                 if closed_dist:
-                    with torch.no_grad():
-                        rel, scal = edge_scalars(layer, c0, None, i64)
+                    if not reduce:                            # (reduce: x_i - x_j and the distance are by-products of the tail kernel)
+                        with torch.no_grad():
+                            rel, scal = edge_scalars(layer, c0, None, i64)
                 else:
                     rel, scal = edge_scalars(layer, c, e, i64)                               # (only the scalars' graph is used below)
             if f0.is_cuda and _GRAD_GEMM:
@@ -717,28 +725,44 @@ def _backward_native(ctx, g_node, g_coors):
                 w4p = torch.zeros(64, dtype=torch.float32, device=feats.device)
                 w4p[:hid3] = lin_b.weight.detach()[0]
                 norm = layer.norm_coors
-                tail_out = _ops.edge_tail_bwd(
-                    u16, c0, i32, None if pm is None else pm.contiguous().view(torch.uint8), g_coors[lo:hi_].contiguous(), g_msum, w3p, b3p, w4p,
-                    lin_b.bias.detach().contiguous(), layer.coors_norm.scale.detach() if norm else None,
-                    layer.coors_norm.eps if norm else 0.0, layer.coor_weights_clamp_value, bc, n, k, gate=gate)
-                gu16, g_rel, g_hid, a3, g_w, g_sc = tail_out[:6]
-                if gate is not None:
-                    g_gate = tail_out[6]
-                    grads_by_id[id(layer.edge_gate[0].weight)] += _tn(g_gate[:, None], mm_pre.view(ec, 16))[:, :m]
-                    grads_by_id[id(layer.edge_gate[0].bias)] += g_gate.sum()[None]
-                    del mm_pre, g_gate
-                grads_by_id[id(lin_a.weight)] += _tn(g_hid, mm.view(ec, 16))[:hid3, :m]
-                grads_by_id[id(lin_a.bias)] += g_hid.sum(dim=0)[:hid3]
-                grads_by_id[id(lin_b.weight)] += _tn(g_w[:, None], a3)[:, :hid3]
-                grads_by_id[id(lin_b.bias)] += g_w.sum()[None]
-                if norm:
-                    grads_by_id[id(layer.coors_norm.scale)] += g_sc.sum()[None]
-                del g_hid, a3, mm
+                tail_args = (u16, c0, i32, pm8, g_coors[lo:hi_].contiguous(), g_msum, w3p, b3p, w4p, lin_b.bias.detach().contiguous(),
+                             layer.coors_norm.scale.detach() if norm else None, layer.coors_norm.eps if norm else 0.0,
+                             layer.coor_weights_clamp_value, bc, n, k)
+                bias2 = None
+                if reduce:
+                    gu16, g_rel, sums, rel4, dist = _ops.edge_tail_bwd(*tail_args, gate=gate, reduce=True, want_rel=closed_dist)
+                    grads_by_id[id(lin_a.weight)] += sums[:1024].view(64, 16)[:hid3, :m]
+                    grads_by_id[id(lin_a.bias)] += sums[1024:1024 + hid3]
+                    grads_by_id[id(lin_b.weight)] += sums[1088:1088 + hid3][None, :]
+                    grads_by_id[id(lin_b.bias)] += sums[1184:1185]
+                    if norm:
+                        grads_by_id[id(layer.coors_norm.scale)] += sums[1185:1186]
+                    if gate is not None:
+                        grads_by_id[id(layer.edge_gate[0].weight)] += sums[1168:1168 + m][None, :]
+                        grads_by_id[id(layer.edge_gate[0].bias)] += sums[1186:1187]
+                    bias2 = sums[1152:1152 + m]                                  # column sums of gU = d loss / d edge_mlp's last bias
+                    if closed_dist:
+                        rel, scal = rel4, dist.view(bc, n, k, 1)
+                else:
+                    tail_out = _ops.edge_tail_bwd(*tail_args, gate=gate)
+                    gu16, g_rel, g_hid, a3, g_w, g_sc = tail_out[:6]
+                    if gate is not None:
+                        g_gate = tail_out[6]
+                        grads_by_id[id(layer.edge_gate[0].weight)] += _tn(g_gate[:, None], mm_pre.view(ec, 16))[:, :m]
+                        grads_by_id[id(layer.edge_gate[0].bias)] += g_gate.sum()[None]
+                        del mm_pre, g_gate
+                    grads_by_id[id(lin_a.weight)] += _tn(g_hid, mm.view(ec, 16))[:hid3, :m]
+                    grads_by_id[id(lin_a.bias)] += g_hid.sum(dim=0)[:hid3]
+                    grads_by_id[id(lin_b.weight)] += _tn(g_w[:, None], a3)[:, :hid3]
+                    grads_by_id[id(lin_b.bias)] += g_w.sum()[None]
+                    if norm:
+                        grads_by_id[id(layer.coors_norm.scale)] += g_sc.sum()[None]
+                    del g_hid, a3, mm
                 g_coors_in[lo:hi_] += g_coors[lo:hi_]                              # (the residual; g_rel reaches the coordinates below)
                 if i64 is not None:
                     dest_lists = _ops.dest_lists(i32, bc, n, k, feats.device)                  # (shared with the E x H passes below)
         else:
-            closed_dist, g_rel = False, None
+            closed_dist, g_rel, bias2 = False, None, None
             # ---- 1. the small tail, through autograd
             with torch.enable_grad():
                 f = f0.detach().requires_grad_(True)
@@ -796,12 +820,15 @@ def _backward_native(ctx, g_node, g_coors):
             grads_by_id[id(lin0.bias)] += gz_i.sum(dim=0)[:h]
             g_scal = g_scal.view_as(scal)
             grads_by_id[id(lin3.weight)] += g_w2[:m, :h]
-            grads_by_id[id(lin3.bias)] += gu16[:, :m].sum(dim=0)
+            grads_by_id[id(lin3.bias)] += bias2 if bias2 is not None else gu16[:, :m].sum(dim=0)
             del gz_i, gz_j
         # d loss / d scalars -> coordinates (through d = |x_i - x_j|^2 and the fourier terms) and edge features
         if closed_dist:
             with torch.no_grad():                                   # d = |rel|^2:  d loss / d rel += 2 g_d rel
-                g_rel[:, :3] += (2.0 * g_scal.reshape(ec, 1)) * rel.reshape(ec, 3)
+                if rel.shape[-1] == 4:                              # (the tail kernel's (E, 4) rows, 4th column 0)
+                    g_rel.addcmul_(g_scal.reshape(ec, 1), rel, value=2.0)
+                else:
+                    g_rel[:, :3] += (2.0 * g_scal.reshape(ec, 1)) * rel.reshape(ec, 3)
         else:
             sg = torch.autograd.grad([scal], [c] + ([e] if want_ge else []), [g_scal], allow_unused=True)
             if sg[0] is not None:

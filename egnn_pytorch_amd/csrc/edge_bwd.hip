@@ -537,22 +537,49 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
         }
     }
 
-    if constexpr (WANT_W2 || WANT_S) {
+    // The all-edge partials: one per WORKGROUP for d/d W_2 and (S = 1) d/d W_s -- the four waves' accumulators (and the four lane
+    // groups' of d/d W_s) are added up through LDS in a fixed order (wave 0 .. 3, lane group 0 .. 3): 4x / 16x smaller partial
+    // arrays for the host's final sum (1.1 GB -> 0.27 GB at the north-star shape).
+    if constexpr (WANT_W2) {
+        f32x4* red = reinterpret_cast<f32x4*>(xchall);
+#pragma unroll
+        for (int bl = 0; bl < 2 * CH; ++bl) {
+            __syncthreads();
+            if (wave > 0) red[(wave - 1) * 64 + lane] = dW2[bl];
+            __syncthreads();
+            if (wave == 0 && bl < 2 * nst) {
+                f32x4 sum = dW2[bl];
+                sum += red[lane];
+                sum += red[64 + lane];
+                sum += red[128 + lane];
+                const int col = st0 * 32 + 16 * bl + hq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p.dW2_part[((size_t)slab * 16 + 4 * g + r) * p.Hp + col] = sum[r] * w2_out_scale;
+            }
+        }
+    }
+    if constexpr (WANT_S && !MW) {
+        static_assert(2 * CH * BW_THREADS * 4 <= BW_WAVES * 32 * XLD * 4, "the exchange buffer holds the d/d W_s partials");
+        float* red = xchall;
+        __syncthreads();
+#pragma unroll
+        for (int bl = 0; bl < 2 * CH; ++bl) red[bl * BW_THREADS + tid] = dws[bl][0];
+        __syncthreads();
+        for (int o = tid; o < 2 * nst * 16; o += BW_THREADS) {
+            const int bl = o >> 4, h16 = o & 15;
+            float sum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) sum += red[bl * BW_THREADS + u * 16 + h16];       // u = 4 wave + lane group
+            p.dWs_part[(size_t)slab * p.Hp + st0 * 32 + 16 * bl + h16] = sum * rows_scale;
+        }
+    }
+    if constexpr (MW) {
         const size_t w = (size_t)slab * BW_WAVES + wave;
 #pragma unroll
         for (int bl = 0; bl < 2 * CH; ++bl) {
             if (bl < 2 * nst) {
                 const int col = st0 * 32 + 16 * bl + hq;
-                if constexpr (WANT_W2) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) p.dW2_part[(w * 16 + 4 * g + r) * p.Hp + col] = dW2[bl][r] * w2_out_scale;
-                }
-                if constexpr (WANT_S && !MW) {
-#pragma unroll
-                    for (int c = 0; c < ST; ++c)
-                        if (c < S) p.dWs_part[((w * 4 + g) * S + c) * p.Hp + col] = dws[bl][c] * rows_scale;
-                }
-                if constexpr (MW) {                             // one partial per wave (rows = scalars); the host undoes scal_scale
+                {                             // one partial per wave (rows = scalars); the host undoes scal_scale
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (4 * g + r < S) p.dWs_part[((w * 4) * S + 4 * g + r) * p.Hp + col] = dWsm[bl][r] * (rows_scale * (1.0f / GT_UP));

@@ -11,6 +11,12 @@
 // gradients of coors_mlp are tall products of (g_hid, a3) plus g_w and the per-edge term of d/d CoorsNorm.scale.  In ATen this
 // chain is some thirty elementwise / reduction / small-GEMM passes over E x 16 and E x 64 tensors (6 ms at the north-star shape);
 // here one lane walks its edge's 64 hidden values with the weights broadcast from LDS.
+//
+// REDUCE (args.part): the parameter gradients of coors_mlp / CoorsNorm / the edge gate / edge_mlp's last bias are sums over ALL edges
+// of per-edge products.  Instead of writing the E x 64 factors out for library reductions (1.07 GB at the north-star shape, read
+// back by two split-K products and three column sums), every wave reduces its 64 edges in LDS -- 16 hidden columns at a time, lane
+// (t, c-group) owning four entries of d/d W3 -- and leaves one row of 1192 partial sums; egnn_sum_parts_f32 adds the rows up in
+// fixed order.
 #include "egnn_common.h"
 
 namespace {
@@ -18,7 +24,11 @@ namespace {
 constexpr int TM = 16;       // padded m_dim
 constexpr int TH = 64;       // padded hidden width of coors_mlp (4 m_dim)
 constexpr int SLD = 36;      // floats per row of the store staging (144 B: the 16-byte writes of 16 lanes hit 64 distinct banks)
+constexpr int RLD = 20;      // REDUCE: floats per row of a 16-column block of g_hid / a3
+constexpr int QLD = 40;      // REDUCE: floats per row of the per-edge scalar terms
+constexpr int PART = 1192;   // REDUCE: partial sums per wave: d/d W3 (64 x 16) | d/d b3 (64) | d/d W4 (64) | 40 scalar-term sums (EGNN_TAIL_PART_FLOATS)
 
+template <bool REDUCE>
 __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail_args p)
 {
     // weights in LDS (broadcast reads): as plain global loads they would sit in vector registers -- the compiler cannot prove
@@ -31,16 +41,22 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
     __syncthreads();
     // the two E x 64 outputs leave through LDS: a lane produces 4 columns of ITS row per iteration (16 bytes at a 256-byte stride
     // across the wave), staged per wave as [64 rows][32 columns] and written out as whole 128-byte lines, 8 rows per instruction
-    __shared__ __attribute__((aligned(16))) float stage[4][2][64][SLD];
+    constexpr int STAGE_FLOATS = REDUCE ? 4 * (64 * TM + 64 * QLD + 64) : 4 * 2 * 64 * SLD;
+    __shared__ __attribute__((aligned(16))) float stage_raw[STAGE_FLOATS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float (*stage)[2][64][SLD] = reinterpret_cast<float (*)[2][64][SLD]>(stage_raw);          // (!REDUCE)
+    float* sm = stage_raw + wave * (64 * TM + 64 * QLD + 64);                                   // REDUCE: [64][16] post-gate messages
+    float* sblk = sm + 64 * TM;                                                                // [64][RLD] g_hid block | [64][RLD] a3 block; later [64][QLD]
+    float* sgwe = sblk + 64 * QLD;                                                             // [64] g_w per edge
     const int64_t E = (int64_t)p.B * p.N * p.K;
     const int64_t e_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = e_raw < E;                                               // (lanes behind the last edge compute a copy of it and store nothing)
+    const bool live = e_raw < E;                                               // (lanes behind the last edge compute a copy of it with every gradient zero, and store nothing)
     const int64_t e = live ? e_raw : E - 1;
     const int K = p.K, N = p.N;
     const int64_t ig = e / K;                                                  // global node (b N + i)
     const int64_t jg = p.idx ? (ig / N) * N + p.idx[e] : (ig / N) * N + (e - ig * K);
-    const bool pm = p.pair_mask ? p.pair_mask[e] != 0 : true;
+    const bool pm = live && (p.pair_mask ? p.pair_mask[e] != 0 : true);
+    float* wpart = REDUCE ? p.part + ((size_t)blockIdx.x * 4 + wave) * PART : nullptr;      // this wave's row of partial sums
 
     float u[TM], sgu[TM], m[TM];
     {
@@ -105,9 +121,15 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
 #pragma unroll
     for (int d = 0; d < 3; ++d) g_relp[d] = wc * g[d];
     f32x4 grel;
+    float gsc_e = 0.f;                                                         // this edge's term of d/d CoorsNorm.scale
+    if (p.rel_out && live) {
+        *reinterpret_cast<f32x4*>(p.rel_out + e * 4) = f32x4{rel[0], rel[1], rel[2], 0.f};
+        p.dist_out[e] = (rel[0] * rel[0] + rel[1] * rel[1]) + rel[2] * rel[2];
+    }
     if (p.norm_coors) {
         const float dot = g_relp[0] * rel[0] + g_relp[1] * rel[1] + g_relp[2] * rel[2];
-        if (p.g_scale && live) p.g_scale[e] = dot / den;
+        gsc_e = dot / den;
+        if (!REDUCE && p.g_scale && live) p.g_scale[e] = gsc_e;
         const float k1 = scale / den;
         const float k2 = rn >= p.eps ? dot * scale / (den * den * fmaxf(rn, 1e-30f)) : 0.f;
 #pragma unroll
@@ -124,7 +146,12 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
     if (jg == ig) grel = f32x4{0.f, 0.f, 0.f, 0.f};
     if (live) {
         *reinterpret_cast<f32x4*>(p.g_rel + e * 4) = grel;
-        p.g_w[e] = g_w;
+        if (!REDUCE) p.g_w[e] = g_w;
+    }
+    if constexpr (REDUCE) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(sm + lane * TM + 4 * q) = f32x4{m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]};
+        sgwe[lane] = g_w;
     }
 
     // coors_mlp backward; g_m accumulates W3^T g_hid
@@ -148,6 +175,34 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
 #pragma unroll
             for (int c = 0; c < TM; ++c) gm[c] = __builtin_fmaf(sW3[t * TM + c], gh, gm[c]);
         }
+        if constexpr (REDUCE) {
+            const int q4 = (t0 >> 2) & 3;                                         // 4 iterations fill a block of 16 hidden columns
+            *reinterpret_cast<f32x4*>(sblk + lane * RLD + 4 * q4) = ghv;
+            *reinterpret_cast<f32x4*>(sblk + 64 * RLD + lane * RLD + 4 * q4) = a3v;
+            if (q4 == 3) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                // lane (tt, cg): d/d W3[t][4 cg .. 4 cg + 3], and the column sums d/d b3[t], d/d W4[t], over the wave's 64 edges in order
+                const int tt = lane & 15, cg = lane >> 4, tb = t0 >> 4;
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                float accb = 0.f, accw = 0.f;
+#pragma unroll 4
+                for (int ee = 0; ee < 64; ++ee) {
+                    const float gh = sblk[ee * RLD + tt];
+                    const float a3 = sblk[64 * RLD + ee * RLD + tt];
+                    const f32x4 m4 = *reinterpret_cast<const f32x4*>(sm + ee * TM + 4 * cg);
+                    acc += m4 * gh;
+                    accb += gh;
+                    accw = __builtin_fmaf(sgwe[ee], a3, accw);
+                }
+                *reinterpret_cast<f32x4*>(wpart + (16 * tb + tt) * TM + 4 * cg) = acc;
+                if (cg == 0) wpart[TH * TM + 16 * tb + tt] = accb;
+                if (cg == 1) wpart[TH * TM + TH + 16 * tb + tt] = accw;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+            continue;
+        }
         const int part = (t0 >> 2) & 7;                                          // 8 iterations fill 32 columns = one line per row
         *reinterpret_cast<f32x4*>(&stage[wave][0][lane][4 * part]) = ghv;
         *reinterpret_cast<f32x4*>(&stage[wave][1][lane][4 * part]) = a3v;
@@ -168,15 +223,16 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
             __builtin_amdgcn_wave_barrier();
         }
     }
+    float gs = 0.f;
     if (p.gate_w) {
         // through the gate: m = m0 gt  =>  d/d m0 = gm gt + (gm . m0) gt (1 - gt) gate_w,   d/d (gate pre-activation) = (gm . m0) gt (1 - gt)
         float dot = 0.f;
 #pragma unroll
         for (int c = 0; c < TM; ++c) dot = __builtin_fmaf(gm[c], u[c] * sgu[c], dot);
-        const float gs = dot * gt * gtc;
+        gs = dot * gt * gtc;
 #pragma unroll
         for (int c = 0; c < TM; ++c) gm[c] = __builtin_fmaf(gs, sgw[c], gm[c] * gt);
-        if (live) p.g_gate[e] = gs;
+        if (!REDUCE && live) p.g_gate[e] = gs;
     }
     f32x4* gup = reinterpret_cast<f32x4*>(p.gU + e * TM);
 #pragma unroll
@@ -188,7 +244,47 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
             v[c] = gm[cc] * (sgu[cc] * (1.0f + u[cc] * (1.0f - sgu[cc])));
         }
         if (live) gup[q] = v;
+        if constexpr (REDUCE) {
+            // per-edge scalar terms, summed over the wave's edges below: [0, 16) d loss / d u (-> edge_mlp's last bias),
+            // [16, 32) gate term x SiLU(u) (-> d/d gate weight), 32 g_w (-> d/d b4), 33 CoorsNorm.scale term, 34 gate term (-> d/d gate bias)
+            *reinterpret_cast<f32x4*>(sblk + lane * QLD + 4 * q) = v;
+            *reinterpret_cast<f32x4*>(sblk + lane * QLD + 16 + 4 * q) =
+                f32x4{gs * (u[4 * q] * sgu[4 * q]), gs * (u[4 * q + 1] * sgu[4 * q + 1]), gs * (u[4 * q + 2] * sgu[4 * q + 2]), gs * (u[4 * q + 3] * sgu[4 * q + 3])};
+        }
     }
+    if constexpr (REDUCE) {
+        *reinterpret_cast<f32x4*>(sblk + lane * QLD + 32) = f32x4{g_w, gsc_e, gs, 0.f};
+        *reinterpret_cast<f32x4*>(sblk + lane * QLD + 36) = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < QLD) {
+            float acc = 0.f;
+#pragma unroll 8
+            for (int ee = 0; ee < 64; ++ee) acc += sblk[ee * QLD + lane];
+            wpart[TH * TM + 2 * TH + lane] = acc;
+        }
+    }
+}
+
+// Pooled messages for the backward's node-level part: m_sum[node] = sum over the node's K edges of pair_mask * SiLU(u) * gate
+// (egnn_pytorch.py:287-290, :319-326) -- 16 lanes (channels) per node, the edge gate's dot product as a DPP row sum.
+__global__ __launch_bounds__(256) void edge_pool_kernel(const float* __restrict__ u, const float* __restrict__ gate_w, const float* __restrict__ gate_b,
+                                                        const uint8_t* __restrict__ pair_mask, int64_t nodes, int K, float* __restrict__ m_sum)
+{
+    const int c = threadIdx.x & 15;
+    const int64_t node_raw = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t node = node_raw < nodes ? node_raw : nodes - 1;
+    const float gw = gate_w ? gate_w[c] : 0.f;
+    const float gb = gate_w ? gate_b[0] : 0.f;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const int64_t e = node * K + k;
+        float m = egnn_silu(u[e * TM + c]);
+        if (gate_w) m *= egnn_sigmoid(egnn_row16_sum(gw * m) + gb);
+        if (pair_mask && !pair_mask[e]) m = 0.f;
+        acc += m;
+    }
+    if (node_raw < nodes) m_sum[node * TM + c] = acc;
 }
 
 }  // namespace
@@ -197,18 +293,35 @@ extern "C" int egnn_edge_tail_bwd_f32(const egnn_edge_tail_args* args, void* str
 {
     if (!args) return EGNN_E_NULLPTR;
     const egnn_edge_tail_args& a = *args;
-    if (!a.u || !a.coors || !a.g_coors_out || !a.g_msum || !a.W3 || !a.b3 || !a.W4 || !a.b4 || !a.gU || !a.g_rel || !a.g_hid || !a.a3 || !a.g_w)
-        return EGNN_E_NULLPTR;
-    if (a.norm_coors && (!a.scale || !a.g_scale)) return EGNN_E_NULLPTR;
-    if (a.gate_w && (!a.gate_b || !a.g_gate)) return EGNN_E_NULLPTR;
+    if (!a.u || !a.coors || !a.g_coors_out || !a.g_msum || !a.W3 || !a.b3 || !a.W4 || !a.b4 || !a.gU || !a.g_rel) return EGNN_E_NULLPTR;
+    if (!a.part && (!a.g_hid || !a.a3 || !a.g_w)) return EGNN_E_NULLPTR;
+    if (a.norm_coors && (!a.scale || (!a.part && !a.g_scale))) return EGNN_E_NULLPTR;
+    if (a.gate_w && (!a.gate_b || (!a.part && !a.g_gate))) return EGNN_E_NULLPTR;
+    if ((a.rel_out == nullptr) != (a.dist_out == nullptr)) return EGNN_E_NULLPTR;
     if (a.B <= 0 || a.N <= 0 || a.K <= 0) return EGNN_E_SHAPE;
     if (a.idx == nullptr && a.K != a.N) return EGNN_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(a.u) & 15) || (reinterpret_cast<uintptr_t>(a.gU) & 15) || (reinterpret_cast<uintptr_t>(a.g_rel) & 15) ||
-        (reinterpret_cast<uintptr_t>(a.g_hid) & 15) || (reinterpret_cast<uintptr_t>(a.a3) & 15))
+        (reinterpret_cast<uintptr_t>(a.g_hid) & 15) || (reinterpret_cast<uintptr_t>(a.a3) & 15) || (reinterpret_cast<uintptr_t>(a.part) & 15) ||
+        (reinterpret_cast<uintptr_t>(a.rel_out) & 15))
         return EGNN_E_ALIGN;
     const int64_t E = (int64_t)a.B * a.N * a.K;
     const int64_t blocks = (E + 255) / 256;
     if (blocks >= ((int64_t)1 << 31)) return EGNN_E_SHAPE;
-    hipLaunchKernelGGL(edge_tail_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (a.part) hipLaunchKernelGGL(edge_tail_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(edge_tail_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return egnn_launch_status();
+}
+
+extern "C" int egnn_edge_tail_part_floats(void) { return PART; }
+
+extern "C" int egnn_edge_pool_f32(const float* u, const float* gate_w, const float* gate_b, const uint8_t* pair_mask, int B, int N, int K,
+                                  float* m_sum, void* stream)
+{
+    if (!u || !m_sum || (gate_w && !gate_b)) return EGNN_E_NULLPTR;
+    if (B <= 0 || N <= 0 || K <= 0) return EGNN_E_SHAPE;
+    const int64_t nodes = (int64_t)B * N;
+    const int64_t blocks = (nodes + 15) / 16;
+    if (blocks >= ((int64_t)1 << 31)) return EGNN_E_SHAPE;
+    hipLaunchKernelGGL(edge_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), u, gate_w, gate_b, pair_mask, nodes, K, m_sum);
     return egnn_launch_status();
 }

@@ -314,6 +314,7 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
 {
     for (int64_t o = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; o < count; o += (int64_t)gridDim.x * 1024) {
         f32x4 acc = *reinterpret_cast<const f32x4*>(parts + o);
+#pragma unroll 8
         for (int p = 1; p < nparts; ++p) acc += *reinterpret_cast<const f32x4*>(parts + (size_t)p * count + o);     // fixed order
         *reinterpret_cast<f32x4*>(out + o) = acc * scale;
     }

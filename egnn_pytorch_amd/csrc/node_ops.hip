@@ -205,13 +205,19 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ X
     const int64_t quads = count >> 2;
     const int64_t stride = (int64_t)gridDim.x * 256;
     uint32_t m = 0u;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += stride) {
-        const uint4 v = reinterpret_cast<const uint4*>(X)[q];
+    auto fold = [&](const uint4 v) {
         const uint32_t a = v.x & 0x7fffffffu, b = v.y & 0x7fffffffu, c = v.z & 0x7fffffffu, d = v.w & 0x7fffffffu;
         const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
         const uint32_t t = ab > cd ? ab : cd;
         m = m > t ? m : t;
+    };
+    int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; q + 3 * stride < quads; q += 4 * stride) {                  // four independent 16-byte loads in flight per thread
+        const uint4 v0 = reinterpret_cast<const uint4*>(X)[q], v1 = reinterpret_cast<const uint4*>(X)[q + stride];
+        const uint4 v2 = reinterpret_cast<const uint4*>(X)[q + 2 * stride], v3 = reinterpret_cast<const uint4*>(X)[q + 3 * stride];
+        fold(v0); fold(v1); fold(v2); fold(v3);
     }
+    for (; q < quads; q += stride) fold(reinterpret_cast<const uint4*>(X)[q]);
     if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
         const uint32_t t = __float_as_uint(X[(quads << 2) + threadIdx.x]) & 0x7fffffffu;
         m = m > t ? m : t;
@@ -267,8 +273,8 @@ extern "C" int egnn_absmax_f32(const float* X, int64_t count, uint32_t* out_bits
     if (reinterpret_cast<uintptr_t>(X) & 15) return EGNN_E_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(out_bits, 0, sizeof(uint32_t), s) != hipSuccess) return (int)hipGetLastError();
-    int64_t blocks = ((count >> 2) + 256 * 8 - 1) / (256 * 8);           // ~8 quads per thread
-    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    int64_t blocks = ((count >> 2) + 256 * 16 - 1) / (256 * 16);         // ~16 quads per thread
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, count, out_bits);
     return egnn_launch_status();
 }

@@ -327,8 +327,8 @@ int egnn_edge_bwd_dz_f32(const egnn_edge_args* args, void* stream);
  * dz = (W2^T gU) SiLU'(z), and contracts them in registers:
  *     part_rows[q / 16, :]   = sum of dz over tile q / 16     (d/d P_i or d/d P_j after egnn_rows_gather_sum_f32 over each node's
  *                              consecutive tiles -- fixed order, no float atomics; row_pairs: one row per node directly)
- *     dW2_part (n_slabs * 4, 16, Hp),  if not NULL:  partial sums of gU^T a  -> d loss / d edge_mlp.3.weight  = sum over dim 0
- *     dWs_part (n_slabs * 16, S, Hp) -- S > 1: rows multiples of 4 only, times scal_scale[c] -- and ds_part (n_chunks, E, S),
+ *     dW2_part (n_slabs, 16, Hp),  if not NULL:  partial sums of gU^T a  -> d loss / d edge_mlp.3.weight  = sum over dim 0
+ *     dWs_part (S = 1: (n_slabs, Hp);  S > 1: (n_slabs * 16, S, Hp), rows multiples of 4 only, times scal_scale[c]) and ds_part (n_chunks, E, S),
  *                              if not NULL (both or neither): partial sums of s^T dz
  *                              -> d loss / d (scalar columns of edge_mlp.0.weight), and dz W_s over each column chunk
  *                              -> d loss / d scalars = sum over dim 0   (n_chunks = ceil(Hp / 32 / egnn_edge_bwd_chunk_steps()))
@@ -369,6 +369,12 @@ typedef struct egnn_edge_bwd_args {
     int64_t work_bytes;         /*   the scalars' first-layer terms, in list order), written by a first launch, read once per column chunk */
 } egnn_edge_bwd_args;
 
+int egnn_edge_tail_part_floats(void);
+/* The pooled messages the backward's node-level part starts from (egnn_pytorch.py:287-290, :319-326, sum pooling): m_sum (B*N, 16) =
+ * sum over k of pair_mask * SiLU(u) * gate, from u (E, 16) = edge_mlp's second Linear output; gate_w (16) / gate_b (1) or NULL,
+ * pair_mask (E) bytes or NULL. */
+int egnn_edge_pool_f32(const float* u, const float* gate_w, const float* gate_b, const uint8_t* pair_mask, int B, int N, int K,
+                       float* m_sum, void* stream);
 int egnn_edge_bwd_pass_f32(const egnn_edge_bwd_args* args, void* stream);
 int egnn_edge_bwd_chunk_steps(void);    /* hidden steps (of 32 columns) one workgroup owns: sizes ds_part */
 /* bytes of egnn_edge_bwd_args.work for a list of L entries; want_w2 / want_s = dW2_part / dWs_part not NULL; 0 = outside the limits */
@@ -406,6 +412,12 @@ typedef struct egnn_edge_tail_args {
     const float* gate_w;        /* (16) edge_gate.0.weight zero padded, or NULL (soft_edges=False): m_ij = SiLU(u) sigmoid(gate_w . SiLU(u) + gate_b) */
     const float* gate_b;        /* (1) */
     float* g_gate;              /* out (E): d loss / d (gate pre-activation) -- d/d gate_w = sum_e g_gate[e] SiLU(u_e), d/d gate_b = sum_e g_gate[e] */
+    float* part;                /* out or NULL: (ceil(E / 256) * 4, egnn_edge_tail_part_floats()) -- per wave of 64 edges the sums the parameter gradients */
+                                /*   are made of, INSTEAD of g_hid / a3 / g_w / g_scale / g_gate (those may be NULL): [0, 1024) d/d W3 (64 x 16), */
+                                /*   [1024, 1088) d/d b3, [1088, 1152) d/d W4, then 40 scalars: [0, 16) column sums of gU, [16, 32) d/d gate_w, */
+                                /*   32 d/d b4, 33 d/d CoorsNorm.scale, 34 d/d gate_b, rest 0.  Summed over rows by egnn_sum_parts_f32 (fixed order). */
+    float* rel_out;             /* out or NULL: (E, 4) x_i - x_j (4th 0) and, with it, dist_out (E) = |x_i - x_j|^2 -- what the backward of the */
+    float* dist_out;            /*   distance path needs (d loss / d rel += 2 g_dist rel), by-products of this pass */
 } egnn_edge_tail_args;
 
 int egnn_edge_tail_bwd_f32(const egnn_edge_tail_args* args, void* stream);

@@ -437,6 +437,72 @@ def test_tail_kernel_matches_closed_form(kw, use_mask, dense):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw,use_mask,dense", TAIL_CASES)
+def test_tail_kernel_reduce_mode_and_pool_match_closed_form(kw, use_mask, dense):
+    """egnn_edge_tail_bwd_f32 with `part` (every wave sums its edges' parameter-gradient terms; egnn_sum_parts_f32 adds the rows up)
+    against the float64 specification: gU / g_rel as in the plain mode, the summed terms against the spec's tall products, the
+    by-products rel / dist, two runs bit-identical; and egnn_edge_pool_f32 against the masked, gated message sum."""
+    from egnn_pytorch_amd import _ops, autograd as A
+    layer, u, coors, idx, pm, gc, g_msum, _ = _tail_case(kw, use_mask, dense, torch.float32, "cuda", n=40, b=3)
+    b, n, k, m = u.shape
+    layer64 = __import__("copy").deepcopy(layer).double()
+    want = A.tail_edge_backward(layer64, u.double(), coors.double(), idx, pm, gc.double(), g_msum.double())
+    e = b * n * k
+    u16 = torch.zeros(b, n, k, 16, device="cuda"); u16[..., :m] = u
+    gm16 = torch.zeros(b, n, 16, device="cuda"); gm16[..., :m] = g_msum
+    la, lb = layer.coors_mlp[0], layer.coors_mlp[3]
+    hid3 = la.weight.shape[0]
+    w3p = torch.zeros(64, 16, device="cuda"); w3p[:hid3, :m] = la.weight.detach()
+    b3p = torch.zeros(64, device="cuda"); b3p[:hid3] = la.bias.detach()
+    w4p = torch.zeros(64, device="cuda"); w4p[:hid3] = lb.weight.detach()[0]
+    norm = layer.norm_coors
+    gate = None
+    if layer.edge_gate is not None:
+        gw16 = torch.zeros(16, device="cuda"); gw16[:m] = layer.edge_gate[0].weight.detach()[0]
+        gate = (gw16, layer.edge_gate[0].bias.detach().contiguous())
+    pm8 = None if pm is None else pm.contiguous().view(torch.uint8)
+    args = (u16, coors.contiguous(), None if idx is None else idx.to(torch.int32).contiguous(), pm8, gc.contiguous(), gm16, w3p, b3p, w4p,
+            lb.bias.detach().contiguous(), layer.coors_norm.scale.detach() if norm else None, layer.coors_norm.eps if norm else 0.0,
+            layer.coor_weights_clamp_value, b, n, k)
+    gu, g_rel, sums, rel, dist = _ops.edge_tail_bwd(*args, gate=gate, reduce=True, want_rel=True)
+    again = _ops.edge_tail_bwd(*args, gate=gate, reduce=True, want_rel=True)
+    assert torch.equal(sums, again[2]) and torch.equal(gu, again[0])
+    plain = _ops.edge_tail_bwd(*args, gate=gate)
+    assert torch.equal(gu, plain[0]) and torch.equal(g_rel, plain[1])               # same per-edge arithmetic in both modes
+    pg = _tail_param_grads(want)
+    got = {"coors_mlp.0.weight": sums[:1024].view(64, 16)[:hid3, :m], "coors_mlp.0.bias": sums[1024:1024 + hid3],
+           "coors_mlp.3.weight": sums[1088:1088 + hid3][None], "coors_mlp.3.bias": sums[1184:1185],
+           "coors_norm.scale": sums[1185:1186] if norm else None,
+           "edge_gate.0.weight": sums[1168:1168 + m][None] if gate is not None else None,
+           "edge_gate.0.bias": sums[1186:1187] if gate is not None else None}
+    l1 = {"coors_mlp.3.bias": "g_w", "coors_norm.scale": "g_scale", "edge_gate.0.bias": "g_gate"}
+    for key, t in got.items():
+        if t is None:
+            continue
+        ref = pg[key].reshape(t.shape)
+        scale = max(1e-30, float(ref.abs().max()))
+        if key in l1:                                   # a scalar: a sum of E signed terms that may cancel -- measured against their L1 norm
+            scale = max(scale, float(want[l1[key]].abs().sum()))
+        assert float((t.double() - ref).abs().max()) <= 2e-5 * scale, key
+    col = want["g_u"].reshape(e, m).sum(dim=0)
+    assert float((sums[1152:1152 + m].double() - col).abs().max()) <= 2e-5 * max(1e-30, float(col.abs().max()))
+    assert float(sums[1187:].abs().max()) == 0.0
+    j = torch.arange(n, device="cuda")[None, None, :].expand(b, n, n) if idx is None else idx
+    bi = torch.arange(b, device="cuda")[:, None, None]
+    rel_ref = (coors[:, :, None, :] - coors[bi, j]).reshape(e, 3)
+    assert torch.equal(rel[:, :3], rel_ref) and float(rel[:, 3].abs().max()) == 0.0
+    torch.testing.assert_close(dist, (rel_ref.double() ** 2).sum(-1).float(), rtol=1e-6, atol=1e-6)
+    # pooled messages
+    mm = torch.nn.functional.silu(u16.double())
+    if gate is not None:
+        mm = mm * torch.sigmoid(mm @ gate[0].double() + gate[1].double())[..., None]
+    if pm is not None:
+        mm = mm.masked_fill(~pm[..., None], 0.0)
+    pooled = _ops.edge_pool(u16, gate, pm8, b, n, k)
+    assert float((pooled.double() - mm.sum(dim=2)).abs().max()) <= 2e-6 * float(mm.sum(dim=2).abs().max())
+
+
+@pytest.mark.gpu
 def test_backward_full_size_properties():
     """The native backward at the north-star size (B=64, N=1024, dim=512, k=32, ragged masks) through size-independent properties:
     two runs bit-identical (every sum over edges has a fixed order, no float atomics), the backward is linear in the cotangent
