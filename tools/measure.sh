@@ -3,6 +3,7 @@
 #   * full GPU test suite + smoke()
 #   * the default bench line with the reference timed on the host cores, on the MI355X through PyTorch eager, and one training step
 #   * ragged masks and the other BASELINE.json configs at full size
+#   * one training step with per-kernel HIP-event times, the EGNN_Network configurations under autograd, rocprofv3 kernel trace of the training step
 #   * tools/profile.sh: rocprofv3 kernel trace + stats of the default command and one PMC pass per counter group
 # Everything lands under gpurun_out/prof_<tag>/; the summaries to keep are copied into profiles/<tag>/ afterwards.
 TAG="${1:-r03_final}"
@@ -20,5 +21,8 @@ for w in c2_dense c3_network c4_sparse c5_shard; do
   python bench.py --workload $w > $OUT/bench_$w.json 2>> $OUT/bench_line.err; head -c 160 $OUT/bench_$w.json; echo
 done
 python bench.py --workload c4_sparse --no-cpu-baseline --train-step > $OUT/bench_train_step_c4_sparse.json 2>> $OUT/bench_line.err
+python tools/train_step_probe.py 3 > $OUT/train_step_kernels.txt 2>&1; tail -2 $OUT/train_step_kernels.txt | cut -c1-400
+EGNN_PROBE_PHASES=1 python tools/net_train_probe.py > $OUT/net_train_step.txt 2>&1; grep "^c[35]" $OUT/net_train_step.txt
+bash tools/train_trace.sh $TAG > $OUT/train_trace.log 2>&1; cp gpurun_out/train_$TAG/kernels.txt $OUT/train_step_kernel_trace.txt; tail -1 $OUT/train_trace.log
 bash tools/profile.sh $TAG 2>&1 | tail -70
 rm -f $OUT/trace/*kernel_trace.csv $OUT/trace/*/*kernel_trace.csv $OUT/pmc*/*/*kernel_trace.csv $OUT/pmc*/*kernel_trace.csv 2>/dev/null

@@ -22,3 +22,11 @@ for name, kw, b, n in (("c3_network", dict(depth=3, dim=128, num_nearest_neighbo
         torch.cuda.synchronize(); t2 = time.perf_counter()
         net.zero_grad(); feats.grad = None; coors.grad = None
     print(f"{name}: forward {1e3 * (t1 - t0):.2f} ms, backward {1e3 * (t2 - t1):.2f} ms, peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+    if os.environ.get("EGNN_PROBE_PHASES"):
+        from egnn_pytorch_amd import _ops
+        with _ops.phase_timer() as t:
+            f, c = net(feats, coors, mask=mask)
+            (f.square().mean() + c.square().mean()).backward()
+            torch.cuda.synchronize()
+        print({k: round(sum(v), 3) for k, v in t.summary().items()}, flush=True)
+        net.zero_grad(); feats.grad = None; coors.grad = None
