@@ -63,7 +63,7 @@ def edge_mfmas(s: int) -> int:
     return 1 if s <= 1 else (3 if s <= 4 else (4 if s <= 5 else (6 if s <= 8 else 12)))
 
 
-def scalar_table(ws: torch.Tensor):
+def scalar_table(ws: torch.Tensor, amax=None):
     """(S, Hp) fp32 scalar weights -> (Wst, ws_inv_scale).  Wst is (Hp, 4 * edge_mfmas(S), 2) fp16: per hidden unit h
     the (fp16, fp16) words that sit in K-slots 4g+2, 4g+3 of lane group g of first-layer MFMA m
     (v_mfma_f32_16x16x16_f16; K-slots 4g, 4g+1 belong to the (hi, lo) pair of P_i), term index 4 m + g = 3 s + kind:
@@ -73,7 +73,7 @@ def scalar_table(ws: torch.Tensor):
     with s' = s / c the per-edge scalar and c = ws_scale the power of two that brings max|W| into [1, 2).  The five
     products add up to W * s with ~2^-22 relative error for |s'| < 6e7 (dist^2: |rel| < ~7000 length units)."""
     s_, hp = ws.shape
-    c = pow2_scale(float(ws.abs().max()) if ws.numel() else 0.0)
+    c = pow2_scale((float(ws.abs().max()) if ws.numel() else 0.0) if amax is None else amax)       # (amax: max |ws| if the caller has it)
     w = (ws * c).t().contiguous()                                    # (Hp, S)
     wa = w * SCALAR_SHIFT
     hi, ahi = w.half(), wa.half()
@@ -122,9 +122,37 @@ def split_f16(w: torch.Tensor):
     return pack_tiles(hi), pack_tiles(lo), 1.0 / scale, npad
 
 
+def _f32_mul(a: float, b: float) -> float:
+    """a * b rounded to fp32 (what max |w * b| is for fp32 tensors when a = max |w|: rounding is monotone)."""
+    import numpy as np
+    return float(np.float32(a) * np.float32(abs(b)))
+
+
+def split_f16_device(pieces, n_rows: int, k: int, amax: float, factor: float = 1.0):
+    """split_f16 of the (n_rows, k) matrix made of `pieces` = [(X, first image row, transposed)], X a 2-D fp32 view with unit column
+    stride holding the rows from `first image row` on (or, transposed, X^T does), everything else zero, times `factor`: the same
+    (W_hi, W_lo, inv_scale, w_rows) bit for bit -- one memset and one egnn_split_scaled_f16 launch per image / piece instead of ~22
+    small tensor ops and a host read.  amax = max |X| over the pieces (the caller reads all of a layer's maxima in ONE transfer)."""
+    from . import _abi, _ops
+    dev = pieces[0][0].device
+    npad, kpad = (n_rows + 255) // 256 * 256, (k + 31) // 32 * 32
+    scale = pow2_scale(_f32_mul(amax, factor))
+    hi = torch.zeros(npad * kpad, dtype=torch.float16, device=dev)
+    lo = torch.zeros(npad * kpad, dtype=torch.float16, device=dev)
+    lib = _abi.load()
+    for x, row0, transposed in pieces:
+        assert x.dtype == torch.float32 and x.stride(1) == 1 and row0 % 32 == 0
+        off = row0 * kpad * 2                                        # bytes: whole 32-row blocks are contiguous in the packed layout
+        rc = lib.egnn_split_scaled_f16(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], float(scale * factor), int(transposed),
+                                       hi.data_ptr() + off, lo.data_ptr() + off, kpad, None, _ops._stream())
+        _abi.check(rc, "egnn_split_scaled_f16")
+    return hi, lo, 1.0 / scale, npad
+
+
 def pack(layer) -> dict:
     """Build the kernel-side weight set of one EGNN layer.  All outputs are fp32, contiguous, on the
-    parameters' device."""
+    parameters' device.  On the GPU the seven GEMM weight images come from split_f16_device and every maximum the scales are
+    chosen from is read in one transfer (an optimizer step invalidates the cache: this runs once per layer and training step)."""
     w1 = layer.edge_mlp[0].weight.detach().float()
     b1 = layer.edge_mlp[0].bias.detach().float()
     w2 = layer.edge_mlp[3].weight.detach().float()
@@ -138,6 +166,19 @@ def pack(layer) -> dict:
     hp = padded_hidden(h)
     check_scalars(s)
     z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+    on_dev = w1.is_cuda
+    am = None
+    if on_dev:
+        # every maximum the power-of-two scales below are chosen from, in ONE host read
+        zero = torch.zeros((), dtype=torch.float32, device=dev)
+        mx = lambda t: t.abs().max() if t.numel() else zero
+        tens = [mx(w1[:, :dim]), mx(w1[:, dim:2 * dim]), mx(w1[:, 2 * dim:]), mx(w2)]
+        tens.append(mx(layer.coors_mlp[0].weight.detach().float()) if layer.coors_mlp is not None else zero)
+        if layer.node_mlp is not None:
+            tens += [mx(layer.node_mlp[0].weight.detach().float()), mx(layer.node_mlp[3].weight.detach().float())]
+        else:
+            tens += [zero, zero]
+        am = dict(zip(("wi", "wj", "ws", "w2", "w3", "w5", "w6"), torch.stack(tens).tolist()))
 
     wcat = z(2 * hp, dim)
     wcat[:h] = w1[:, :dim] * NEG_LOG2E
@@ -146,11 +187,11 @@ def pack(layer) -> dict:
     bcat[:h] = b1 * NEG_LOG2E
     ws = z(s, hp)
     ws[:, :h] = w1[:, 2 * dim:].t() * NEG_LOG2E
-    wst, ws_inv_scale = scalar_table(ws)
+    wst, ws_inv_scale = scalar_table(ws, None if am is None else _f32_mul(am["ws"], NEG_LOG2E))
 
     w2p = z(M_PAD, hp)
     w2p[:m, :h] = w2 * NEG_LN2
-    amax = float(w2p.abs().max())
+    amax = float(w2p.abs().max()) if am is None else _f32_mul(am["w2"], NEG_LN2)
     w2_scale = 2.0 ** (-math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
     w2s = w2p * w2_scale                                   # max |.| in [1, 2)
     w2_hi = w2s.half()
@@ -162,20 +203,29 @@ def pack(layer) -> dict:
     b2p = z(M_PAD)
     b2p[:m] = b2
 
-    out = dict(H=h, Hp=hp, S=s, Wcat=wcat, Wcat_split=split_f16(wcat), bcat=bcat, Ws=ws, Wst=wst,
+    w_i, w_j = w1[:, :dim], w1[:, dim:2 * dim]
+    if on_dev:
+        wcat_split = split_f16_device([(w_i, 0, False), (w_j, hp, False)], 2 * hp, dim, max(am["wi"], am["wj"]), NEG_LOG2E)
+    else:
+        wcat_split = split_f16(wcat)
+    out = dict(H=h, Hp=hp, S=s, Wcat=wcat, Wcat_split=wcat_split, bcat=bcat, Ws=ws, Wst=wst,
                ws_inv_scale=ws_inv_scale, W2h=w2h, w2_inv_scale=1.0 / w2_scale, b2=b2p)
     # backward, d/d feats = dP_i W_i + dP_j W_j (natural units): the W operands of that GEMM are the transposes, (dim, Hp)
-    wit, wjt = z(dim, hp), z(dim, hp)
-    wit[:, :h] = w1[:, :dim].t()
-    wjt[:, :h] = w1[:, dim:2 * dim].t()
-    out["WiT_split"] = split_f16(wit)
-    out["WjT_split"] = split_f16(wjt)
+    if on_dev:
+        out["WiT_split"] = split_f16_device([(w_i, 0, True)], dim, hp, am["wi"])
+        out["WjT_split"] = split_f16_device([(w_j, 0, True)], dim, hp, am["wj"])
+    else:
+        wit, wjt = z(dim, hp), z(dim, hp)
+        wit[:, :h] = w_i.t()
+        wjt[:, :h] = w_j.t()
+        out["WiT_split"] = split_f16(wit)
+        out["WjT_split"] = split_f16(wjt)
     if nb == 1:
         # backward (egnn_edge_bwd_dz_f32): W2^T in natural units as A fragments of v_mfma_f32_16x16x16_f16,
         # [step][hb][hi|lo][lane = 16 g + r][u] = W2[4 g + u][32 step + 16 hb + r]
         w2t = z(hp, 16)
         w2t[:h, :m] = w2.t()
-        t_scale = pow2_scale(float(w2t.abs().max()) if w2t.numel() else 0.0)
+        t_scale = pow2_scale((float(w2t.abs().max()) if w2t.numel() else 0.0) if am is None else am["w2"])
         w2ts = w2t * t_scale
         t_hi = w2ts.half()
         t_lo = (w2ts - t_hi.float()).half()
@@ -192,7 +242,7 @@ def pack(layer) -> dict:
         w3 = layer.coors_mlp[0].weight.detach().float()          # (4m, m)
         w3p = z(C_PAD, M_PAD)
         w3p[:4 * m, :m] = w3
-        a3 = float(w3p.abs().max())
+        a3 = float(w3p.abs().max()) if am is None else am["w3"]
         w3_scale = 2.0 ** (-math.floor(math.log2(a3))) if a3 > 0 and math.isfinite(a3) else 1.0
         w3s = w3p * w3_scale
         w3_hi = w3s.half()
@@ -210,11 +260,18 @@ def pack(layer) -> dict:
                    b5=layer.node_mlp[0].bias.detach().float().contiguous(),
                    W6=layer.node_mlp[3].weight.detach().float().contiguous(),
                    b6=layer.node_mlp[3].bias.detach().float().contiguous())
-        out["W5_split"] = split_f16(out["W5"])
-        out["W6_split"] = split_f16(out["W6"])
-        # backward: d/d (node_mlp input) = g W5, d/d (hidden) = g W6 -- the W operands are the transposes
-        out["W5T_split"] = split_f16(out["W5"].t().contiguous())
-        out["W6T_split"] = split_f16(out["W6"].t().contiguous())
+        w5, w6 = out["W5"], out["W6"]
+        # (backward: d/d (node_mlp input) = g W5, d/d (hidden) = g W6 -- the W operands are the transposes)
+        if on_dev:
+            out["W5_split"] = split_f16_device([(w5, 0, False)], w5.shape[0], w5.shape[1], am["w5"])
+            out["W6_split"] = split_f16_device([(w6, 0, False)], w6.shape[0], w6.shape[1], am["w6"])
+            out["W5T_split"] = split_f16_device([(w5, 0, True)], w5.shape[1], w5.shape[0], am["w5"])
+            out["W6T_split"] = split_f16_device([(w6, 0, True)], w6.shape[1], w6.shape[0], am["w6"])
+        else:
+            out["W5_split"] = split_f16(w5)
+            out["W6_split"] = split_f16(w6)
+            out["W5T_split"] = split_f16(w5.t().contiguous())
+            out["W6T_split"] = split_f16(w6.t().contiguous())
         if layer.norm_feats:
             out.update(gamma=layer.node_norm.weight.detach().float().contiguous(),
                        beta=layer.node_norm.bias.detach().float().contiguous(),

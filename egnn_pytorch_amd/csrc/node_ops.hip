@@ -285,7 +285,8 @@ extern "C" int egnn_split_scaled_f16(const float* X, int64_t ldx, int64_t rows, 
     if (!X || !hi || !lo) return EGNN_E_NULLPTR;
     const int64_t k_extent = transposed ? rows : cols;                  // the K dimension of the image
     const int64_t img_rows = transposed ? cols : rows;
-    if (rows <= 0 || cols <= 0 || ldx < cols || Kp < k_extent || (Kp % 32) != 0 || !(scale > 0.f)) return EGNN_E_SHAPE;
+    if (rows <= 0 || cols <= 0 || ldx < cols || Kp < k_extent || (Kp % 32) != 0 || !(scale != 0.f) || !(fabsf(scale) < __builtin_inff()))
+        return EGNN_E_SHAPE;                                                // (a negative factor -- the forward's -log2 e -- is fine)
     // the grid covers the padded image exactly: image rows up to a multiple of 32, K up to Kp (tiles of 64 x 32 or 32 x 64 of X)
     const int64_t rows_cover = transposed ? Kp : (img_rows + 31) / 32 * 32;
     const int64_t cols_cover = transposed ? (img_rows + 31) / 32 * 32 : Kp;

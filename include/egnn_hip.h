@@ -175,8 +175,9 @@ int egnn_linear_hl_drop_f32(const void* A_hi, const void* A_lo, const void* W_hi
 /* The backward's node-level gradient products (autograd of egnn_pytorch.py:287, 336: d/d feats = dP W, d/d W = dP^T feats) on the same
  * split-f16 matrix-core GEMM as the forward.
  * egnn_split_scaled_f16: X (rows, cols) fp32 -> packed (hi, lo) images of scale * X (transposed = 0: `rows` image rows, K = cols) or of
- *     its transpose (transposed = 1: `cols` image rows, K = rows); scale > 0 (a power of two that lifts small gradients off fp16's
- *     subnormals); image rows padded to a multiple of 32 and K to Kp with zeros (both written).
+ *     its transpose (transposed = 1: `cols` image rows, K = rows); scale finite and non-zero (for gradients a power of two that lifts
+ *     small values off fp16's subnormals; for the weight images of the Python module's re-layout a power of two times the kernels'
+ *     unit factor); image rows padded to a multiple of 32 and K to Kp with zeros (both written).
  * egnn_linear_hl_splitk_f32: C_parts[p] (M, ldc) = w_inv_scale * A[:, K range p] W[:, K range p]^T for p < k_splits -- a contraction
  *     that is deep (K = B N nodes) and has a small output fills the chip only when K is cut; parts are summed in fixed order by
  * egnn_sum_parts_f32: out[o] = scale * sum_p parts[p][o], o < count (count % 4 == 0).

@@ -576,3 +576,30 @@ def test_silu_bwd_matches_autograd():
     a, gz = _ops.silu_bwd_(z.clone(), gr.clone())
     assert float((a.double() - a64.detach()).abs().max()) <= 2e-6 * float(a64.abs().max())
     assert float((gz.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("kw", [dict(dim=512, num_nearest_neighbors=32), dict(dim=20, m_dim=8, edge_dim=3, fourier_features=2, soft_edges=True),
+                                dict(dim=24, m_dim=40, norm_feats=True, norm_coors=True), dict(dim=16, update_feats=False),
+                                dict(dim=16, update_coors=False, edge_dim=1)])
+def test_device_weight_pack_equals_the_tensor_op_pack(kw):
+    """_weights.pack on the GPU (seven GEMM weight images from egnn_split_scaled_f16, all scale maxima in one host read) against the
+    same function on the CPU (plain tensor ops; itself bit-identical to the C packer, tests/test_host_logic.py): every packed image,
+    table and scale equal bit for bit -- with default-initialised and with rescaled weights."""
+    from egnn_pytorch_amd import EGNN, _weights
+    for mul in (1.0, 37.0):
+        torch.manual_seed(7)
+        layer = EGNN(**kw)
+        with torch.no_grad():
+            for p in layer.parameters():
+                p.mul_(mul)
+        want = _weights.pack(layer)
+        got = _weights.pack(layer.cuda())
+        assert set(want) == set(got)
+        for key, a in want.items():
+            b = got[key]
+            if isinstance(a, tuple):                            # (hi, lo, inv_scale, rows)
+                assert torch.equal(a[0], b[0].cpu()) and torch.equal(a[1], b[1].cpu()) and a[2:] == b[2:], key
+            elif torch.is_tensor(a):
+                assert torch.equal(a, b.cpu()), key
+            else:
+                assert a == b, key
