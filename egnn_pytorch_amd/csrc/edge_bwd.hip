@@ -71,6 +71,9 @@ constexpr int CH_S = EGNN_BWD_CHUNK_STEPS;   // steps of 32 hidden columns a wor
 constexpr int CH_W2 = EGNN_BWD_CH_W2;                     // ... of the variant with the d/d W_2 tiles only: one step fewer keeps it at 3 workgroups per CU
 constexpr int XLD = 36;                      // floats per exchange row: 144 B -> rows 4 apart sit 16 banks apart (transposed pick-up)
 constexpr float DZ_UP = 256.f;               // dz (scaled units, < 2^7) x 2^8 before the f16 split: keeps small values off the subnormals
+#ifndef EGNN_BWD_VALU_TILE_SUM
+#define EGNN_BWD_VALU_TILE_SUM 1
+#endif
 #ifndef EGNN_BWD_A_UP
 #define EGNN_BWD_A_UP 64.f
 #endif
@@ -442,10 +445,17 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
                     for (int r = 0; r < 4; ++r) {
                         const float y = x[t][r];
                         sgv[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
-                        znv[r] = y * (-0.6931471805599453f * A_UP);
-                        av4[r] = znv[r] * sgv[r];
-                        const float t1 = __builtin_fmaf(sgv[r], -1.0f / A_UP, 1.0f / A_UP);      // (1 - sigma) / A_UP
-                        spv[r] = __builtin_fmaf(av4[r], t1, sgv[r]);
+                        if constexpr (WANT_W2) {
+                            znv[r] = y * (-0.6931471805599453f * A_UP);
+                            av4[r] = znv[r] * sgv[r];
+                            const float t1 = __builtin_fmaf(sgv[r], -1.0f / A_UP, 1.0f / A_UP);      // (1 - sigma) / A_UP
+                            spv[r] = __builtin_fmaf(av4[r], t1, sgv[r]);
+                        } else {
+                            // a = SiLU(z) is not needed without d/d W_2: SiLU'(z) = sigma (1 + z (1 - sigma)), z = -ln2 y -- one instruction fewer
+                            const float tc = __builtin_fmaf(sgv[r], 0.6931471805599453f, -0.6931471805599453f);      // -ln2 (1 - sigma)
+                            spv[r] = sgv[r] * __builtin_fmaf(y, tc, 1.0f);
+                            znv[r] = 0.f; av4[r] = 0.f;
+                        }
                         dz4[r] = ga[r] * spv[r];
                         asm("" : "+v"(dz4[r]));                    // (scalar multiplies: v_pk_mul_f32 costs 9.3 cycles per pair against 2 x 2.9)
                     }
@@ -458,8 +468,22 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
                                 if constexpr (!MW) dws[2 * st + hb][c] = __builtin_fmaf(dz4[r], sv[t][r][c], dws[2 * st + hb][c]);
                             }
                     }
+                    // The tile's sum of dz.  Without a second use of dz on the matrix cores (d/d W_s at S > 1) it is plain fp32 adds: the
+                    // lane's four entries, then the four lane groups through the row-swap instructions (egnn_column_sum4_reg) -- no
+                    // (hi, lo) split of dz (a v_fma_mix_f32 and a conversion per value) and two MFMAs per tile fewer; padding entries carry
+                    // gU = 0, so their dz is 0.
+                    if constexpr (!MW && EGNN_BWD_VALU_TILE_SUM) {
+                        float tsum = egnn_column_sum4_reg((dz4[0] + dz4[1]) + (dz4[2] + dz4[3]));
+                        if constexpr (PAIR) {
+                            if (t == 0) dPc[0] = tsum;
+                            else buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)q0 >> 5) * row_bytes) + (hoff + 16 * hb) * 4, (dPc[0] + tsum) * rows_scale);
+                        } else {
+                            buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)(q0 + 16 * t) >> 4) * row_bytes) + (hoff + 16 * hb) * 4, tsum * rows_scale);
+                        }
+                    }
                     // (hi, lo) halves: hi = RNE pair conversion, lo = product - hi as ONE v_fma_mix_f32 per value (the f16 operand read in place)
                     f16x4 dh, dl;
+                    if constexpr (MW || !EGNN_BWD_VALU_TILE_SUM) {
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
                         const f16x2 hi = __builtin_convertvector((f32x2v){dz4[r], dz4[r + 1]}, f16x2);
@@ -472,6 +496,8 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
                         dl[r] = lo[0]; dl[r + 1] = lo[1];
                     }
                     // sum over each node's edges of the tile: rows = the tile's local nodes
+                    }
+                    if constexpr (MW || !EGNN_BWD_VALU_TILE_SUM) {
                     f32x4 dP = (PAIR && t == 1) ? dPc : f32x4{0.f, 0.f, 0.f, 0.f};
                     dP = __builtin_amdgcn_mfma_f32_16x16x16f16(ind[t], dh, dP, 0, 0, 0);
                     dP = __builtin_amdgcn_mfma_f32_16x16x16f16(ind[t], dl, dP, 0, 0, 0);
@@ -481,6 +507,7 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
                         else buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)q0 >> 5) * row_bytes) + (hoff + 16 * hb) * 4, dP[0] * rows_scale);
                     } else {
                         buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)(q0 + 16 * t) >> 4) * row_bytes) + (hoff + 16 * hb) * 4, dP[0] * rows_scale);
+                    }
                     }
                     if constexpr (MW) {
                         f32x4 d = dWsm[2 * st + hb];

@@ -59,6 +59,21 @@ __device__ __forceinline__ float egnn_column_sum4(float v, float* scratch64, int
     return t;
 }
 
+// For each column e = lane & 15: the sum over the four 16-lane rows, in every lane, in registers: gfx950's row-swap instructions
+// (v_permlane16_swap: odd rows of the first operand <-> even rows of the second; v_permlane32_swap: upper half <-> lower half) on two
+// copies of the value, as inline assembly (see above: the builtin's second result is folded away).  Order: (row0 + row1) + (row2 + row3).
+#ifndef EGNN_NO_PERMLANE_SWAP
+__device__ __forceinline__ float egnn_column_sum4_reg(float v)
+{
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    const float s = a + b;
+    float c = s, d = s;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));
+    return c + d;
+}
+#endif
+
 // Inclusive prefix sum over the 64 lanes (row_shr 1/2/4/8 inside the rows, then row_bcast15 / row_bcast31).
 __device__ __forceinline__ int egnn_wave_inclusive_scan(int v)
 {
