@@ -15,8 +15,7 @@
 
 namespace {
 
-constexpr int EL_THREADS = 256;
-constexpr int EL_WAVES = 4;
+constexpr int EL_MAX_THREADS = 1024;     // up to 16 waves per graph, each with its own histogram (as many as fit in LDS)
 
 // hist[w][j] = number of edges of wave w's rows that arrive at j;  then (pass 2) per destination j: deg, tiles, and the
 // graph-local exclusive scans first[j] (entries) / tseg[j] (tiles); returns the graph's totals through LDS slots
@@ -25,6 +24,7 @@ __device__ __forceinline__ void hist_and_scan(const int32_t* __restrict__ idx, i
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int EL_THREADS = blockDim.x, EL_WAVES = blockDim.x >> 6;
     for (int o = tid; o < EL_WAVES * N; o += EL_THREADS) hist[o] = 0;
     __syncthreads();
     const int rows_per_wave = (N + EL_WAVES - 1) / EL_WAVES;
@@ -60,9 +60,10 @@ __device__ __forceinline__ void hist_and_scan(const int32_t* __restrict__ idx, i
     __syncthreads();
 }
 
-__global__ __launch_bounds__(EL_THREADS) void dest_totals_kernel(const int32_t* __restrict__ idx, int N, int K, int64_t* __restrict__ tiles_per_graph)
+__global__ __launch_bounds__(EL_MAX_THREADS) void dest_totals_kernel(const int32_t* __restrict__ idx, int N, int K, int64_t* __restrict__ tiles_per_graph)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int EL_THREADS = blockDim.x, EL_WAVES = blockDim.x >> 6;
     int* hist = reinterpret_cast<int*>(smem);
     int* scan_e = hist + EL_WAVES * N;
     int* scan_t = scan_e + EL_THREADS;
@@ -71,12 +72,13 @@ __global__ __launch_bounds__(EL_THREADS) void dest_totals_kernel(const int32_t* 
     if (threadIdx.x == 0) tiles_per_graph[blockIdx.x] = totals[1];
 }
 
-__global__ __launch_bounds__(EL_THREADS) void dest_lists_kernel(const int32_t* __restrict__ idx, int B, int N, int K,
+__global__ __launch_bounds__(EL_MAX_THREADS) void dest_lists_kernel(const int32_t* __restrict__ idx, int B, int N, int K,
                                                                 const int64_t* __restrict__ tiles_per_graph, int32_t* __restrict__ ent,
                                                                 int64_t* __restrict__ tile_seg, int64_t* __restrict__ csr_order,
                                                                 int64_t* __restrict__ csr_seg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int EL_THREADS = blockDim.x, EL_WAVES = blockDim.x >> 6;
     int* hist = reinterpret_cast<int*>(smem);
     int* scan_e = hist + EL_WAVES * N;
     int* scan_t = scan_e + EL_THREADS;
@@ -143,7 +145,12 @@ extern "C" int egnn_dest_lists_i32(const int32_t* idx, int B, int N, int K, int3
     if (!idx && K != N) return EGNN_E_SHAPE;
     if ((int64_t)B * N * K > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;       // edge ids are int32 in the entry list
     if (ent_capacity < egnn_dest_lists_capacity(B, N, K)) return EGNN_E_SHAPE;
-    const size_t lds = ((size_t)EL_WAVES * N + 2 * EL_THREADS + 2 + N) * sizeof(int);
+    // as many waves per graph as histograms fit in LDS (16, 8 or 4): one workgroup per graph is all the parallelism there is
+    int waves = 16;
+    auto lds_for = [&](int w) { return ((size_t)w * N + 2 * (size_t)w * 64 + 2 + N) * sizeof(int); };
+    while (waves > 4 && lds_for(waves) > 96 * 1024) waves >>= 1;
+    const size_t lds = lds_for(waves);
+    const int EL_THREADS = waves * 64;
     if (lds > 160 * 1024) return EGNN_E_UNSUPPORTED;                        // N <= ~8000 destinations per graph
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (lds > 64 * 1024) {
