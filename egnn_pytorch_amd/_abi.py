@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -82,7 +82,7 @@ class EdgeTailArgs(Structure):
         ("g_msum", c_void_p), ("W3", c_void_p), ("b3", c_void_p), ("W4", c_void_p), ("b4", c_void_p), ("scale", c_void_p),
         ("gU", c_void_p), ("g_rel", c_void_p), ("g_hid", c_void_p), ("a3", c_void_p), ("g_w", c_void_p), ("g_scale", c_void_p),
         ("gate_w", c_void_p), ("gate_b", c_void_p), ("g_gate", c_void_p),
-        ("part", c_void_p), ("rel_out", c_void_p), ("dist_out", c_void_p),
+        ("part", c_void_p), ("rel_out", c_void_p), ("dist_out", c_void_p), ("amax_gu", c_void_p),
     ]
 
 
@@ -229,7 +229,7 @@ def load():
     lib.egnn_split_scaled_both_f16.argtypes = [c_void_p, c_int64, c_int64, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                                c_void_p, c_void_p]
     lib.egnn_silu_bwd_f32.restype = c_int
-    lib.egnn_silu_bwd_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
+    lib.egnn_silu_bwd_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
     lib.egnn_unsplit_words_f32.restype = c_int
     lib.egnn_unsplit_words_f32.argtypes = [c_void_p, c_int64, c_int64, c_int, c_void_p]
     lib.egnn_edge_mfmas.restype = c_int
@@ -260,7 +260,7 @@ def load():
     lib.egnn_edge_features_gather_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                                   c_int, c_int, c_int, c_void_p, c_void_p]
     lib.egnn_rows_gather_sum_f32.restype = c_int
-    lib.egnn_rows_gather_sum_f32.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]
+    lib.egnn_rows_gather_sum_f32.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p]
 
     lib.egnn_packed_weights_bytes.restype = c_size_t
     lib.egnn_packed_weights_bytes.argtypes = [POINTER(LayerDesc)]

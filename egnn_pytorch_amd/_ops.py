@@ -388,15 +388,22 @@ def token_attn(q, kv_tok, b, n, heads, dim_head, scale):
     return out
 
 
-def rows_gather_sum(rows, order, seg_ptr, n_out):
-    """out[r] = sum of rows[order[p]] over p in [seg_ptr[r], seg_ptr[r+1]), fixed order -- egnn_rows_gather_sum_f32."""
+def bits_to_floats(bits):
+    """The floats behind a tensor of max-|x| bit patterns (egnn_absmax_f32's contract), in ONE host read."""
+    return bits.view(torch.float32).tolist()
+
+
+def rows_gather_sum(rows, order, seg_ptr, n_out, want_amax=False):
+    """out[r] = sum of rows[order[p]] over p in [seg_ptr[r], seg_ptr[r+1]), fixed order -- egnn_rows_gather_sum_f32.
+    want_amax: returns (out, bits) with bits = a 1-element int32 tensor holding the bit pattern of max |out| (a by-product)."""
     cols = rows.shape[1]
     out = empty(n_out, cols, dtype=torch.float32, device=rows.device)
+    bits = torch.empty(1, dtype=torch.int32, device=rows.device) if want_amax else None
     with _timed("rows_gather_sum"):
         rc = _abi.load().egnn_rows_gather_sum_f32(_ptr(rows), rows.stride(0), _ptr(order), _ptr(seg_ptr), n_out, cols, _ptr(out),
-                                                  cols, _stream())
+                                                  cols, _ptr(bits), _stream())
     _abi.check(rc, "egnn_rows_gather_sum_f32")
-    return out
+    return (out, bits) if want_amax else out
 
 
 def split_scaled(x2d, scale, transposed=False, w_image=False):
@@ -429,11 +436,13 @@ def split_scaled_both(x2d, scale):
 
 
 def silu_bwd_(z, g):
-    """z <- SiLU(z), g <- g * SiLU'(z), in place, one pass (egnn_silu_bwd_f32).  Returns (z, g)."""
+    """z <- SiLU(z), g <- g * SiLU'(z), in place, one pass (egnn_silu_bwd_f32).  Returns (z, g, bits): bits = the bit patterns of
+    max |SiLU(z)| and max |g SiLU'(z)| (2-element int32 tensor; bits_to_floats)."""
+    bits = torch.empty(2, dtype=torch.int32, device=z.device)
     with _timed("silu_bwd"):
-        rc = _abi.load().egnn_silu_bwd_f32(_ptr(z), _ptr(g), _ptr(z), _ptr(g), z.numel(), _stream())
+        rc = _abi.load().egnn_silu_bwd_f32(_ptr(z), _ptr(g), _ptr(z), _ptr(g), z.numel(), _ptr(bits), _stream())
     _abi.check(rc, "egnn_silu_bwd_f32")
-    return z, g
+    return z, g, bits
 
 
 class GradOperand:
@@ -497,10 +506,10 @@ def grad_nn(g2d, wsplit_t, n, residual=None, name="grad_nn", amax=None):
     return linear_hl(a, (whi, wlo, inv / scale, w_rows), n, None, residual=residual, name=name)
 
 
-def grad_tn_operand(x2d):
+def grad_tn_operand(x2d, amax=None):
     """The right-hand operand of grad_tn, prepared once for several products with the same x2d: (packed image of (s x2d)^T, rows, s)
-    or None when x2d is all zero / not finite."""
-    sx = grad_scale(absmax(x2d))
+    or None when x2d is all zero / not finite.  amax: max |x2d| if the caller has it."""
+    sx = grad_scale(absmax(x2d) if amax is None else amax)
     if sx is None:
         return None
     w, w_rows = split_scaled(x2d, sx, transposed=True, w_image=True)  # (n rows, K = r)
@@ -602,7 +611,7 @@ def edge_tail_bwd(u16, coors, idx32, pair_mask, g_coors_out, g_msum16, w3p, b3p,
     Returns (gU (E, 16), g_rel (E, 4), g_hid (E, 64), a3 (E, 64), g_w (E,), g_scale (E,) or None); with gate = (gate_w (16) zero
     padded, gate_b (1)) -- soft_edges -- a seventh element g_gate (E,) = d loss / d (gate pre-activation).
     reduce: the kernel sums the parameter gradients' per-edge terms itself -- returns (gU, g_rel, sums (1192,), rel (E, 4) or None,
-    dist (E,) or None): sums = [d/d W3 (64 x 16) | d/d b3 (64) | d/d W4 (64) | column sums of gU (16) | d/d gate_w (16) | d/d b4 |
+    dist (E,) or None, bits of max |gU| (1-element int32 tensor)): sums = [d/d W3 (64 x 16) | d/d b3 (64) | d/d W4 (64) | column sums of gU (16) | d/d gate_w (16) | d/d b4 |
     d/d CoorsNorm.scale | d/d gate_b | 0...]; want_rel: also x_i - x_j and |x_i - x_j|^2 per edge."""
     dev = u16.device
     e = b * n * k
@@ -622,6 +631,8 @@ def edge_tail_bwd(u16, coors, idx32, pair_mask, g_coors_out, g_msum16, w3p, b3p,
         a.g_coors_out, a.g_msum = g_coors_out.data_ptr(), g_msum16.data_ptr()
         a.W3, a.b3, a.W4, a.b4, a.scale = w3p.data_ptr(), b3p.data_ptr(), w4p.data_ptr(), b4.data_ptr(), _ptr(scale)
         a.gU, a.g_rel, a.part = gu.data_ptr(), g_rel.data_ptr(), part.data_ptr()
+        gu_bits = torch.empty(1, dtype=torch.int32, device=dev)
+        a.amax_gu = gu_bits.data_ptr()
         if gate is not None:
             a.gate_w, a.gate_b = gate[0].data_ptr(), gate[1].data_ptr()
         rel = dist = None
@@ -631,7 +642,7 @@ def edge_tail_bwd(u16, coors, idx32, pair_mask, g_coors_out, g_msum16, w3p, b3p,
         with _timed("edge_tail_bwd"):
             rc = lib.egnn_edge_tail_bwd_f32(byref(a), _stream())
         _abi.check(rc, "egnn_edge_tail_bwd_f32")
-        return gu, g_rel, sum_rows(part), rel, dist
+        return gu, g_rel, sum_rows(part), rel, dist, gu_bits
     g_hid = empty(e, 64, **f32)
     a3 = empty(e, 64, **f32)
     g_w = empty(e, **f32)

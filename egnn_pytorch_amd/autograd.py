@@ -514,7 +514,11 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
     if not s_first:
         g_ws, g_scal = o["ws"], o["scal"]
     ident = torch.arange(o["rows"].shape[0], device=dev)
-    gz_j = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n)
+    if dev.type == "cuda":
+        gz_j, bits = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n, want_amax=True)
+        gz_j.amax_bits = bits                                 # (max |d/d P_j| as a by-product: the scale of its gradient GEMM operands)
+    else:
+        gz_j = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n)
     return gz_i, gz_j, g_ws, g_scal, g_w2
 
 
@@ -538,16 +542,18 @@ def _node_mlp_backward(layer, w, f, m_i, g_out, grads_by_id):
         go = _ops.GradOperand(g2d)
         g_a1 = _ops.grad_nn(go, w["W6T_split"], 2 * dim, name="bwd_node_mlp")
         if z1.numel() % 4 == 0:
-            a1, g_z1 = _ops.silu_bwd_(z1, g_a1)
+            a1, g_z1, bits = _ops.silu_bwd_(z1, g_a1)
+            amax_a1, amax_gz = _ops.bits_to_floats(bits)               # (by-products of the pass: no absmax launches for these two)
         else:
             sg = torch.sigmoid(z1)
             a1, g_z1 = z1 * sg, g_a1 * (sg * (1 + z1 * (1 - sg)))
+            amax_a1 = amax_gz = None
         if lin6.weight.requires_grad:
-            grads_by_id[id(lin6.weight)] += _ops.grad_tn(go, a1, name="bwd_node_mlp_w")
+            grads_by_id[id(lin6.weight)] += _ops.grad_tn(go, a1, name="bwd_node_mlp_w", x_operand=_ops.grad_tn_operand(a1, amax_a1))
         if lin6.bias.requires_grad:
             grads_by_id[id(lin6.bias)] += g2d.sum(dim=0)
         del go, a1
-        gz = _ops.GradOperand(g_z1)
+        gz = _ops.GradOperand(g_z1, amax=amax_gz)
         g_in = _ops.grad_nn(gz, w["W5T_split"], dim + m, name="bwd_node_mlp")
         if lin5.weight.requires_grad:
             grads_by_id[id(lin5.weight)] += _ops.grad_tn(gz, in32, name="bwd_node_mlp_w")
@@ -728,9 +734,9 @@ def _backward_native(ctx, g_node, g_coors):
                 tail_args = (u16, c0, i32, pm8, g_coors[lo:hi_].contiguous(), g_msum, w3p, b3p, w4p, lin_b.bias.detach().contiguous(),
                              layer.coors_norm.scale.detach() if norm else None, layer.coors_norm.eps if norm else 0.0,
                              layer.coor_weights_clamp_value, bc, n, k)
-                bias2 = None
+                bias2 = gu_bits = None
                 if reduce:
-                    gu16, g_rel, sums, rel4, dist = _ops.edge_tail_bwd(*tail_args, gate=gate, reduce=True, want_rel=closed_dist)
+                    gu16, g_rel, sums, rel4, dist, gu_bits = _ops.edge_tail_bwd(*tail_args, gate=gate, reduce=True, want_rel=closed_dist)
                     grads_by_id[id(lin_a.weight)] += sums[:1024].view(64, 16)[:hid3, :m]
                     grads_by_id[id(lin_a.bias)] += sums[1024:1024 + hid3]
                     grads_by_id[id(lin_b.weight)] += sums[1088:1088 + hid3][None, :]
@@ -762,7 +768,7 @@ def _backward_native(ctx, g_node, g_coors):
                 if i64 is not None:
                     dest_lists = _ops.dest_lists(i32, bc, n, k, feats.device)                  # (shared with the E x H passes below)
         else:
-            closed_dist, g_rel, bias2 = False, None, None
+            closed_dist, g_rel, bias2, gu_bits = False, None, None, None
             # ---- 1. the small tail, through autograd
             with torch.enable_grad():
                 f = f0.detach().requires_grad_(True)
@@ -790,7 +796,7 @@ def _backward_native(ctx, g_node, g_coors):
             gu16 = torch.zeros(ec, 16, dtype=torch.float32, device=feats.device)
             gu16[:, :m] = g_u.reshape(ec, m)
         # ---- 2. the E x H work: d/d P_i, d/d P_j (per node), d/d W_s, d/d scalars, d/d W_2
-        amax = _ops.absmax(gu16)
+        amax = _ops.bits_to_floats(gu_bits)[0] if gu_bits is not None else _ops.absmax(gu16)
         gu_scale = _weights.pow2_scale(amax) if amax > 0 else 1.0
         with torch.no_grad():
             f2d = f0.view(bc * n, dim)
@@ -804,7 +810,8 @@ def _backward_native(ctx, g_node, g_coors):
             gw1 = grads_by_id[id(lin0.weight)]
             if f2d.is_cuda and _GRAD_GEMM:
                 # (each matrix: one absmax, one read for its plain and transposed images; feats^T split once for both weight gradients)
-                op_i, op_j = _ops.GradOperand(gz_i), _ops.GradOperand(gz_j)
+                jb = getattr(gz_j, "amax_bits", None)
+                op_i, op_j = _ops.GradOperand(gz_i), _ops.GradOperand(gz_j, amax=None if jb is None else _ops.bits_to_floats(jb)[0])
                 t = _ops.grad_nn(op_i, w["WiT_split"], dim, name="bwd_dfeats")
                 t = _ops.grad_nn(op_j, w["WjT_split"], dim, residual=t, name="bwd_dfeats")
                 g_feats[lo:hi_] += t.view(bc, n, dim)

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
         if (!REDUCE && live) p.g_gate[e] = gs;
     }
     f32x4* gup = reinterpret_cast<f32x4*>(p.gU + e * TM);
+    uint32_t gu_max = 0u;                                                      // max |gU| over this lane's edge (dead lanes: all zero)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         f32x4 v;
@@ -244,6 +245,8 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
             v[c] = gm[cc] * (sgu[cc] * (1.0f + u[cc] * (1.0f - sgu[cc])));
         }
         if (live) gup[q] = v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const uint32_t tb = egnn_abs_bits(v[c]); gu_max = gu_max > tb ? gu_max : tb; }
         if constexpr (REDUCE) {
             // per-edge scalar terms, summed over the wave's edges below: [0, 16) d loss / d u (-> edge_mlp's last bias),
             // [16, 32) gate term x SiLU(u) (-> d/d gate weight), 32 g_w (-> d/d b4), 33 CoorsNorm.scale term, 34 gate term (-> d/d gate bias)
@@ -263,6 +266,10 @@ __global__ __launch_bounds__(256) void edge_tail_bwd_kernel(const egnn_edge_tail
             for (int ee = 0; ee < 64; ++ee) acc += sblk[ee * QLD + lane];
             wpart[TH * TM + 2 * TH + lane] = acc;
         }
+    }
+    if (p.amax_gu) {
+        __shared__ uint32_t amax_slot;
+        egnn_block_absmax_commit(gu_max, &amax_slot, p.amax_gu);
     }
 }
 
@@ -307,6 +314,7 @@ extern "C" int egnn_edge_tail_bwd_f32(const egnn_edge_tail_args* args, void* str
     const int64_t E = (int64_t)a.B * a.N * a.K;
     const int64_t blocks = (E + 255) / 256;
     if (blocks >= ((int64_t)1 << 31)) return EGNN_E_SHAPE;
+    if (a.amax_gu && hipMemsetAsync(a.amax_gu, 0, sizeof(uint32_t), static_cast<hipStream_t>(stream)) != hipSuccess) return (int)hipGetLastError();
     if (a.part) hipLaunchKernelGGL(edge_tail_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     else hipLaunchKernelGGL(edge_tail_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return egnn_launch_status();

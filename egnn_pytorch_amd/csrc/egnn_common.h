@@ -86,6 +86,21 @@ __device__ __forceinline__ int egnn_wave_inclusive_scan(int v)
     return v;
 }
 
+// max |x| by-products of kernels whose output is the next gradient GEMM's operand (the host picks the operand's power-of-two scale
+// from it, egnn_absmax_f32's contract: the bit pattern of the float, integer atomicMax, order independent; a NaN's pattern wins).
+// m = the thread's running maximum of (bits & 0x7fffffff); slot = one word of workgroup LDS, zeroed here.
+__device__ __forceinline__ uint32_t egnn_abs_bits(float x) { return __builtin_bit_cast(uint32_t, x) & 0x7fffffffu; }
+__device__ __forceinline__ void egnn_block_absmax_commit(uint32_t m, uint32_t* slot, uint32_t* out_bits)
+{
+    if (threadIdx.x == 0) *slot = 0u;
+    __syncthreads();
+    if (m) atomicMax(slot, m);
+    __syncthreads();
+    // (tens of thousands of workgroups on one word: only those that would raise it go to the atomic unit -- a stale read costs one
+    // redundant atomic, never a wrong result)
+    if (threadIdx.x == 0 && *slot > __atomic_load_n(out_bits, __ATOMIC_RELAXED)) atomicMax(out_bits, *slot);
+}
+
 #pragma GCC poison __shfl __shfl_xor __shfl_up __shfl_down
 
 // Range status (include/egnn_hip.h: EGNN_RANGE_*): an atomic from the lanes that saw a violation, nothing otherwise.

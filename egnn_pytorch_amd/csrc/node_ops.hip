@@ -181,8 +181,10 @@ __global__ __launch_bounds__(256) void split_scaled_kernel(const float* __restri
 }
 
 // a = SiLU(z) and gz = g SiLU'(z) in one pass (the backward of node_mlp's activation, egnn_pytorch.py:196-201); a_out may be z, gz_out may be g
-__global__ __launch_bounds__(256) void silu_bwd_kernel(const float* z, const float* g, float* a_out, float* gz_out, int64_t quads)
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const float* z, const float* g, float* a_out, float* gz_out, int64_t quads, uint32_t* amax_bits)
 {
+    __shared__ uint32_t slot_a, slot_g;
+    uint32_t ma = 0u, mg = 0u;
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (int64_t)gridDim.x * 256) {
         const f32x4 zv = reinterpret_cast<const f32x4*>(z)[q];
         const f32x4 gv = reinterpret_cast<const f32x4*>(g)[q];
@@ -192,9 +194,16 @@ __global__ __launch_bounds__(256) void silu_bwd_kernel(const float* z, const flo
             const float sg = 1.0f / (1.0f + __expf(-zv[u]));
             av[u] = zv[u] * sg;
             dv[u] = gv[u] * (sg * (1.0f + zv[u] * (1.0f - sg)));
+            const uint32_t ta = egnn_abs_bits(av[u]), tg = egnn_abs_bits(dv[u]);
+            ma = ma > ta ? ma : ta;
+            mg = mg > tg ? mg : tg;
         }
         reinterpret_cast<f32x4*>(a_out)[q] = av;
         reinterpret_cast<f32x4*>(gz_out)[q] = dv;
+    }
+    if (amax_bits) {
+        egnn_block_absmax_commit(ma, &slot_a, amax_bits);
+        egnn_block_absmax_commit(mg, &slot_g, amax_bits + 1);
     }
 }
 
@@ -315,7 +324,7 @@ extern "C" int egnn_split_scaled_both_f16(const float* X, int64_t ldx, int64_t r
     return egnn_launch_status();
 }
 
-extern "C" int egnn_silu_bwd_f32(const float* z, const float* g, float* a_out, float* gz_out, int64_t count, void* stream)
+extern "C" int egnn_silu_bwd_f32(const float* z, const float* g, float* a_out, float* gz_out, int64_t count, uint32_t* amax_bits, void* stream)
 {
     if (!z || !g || !a_out || !gz_out) return EGNN_E_NULLPTR;
     if (count <= 0 || (count % 4) != 0) return EGNN_E_SHAPE;
@@ -323,7 +332,8 @@ extern "C" int egnn_silu_bwd_f32(const float* z, const float* g, float* a_out, f
         return EGNN_E_ALIGN;
     int64_t blocks = (count / 4 + 256 * 4 - 1) / (256 * 4);
     blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
-    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), z, g, a_out, gz_out, count / 4);
+    if (amax_bits && hipMemsetAsync(amax_bits, 0, 2 * sizeof(uint32_t), static_cast<hipStream_t>(stream)) != hipSuccess) return (int)hipGetLastError();
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), z, g, a_out, gz_out, count / 4, amax_bits);
     return egnn_launch_status();
 }
 

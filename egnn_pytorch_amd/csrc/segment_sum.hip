@@ -11,8 +11,10 @@ namespace {
 
 __global__ __launch_bounds__(256) void rows_gather_sum_kernel(const float* __restrict__ rows, int64_t ld, const int64_t* __restrict__ order,
                                                               const int64_t* __restrict__ seg_ptr, int cols, float* __restrict__ out,
-                                                              int64_t ldo)
+                                                              int64_t ldo, uint32_t* __restrict__ amax_bits)
 {
+    __shared__ uint32_t amax_slot;
+    uint32_t mx = 0u;
     const int64_t r = blockIdx.x;
     const int64_t p0 = seg_ptr[r], p1 = seg_ptr[r + 1];
     for (int c = threadIdx.x * 4; c < cols; c += 256 * 4) {
@@ -26,20 +28,26 @@ __global__ __launch_bounds__(256) void rows_gather_sum_kernel(const float* __res
         }
         if (p < p1) acc += *reinterpret_cast<const f32x4*>(rows + order[p] * ld + c);
         *reinterpret_cast<f32x4*>(out + r * ldo + c) = acc;
+        if (amax_bits) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t t = egnn_abs_bits(acc[u]); mx = mx > t ? mx : t; }
+        }
     }
+    if (amax_bits) egnn_block_absmax_commit(mx, &amax_slot, amax_bits);
 }
 
 }  // namespace
 
 extern "C" int egnn_rows_gather_sum_f32(const float* rows, int64_t ld, const int64_t* order, const int64_t* seg_ptr, int64_t n_out,
-                                        int cols, float* out, int64_t ldo, void* stream)
+                                        int cols, float* out, int64_t ldo, uint32_t* amax_bits, void* stream)
 {
     if (!rows || !order || !seg_ptr || !out) return EGNN_E_NULLPTR;
     if (n_out <= 0 || cols <= 0 || (cols % 4) != 0 || ld < cols || ldo < cols || (ld % 4) != 0 || (ldo % 4) != 0) return EGNN_E_SHAPE;
     if (n_out > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(rows) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return EGNN_E_ALIGN;
+    if (amax_bits && hipMemsetAsync(amax_bits, 0, sizeof(uint32_t), static_cast<hipStream_t>(stream)) != hipSuccess) return (int)hipGetLastError();
     hipLaunchKernelGGL(rows_gather_sum_kernel, dim3((unsigned)n_out), dim3(256), 0, static_cast<hipStream_t>(stream), rows, ld, order,
-                       seg_ptr, cols, out, ldo);
+                       seg_ptr, cols, out, ldo, amax_bits);
     return egnn_launch_status();
 }
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 24
+#define EGNN_ABI_VERSION 25
 
 enum {
     EGNN_OK = 0,
@@ -190,8 +190,9 @@ int egnn_split_scaled_f16(const float* X, int64_t ldx, int64_t rows, int cols, f
 int egnn_split_scaled_both_f16(const float* X, int64_t ldx, int64_t rows, int cols, float scale, void* hi, void* lo, int Kp,
                                void* hiT, void* loT, int KpT, int32_t* status, void* stream);
 /* backward of an MLP's SiLU (node_mlp, egnn_pytorch.py:196-201) in one pass: a_out = SiLU(z), gz_out = g * SiLU'(z); count % 4 == 0,
- * 16-byte aligned; a_out may be z and gz_out may be g (element-wise). */
-int egnn_silu_bwd_f32(const float* z, const float* g, float* a_out, float* gz_out, int64_t count, void* stream);
+ * 16-byte aligned; a_out may be z and gz_out may be g (element-wise); amax_bits (2 words) or NULL: the bit patterns of max |a_out| and
+ * max |gz_out| (egnn_absmax_f32's contract) -- both are operands of the next gradient GEMMs. */
+int egnn_silu_bwd_f32(const float* z, const float* g, float* a_out, float* gz_out, int64_t count, uint32_t* amax_bits, void* stream);
 int egnn_linear_hl_splitk_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo, float w_inv_scale, float* C_parts,
                               int64_t ldc, int64_t M, int N, int Kp, int w_rows, int k_splits, void* stream);
 int egnn_sum_parts_f32(const float* parts, int nparts, int64_t count, float scale, float* out, void* stream);
@@ -419,6 +420,7 @@ typedef struct egnn_edge_tail_args {
                                 /*   32 d/d b4, 33 d/d CoorsNorm.scale, 34 d/d gate_b, rest 0.  Summed over rows by egnn_sum_parts_f32 (fixed order). */
     float* rel_out;             /* out or NULL: (E, 4) x_i - x_j (4th 0) and, with it, dist_out (E) = |x_i - x_j|^2 -- what the backward of the */
     float* dist_out;            /*   distance path needs (d loss / d rel += 2 g_dist rel), by-products of this pass */
+    uint32_t* amax_gu;          /* out or NULL: the bit pattern of max |gU| (egnn_absmax_f32's contract) -- the scale of the next pass's fp16 split */
 } egnn_edge_tail_args;
 
 int egnn_edge_tail_bwd_f32(const egnn_edge_tail_args* args, void* stream);
@@ -426,9 +428,9 @@ int egnn_edge_tail_bwd_f32(const egnn_edge_tail_args* args, void* stream);
 /* Backward of the neighbour gather (egnn_pytorch.py:275): out[r, :] = sum of rows[order[p], :] for p in [seg_ptr[r], seg_ptr[r+1]),
  * in that order -- with `order` = the edges sorted (stably) by destination node this is d loss / d P_j from dZ, a fixed-order
  * read-only reduction (no float atomics: bit-reproducible).  rows (n_rows, ld) fp32, out (n_out, ldo) fp32, cols % 4 == 0,
- * order / seg_ptr int64 (seg_ptr has n_out + 1 entries). */
+ * order / seg_ptr int64 (seg_ptr has n_out + 1 entries).  amax_bits or NULL: the bit pattern of max |out| (egnn_absmax_f32's contract). */
 int egnn_rows_gather_sum_f32(const float* rows, int64_t ld, const int64_t* order, const int64_t* seg_ptr, int64_t n_out,
-                             int cols, float* out, int64_t ldo, void* stream);
+                             int cols, float* out, int64_t ldo, uint32_t* amax_bits, void* stream);
 
 /* Number of chained first-layer MFMAs the edge kernel is instantiated with for S per-edge scalars (>= ceil(3 S / 4); one of 1, 3, 4, 6, 12). */
 int egnn_edge_mfmas(int S);

@@ -464,7 +464,8 @@ def test_tail_kernel_reduce_mode_and_pool_match_closed_form(kw, use_mask, dense)
     args = (u16, coors.contiguous(), None if idx is None else idx.to(torch.int32).contiguous(), pm8, gc.contiguous(), gm16, w3p, b3p, w4p,
             lb.bias.detach().contiguous(), layer.coors_norm.scale.detach() if norm else None, layer.coors_norm.eps if norm else 0.0,
             layer.coor_weights_clamp_value, b, n, k)
-    gu, g_rel, sums, rel, dist = _ops.edge_tail_bwd(*args, gate=gate, reduce=True, want_rel=True)
+    gu, g_rel, sums, rel, dist, gu_bits = _ops.edge_tail_bwd(*args, gate=gate, reduce=True, want_rel=True)
+    assert _ops.bits_to_floats(gu_bits)[0] == float(gu.abs().max())
     again = _ops.edge_tail_bwd(*args, gate=gate, reduce=True, want_rel=True)
     assert torch.equal(sums, again[2]) and torch.equal(gu, again[0])
     plain = _ops.edge_tail_bwd(*args, gate=gate)

@@ -311,7 +311,8 @@ def test_rows_gather_sum_fixed_order():
     ds, order = torch.sort(dest, stable=True)
     seg = torch.searchsorted(ds, torch.arange(n_out + 1, device="cuda"))
     out = _ops.rows_gather_sum(rows, order, seg, n_out)
-    out2 = _ops.rows_gather_sum(rows, order, seg, n_out)
+    out2, bits = _ops.rows_gather_sum(rows, order, seg, n_out, want_amax=True)
+    assert _ops.bits_to_floats(bits)[0] == float(out.abs().max())                # the by-product: max |out|, exact
     assert torch.equal(out, out2)
     # sequential fp32 reference for a few rows (pairs of rows are added one after the other in list order)
     for r in (7, 0, 123, n_out - 1):
@@ -573,7 +574,8 @@ def test_silu_bwd_matches_autograd():
         z64 = z.double().requires_grad_(True)
         a64 = torch.nn.functional.silu(z64)
         want = torch.autograd.grad(a64, z64, gr.double())[0]
-    a, gz = _ops.silu_bwd_(z.clone(), gr.clone())
+    a, gz, bits = _ops.silu_bwd_(z.clone(), gr.clone())
+    assert _ops.bits_to_floats(bits) == [float(a.abs().max()), float(gz.abs().max())]
     assert float((a.double() - a64.detach()).abs().max()) <= 2e-6 * float(a64.abs().max())
     assert float((gz.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
 
