@@ -19,6 +19,8 @@
 // fixed order.
 #include "egnn_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int TM = 16;       // padded m_dim
@@ -294,6 +296,272 @@ __global__ __launch_bounds__(256) void edge_pool_kernel(const float* __restrict_
     if (node_raw < nodes) m_sum[node * TM + c] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The REDUCE variant with coors_mlp on the matrix cores.  In the kernel above every lane owns an edge and walks coors_mlp's 64 x 16
+// weights three times with scalar FMAs (forward, recompute, backward: ~3100 of its ~6100 VALU instructions per wave).  Here a wave
+// takes its 64 edges as four tiles of 16 with the EDGES as the N dimension of v_mfma_f32_16x16x16_f16 (the forward kernel's
+// transposed formulation): lane (g, e) holds channels 4g .. 4g+3 of edge e --
+//     hid^T (64 x 16 e) = W3 (64 x 16) m^T          A = W3 rows as split-f16 fragments (LDS), B = the lane's 4 messages, split f16 x 3
+//     gm^T  (16 x 16 e) = W3^T (16 x 64) q^T        q = W4 SiLU'(hid), O(1); its D layout IS the B layout of the second product;
+//                                                   the edge's g_w is a per-column factor applied to the fp32 result
+// -- and the per-edge scalar section runs once per tile (replicated over the four lane groups).  The sums over edges (REDUCE) take
+// each tile's g_hid / a3 / m through LDS: lane t owns row t of d/d W3 over the wave's edges.  Same outputs and `part` layout as
+// edge_tail_bwd_kernel<true>; the summation order differs (tests compare both with the float64 specification).
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void tail_split4(const f32x4 v, h16x4& hi, h16x4& lo)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const _Float16 h = (_Float16)v[u];
+        hi[u] = h;
+        lo[u] = (_Float16)(v[u] - (float)h);
+    }
+}
+
+constexpr int GLD = 68;      // floats per row of a tile's g_hid / a3 staging (64 columns + 4: rows 16 banks apart for the 16-byte writes)
+
+__global__ __launch_bounds__(256) void edge_tail_mfma_kernel(const egnn_edge_tail_args p)
+{
+    __shared__ uint2 fragA[4][2][64];            // W3 rows: [t block][hi | lo][lane (g, m)] = W3[16 tb + m][4g .. 4g+3] x s3
+    __shared__ uint2 fragB[4][2][64];            // W3^T:    [t block][hi | lo][lane (g, m)] = W3[16 tb + 4g .. +3][m] x s3
+    __shared__ float sb3[TH], sW4[TH], sgw[TM];
+    __shared__ uint32_t w3max;
+    __shared__ __attribute__((aligned(16))) float stage_raw[4 * (2 * 16 * GLD + 16 * TM + 16)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, ee = lane & 15;
+    // ---- weights: power-of-two scale from max |W3| (hi / lo halves in fp16's normal range), fragments, biases
+    if (tid == 0) w3max = 0u;
+    __syncthreads();
+    {
+        uint32_t m = 0u;
+        for (int o = tid; o < TH * TM; o += 256) { const uint32_t t = egnn_abs_bits(p.W3[o]); m = m > t ? m : t; }
+        if (m) atomicMax(&w3max, m);
+    }
+    if (tid < TM) sgw[tid] = p.gate_w ? p.gate_w[tid] : 0.f;
+    if (tid < TH) { sb3[tid] = p.b3[tid]; sW4[tid] = p.W4[tid]; }
+    __syncthreads();
+    const uint32_t ebits = w3max & 0x7f800000u;                                 // exponent field of max |W3|
+    const float s3 = (ebits && ebits < 0x7e800000u) ? __uint_as_float(0x7f000000u - ebits) : 1.0f;       // 2^-floor(log2 max): max |W3| s3 in [1, 2)
+    const float inv_s3 = 1.0f / s3;
+    {
+        const int tb = tid >> 6, l = tid & 63, lg = l >> 4, lm = l & 15;
+        f32x4 a, b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a[r] = p.W3[(16 * tb + lm) * TM + 4 * lg + r] * s3;
+            b[r] = p.W3[(16 * tb + 4 * lg + r) * TM + lm] * s3;
+        }
+        h16x4 hi, lo;
+        tail_split4(a, hi, lo);
+        fragA[tb][0][l] = __builtin_bit_cast(uint2, hi); fragA[tb][1][l] = __builtin_bit_cast(uint2, lo);
+        tail_split4(b, hi, lo);
+        fragB[tb][0][l] = __builtin_bit_cast(uint2, hi); fragB[tb][1][l] = __builtin_bit_cast(uint2, lo);
+    }
+    __syncthreads();
+
+    float* sgh = stage_raw + wave * (2 * 16 * GLD + 16 * TM + 16);            // [16 e][GLD] g_hid of the tile
+    float* sa3 = sgh + 16 * GLD;                                              // [16 e][GLD] a3
+    float* smm = sa3 + 16 * GLD;                                              // [16 e][16]  post-gate messages
+    float* sgwe = smm + 16 * TM;                                              // [16] g_w
+    const int64_t E = (int64_t)p.B * p.N * p.K;
+    const int K = p.K, N = p.N;
+    float* wpart = p.part + ((size_t)blockIdx.x * 4 + wave) * PART;
+    const float gb = p.gate_w ? p.gate_b[0] : 0.f;
+    const float b4 = p.b4[0];
+    const float cscale = p.norm_coors ? p.scale[0] : 1.f;
+
+    float acc3[TM];                             // lane t = lane: d/d W3[t][0..15] over the wave's 64 edges
+#pragma unroll
+    for (int c = 0; c < TM; ++c) acc3[c] = 0.f;
+    float accb = 0.f, accw = 0.f;               // d/d b3[t], d/d W4[t]
+    f32x4 s_gu = f32x4{0.f, 0.f, 0.f, 0.f}, s_gate = f32x4{0.f, 0.f, 0.f, 0.f};     // per (g, ee): sums over the four tiles of gU[4g+r], gs m0[4g+r]
+    float s_gw = 0.f, s_sc = 0.f, s_gs = 0.f;
+    uint32_t gu_max = 0u;
+
+#pragma unroll 1
+    for (int tt = 0; tt < 4; ++tt) {
+        const int64_t e_raw = (int64_t)blockIdx.x * 256 + wave * 64 + 16 * tt + ee;
+        const bool live = e_raw < E;
+        const int64_t e = live ? e_raw : E - 1;
+        const int64_t ig = e / K;
+        const int64_t jg = p.idx ? (ig / N) * N + p.idx[e] : (ig / N) * N + (e - ig * K);
+        const bool pm = live && (p.pair_mask ? p.pair_mask[e] != 0 : true);
+        const f32x4 u4 = *reinterpret_cast<const f32x4*>(p.u + e * TM + 4 * g);
+        f32x4 sgu, m0, m4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sgu[r] = egnn_sigmoid(u4[r]); m0[r] = u4[r] * sgu[r]; }
+        float gt = 1.f, gtc = 0.f;
+        m4 = m0;
+        if (p.gate_w) {
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ps = __builtin_fmaf(sgw[4 * g + r], m0[r], ps);
+            const float sgate = egnn_column_sum4_reg(ps) + gb;
+            gt = egnn_sigmoid(sgate);
+            gtc = egnn_sigmoid(-sgate);
+            m4 = m0 * gt;
+        }
+        h16x4 mh, ml;
+        tail_split4(m4, mh, ml);
+        // ---- coors_mlp forward: hid^T, a3, q = W4 SiLU'(hid); w = W4 . a3 + b4
+        float hid[4][4], sgh4[4][4];
+        float wpartial = 0.f;
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+            const h16x4 ah = __builtin_bit_cast(h16x4, fragA[tb][0][lane]), al = __builtin_bit_cast(h16x4, fragA[tb][1][lane]);
+            f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+            d = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, mh, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, ml, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x16f16(al, mh, d, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 16 * tb + 4 * g + r;
+                const float h = __builtin_fmaf(d[r], inv_s3, sb3[t]);
+                const float sg = egnn_sigmoid(h);
+                hid[tb][r] = h;
+                sgh4[tb][r] = sg;
+                wpartial = __builtin_fmaf(sW4[t], h * sg, wpartial);
+            }
+        }
+        const float w = egnn_column_sum4_reg(wpartial) + b4;
+        // ---- the edge's scalar section (every lane group computes its edge's copy)
+        float rel[3], relp[3], gco[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            rel[d] = p.coors[ig * 3 + d] - p.coors[jg * 3 + d];
+            gco[d] = p.g_coors_out[ig * 3 + d];
+        }
+        float rn = 0.f, den = 1.f;
+        if (p.norm_coors) {
+            rn = sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]);
+            den = fmaxf(rn, p.eps);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) relp[d] = rel[d] / den * cscale;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) relp[d] = rel[d];
+        }
+        const float wm = pm ? w : 0.f;
+        const bool clamped = p.clamp >= 0.f && !(wm >= -p.clamp && wm <= p.clamp);
+        const float wc = p.clamp >= 0.f ? fminf(fmaxf(wm, -p.clamp), p.clamp) : wm;
+        const float g_wc = gco[0] * relp[0] + gco[1] * relp[1] + gco[2] * relp[2];
+        const float g_w = (pm && !clamped) ? g_wc : 0.f;
+        float g_relp[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) g_relp[d] = wc * gco[d];
+        f32x4 grel;
+        float gsc_e = 0.f;
+        if (p.norm_coors) {
+            const float dot = g_relp[0] * rel[0] + g_relp[1] * rel[1] + g_relp[2] * rel[2];
+            gsc_e = dot / den;
+            const float k1 = cscale / den;
+            const float k2 = rn >= p.eps ? dot * cscale / (den * den * fmaxf(rn, 1e-30f)) : 0.f;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) grel[d] = g_relp[d] * k1 - k2 * rel[d];
+        } else {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) grel[d] = g_relp[d];
+        }
+        grel[3] = 0.f;
+        if (jg == ig) grel = f32x4{0.f, 0.f, 0.f, 0.f};                          // (self pair: see edge_tail_bwd_kernel)
+        if (live && g == 0) {
+            *reinterpret_cast<f32x4*>(p.g_rel + e * 4) = grel;
+            if (p.rel_out) {
+                *reinterpret_cast<f32x4*>(p.rel_out + e * 4) = f32x4{rel[0], rel[1], rel[2], 0.f};
+                p.dist_out[e] = (rel[0] * rel[0] + rel[1] * rel[1]) + rel[2] * rel[2];
+            }
+        }
+        // ---- coors_mlp backward: gm^T = g_w W3^T q^T; the tile's g_hid / a3 / m / g_w go to LDS for the sums over edges
+        f32x4 gmacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+            f32x4 q, ghv, a3v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float h = hid[tb][r], sg = sgh4[tb][r];
+                q[r] = sW4[16 * tb + 4 * g + r] * (sg * (1.0f + h * (1.0f - sg)));
+                ghv[r] = g_w * q[r];
+                a3v[r] = h * sg;
+            }
+            *reinterpret_cast<f32x4*>(sgh + ee * GLD + 16 * tb + 4 * g) = ghv;
+            *reinterpret_cast<f32x4*>(sa3 + ee * GLD + 16 * tb + 4 * g) = a3v;
+            h16x4 qh, ql;
+            tail_split4(q, qh, ql);
+            const h16x4 bh = __builtin_bit_cast(h16x4, fragB[tb][0][lane]), bl = __builtin_bit_cast(h16x4, fragB[tb][1][lane]);
+            gmacc = __builtin_amdgcn_mfma_f32_16x16x16f16(bh, qh, gmacc, 0, 0, 0);
+            gmacc = __builtin_amdgcn_mfma_f32_16x16x16f16(bh, ql, gmacc, 0, 0, 0);
+            gmacc = __builtin_amdgcn_mfma_f32_16x16x16f16(bl, qh, gmacc, 0, 0, 0);
+        }
+        *reinterpret_cast<f32x4*>(smm + ee * TM + 4 * g) = m4;
+        if (g == 0) sgwe[ee] = g_w;
+        f32x4 gm;
+        const float gk = g_w * inv_s3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gm[r] = __builtin_fmaf(gmacc[r], gk, pm ? p.g_msum[ig * TM + 4 * g + r] : 0.f);
+        float gs = 0.f;
+        if (p.gate_w) {
+            float dp = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dp = __builtin_fmaf(gm[r], m0[r], dp);
+            gs = egnn_column_sum4_reg(dp) * gt * gtc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gm[r] = __builtin_fmaf(gs, sgw[4 * g + r], gm[r] * gt);
+        }
+        f32x4 gu;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gu[r] = gm[r] * (sgu[r] * (1.0f + u4[r] * (1.0f - sgu[r])));
+            const uint32_t tbits = egnn_abs_bits(gu[r]);
+            gu_max = gu_max > tbits ? gu_max : tbits;
+        }
+        if (live) *reinterpret_cast<f32x4*>(p.gU + e * TM + 4 * g) = gu;
+        s_gu += gu;
+        s_gate += m0 * gs;
+        if (g == 0) { s_gw += g_w; s_sc += gsc_e; s_gs += gs; }
+        // ---- sums over the tile's 16 edges: lane t = lane owns row t of d/d W3, d/d b3[t], d/d W4[t]
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+        for (int x = 0; x < 16; ++x) {
+            const float gh = sgh[x * GLD + lane];
+            accb += gh;
+            accw = __builtin_fmaf(sgwe[x], sa3[x * GLD + lane], accw);
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const f32x4 mv = *reinterpret_cast<const f32x4*>(smm + x * TM + 4 * c4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc3[4 * c4 + r] = __builtin_fmaf(gh, mv[r], acc3[4 * c4 + r]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- this wave's row of partial sums
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4)
+        *reinterpret_cast<f32x4*>(wpart + lane * TM + 4 * c4) = f32x4{acc3[4 * c4], acc3[4 * c4 + 1], acc3[4 * c4 + 2], acc3[4 * c4 + 3]};
+    wpart[TH * TM + lane] = accb;
+    wpart[TH * TM + TH + lane] = accw;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float a = egnn_row16_sum(s_gu[r]), b = egnn_row16_sum(s_gate[r]);
+        if (ee == 0) { wpart[TH * TM + 2 * TH + 4 * g + r] = a; wpart[TH * TM + 2 * TH + 16 + 4 * g + r] = b; }
+    }
+    {
+        const float a = egnn_row16_sum(s_gw), b = egnn_row16_sum(s_sc), c = egnn_row16_sum(s_gs);
+        if (lane == 0) {
+            wpart[TH * TM + 2 * TH + 32] = a; wpart[TH * TM + 2 * TH + 33] = b; wpart[TH * TM + 2 * TH + 34] = c;
+#pragma unroll
+            for (int o = 35; o < 40; ++o) wpart[TH * TM + 2 * TH + o] = 0.f;
+        }
+    }
+    if (p.amax_gu) {
+        __shared__ uint32_t amax_slot;
+        egnn_block_absmax_commit(gu_max, &amax_slot, p.amax_gu);
+    }
+}
+
 }  // namespace
 
 extern "C" int egnn_edge_tail_bwd_f32(const egnn_edge_tail_args* args, void* stream)
@@ -315,7 +583,10 @@ extern "C" int egnn_edge_tail_bwd_f32(const egnn_edge_tail_args* args, void* str
     const int64_t blocks = (E + 255) / 256;
     if (blocks >= ((int64_t)1 << 31)) return EGNN_E_SHAPE;
     if (a.amax_gu && hipMemsetAsync(a.amax_gu, 0, sizeof(uint32_t), static_cast<hipStream_t>(stream)) != hipSuccess) return (int)hipGetLastError();
-    if (a.part) hipLaunchKernelGGL(edge_tail_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    // (EGNN_TAIL_SCALAR=1: the reduce variant with coors_mlp as per-lane FMAs, for A/B and debugging)
+    static const bool scalar_tail = [] { const char* v = getenv("EGNN_TAIL_SCALAR"); return v && v[0] == '1'; }();
+    if (a.part && !scalar_tail) hipLaunchKernelGGL(edge_tail_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else if (a.part) hipLaunchKernelGGL(edge_tail_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     else hipLaunchKernelGGL(edge_tail_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return egnn_launch_status();
 }
