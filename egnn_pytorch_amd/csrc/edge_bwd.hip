@@ -255,8 +255,12 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
     const int chunk = rem / GS;
     const int slab = group * GS + (rem - chunk * GS);
     if (slab >= p.n_slabs) return;                               // (the last group may be partial)
-    const int st0 = chunk * CH;
-    const int nst = (p.Hp / 32 - st0) < CH ? (p.Hp / 32 - st0) : CH;
+    // the hidden steps are dealt out evenly (9 steps in two chunks: 5 + 4, not 8 + 1 -- a chunk of one step pays a round's setup and
+    // its exposed first gather for 32 columns)
+    const int steps_total = p.Hp / 32;
+    const int base = steps_total / n_chunks, extra = steps_total - base * n_chunks;
+    const int st0 = chunk * base + (chunk < extra ? chunk : extra);
+    const int nst = base + (chunk < extra ? 1 : 0);
 
     // the chunk's W2^T fragments and scalar-weight table: once per workgroup
     {

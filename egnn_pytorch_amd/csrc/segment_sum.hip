@@ -3,21 +3,24 @@
 // The backward of the neighbour gather (egnn_pytorch.py:275, feats_j = batched_index_select(feats, nbhd_indices)):
 // d loss / d P_j[j] is the sum of dz over every edge (i, k) whose neighbour is j.  `order` lists the edges sorted by
 // destination (stable, so ties stay in edge order) -- the transposed neighbour list -- which makes the sum a fixed-order
-// read-only reduction: no float atomics, bit-reproducible.  One workgroup per destination row; every wave instruction reads
-// 1 KB of one source row; HBM-bound (each source row is read exactly once).
+// read-only reduction: no float atomics, bit-reproducible.  One WAVE per destination row (four rows per workgroup: narrow rows --
+// the c3 layer's 1152 bytes -- would leave most of a 256-thread workgroup idle); every wave instruction reads 1 KB of one source
+// row; HBM-bound (each source row is read exactly once).
 #include "egnn_common.h"
 
 namespace {
 
 __global__ __launch_bounds__(256) void rows_gather_sum_kernel(const float* __restrict__ rows, int64_t ld, const int64_t* __restrict__ order,
-                                                              const int64_t* __restrict__ seg_ptr, int cols, float* __restrict__ out,
-                                                              int64_t ldo, uint32_t* __restrict__ amax_bits)
+                                                              const int64_t* __restrict__ seg_ptr, int64_t n_out, int cols,
+                                                              float* __restrict__ out, int64_t ldo, uint32_t* __restrict__ amax_bits)
 {
     __shared__ uint32_t amax_slot;
     uint32_t mx = 0u;
-    const int64_t r = blockIdx.x;
-    const int64_t p0 = seg_ptr[r], p1 = seg_ptr[r + 1];
-    for (int c = threadIdx.x * 4; c < cols; c += 256 * 4) {
+    const int64_t r_raw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool live = r_raw < n_out;
+    const int64_t r = live ? r_raw : n_out - 1;
+    const int64_t p0 = seg_ptr[r], p1 = live ? seg_ptr[r + 1] : p0;
+    for (int c = (threadIdx.x & 63) * 4; live && c < cols; c += 64 * 4) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         int64_t p = p0;
         for (; p + 1 < p1; p += 2) {                                   // two rows in flight
@@ -46,8 +49,8 @@ extern "C" int egnn_rows_gather_sum_f32(const float* rows, int64_t ld, const int
     if (n_out > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(rows) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return EGNN_E_ALIGN;
     if (amax_bits && hipMemsetAsync(amax_bits, 0, sizeof(uint32_t), static_cast<hipStream_t>(stream)) != hipSuccess) return (int)hipGetLastError();
-    hipLaunchKernelGGL(rows_gather_sum_kernel, dim3((unsigned)n_out), dim3(256), 0, static_cast<hipStream_t>(stream), rows, ld, order,
-                       seg_ptr, cols, out, ldo, amax_bits);
+    hipLaunchKernelGGL(rows_gather_sum_kernel, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), rows, ld, order,
+                       seg_ptr, n_out, cols, out, ldo, amax_bits);
     return egnn_launch_status();
 }
 
