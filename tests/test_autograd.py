@@ -207,6 +207,11 @@ def test_inference_paths_record_nothing():
     (dict(dim=24, num_nearest_neighbors=48), 96, dict(mask=True)),                                         # multi-round node groups
     (dict(dim=32, edge_dim=4, only_sparse_neighbors=True, norm_coors=True), 40, dict(mask=True, edges=True, adj=True)),   # README-style: 5 scalars
     (dict(dim=32, num_nearest_neighbors=16, fourier_features=1, coor_weights_clamp_value=2.0), 64, dict(mask=False)),     # 3 scalars, one node per tile
+    # round 3: two tiles per source node, the second padded (summed in the kernel); the gate, CoorsNorm, mean pooling and ragged masks through
+    # the matrix-core tail kernel and its in-kernel sums; LayerNorm around the native node_mlp backward
+    (dict(dim=48, num_nearest_neighbors=24, soft_edges=True, norm_coors=True, m_pool_method="mean", norm_feats=True,
+          coor_weights_clamp_value=1.5), 70, dict(mask=True)),
+    (dict(dim=40, num_nearest_neighbors=20, m_dim=12, soft_edges=True), 50, dict(mask=True)),
 ])
 def test_native_backward_kernel_matches_the_aten_recompute(kw, n, flags):
     """The native backwards (E x H work on the HIP kernels, small tail and node-level GEMMs around them) against the pure-ATen
