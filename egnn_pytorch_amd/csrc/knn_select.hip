@@ -291,7 +291,9 @@ extern "C" int egnn_knn_select_f32(const float* coors, const uint8_t* mask, cons
     if (coor_dim < 1 || coor_dim > 8) return EGNN_E_UNSUPPORTED;
     const int C = coor_dim;
     if (K > N) return EGNN_E_K_GT_N;
-    if (N > 4096 || K > 1024) return EGNN_E_UNSUPPORTED;
+    // candidate keys live in registers (ceil(N / 64) per lane) and the graph's coordinates in LDS: N <= 8192 for 3-D coordinates
+    // (128 keys per lane, 104 KB), N <= 4096 otherwise
+    if (N > (C == 3 ? 8192 : 4096) || K > 1024) return EGNN_E_UNSUPPORTED;
     if (B > 65535) return EGNN_E_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (N <= 64) return launch_knn<1>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
@@ -300,7 +302,8 @@ extern "C" int egnn_knn_select_f32(const float* coors, const uint8_t* mask, cons
     if (N <= 512) return launch_knn<8>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
     if (N <= 1024) return launch_knn<16>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
     if (N <= 2048) return launch_knn<32>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
-    return launch_knn<64>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
+    if (N <= 4096) return launch_knn<64>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
+    return launch_knn_c<128, 3>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
 }
 
 extern "C" int egnn_adj_max_degree_u8(const uint8_t* adj, int64_t rows, int N, int32_t* out_dev, void* stream)

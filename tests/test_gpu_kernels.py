@@ -28,12 +28,12 @@ def _dev(x):
 @pytest.mark.parametrize("n,k,use_mask,adj_kind", [
     (16, 4, False, None), (64, 8, True, None), (100, 7, True, None), (256, 32, True, None),
     (1024, 32, True, None), (2048, 16, False, None), (300, 40, True, "random"), (64, 8, True, "chain"),
-    (4096, 8, False, None), (33, 33, True, None), (1024, 100, True, None),
+    (4096, 8, False, None), (33, 33, True, None), (1024, 100, True, None), (6000, 16, True, None), (8192, 32, False, None),
 ])
 def test_knn_select_bit_exact(n, k, use_mask, adj_kind):
     from egnn_pytorch_amd import _ops
     rng = np.random.default_rng(n * 131 + k)
-    b = 3
+    b = 3 if n <= 4096 else 1
     coors = rng.standard_normal((b, n, 3)).astype(np.float32)
     mask = None
     if use_mask:
