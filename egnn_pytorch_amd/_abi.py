@@ -12,11 +12,11 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -29,7 +29,7 @@ SYMBOLS = (
     "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32",
     "egnn_edge_bwd_dz_f32", "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_bwd_work_bytes", "egnn_edge_tail_bwd_f32", "egnn_edge_tail_part_floats", "egnn_edge_pool_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
     "egnn_induced_attn_f32", "egnn_token_attn_f32", "egnn_slot_prep_f32", "egnn_struct_bytes",
-    "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32", "egnn_split_scaled_both_f16", "egnn_silu_bwd_f32",
+    "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32", "egnn_split_scaled_both_f16", "egnn_silu_bwd_f32", "egnn_silu_bwd_drop_f32",
     "egnn_linear_hl_drop_f32",
 )
 
@@ -70,6 +70,7 @@ class EdgeBwdArgs(Structure):
         ("gu_scale", c_float), ("inv_scale", c_float), ("scal", c_void_p), ("Ws", c_void_p), ("scal_scale", c_void_p),
         ("part_rows", c_void_p), ("ld_rows", c_int64),
         ("dW2_part", c_void_p), ("dWs_part", c_void_p), ("ds_part", c_void_p),
+        ("drop_thr", c_uint32), ("drop_seed", c_uint32), ("drop_inv_keep", c_float), ("drop_eid0", c_int64),
         ("row_pairs", c_int32), ("work", c_void_p), ("work_bytes", c_int64),
     ]
 
@@ -83,6 +84,7 @@ class EdgeTailArgs(Structure):
         ("gU", c_void_p), ("g_rel", c_void_p), ("g_hid", c_void_p), ("a3", c_void_p), ("g_w", c_void_p), ("g_scale", c_void_p),
         ("gate_w", c_void_p), ("gate_b", c_void_p), ("g_gate", c_void_p),
         ("part", c_void_p), ("rel_out", c_void_p), ("dist_out", c_void_p), ("amax_gu", c_void_p),
+        ("drop_thr", c_uint32), ("drop_seed", c_uint32), ("drop_inv_keep", c_float), ("drop_eid0", c_int64),
     ]
 
 
@@ -230,6 +232,8 @@ def load():
                                                c_void_p, c_void_p]
     lib.egnn_silu_bwd_f32.restype = c_int
     lib.egnn_silu_bwd_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
+    lib.egnn_silu_bwd_drop_f32.restype = c_int
+    lib.egnn_silu_bwd_drop_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_uint32, c_uint32, c_float, c_int64, c_int, c_void_p]
     lib.egnn_unsplit_words_f32.restype = c_int
     lib.egnn_unsplit_words_f32.argtypes = [c_void_p, c_int64, c_int64, c_int, c_void_p]
     lib.egnn_edge_mfmas.restype = c_int

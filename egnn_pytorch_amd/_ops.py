@@ -435,12 +435,18 @@ def split_scaled_both(x2d, scale):
     return PackedHL(hi, lo, rows, kp), PackedHL(hit, lot, cols, kpt)
 
 
-def silu_bwd_(z, g):
+def silu_bwd_(z, g, drop=None, row0=0):
     """z <- SiLU(z), g <- g * SiLU'(z), in place, one pass (egnn_silu_bwd_f32).  Returns (z, g, bits): bits = the bit patterns of
-    max |SiLU(z)| and max |g SiLU'(z)| (2-element int32 tensor; bits_to_floats)."""
+    max |SiLU(z)| and max |g SiLU'(z)| (2-element int32 tensor; bits_to_floats).  drop = (p, seed): training-mode dropout between
+    the Linear that produced z (rows, cols) and the SiLU -- the forward's hash mask of rows row0 .. (egnn_silu_bwd_drop_f32)."""
     bits = torch.empty(2, dtype=torch.int32, device=z.device)
     with _timed("silu_bwd"):
-        rc = _abi.load().egnn_silu_bwd_f32(_ptr(z), _ptr(g), _ptr(z), _ptr(g), z.numel(), _ptr(bits), _stream())
+        if drop is None:
+            rc = _abi.load().egnn_silu_bwd_f32(_ptr(z), _ptr(g), _ptr(z), _ptr(g), z.numel(), _ptr(bits), _stream())
+        else:
+            from . import _dropout
+            rc = _abi.load().egnn_silu_bwd_drop_f32(_ptr(z), _ptr(g), _ptr(z), _ptr(g), z.numel(), _ptr(bits), _dropout.threshold(drop[0]),
+                                                    int(drop[1]), 1.0 / (1.0 - drop[0]), int(row0), z.shape[-1], _stream())
     _abi.check(rc, "egnn_silu_bwd_f32")
     return z, g, bits
 
@@ -606,7 +612,7 @@ def edge_pool(u16, gate, pair_mask, b, n, k):
 
 
 def edge_tail_bwd(u16, coors, idx32, pair_mask, g_coors_out, g_msum16, w3p, b3p, w4p, b4, scale, eps, clamp, b, n, k, gate=None,
-                  reduce=False, want_rel=False):
+                  reduce=False, want_rel=False, drop=None, eid0=0):
     """egnn_edge_tail_bwd_f32 (include/egnn_hip.h): the per-edge closed-form backward behind edge_mlp's second Linear.
     Returns (gU (E, 16), g_rel (E, 4), g_hid (E, 64), a3 (E, 64), g_w (E,), g_scale (E,) or None); with gate = (gate_w (16) zero
     padded, gate_b (1)) -- soft_edges -- a seventh element g_gate (E,) = d loss / d (gate pre-activation).
@@ -633,6 +639,9 @@ def edge_tail_bwd(u16, coors, idx32, pair_mask, g_coors_out, g_msum16, w3p, b3p,
         a.gU, a.g_rel, a.part = gu.data_ptr(), g_rel.data_ptr(), part.data_ptr()
         gu_bits = torch.empty(1, dtype=torch.int32, device=dev)
         a.amax_gu = gu_bits.data_ptr()
+        if drop is not None:                                  # training-mode dropout in coors_mlp: the forward's hash mask (p, seed), edges numbered from eid0
+            from . import _dropout
+            a.drop_thr, a.drop_seed, a.drop_inv_keep, a.drop_eid0 = _dropout.threshold(drop[0]), int(drop[1]), 1.0 / (1.0 - drop[0]), int(eid0)
         if gate is not None:
             a.gate_w, a.gate_b = gate[0].data_ptr(), gate[1].data_ptr()
         rel = dist = None
@@ -672,7 +681,8 @@ def edge_tail_bwd(u16, coors, idx32, pair_mask, g_coors_out, g_msum16, w3p, b3p,
 ROUNDS_PER_SLAB = int(os.environ.get("EGNN_BWD_ROUNDS_PER_SLAB", "8"))
 
 
-def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, ws_nat=None, want_w2=False, n_slabs=None, row_pairs=False):
+def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, ws_nat=None, want_w2=False, n_slabs=None, row_pairs=False,
+                  drop=None, eid0=0):
     """One pass of egnn_edge_bwd_pass_f32 (include/egnn_hip.h) over the entry list ent (autograd.entry_list).  proj = (B*N, 2 Hp)
     fp32 P_i | P_j rows.  Returns a dict: rows (L / 16, Hp) partial rows, one per tile; with want_w2: w2 = d/d W_2 (16, Hp); with ws_nat (the
     natural-units scalar weights (Hp, S)): ws = d/d W_s (Hp, S) and scal = d/d scalars (E, S) -- the partial arrays of the
@@ -699,6 +709,9 @@ def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, w
     a.scal = scal.data_ptr()
     a.part_rows, a.ld_rows = rows.data_ptr(), hp
     a.row_pairs = int(row_pairs)
+    if drop is not None:                                      # training-mode dropout in edge_mlp: the forward's hash mask (p, seed)
+        from . import _dropout
+        a.drop_thr, a.drop_seed, a.drop_inv_keep, a.drop_eid0 = _dropout.threshold(drop[0]), int(drop[1]), 1.0 / (1.0 - drop[0]), int(eid0)
     if want_w2:
         dw2 = empty(n_slabs, 16, hp, dtype=torch.float32, device=dev)
         a.dW2_part = dw2.data_ptr()

@@ -311,6 +311,16 @@ def _chunk_graphs(layer, n, k, batch):
     return max(1, min(batch, int(_CHUNK_BUDGET_BYTES // max(per_graph, 1.0))))
 
 
+def _dropout_native_ok(layer):
+    """Training-mode dropout on the native backward: the kernels that re-evaluate the forward's hash masks are built for the standard
+    layer with the distance as the only per-edge scalar (egnn_edge_bwd_pass_f32 with drop_thr, the matrix-core tail kernel,
+    egnn_silu_bwd_drop_f32); everything else differentiates the masked layer on the recompute path."""
+    return (_NATIVE_MODE != "dz" and _TAIL_KERNEL and _TAIL_REDUCE and _GRAD_GEMM and _FUSED_SPLIT == "dest"
+            and layer.fourier_features == 0 and layer.edge_dim == 0 and layer.m_dim <= 16
+            and layer.coors_mlp is not None and layer.node_mlp is not None and layer.dim % 2 == 0
+            and os.environ.get("EGNN_TAIL_SCALAR", "0") != "1" and os.environ.get("EGNN_BWD_DROP_NATIVE", "1") != "0")
+
+
 class EGNNFunction(torch.autograd.Function):
     """forward: HIP kernels; backward: chunked recompute through autograd (module docstring)."""
 
@@ -324,7 +334,7 @@ class EGNNFunction(torch.autograd.Function):
         if layer.dropout_active():
             from . import _dropout
             drop = (layer.dropout_p, _dropout.draw_seed())
-        native = _NATIVE and layer.m_dim <= 16 and coors.shape[-1] == 3 and drop is None
+        native = _NATIVE and layer.m_dim <= 16 and coors.shape[-1] == 3 and (drop is None or _dropout_native_ok(layer))
         with torch.no_grad():
             node_out, coors_out, order, idx, rank, valid_radius, u_pre, proj = layer._forward_hip_checked(
                 feats, coors, edges, mask, adj_mat, order_hint, want_u=native, drop_seed=None if drop is None else drop[1])
@@ -481,7 +491,7 @@ def entry_list(eids, keys, n_keys):
     return ent, seg
 
 
-def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists=None, proj=None):
+def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists=None, proj=None, drop=None, eid0=0):
     """egnn_edge_bwd_pass_f32 (csrc/edge_bwd.hip) twice -- entries grouped by source node, then by neighbour: z, SiLU(z) and dz
     are recomputed and contracted in registers, nothing of size E x H reaches memory.  Same returns as _edge_contract_dz."""
     from . import _ops
@@ -497,7 +507,7 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
     # by source every node has ceil(K / 16) tiles: two (16 < K <= 32) are summed inside the kernel, one IS the node's row -- no gather-sum
     pairs = 16 < k <= 32 and s_first and not want_w2_first
     o = _ops.edge_bwd_pass(w, proj, i32, gu16, gu_scale, sc2, ent, bc, n, k, by_dest=False, ws_nat=w_s if s_first else None,
-                           want_w2=want_w2_first, row_pairs=pairs)
+                           want_w2=want_w2_first, row_pairs=pairs, drop=drop, eid0=eid0)
     g_ws, g_scal, g_w2 = o.get("ws"), o.get("scal"), o.get("w2")
     if pairs or k <= 16:
         gz_i = o["rows"][:bc * n]
@@ -508,7 +518,8 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
     if dest_lists is None:
         dest_lists = _ops.dest_lists(i32, bc, n, k, dev)                 # (dense: destination = k)
     ent, seg = dest_lists.ent, dest_lists.tile_seg
-    o = _ops.edge_bwd_pass(w, proj, i32, gu16, gu_scale, sc2, ent, bc, n, k, by_dest=True, ws_nat=None if s_first else w_s, want_w2=g_w2 is None)
+    o = _ops.edge_bwd_pass(w, proj, i32, gu16, gu_scale, sc2, ent, bc, n, k, by_dest=True, ws_nat=None if s_first else w_s, want_w2=g_w2 is None,
+                           drop=drop, eid0=eid0)
     if g_w2 is None:
         g_w2 = o["w2"]
     if not s_first:
@@ -522,12 +533,14 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
     return gz_i, gz_j, g_ws, g_scal, g_w2
 
 
-def _node_mlp_backward(layer, w, f, m_i, g_out, grads_by_id):
+def _node_mlp_backward(layer, w, f, m_i, g_out, grads_by_id, drop=None, row0=0):
     """Backward of the node update out = node_mlp(cat(node_norm(f), m_i)) + f (egnn_pytorch.py:335-337) on the split-f16 GEMMs:
     the hidden pre-activation recomputed by the forward's GEMM, then per Linear one NN product (d/d input) and one split-K TN product
     (d/d weight) that share one (plain, transposed) split of the incoming gradient; SiLU and its derivative in one pass
     (egnn_silu_bwd_f32).  node_norm (LayerNorm or Identity, element-wise per node) stays with autograd.  f: (bc, n, dim) leaf that
-    requires grad; m_i (bc, n, m); g_out (bc, n, dim).  Adds the parameter gradients into grads_by_id; returns (d/d f, d/d m_i)."""
+    requires grad; m_i (bc, n, m); g_out (bc, n, dim).  Adds the parameter gradients into grads_by_id; returns (d/d f, d/d m_i).
+    drop = (p, seed), row0: training-mode dropout behind the first Linear -- the forward's hash mask of node rows row0 .. is
+    re-evaluated inside the SiLU-backward pass."""
     from . import _ops
     bc, n, dim = f.shape
     m = m_i.shape[-1]
@@ -542,7 +555,7 @@ def _node_mlp_backward(layer, w, f, m_i, g_out, grads_by_id):
         go = _ops.GradOperand(g2d)
         g_a1 = _ops.grad_nn(go, w["W6T_split"], 2 * dim, name="bwd_node_mlp")
         if z1.numel() % 4 == 0:
-            a1, g_z1, bits = _ops.silu_bwd_(z1, g_a1)
+            a1, g_z1, bits = _ops.silu_bwd_(z1, g_a1, drop, row0)
             amax_a1, amax_gz = _ops.bits_to_floats(bits)               # (by-products of the pass: no absmax launches for these two)
         else:
             sg = torch.sigmoid(z1)
@@ -613,6 +626,8 @@ def _backward_native(ctx, g_node, g_coors):
     if g_coors is None:
         g_coors = torch.zeros_like(coors)
     u_all = ctx.saved_tensors[6].view(b, n, k, 16)
+    drop = getattr(ctx, "drop", None)                    # (p, seed) of a training-mode forward (_dropout_native_ok), else None
+    reduce = False
     fused = _NATIVE_MODE != "dz" and s_in <= 5           # (egnn_edge_bwd_pass_f32 is built for up to 5 per-edge scalars)
     proj_all = None
     if len(ctx.saved_tensors) > 7 and ctx.saved_tensors[7].numel() and fused:
@@ -701,7 +716,7 @@ def _backward_native(ctx, g_node, g_coors):
                 else:
                     rel, scal = edge_scalars(layer, c, e, i64)                               # (only the scalars' graph is used below)
             if f0.is_cuda and _GRAD_GEMM:
-                g_f, g_mi = _node_mlp_backward(layer, w, f, m_i[..., :m], g_node[lo:hi_], grads_by_id)
+                g_f, g_mi = _node_mlp_backward(layer, w, f, m_i[..., :m], g_node[lo:hi_], grads_by_id, drop, lo * n)
                 g_feats[lo:hi_] += g_f
             else:
                 with torch.enable_grad():
@@ -736,7 +751,8 @@ def _backward_native(ctx, g_node, g_coors):
                              layer.coor_weights_clamp_value, bc, n, k)
                 bias2 = gu_bits = None
                 if reduce:
-                    gu16, g_rel, sums, rel4, dist, gu_bits = _ops.edge_tail_bwd(*tail_args, gate=gate, reduce=True, want_rel=closed_dist)
+                    gu16, g_rel, sums, rel4, dist, gu_bits = _ops.edge_tail_bwd(*tail_args, gate=gate, reduce=True, want_rel=closed_dist,
+                                                                               drop=drop, eid0=lo * n * k)
                     grads_by_id[id(lin_a.weight)] += sums[:1024].view(64, 16)[:hid3, :m]
                     grads_by_id[id(lin_a.bias)] += sums[1024:1024 + hid3]
                     grads_by_id[id(lin_b.weight)] += sums[1088:1088 + hid3][None, :]
@@ -803,7 +819,12 @@ def _backward_native(ctx, g_node, g_coors):
             sc2 = scal.detach().reshape(ec, s_in).contiguous()
             contract = _edge_contract_fused if fused else _edge_contract_dz
             proj = None if proj_all is None else proj_all[lo * n:hi_ * n]
-            gz_i, gz_j, g_ws, g_scal, g_w2 = contract(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists, proj)
+            if drop is not None:
+                assert fused and tail_kernel and reduce and closed_dist                # (_dropout_native_ok: nothing else keeps u)
+                gz_i, gz_j, g_ws, g_scal, g_w2 = contract(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists, proj,
+                                                          drop, lo * n * k)
+            else:
+                gz_i, gz_j, g_ws, g_scal, g_w2 = contract(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists, proj)
             # ---- 3. node-level products: d/d feats = dP_i W_i + dP_j W_j, d/d W_i = dP_i^T feats, d/d W_j = dP_j^T feats.  On the
             # device: the forward's split-f16 matrix-core GEMM (operands pre-scaled by powers of two, the weight gradients split-K
             # over the B N nodes with the parts summed in fixed order) -- the fp32 library GEMMs they replace ran at 60 - 130 TFLOP/s

@@ -224,8 +224,10 @@ __global__ __launch_bounds__(256) void edge_bwd_prep_kernel(const egnn_edge_bwd_
 // NM: first-layer MFMAs of the scalar term (egnn_edge_mfmas(S)); ST: register bound on S (per-edge scalars); WANT_W2: also
 // d/d W_2; WANT_S: also d/d W_s and d/d s; CH: steps of 32 hidden columns the workgroup owns
 // PAIR: the two tiles of a round belong to one node (by source, 16 < K <= 32): one partial row per round = the node's row
-template <int NM, int ST, bool WANT_W2, bool WANT_S, int CH, bool PAIR = false>
-__global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WANT_S) && ST > 1)) ? 2 : (WANT_W2 ? EGNN_BWD_W2_BLOCKS : (WANT_S ? EGNN_BWD_S_BLOCKS : EGNN_BWD_DEST_BLOCKS))) void edge_bwd_kernel(const egnn_edge_bwd_args p, const BwdPrep w)
+// DROP: training-mode dropout behind edge_mlp's first Linear (egnn_pytorch.py:178-184): the forward's hash mask (csrc/egnn_common.h:
+// row = global edge id, column = hidden unit) re-evaluated on z and on SiLU'
+template <int NM, int ST, bool WANT_W2, bool WANT_S, int CH, bool PAIR = false, bool DROP = false>
+__global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WANT_S) && ST > 1)) ? 2 : (WANT_W2 ? EGNN_BWD_W2_BLOCKS : (WANT_S ? (DROP ? 3 : EGNN_BWD_S_BLOCKS) : EGNN_BWD_DEST_BLOCKS))) void edge_bwd_kernel(const egnn_edge_bwd_args p, const BwdPrep w)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* w2t = reinterpret_cast<_Float16*>(smem);                                  // [CH][hb][hi|lo][64][4] halves
@@ -332,9 +334,14 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
         float sv[2][4][MW ? 1 : ST];
         f16x4 sth[2], stl[2];                      // MW: the tile's scalars transposed, A fragment [m = scalar][k = entry]
         f16x4 gth[2], gtl[2], ind[2];
+        uint32_t ekey[DROP ? 2 : 1][4];             // DROP: the mask's row key of entry (t, r)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const i32x4 e4 = *reinterpret_cast<const i32x4*>(p.ent + q0 + 16 * t + 4 * g);
+            if constexpr (DROP) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ekey[t][r] = egnn_drop_base(p.drop_seed, EGNN_DROP_SITE_EDGE, (uint32_t)((int64_t)e4[r] + p.drop_eid0));
+            }
             const int tile = (q0 >> 4) + t;
             ownoff[t] = (int)((size_t)__builtin_amdgcn_readfirstlane(w.own[tile]) * p.ldp * 4);
             f32x4 st4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -447,7 +454,12 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
                     f32x4 av4, dz4;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float y = x[t][r];
+                        float y = x[t][r];
+                        bool keep = true;
+                        if constexpr (DROP) {                      // (y = -log2(e) z: the rescaling commutes; a dropped unit sees z = 0)
+                            keep = egnn_drop_hash(ekey[t][r], (uint32_t)col) >= p.drop_thr;
+                            y = keep ? y * p.drop_inv_keep : 0.f;
+                        }
                         sgv[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
                         if constexpr (WANT_W2) {
                             znv[r] = y * (-0.6931471805599453f * A_UP);
@@ -460,6 +472,7 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
                             spv[r] = sgv[r] * __builtin_fmaf(y, tc, 1.0f);
                             znv[r] = 0.f; av4[r] = 0.f;
                         }
+                        if constexpr (DROP) spv[r] = keep ? spv[r] * p.drop_inv_keep : 0.f;      // d (dropped z) / d z
                         dz4[r] = ga[r] * spv[r];
                         asm("" : "+v"(dz4[r]));                    // (scalar multiplies: v_pk_mul_f32 costs 9.3 cycles per pair against 2 x 2.9)
                     }
@@ -620,7 +633,7 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
     }
 }
 
-template <int NM, int ST, bool W2, bool SS, int CH, bool PAIR = false>
+template <int NM, int ST, bool W2, bool SS, int CH, bool PAIR = false, bool DROP = false>
 int launch_v(const egnn_edge_bwd_args& a, hipStream_t s)
 {
     if (a.row_pairs && !PAIR) return EGNN_E_UNSUPPORTED;
@@ -632,13 +645,24 @@ int launch_v(const egnn_edge_bwd_args& a, hipStream_t s)
     if (!a.work || a.work_bytes < (int64_t)prep_bytes(a.L, NM, W2, S1)) return EGNN_E_SHAPE;
     const BwdPrep w = prep_carve(a.work, a.L, NM, W2, S1);
     hipLaunchKernelGGL((edge_bwd_prep_kernel<NM>), dim3((unsigned)((a.L + 255) / 256)), dim3(256), 0, s, a, w);
-    hipLaunchKernelGGL((edge_bwd_kernel<NM, ST, W2, SS, CH, PAIR>), grid, dim3(BW_THREADS), lds, s, a, w);
+    hipLaunchKernelGGL((edge_bwd_kernel<NM, ST, W2, SS, CH, PAIR, DROP>), grid, dim3(BW_THREADS), lds, s, a, w);
     return egnn_launch_status();
 }
 
 template <int NM, int ST>
 int launch(const egnn_edge_bwd_args& a, hipStream_t s)
 {
+    if (a.drop_thr) {
+        // training-mode dropout: instantiated for the distance as the only per-edge scalar
+        if constexpr (NM == 1 && ST == 1) {
+            if (a.dW2_part && a.dWs_part) return launch_v<NM, ST, true, true, CH_S, false, true>(a, s);
+            if (a.dW2_part) return launch_v<NM, ST, true, false, CH_W2, false, true>(a, s);
+            if (a.dWs_part) return a.row_pairs ? launch_v<NM, ST, false, true, CH_S, true, true>(a, s) : launch_v<NM, ST, false, true, CH_S, false, true>(a, s);
+            return launch_v<NM, ST, false, false, CH_S, false, true>(a, s);
+        } else {
+            return EGNN_E_UNSUPPORTED;
+        }
+    }
     if (a.dW2_part && a.dWs_part) {
         // (everything in one pass: built for S = 1 only; with more scalars its registers do not fit 2 workgroups per CU)
         if constexpr (ST == 1) return launch_v<NM, ST, true, true, CH_S>(a, s);
@@ -676,6 +700,7 @@ extern "C" int egnn_edge_bwd_pass_f32(const egnn_edge_bwd_args* args, void* stre
     if (a.S > 5 || a.wst_terms != 4 * (a.S <= 1 ? 1 : (a.S <= 4 ? 3 : 4))) return EGNN_E_UNSUPPORTED;
     if (a.dWs_part && a.S > 1 && !a.scal_scale) return EGNN_E_NULLPTR;
     if (!(a.ws_inv_scale > 0.f) || !(a.gu_scale > 0.f) || !(a.inv_scale > 0.f)) return EGNN_E_SHAPE;
+    if (a.drop_thr && !(a.drop_inv_keep >= 1.f)) return EGNN_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(a.Pi) & 15) || (reinterpret_cast<uintptr_t>(a.Pj) & 15) || (reinterpret_cast<uintptr_t>(a.W2Th) & 15) ||
         (reinterpret_cast<uintptr_t>(a.gU) & 15) || (reinterpret_cast<uintptr_t>(a.ent) & 15) ||
         (reinterpret_cast<uintptr_t>(a.Wst) & 3) || (reinterpret_cast<uintptr_t>(a.work) & 15))

@@ -405,8 +405,13 @@ __global__ __launch_bounds__(256) void edge_tail_mfma_kernel(const egnn_edge_tai
         h16x4 mh, ml;
         tail_split4(m4, mh, ml);
         // ---- coors_mlp forward: hid^T, a3, q = W4 SiLU'(hid); w = W4 . a3 + b4
+        // (training-mode dropout behind coors_mlp's first Linear, egnn_pytorch.py:203-208: the forward's hash mask -- row = global edge
+        // id, column = hidden unit -- re-evaluated here; the keep bits of the lane's 16 units are reused by the backward below)
         float hid[4][4], sgh4[4][4];
         float wpartial = 0.f;
+        uint32_t kbits = 0xffffu;
+        const uint32_t ckey = egnn_drop_base(p.drop_seed, EGNN_DROP_SITE_COORS, (uint32_t)(e + p.drop_eid0));
+        if (p.drop_thr) kbits = 0u;
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb) {
             const h16x4 ah = __builtin_bit_cast(h16x4, fragA[tb][0][lane]), al = __builtin_bit_cast(h16x4, fragA[tb][1][lane]);
@@ -417,7 +422,12 @@ __global__ __launch_bounds__(256) void edge_tail_mfma_kernel(const egnn_edge_tai
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int t = 16 * tb + 4 * g + r;
-                const float h = __builtin_fmaf(d[r], inv_s3, sb3[t]);
+                float h = __builtin_fmaf(d[r], inv_s3, sb3[t]);
+                if (p.drop_thr) {
+                    const bool keep = egnn_drop_hash(ckey, (uint32_t)t) >= p.drop_thr;
+                    h = keep ? h * p.drop_inv_keep : 0.f;
+                    kbits |= keep ? (1u << (4 * tb + r)) : 0u;
+                }
                 const float sg = egnn_sigmoid(h);
                 hid[tb][r] = h;
                 sgh4[tb][r] = sg;
@@ -481,6 +491,7 @@ __global__ __launch_bounds__(256) void edge_tail_mfma_kernel(const egnn_edge_tai
             for (int r = 0; r < 4; ++r) {
                 const float h = hid[tb][r], sg = sgh4[tb][r];
                 q[r] = sW4[16 * tb + 4 * g + r] * (sg * (1.0f + h * (1.0f - sg)));
+                if (p.drop_thr) q[r] = ((kbits >> (4 * tb + r)) & 1u) ? q[r] * p.drop_inv_keep : 0.f;       // d (dropped hid) / d hid
                 ghv[r] = g_w * q[r];
                 a3v[r] = h * sg;
             }
@@ -573,6 +584,7 @@ extern "C" int egnn_edge_tail_bwd_f32(const egnn_edge_tail_args* args, void* str
     if (a.norm_coors && (!a.scale || (!a.part && !a.g_scale))) return EGNN_E_NULLPTR;
     if (a.gate_w && (!a.gate_b || (!a.part && !a.g_gate))) return EGNN_E_NULLPTR;
     if ((a.rel_out == nullptr) != (a.dist_out == nullptr)) return EGNN_E_NULLPTR;
+    if (a.drop_thr && !(a.drop_inv_keep >= 1.f)) return EGNN_E_SHAPE;
     if (a.B <= 0 || a.N <= 0 || a.K <= 0) return EGNN_E_SHAPE;
     if (a.idx == nullptr && a.K != a.N) return EGNN_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(a.u) & 15) || (reinterpret_cast<uintptr_t>(a.gU) & 15) || (reinterpret_cast<uintptr_t>(a.g_rel) & 15) ||
@@ -585,6 +597,7 @@ extern "C" int egnn_edge_tail_bwd_f32(const egnn_edge_tail_args* args, void* str
     if (a.amax_gu && hipMemsetAsync(a.amax_gu, 0, sizeof(uint32_t), static_cast<hipStream_t>(stream)) != hipSuccess) return (int)hipGetLastError();
     // (EGNN_TAIL_SCALAR=1: the reduce variant with coors_mlp as per-lane FMAs, for A/B and debugging)
     static const bool scalar_tail = [] { const char* v = getenv("EGNN_TAIL_SCALAR"); return v && v[0] == '1'; }();
+    if (a.drop_thr && (!a.part || scalar_tail)) return EGNN_E_UNSUPPORTED;       // (dropout: the matrix-core variant only)
     if (a.part && !scalar_tail) hipLaunchKernelGGL(edge_tail_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     else if (a.part) hipLaunchKernelGGL(edge_tail_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     else hipLaunchKernelGGL(edge_tail_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);

@@ -181,7 +181,11 @@ __global__ __launch_bounds__(256) void split_scaled_kernel(const float* __restri
 }
 
 // a = SiLU(z) and gz = g SiLU'(z) in one pass (the backward of node_mlp's activation, egnn_pytorch.py:196-201); a_out may be z, gz_out may be g
-__global__ __launch_bounds__(256) void silu_bwd_kernel(const float* z, const float* g, float* a_out, float* gz_out, int64_t quads, uint32_t* amax_bits)
+// drop_thr != 0: nn.Dropout sits between the Linear and the SiLU (egnn_pytorch.py:196-201): z is the Linear's output, the forward's
+// hash mask (site node, row = row0 + element / cols, column = element % cols) is re-evaluated: z_d = keep ? z k : 0, a = SiLU(z_d),
+// gz = g SiLU'(z_d) (keep ? k : 0).
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const float* z, const float* g, float* a_out, float* gz_out, int64_t quads, uint32_t* amax_bits,
+                                                       uint32_t drop_thr, uint32_t drop_seed, float drop_inv_keep, int64_t row0, int cols)
 {
     __shared__ uint32_t slot_a, slot_g;
     uint32_t ma = 0u, mg = 0u;
@@ -189,11 +193,24 @@ __global__ __launch_bounds__(256) void silu_bwd_kernel(const float* z, const flo
         const f32x4 zv = reinterpret_cast<const f32x4*>(z)[q];
         const f32x4 gv = reinterpret_cast<const f32x4*>(g)[q];
         f32x4 av, dv;
+        uint32_t key = 0u;
+        int col0 = 0;
+        if (drop_thr) {                                          // (cols % 4 == 0: a quad stays inside one row)
+            const int64_t row = (q * 4) / cols;
+            col0 = (int)(q * 4 - row * cols);
+            key = egnn_drop_base(drop_seed, EGNN_DROP_SITE_NODE, (uint32_t)(row0 + row));
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float sg = 1.0f / (1.0f + __expf(-zv[u]));
-            av[u] = zv[u] * sg;
-            dv[u] = gv[u] * (sg * (1.0f + zv[u] * (1.0f - sg)));
+            float zz = zv[u], gk = 1.0f;
+            if (drop_thr) {
+                const bool keep = egnn_drop_hash(key, (uint32_t)(col0 + u)) >= drop_thr;
+                zz = keep ? zz * drop_inv_keep : 0.f;
+                gk = keep ? drop_inv_keep : 0.f;
+            }
+            const float sg = 1.0f / (1.0f + __expf(-zz));
+            av[u] = zz * sg;
+            dv[u] = gv[u] * (sg * (1.0f + zz * (1.0f - sg))) * gk;
             const uint32_t ta = egnn_abs_bits(av[u]), tg = egnn_abs_bits(dv[u]);
             ma = ma > ta ? ma : ta;
             mg = mg > tg ? mg : tg;
@@ -324,8 +341,18 @@ extern "C" int egnn_split_scaled_both_f16(const float* X, int64_t ldx, int64_t r
     return egnn_launch_status();
 }
 
+extern "C" int egnn_silu_bwd_drop_f32(const float* z, const float* g, float* a_out, float* gz_out, int64_t count, uint32_t* amax_bits,
+                                      uint32_t drop_thr, uint32_t drop_seed, float drop_inv_keep, int64_t row0, int cols, void* stream);
+
 extern "C" int egnn_silu_bwd_f32(const float* z, const float* g, float* a_out, float* gz_out, int64_t count, uint32_t* amax_bits, void* stream)
 {
+    return egnn_silu_bwd_drop_f32(z, g, a_out, gz_out, count, amax_bits, 0u, 0u, 1.f, 0, 4, stream);
+}
+
+extern "C" int egnn_silu_bwd_drop_f32(const float* z, const float* g, float* a_out, float* gz_out, int64_t count, uint32_t* amax_bits,
+                                      uint32_t drop_thr, uint32_t drop_seed, float drop_inv_keep, int64_t row0, int cols, void* stream)
+{
+    if (drop_thr && (!(drop_inv_keep >= 1.f) || cols <= 0 || (cols % 4) != 0 || row0 < 0 || row0 + count / cols > 0xffffffffLL)) return EGNN_E_SHAPE;
     if (!z || !g || !a_out || !gz_out) return EGNN_E_NULLPTR;
     if (count <= 0 || (count % 4) != 0) return EGNN_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(a_out) | reinterpret_cast<uintptr_t>(gz_out)) & 15)
@@ -333,7 +360,8 @@ extern "C" int egnn_silu_bwd_f32(const float* z, const float* g, float* a_out, f
     int64_t blocks = (count / 4 + 256 * 4 - 1) / (256 * 4);
     blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
     if (amax_bits && hipMemsetAsync(amax_bits, 0, 2 * sizeof(uint32_t), static_cast<hipStream_t>(stream)) != hipSuccess) return (int)hipGetLastError();
-    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), z, g, a_out, gz_out, count / 4, amax_bits);
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), z, g, a_out, gz_out, count / 4, amax_bits,
+                       drop_thr, drop_seed, drop_inv_keep, row0, cols);
     return egnn_launch_status();
 }
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 25
+#define EGNN_ABI_VERSION 26
 
 enum {
     EGNN_OK = 0,
@@ -193,6 +193,11 @@ int egnn_split_scaled_both_f16(const float* X, int64_t ldx, int64_t rows, int co
  * 16-byte aligned; a_out may be z and gz_out may be g (element-wise); amax_bits (2 words) or NULL: the bit patterns of max |a_out| and
  * max |gz_out| (egnn_absmax_f32's contract) -- both are operands of the next gradient GEMMs. */
 int egnn_silu_bwd_f32(const float* z, const float* g, float* a_out, float* gz_out, int64_t count, uint32_t* amax_bits, void* stream);
+/* ... with training-mode dropout between the Linear and the SiLU (node_mlp, egnn_pytorch.py:196-201): z (rows, cols) is the Linear's
+ * output; the forward's mask (egnn_linear_hl_drop_f32: site node, row = row0 + r, column c) is re-evaluated: z_d = keep ? z *
+ * drop_inv_keep : 0, a_out = SiLU(z_d), gz_out = g SiLU'(z_d) (keep ? drop_inv_keep : 0).  cols % 4 == 0. */
+int egnn_silu_bwd_drop_f32(const float* z, const float* g, float* a_out, float* gz_out, int64_t count, uint32_t* amax_bits,
+                           uint32_t drop_thr, uint32_t drop_seed, float drop_inv_keep, int64_t row0, int cols, void* stream);
 int egnn_linear_hl_splitk_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo, float w_inv_scale, float* C_parts,
                               int64_t ldc, int64_t M, int N, int Kp, int w_rows, int k_splits, void* stream);
 int egnn_sum_parts_f32(const float* parts, int nparts, int64_t count, float scale, float* out, void* stream);
@@ -365,6 +370,10 @@ typedef struct egnn_edge_bwd_args {
     float* dW2_part;            /* out or NULL */
     float* dWs_part;            /* out or NULL (with ds_part) */
     float* ds_part;             /* out or NULL (with dWs_part) */
+    uint32_t drop_thr;          /* training-mode dropout behind edge_mlp's first Linear (egnn_pytorch.py:178-184): 0 = none, else the forward's */
+    uint32_t drop_seed;         /*   mask (egnn_edge_args.drop_*) is re-evaluated: keep iff hash(seed, site edge, drop_eid0 + edge id, hidden unit) */
+    float drop_inv_keep;        /*   >= drop_thr, kept units times drop_inv_keep; S = 1 only (EGNN_E_UNSUPPORTED otherwise) */
+    int64_t drop_eid0;          /*   global id of this call's first edge (the forward numbered the whole batch's edges) */
     int row_pairs;              /* 1 (by source with d/d W_s, 16 < K <= 32, the list = 32 entries per node): the two tiles of a node are summed */
                                 /*   in the kernel -- part_rows (L / 32 + 1, ld_rows) holds one row per NODE and no gather-sum is needed */
     void* work;                 /* scratch, 16-byte aligned: the pass's per-entry records (other endpoint's row, fp16 fragments of gU and of */
@@ -421,6 +430,10 @@ typedef struct egnn_edge_tail_args {
     float* rel_out;             /* out or NULL: (E, 4) x_i - x_j (4th 0) and, with it, dist_out (E) = |x_i - x_j|^2 -- what the backward of the */
     float* dist_out;            /*   distance path needs (d loss / d rel += 2 g_dist rel), by-products of this pass */
     uint32_t* amax_gu;          /* out or NULL: the bit pattern of max |gU| (egnn_absmax_f32's contract) -- the scale of the next pass's fp16 split */
+    uint32_t drop_thr;          /* training-mode dropout behind coors_mlp's first Linear (egnn_pytorch.py:203-208): 0 = none, else the forward's mask */
+    uint32_t drop_seed;         /*   (site coors, row = drop_eid0 + edge id, column = hidden unit) is re-evaluated; with `part` only */
+    float drop_inv_keep;
+    int64_t drop_eid0;
 } egnn_edge_tail_args;
 
 int egnn_edge_tail_bwd_f32(const egnn_edge_tail_args* args, void* stream);

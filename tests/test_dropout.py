@@ -120,33 +120,55 @@ def test_training_mode_forward_applies_exactly_the_hash_masks(kw, n, use_mask):
     np.testing.assert_allclose(e1[0].cpu().numpy(), plain[0].cpu().numpy(), atol=1e-4, rtol=0)
 
 
+BWD_CASES = [
+    # (the first three take the NATIVE backward -- the hash masks re-evaluated inside egnn_edge_bwd_pass_f32, the matrix-core tail kernel
+    # and egnn_silu_bwd_drop_f32: one tile per node, two tiles per node summed in the kernel, the gate + CoorsNorm + mean pooling + masks;
+    # the last two -- per-edge features / fourier terms -- the recompute path)
+    (dict(dim=32, num_nearest_neighbors=8, dropout=0.2, norm_feats=True), 40, False, True),
+    (dict(dim=64, num_nearest_neighbors=32, dropout=0.25), 96, True, True),
+    (dict(dim=32, num_nearest_neighbors=20, dropout=0.1, norm_coors=True, soft_edges=True, m_pool_method="mean", coor_weights_clamp_value=2.0), 50, True, True),
+    (dict(dim=32, num_nearest_neighbors=16, dropout=0.2, edge_dim=3, fourier_features=1), 48, True, False),
+    (dict(dim=24, num_nearest_neighbors=8, dropout=0.3, fourier_features=2, m_dim=8), 30, False, False),
+]
+
+
 @pytest.mark.gpu
-def test_training_mode_backward_differentiates_the_masked_layer():
+@pytest.mark.parametrize("kw,n,use_mask,native", BWD_CASES)
+def test_training_mode_backward_differentiates_the_masked_layer(kw, n, use_mask, native):
     """loss.backward() through the drop-in layer in training mode: every gradient equals float64 autograd of the restatement with
     the masks of THAT forward call (the seed comes from torch's CPU generator: torch.manual_seed reproduces it)."""
     from egnn_pytorch_amd import EGNN, _dropout, autograd as A
     torch.manual_seed(21)
-    kw = dict(dim=32, num_nearest_neighbors=8, dropout=0.2, norm_feats=True)
     layer = EGNN(**kw)
+    assert A._dropout_native_ok(layer) == native
     with torch.no_grad():
         for prm in layer.parameters():
             prm.mul_(40.0)
     layer = layer.cuda().train()
     g = torch.Generator().manual_seed(4)
-    b, n = 2, 40
-    feats, coors = torch.randn(b, n, 32, generator=g).cuda(), torch.randn(b, n, 3, generator=g).cuda()
-    rn, rc = torch.randn(b, n, 32, generator=g).cuda(), torch.randn(b, n, 3, generator=g).cuda()
+    b = 3
+    dim, p = kw["dim"], kw["dropout"]
+    feats, coors = torch.randn(b, n, dim, generator=g).cuda(), torch.randn(b, n, 3, generator=g).cuda()
+    edges = torch.randn(b, n, n, kw["edge_dim"], generator=g).cuda() if kw.get("edge_dim") else None
+    mask = (torch.arange(n)[None] < torch.tensor([[n], [n - 3], [n // 2 + 2]])).cuda() if use_mask else None
+    rn, rc = torch.randn(b, n, dim, generator=g).cuda(), torch.randn(b, n, 3, generator=g).cuda()
     torch.manual_seed(77)
     seed = _dropout.draw_seed()
     torch.manual_seed(77)
     f, c = feats.clone().requires_grad_(True), coors.clone().requires_grad_(True)
-    node, co = layer(f, c)
-    got = torch.autograd.grad((node * rn).sum() + (co * rc).sum(), [f, c] + list(layer.parameters()), allow_unused=True)
+    saved = A._FUSED_MAX_GRAPHS
+    A._FUSED_MAX_GRAPHS = 2                                  # two chunks of graphs: the masks' rows are global edge / node ids
+    try:
+        node, co = layer(f, c, edges, mask)
+        got = torch.autograd.grad((node * rn).sum() + (co * rc).sum(), [f, c] + list(layer.parameters()), allow_unused=True)
+    finally:
+        A._FUSED_MAX_GRAPHS = saved
     with torch.no_grad():
-        idx, rank, radius = layer._forward_hip_checked(feats, coors, None, None, None, None, drop_seed=seed)[3:6]
+        idx, rank, radius = layer._forward_hip_checked(feats, coors, edges, mask, None, None, drop_seed=seed)[3:6]
     l64 = copy.deepcopy(layer).double()
     f2, c2 = feats.double().requires_grad_(True), coors.double().requires_grad_(True)
-    n2, co2 = A.layer_given_neighbors(l64, f2, c2, None, None, idx.long(), rank.double(), radius, drop=(0.2, seed))
+    n2, co2 = A.layer_given_neighbors(l64, f2, c2, None if edges is None else edges.double(), mask, idx.long(), rank.double(), radius,
+                                      drop=(p, seed))
     np.testing.assert_allclose(node.detach().cpu().numpy(), n2.detach().cpu().numpy(), atol=1e-4, rtol=0)
     want = torch.autograd.grad((n2 * rn.double()).sum() + (co2 * rc.double()).sum(), [f2, c2] + list(l64.parameters()), allow_unused=True)
     for a, r in zip(got, want):
@@ -155,7 +177,7 @@ def test_training_mode_backward_differentiates_the_masked_layer():
             assert float((a.double() - r).abs().max()) <= 1e-4 * max(1.0, float(r.abs().max()))
     # two training-mode calls draw different masks
     with torch.no_grad():
-        a1, a2 = layer(feats, coors)[0], layer(feats, coors)[0]
+        a1, a2 = layer(feats, coors, edges, mask)[0], layer(feats, coors, edges, mask)[0]
     assert not torch.allclose(a1, a2, atol=1e-3)
 
 
