@@ -313,10 +313,10 @@ def _chunk_graphs(layer, n, k, batch):
 
 def _dropout_native_ok(layer):
     """Training-mode dropout on the native backward: the kernels that re-evaluate the forward's hash masks are built for the standard
-    layer with the distance as the only per-edge scalar (egnn_edge_bwd_pass_f32 with drop_thr, the matrix-core tail kernel,
+    layer with up to five per-edge scalars (egnn_edge_bwd_pass_f32 with drop_thr, the matrix-core tail kernel,
     egnn_silu_bwd_drop_f32); everything else differentiates the masked layer on the recompute path."""
     return (_NATIVE_MODE != "dz" and _TAIL_KERNEL and _TAIL_REDUCE and _GRAD_GEMM and _FUSED_SPLIT == "dest"
-            and layer.fourier_features == 0 and layer.edge_dim == 0 and layer.m_dim <= 16
+            and 2 * layer.fourier_features + 1 + layer.edge_dim <= 5 and layer.m_dim <= 16
             and layer.coors_mlp is not None and layer.node_mlp is not None and layer.dim % 2 == 0
             and os.environ.get("EGNN_TAIL_SCALAR", "0") != "1" and os.environ.get("EGNN_BWD_DROP_NATIVE", "1") != "0")
 
@@ -820,7 +820,7 @@ def _backward_native(ctx, g_node, g_coors):
             contract = _edge_contract_fused if fused else _edge_contract_dz
             proj = None if proj_all is None else proj_all[lo * n:hi_ * n]
             if drop is not None:
-                assert fused and tail_kernel and reduce and closed_dist                # (_dropout_native_ok: nothing else keeps u)
+                assert fused and tail_kernel and reduce                                # (_dropout_native_ok: nothing else keeps u)
                 gz_i, gz_j, g_ws, g_scal, g_w2 = contract(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists, proj,
                                                           drop, lo * n * k)
             else:

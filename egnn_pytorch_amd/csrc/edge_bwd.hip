@@ -653,15 +653,14 @@ template <int NM, int ST>
 int launch(const egnn_edge_bwd_args& a, hipStream_t s)
 {
     if (a.drop_thr) {
-        // training-mode dropout: instantiated for the distance as the only per-edge scalar
-        if constexpr (NM == 1 && ST == 1) {
-            if (a.dW2_part && a.dWs_part) return launch_v<NM, ST, true, true, CH_S, false, true>(a, s);
-            if (a.dW2_part) return launch_v<NM, ST, true, false, CH_W2, false, true>(a, s);
-            if (a.dWs_part) return a.row_pairs ? launch_v<NM, ST, false, true, CH_S, true, true>(a, s) : launch_v<NM, ST, false, true, CH_S, false, true>(a, s);
-            return launch_v<NM, ST, false, false, CH_S, false, true>(a, s);
-        } else {
-            return EGNN_E_UNSUPPORTED;
+        // training-mode dropout: the same variants with the forward's mask re-evaluated (their own instantiations: a hash per value)
+        if (a.dW2_part && a.dWs_part) {
+            if constexpr (ST == 1) return launch_v<NM, ST, true, true, CH_S, false, true>(a, s);
+            else return EGNN_E_UNSUPPORTED;
         }
+        if (a.dW2_part) return launch_v<NM, ST, true, false, CH_W2, false, true>(a, s);
+        if (a.dWs_part) return a.row_pairs ? launch_v<NM, ST, false, true, CH_S, true, true>(a, s) : launch_v<NM, ST, false, true, CH_S, false, true>(a, s);
+        return launch_v<NM, ST, false, false, CH_S, false, true>(a, s);
     }
     if (a.dW2_part && a.dWs_part) {
         // (everything in one pass: built for S = 1 only; with more scalars its registers do not fit 2 workgroups per CU)

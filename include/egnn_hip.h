@@ -372,7 +372,7 @@ typedef struct egnn_edge_bwd_args {
     float* ds_part;             /* out or NULL (with dWs_part) */
     uint32_t drop_thr;          /* training-mode dropout behind edge_mlp's first Linear (egnn_pytorch.py:178-184): 0 = none, else the forward's */
     uint32_t drop_seed;         /*   mask (egnn_edge_args.drop_*) is re-evaluated: keep iff hash(seed, site edge, drop_eid0 + edge id, hidden unit) */
-    float drop_inv_keep;        /*   >= drop_thr, kept units times drop_inv_keep; S = 1 only (EGNN_E_UNSUPPORTED otherwise) */
+    float drop_inv_keep;        /*   >= drop_thr, kept units times drop_inv_keep */
     int64_t drop_eid0;          /*   global id of this call's first edge (the forward numbered the whole batch's edges) */
     int row_pairs;              /* 1 (by source with d/d W_s, 16 < K <= 32, the list = 32 entries per node): the two tiles of a node are summed */
                                 /*   in the kernel -- part_rows (L / 32 + 1, ld_rows) holds one row per NODE and no gather-sum is needed */

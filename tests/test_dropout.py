@@ -123,12 +123,12 @@ def test_training_mode_forward_applies_exactly_the_hash_masks(kw, n, use_mask):
 BWD_CASES = [
     # (the first three take the NATIVE backward -- the hash masks re-evaluated inside egnn_edge_bwd_pass_f32, the matrix-core tail kernel
     # and egnn_silu_bwd_drop_f32: one tile per node, two tiles per node summed in the kernel, the gate + CoorsNorm + mean pooling + masks;
-    # the last two -- per-edge features / fourier terms -- the recompute path)
+    # per-edge features + a fourier pair = five scalars; the last -- nine scalars -- takes the recompute path)
     (dict(dim=32, num_nearest_neighbors=8, dropout=0.2, norm_feats=True), 40, False, True),
     (dict(dim=64, num_nearest_neighbors=32, dropout=0.25), 96, True, True),
     (dict(dim=32, num_nearest_neighbors=20, dropout=0.1, norm_coors=True, soft_edges=True, m_pool_method="mean", coor_weights_clamp_value=2.0), 50, True, True),
-    (dict(dim=32, num_nearest_neighbors=16, dropout=0.2, edge_dim=3, fourier_features=1), 48, True, False),
-    (dict(dim=24, num_nearest_neighbors=8, dropout=0.3, fourier_features=2, m_dim=8), 30, False, False),
+    (dict(dim=32, num_nearest_neighbors=16, dropout=0.2, edge_dim=2, fourier_features=1), 48, True, True),
+    (dict(dim=24, num_nearest_neighbors=8, dropout=0.3, fourier_features=2, edge_dim=4, m_dim=8), 30, False, False),
 ]
 
 
