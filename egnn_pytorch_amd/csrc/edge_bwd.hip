@@ -71,6 +71,9 @@ constexpr int CH_S = EGNN_BWD_CHUNK_STEPS;   // steps of 32 hidden columns a wor
 constexpr int CH_W2 = EGNN_BWD_CH_W2;                     // ... of the variant with the d/d W_2 tiles only: one step fewer keeps it at 3 workgroups per CU
 constexpr int XLD = 36;                      // floats per exchange row: 144 B -> rows 4 apart sit 16 banks apart (transposed pick-up)
 constexpr float DZ_UP = 256.f;               // dz (scaled units, < 2^7) x 2^8 before the f16 split: keeps small values off the subnormals
+#ifndef EGNN_BWD_LO_MFMA
+#define EGNN_BWD_LO_MFMA 1
+#endif
 #ifndef EGNN_BWD_VALU_TILE_SUM
 #define EGNN_BWD_VALU_TILE_SUM 1
 #endif
@@ -286,6 +289,10 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
     // (32-bit offsets here as well: a 64-bit per-lane address per half step would be hoisted out of the round loop -- 2 registers each)
     const __amdgpu_buffer_rsrc_t ws_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(WANT_S ? p.Ws : p.Pi), 0, (uint32_t)((size_t)p.Hp * S * 4), 0x00020000);
 
+    // -I_16 as an A fragment (lane (g, m): k = 4g .. 4g+3): the residual of a split on the matrix cores
+    f16x4 neg_ident;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) neg_ident[r] = (hq == 4 * g + r) ? (_Float16)-1.f : (_Float16)0.f;
     float* xch = xchall + wave * (32 * XLD);
     // parking: lane l holds 16-byte chunk l & 7 of the line of entry 8 qq + (l >> 3)
     float* xw = xch + (lane >> 3) * XLD + 4 * (lane & 7);
@@ -533,7 +540,28 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
                         d = __builtin_amdgcn_mfma_f32_16x16x16f16(stl[t], dh, d, 0, 0, 0);
                         dWsm[2 * st + hb] = d;
                     }
-                    if constexpr (WANT_W2) {
+                    if constexpr (WANT_W2 && EGNN_BWD_LO_MFMA) {
+                        // (hi, lo) of a = SiLU(z): hi by pair conversion, the residual a - hi on the matrix cores (A = -I, B = hi, C = a:
+                        // exact), like the forward's split -- no v_fma_mix_f32 per value
+                        f16x4 ah, al;
+#pragma unroll
+                        for (int r = 0; r < 4; r += 2) {
+                            const f16x2 hi = __builtin_convertvector((f32x2v){av4[r], av4[r + 1]}, f16x2);
+                            ah[r] = hi[0]; ah[r + 1] = hi[1];
+                        }
+                        const f32x4 lo32 = __builtin_amdgcn_mfma_f32_16x16x16f16(neg_ident, ah, av4, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; r += 2) {
+                            const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(lo32[r], lo32[r + 1]));
+                            al[r] = lo[0]; al[r + 1] = lo[1];
+                        }
+                        f32x4 d = dW2[2 * st + hb];
+                        d = __builtin_amdgcn_mfma_f32_16x16x16f16(gth[t], ah, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x16f16(gth[t], al, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x16f16(gtl[t], ah, d, 0, 0, 0);
+                        dW2[2 * st + hb] = d;
+                    }
+                    if constexpr (WANT_W2 && !EGNN_BWD_LO_MFMA) {
                         f16x4 ah, al;
 #pragma unroll
                         for (int r = 0; r < 4; r += 2) {
