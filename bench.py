@@ -261,7 +261,9 @@ def main():
                          "barrier / max-over-ranks timing, rank-0 JSON -- on CPU with this backend and a dummy step; no GPU work, "
                          "no numbers of any meaning")
     ap.add_argument("--ragged-mask", action="store_true", help="ragged masks (len ~ U{N/2..N}) instead of all-True")
-    ap.add_argument("--train-step", action="store_true", help="also time forward + backward of the same workload (not part of `value`)")
+    ap.add_argument("--train-step", action="store_true", help="also time forward + backward of the same workload (not part of `value`); "
+                                                               "on by default for the single-layer workloads at N = 1")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the forward + backward timing")
     ap.add_argument("--reference-eager", action="store_true",
                     help="also time the reference module on the MI355X through PyTorch eager (secondary baseline)")
     args = ap.parse_args()
@@ -421,8 +423,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload, kwargs, n)
         if args.reference_eager and world == 1:
             out["reference_gpu_eager"] = reference_gpu_eager(kwargs, b, n, device)
-        if args.train_step and world == 1 and not is_net:
-            out["train_step"] = train_step(layer, feats, coors, mask, edges, adj)
+        if (args.train_step or not args.no_train_step) and world == 1 and not is_net:
+            # after the timed inference region (never part of `value`): must not cost the line if it fails
+            try:
+                out["train_step"] = train_step(layer, feats, coors, mask, edges, adj)
+            except Exception as exc:                           # noqa: BLE001
+                out["train_step"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         print(json.dumps(out), flush=True)
 
     if dist is not None:

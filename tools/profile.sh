@@ -8,7 +8,9 @@ REPO="$(pwd)"
 OUT="$REPO/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+# (the counter passes leave the training step out: its gradient GEMMs share kernel instantiations with node_proj / node_mlp and
+# would be averaged into their counters)
+BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-step"
 cd /tmp
 # the kernel trace runs the DEFAULT bench command (what the driver runs), so its per-kernel averages are the ones the
 # bench line's live measurement has to agree with; the counter passes use a shorter run
