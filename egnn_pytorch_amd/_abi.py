@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -70,6 +70,7 @@ class EdgeBwdArgs(Structure):
         ("gu_scale", c_float), ("inv_scale", c_float), ("scal", c_void_p), ("Ws", c_void_p), ("scal_scale", c_void_p),
         ("part_rows", c_void_p), ("ld_rows", c_int64),
         ("dW2_part", c_void_p), ("dWs_part", c_void_p), ("ds_part", c_void_p),
+        ("WsTh", c_void_p), ("wst_inv_scale", c_float),
         ("drop_thr", c_uint32), ("drop_seed", c_uint32), ("drop_inv_keep", c_float), ("drop_eid0", c_int64),
         ("row_pairs", c_int32), ("work", c_void_p), ("work_bytes", c_int64),
     ]

@@ -722,6 +722,8 @@ def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, w
         dws = empty(n_slabs * 16 if s_in > 1 else n_slabs, s_in, hp, dtype=torch.float32, device=dev)
         ds = empty(n_chunks, e, s_in, dtype=torch.float32, device=dev)
         a.Ws, a.dWs_part, a.ds_part = ws_nat.data_ptr(), dws.data_ptr(), ds.data_ptr()
+        if s_in > 5:                                          # d/d s on the matrix cores: W_s^T fragments (_weights.pack)
+            a.WsTh, a.wst_inv_scale = w["WsTh"].data_ptr(), 1.0 / w["wst_scale"]
         if s_in > 1:
             # d/d W_s on the matrix cores: the scalars enter as split-fp16 fragments, each column brought into [1, 2) at its maximum
             amax = scal.abs().amax(dim=0)

@@ -232,6 +232,19 @@ def pack(layer) -> dict:
         fragt = lambda t: t.view(hp // 32, 2, 16, 4, 4).permute(0, 1, 3, 2, 4).contiguous().view(hp // 32, 2, 64, 4)
         out["W2Th"] = torch.stack([fragt(t_hi), fragt(t_lo)], dim=2).contiguous()      # (Hp/32, 2, 2, 64, 4) fp16
         out["w2t_scale"] = t_scale
+        if s > 5:
+            # backward with more than five per-edge scalars (egnn_edge_bwd_pass_f32, DSM): W_s^T in natural units as A fragments,
+            # [step][hb][hi|lo][lane = 16 g + s][u] = W_s[32 step + 16 hb + 4 g + u][s]
+            wsn = z(hp, 16)
+            wsn[:h, :s] = w1[:, 2 * dim:]
+            s_scale = pow2_scale(float(wsn.abs().max()) if am is None else am["ws"])
+            wss = wsn * s_scale
+            s_hi = wss.half()
+            s_lo = (wss - s_hi.float()).half()
+            # (A operand: lane (g, m = s) holds hidden units 4 g .. 4 g + 3 of the 16-block -- W2Th above is the B-operand form)
+            frags = lambda t: t.view(hp // 32, 2, 4, 4, 16).permute(0, 1, 2, 4, 3).contiguous().view(hp // 32, 2, 64, 4)
+            out["WsTh"] = torch.stack([frags(s_hi), frags(s_lo)], dim=2).contiguous()
+            out["wst_scale"] = s_scale
 
     if layer.edge_gate is not None:
         gw = z(M_PAD)

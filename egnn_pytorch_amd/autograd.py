@@ -628,7 +628,8 @@ def _backward_native(ctx, g_node, g_coors):
     u_all = ctx.saved_tensors[6].view(b, n, k, 16)
     drop = getattr(ctx, "drop", None)                    # (p, seed) of a training-mode forward (_dropout_native_ok), else None
     reduce = False
-    fused = _NATIVE_MODE != "dz" and s_in <= 5           # (egnn_edge_bwd_pass_f32 is built for up to 5 per-edge scalars)
+    # (egnn_edge_bwd_pass_f32: up to 16 per-edge scalars -- beyond five with the all-edge contractions split over the two passes)
+    fused = _NATIVE_MODE != "dz" and (s_in <= 5 or (s_in <= 16 and _FUSED_SPLIT == "dest" and "WsTh" in w))
     proj_all = None
     if len(ctx.saved_tensors) > 7 and ctx.saved_tensors[7].numel() and fused:
         proj_all = ctx.saved_tensors[7]                                   # (B N, 2 Hp): what the forward's edge pass read

@@ -229,13 +229,21 @@ __global__ __launch_bounds__(256) void edge_bwd_prep_kernel(const egnn_edge_bwd_
 // PAIR: the two tiles of a round belong to one node (by source, 16 < K <= 32): one partial row per round = the node's row
 // DROP: training-mode dropout behind edge_mlp's first Linear (egnn_pytorch.py:178-184): the forward's hash mask (csrc/egnn_common.h:
 // row = global edge id, column = hidden unit) re-evaluated on z and on SiLU'
-template <int NM, int ST, bool WANT_W2, bool WANT_S, int CH, bool PAIR = false, bool DROP = false>
+// DSM (more than five per-edge scalars): d/d s = dz W_s contracts over the HIDDEN index, which the transposed tiles hold as their N
+// dimension -- per-lane FMAs (the S <= 5 variants) need 8 S registers and S multiply-adds per value.  Here every dz tile goes through
+// wave-private LDS once, comes back as the B fragment [k = hidden][n = entry] and meets A = W_s^T fragments (split f16 x 3, staged in
+// LDS like W2^T): one accumulator tile per entry tile whatever S is.
+template <int NM, int ST, bool WANT_W2, bool WANT_S, int CH, bool PAIR = false, bool DROP = false, bool DSM = false>
 __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WANT_S) && ST > 1)) ? 2 : (WANT_W2 ? EGNN_BWD_W2_BLOCKS : (WANT_S ? (DROP ? 3 : EGNN_BWD_S_BLOCKS) : EGNN_BWD_DEST_BLOCKS))) void edge_bwd_kernel(const egnn_edge_bwd_args p, const BwdPrep w)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* w2t = reinterpret_cast<_Float16*>(smem);                                  // [CH][hb][hi|lo][64][4] halves
     uint32_t* wstl = reinterpret_cast<uint32_t*>(smem + CH * 2048);                     // [CH * 32][4 NM] words
     float* xchall = reinterpret_cast<float*>(smem + CH * 2048 + CH * 32 * 4 * NM * 4);  // [waves][32][XLD]
+    constexpr int DLD = 20;                                                             // floats per row of a transposed dz tile (80 B: 16-byte reads)
+    _Float16* wsT = reinterpret_cast<_Float16*>(smem + CH * 2048 + CH * 32 * 4 * NM * 4 + BW_WAVES * 32 * XLD * 4);     // DSM: [CH][hb][hi|lo][64][4] halves
+    float* dztall = reinterpret_cast<float*>(smem + CH * 2048 + CH * 32 * 4 * NM * 4 + BW_WAVES * 32 * XLD * 4 + CH * 2048);   // DSM: [waves][2][16][DLD]
+    static_assert(!DSM || (WANT_S && ST > 1), "DSM: d/d s on the matrix cores goes with the MFMA form of d/d W_s");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -273,6 +281,10 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
         for (int o = tid; o < nst * 128; o += BW_THREADS) reinterpret_cast<uint4*>(w2t)[o] = src[o];
         const uint32_t* ts = reinterpret_cast<const uint32_t*>(p.Wst) + (size_t)st0 * 32 * 4 * NM;
         for (int o = tid; o < nst * 32 * 4 * NM; o += BW_THREADS) wstl[o] = ts[o];
+        if constexpr (DSM) {
+            const uint4* srcs = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.WsTh) + (size_t)st0 * 2048);
+            for (int o = tid; o < nst * 128; o += BW_THREADS) reinterpret_cast<uint4*>(wsT)[o] = srcs[o];
+        }
     }
     __syncthreads();
 
@@ -383,9 +395,12 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
             goff[qq] = (uint32_t)(((size_t)othrow * p.ldp + 4 * (lane & 7)) * 4);
         }
 
-        float ps[WANT_S ? 2 : 1][4][ST];          // d/d s of entry (t, r): this lane's hidden units only (summed over hq at the end)
+        float ps[(WANT_S && !DSM) ? 2 : 1][4][ST];          // d/d s of entry (t, r): this lane's hidden units only (summed over hq at the end)
+        f32x4 dsacc[DSM ? 2 : 1];                  // DSM: d/d s^T of tile t: rows s = 4g + r, column = entry hq
 #pragma unroll
-        for (int t = 0; t < (WANT_S ? 2 : 1); ++t)
+        for (int t = 0; t < (DSM ? 2 : 1); ++t) dsacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < ((WANT_S && !DSM) ? 2 : 1); ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -443,7 +458,7 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
                 const f16x4* wt = reinterpret_cast<const f16x4*>(w2t) + (size_t)(st * 2 + hb) * 2 * 64;
                 const f16x4 wthi = wt[lane], wtlo = wt[64 + lane];
                 float wsn[ST];
-                if constexpr (WANT_S) {
+                if constexpr (WANT_S && !DSM) {
 #pragma unroll
                     for (int c = 0; c < ST; ++c) wsn[c] = c < S ? buf_load1f(ws_rsrc, (uint32_t)((hq * S + c) * 4), (hoff + 16 * hb) * S * 4) : 0.f;
                 }
@@ -483,7 +498,27 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
                         dz4[r] = ga[r] * spv[r];
                         asm("" : "+v"(dz4[r]));                    // (scalar multiplies: v_pk_mul_f32 costs 9.3 cycles per pair against 2 x 2.9)
                     }
-                    if constexpr (WANT_S) {
+                    if constexpr (DSM) {
+                        // dz tile -> LDS [entry][hidden] -> B fragment [k = hidden 4g + r][n = entry hq]; A = W_s^T [m = scalar][k = hidden]
+                        float* tl = dztall + (wave * 2 + t) * (16 * DLD);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tl[(4 * g + r) * DLD + hq] = dz4[r];
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                        const f32x4 bt = *reinterpret_cast<const f32x4*>(tl + hq * DLD + 4 * g);
+                        f16x4 bh, bl;
+                        split4(bt, bh, bl);
+                        const f16x4* wf = reinterpret_cast<const f16x4*>(wsT) + (size_t)(st * 2 + hb) * 2 * 64;
+                        const f16x4 ash = wf[lane], asl = wf[64 + lane];
+                        f32x4 dd = dsacc[t];
+                        dd = __builtin_amdgcn_mfma_f32_16x16x16f16(ash, bh, dd, 0, 0, 0);
+                        dd = __builtin_amdgcn_mfma_f32_16x16x16f16(ash, bl, dd, 0, 0, 0);
+                        dd = __builtin_amdgcn_mfma_f32_16x16x16f16(asl, bh, dd, 0, 0, 0);
+                        dsacc[t] = dd;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if constexpr (WANT_S && !DSM) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -593,7 +628,18 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
 #pragma unroll
         for (int st = 0; st < CH; ++st)
             if (st < nst) step(st);
-        if constexpr (WANT_S) {
+        if constexpr (DSM) {
+            // d/d s of this chunk's columns, from the accumulator tiles: lane (g, hq) holds scalars 4g .. 4g+3 of entry hq
+            const float ds_scale = rows_scale * p.wst_inv_scale;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int eid = p.ent[q0 + 16 * t + hq];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (eid >= 0 && 4 * g + r < S) p.ds_part[((size_t)chunk * p.E + eid) * S + 4 * g + r] = dsacc[t][r] * ds_scale;
+            }
+        }
+        if constexpr (WANT_S && !DSM) {
             // d/d s of this chunk's columns: sum over the 16 hidden units of the row, one partial per (chunk, edge)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -661,20 +707,40 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
     }
 }
 
-template <int NM, int ST, bool W2, bool SS, int CH, bool PAIR = false, bool DROP = false>
+template <int NM, int ST, bool W2, bool SS, int CH, bool PAIR = false, bool DROP = false, bool DSM = false>
 int launch_v(const egnn_edge_bwd_args& a, hipStream_t s)
 {
     if (a.row_pairs && !PAIR) return EGNN_E_UNSUPPORTED;
     const int n_chunks = (a.Hp / 32 + CH - 1) / CH;
-    const size_t lds = (size_t)CH * 2048 + (size_t)CH * 32 * 4 * NM * 4 + (size_t)BW_WAVES * 32 * XLD * 4;
+    const size_t lds = (size_t)CH * 2048 + (size_t)CH * 32 * 4 * NM * 4 + (size_t)BW_WAVES * 32 * XLD * 4 +
+                       (DSM ? (size_t)CH * 2048 + (size_t)BW_WAVES * 2 * 16 * 20 * 4 : 0);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_bwd_kernel<NM, ST, W2, SS, CH, PAIR, DROP, DSM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
     const dim3 grid((unsigned)((a.n_slabs + GS - 1) / GS * GS * n_chunks));
     // the pass's per-entry records first (list order; read once per column chunk by the kernel below)
     constexpr bool S1 = SS && ST == 1;
     if (!a.work || a.work_bytes < (int64_t)prep_bytes(a.L, NM, W2, S1)) return EGNN_E_SHAPE;
     const BwdPrep w = prep_carve(a.work, a.L, NM, W2, S1);
     hipLaunchKernelGGL((edge_bwd_prep_kernel<NM>), dim3((unsigned)((a.L + 255) / 256)), dim3(256), 0, s, a, w);
-    hipLaunchKernelGGL((edge_bwd_kernel<NM, ST, W2, SS, CH, PAIR, DROP>), grid, dim3(BW_THREADS), lds, s, a, w);
+    hipLaunchKernelGGL((edge_bwd_kernel<NM, ST, W2, SS, CH, PAIR, DROP, DSM>), grid, dim3(BW_THREADS), lds, s, a, w);
     return egnn_launch_status();
+}
+
+// more than five per-edge scalars (NM = 6: S <= 8, NM = 12: S <= 16): d/d W_s and d/d s on the matrix cores (DSM), d/d W_2 with the other pass
+template <int NM>
+int launch_many(const egnn_edge_bwd_args& a, hipStream_t s)
+{
+    if (a.drop_thr) return EGNN_E_UNSUPPORTED;
+    if (a.dW2_part && a.dWs_part) return EGNN_E_UNSUPPORTED;
+    if (a.dW2_part) return launch_v<NM, 2, true, false, CH_W2>(a, s);
+    if (a.dWs_part) {
+        if (!a.WsTh || !(a.wst_inv_scale > 0.f)) return EGNN_E_NULLPTR;
+        return a.row_pairs ? launch_v<NM, 2, false, true, CH_S, true, false, true>(a, s) : launch_v<NM, 2, false, true, CH_S, false, false, true>(a, s);
+    }
+    return launch_v<NM, 2, false, false, CH_S>(a, s);
 }
 
 template <int NM, int ST>
@@ -706,8 +772,8 @@ extern "C" int egnn_edge_bwd_chunk_steps(void) { return CH_S; }
 
 extern "C" size_t egnn_edge_bwd_work_bytes(int64_t L, int S, int want_w2, int want_s)
 {
-    if (L <= 0 || S < 1 || S > 5) return 0;
-    const int nm = S <= 1 ? 1 : (S <= 4 ? 3 : 4);
+    if (L <= 0 || S < 1 || S > 16) return 0;
+    const int nm = egnn_edge_mfmas(S);
     return prep_bytes(L, nm, want_w2 != 0, want_s != 0 && S == 1);
 }
 
@@ -724,7 +790,7 @@ extern "C" int egnn_edge_bwd_pass_f32(const egnn_edge_bwd_args* args, void* stre
     if (a.E != (int64_t)a.B * a.N * a.K || a.E >= ((int64_t)1 << 31) || a.L >= ((int64_t)1 << 31)) return EGNN_E_SHAPE;
     if ((size_t)a.B * a.N * a.ldp * 4 >= ((size_t)1 << 31)) return EGNN_E_UNSUPPORTED;           // 32-bit (signed scalar) buffer offsets into the P tables
     if ((size_t)(a.L >> 4) * a.ld_rows * 4 >= ((size_t)1 << 31)) return EGNN_E_UNSUPPORTED;         // (scalar offsets are signed)    // ... and into the partial rows
-    if (a.S > 5 || a.wst_terms != 4 * (a.S <= 1 ? 1 : (a.S <= 4 ? 3 : 4))) return EGNN_E_UNSUPPORTED;
+    if (a.S > 16 || a.wst_terms != 4 * egnn_edge_mfmas(a.S)) return EGNN_E_UNSUPPORTED;
     if (a.dWs_part && a.S > 1 && !a.scal_scale) return EGNN_E_NULLPTR;
     if (!(a.ws_inv_scale > 0.f) || !(a.gu_scale > 0.f) || !(a.inv_scale > 0.f)) return EGNN_E_SHAPE;
     if (a.drop_thr && !(a.drop_inv_keep >= 1.f)) return EGNN_E_SHAPE;
@@ -735,5 +801,7 @@ extern "C" int egnn_edge_bwd_pass_f32(const egnn_edge_bwd_args* args, void* stre
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.S == 1) return launch<1, 1>(a, s);
     if (a.S <= 4) return launch<3, 4>(a, s);
-    return launch<4, 5>(a, s);
+    if (a.S <= 5) return launch<4, 5>(a, s);
+    if (a.S <= 8) return launch_many<6>(a, s);
+    return launch_many<12>(a, s);
 }

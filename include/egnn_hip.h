@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 26
+#define EGNN_ABI_VERSION 27
 
 enum {
     EGNN_OK = 0,
@@ -340,8 +340,8 @@ int egnn_edge_bwd_dz_f32(const egnn_edge_args* args, void* stream);
  *                              -> d loss / d (scalar columns of edge_mlp.0.weight), and dz W_s over each column chunk
  *                              -> d loss / d scalars = sum over dim 0   (n_chunks = ceil(Hp / 32 / egnn_edge_bwd_chunk_steps()))
  * The all-edge contractions can ride with either pass (each edge appears once in both lists).  Every element of the outputs is
- * written (no zero-fill needed) except the unused rows of dWs_part at S > 1.  Limits: S <= 5 (EGNN_E_UNSUPPORTED beyond --
- * egnn_edge_bwd_dz_f32 covers those), m_dim <= 16, B*N*K < 2^31, the P table and the partial rows below 4 GB each.  All pointers
+ * written (no zero-fill needed) except the unused rows of dWs_part at S > 1.  Limits: S <= 16 (beyond five scalars d/d s goes to the
+ * matrix cores: WsTh; the all-edge contractions must then be split over the two passes and dropout is not instantiated), m_dim <= 16, B*N*K < 2^31, the P table and the partial rows below 4 GB each.  All pointers
  * device memory. */
 typedef struct egnn_edge_bwd_args {
     int B, N, K;
@@ -370,6 +370,8 @@ typedef struct egnn_edge_bwd_args {
     float* dW2_part;            /* out or NULL */
     float* dWs_part;            /* out or NULL (with ds_part) */
     float* ds_part;             /* out or NULL (with dWs_part) */
+    const void* WsTh;           /* S > 5 with dWs_part: (Hp/32, 2, 2, 64, 4) fp16 fragments of wst_scale * W_s^T, [step][hb][hi|lo][lane = 16 g + s][u] = */
+    float wst_inv_scale;        /*   W_s[32 step + 16 hb + 4 g + u][s] (0 for s >= S): d/d s on the matrix cores;  1 / wst_scale */
     uint32_t drop_thr;          /* training-mode dropout behind edge_mlp's first Linear (egnn_pytorch.py:178-184): 0 = none, else the forward's */
     uint32_t drop_seed;         /*   mask (egnn_edge_args.drop_*) is re-evaluated: keep iff hash(seed, site edge, drop_eid0 + edge id, hidden unit) */
     float drop_inv_keep;        /*   >= drop_thr, kept units times drop_inv_keep */

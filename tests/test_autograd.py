@@ -212,6 +212,9 @@ def test_inference_paths_record_nothing():
     (dict(dim=48, num_nearest_neighbors=24, soft_edges=True, norm_coors=True, m_pool_method="mean", norm_feats=True,
           coor_weights_clamp_value=1.5), 70, dict(mask=True)),
     (dict(dim=40, num_nearest_neighbors=20, m_dim=12, soft_edges=True), 50, dict(mask=True)),
+    # more than five per-edge scalars on the register-contraction kernels (d/d s on the matrix cores): 8 and 13 scalars
+    (dict(dim=32, num_nearest_neighbors=24, edge_dim=3, fourier_features=2, norm_coors=True), 48, dict(mask=True, edges=True)),
+    (dict(dim=32, num_nearest_neighbors=8, edge_dim=12), 40, dict(mask=False, edges=True)),
 ])
 def test_native_backward_kernel_matches_the_aten_recompute(kw, n, flags):
     """The native backwards (E x H work on the HIP kernels, small tail and node-level GEMMs around them) against the pure-ATen
