@@ -14,9 +14,10 @@ Backward = `_backward_native` (fp32, coordinate dimension 3, m_dim <= 16):
                egnn_edge_bwd_pass_f32 (csrc/edge_bwd.hip; `_edge_contract_fused`): one pass over the edges grouped by source node
                (d/d P_i, d/d W_s, d/d scalars) and one over the edges sorted by destination (d/d P_j, d/d W_2), everything
                recomputed and contracted in registers: nothing of size E x H reaches memory (8 GiB peak where the first native
-               backward needed 27).  More than five per-edge scalars (fourier_features >= 2): `_edge_contract_dz`,
-               the first native backward -- egnn_edge_bwd_dz_f32 writes dz and a, reductions / library GEMMs read them;
-             * node-level fp32 library GEMMs give d/d feats and d/d edge_mlp.0 from the per-node sums.
+               backward needed 27); up to 16 per-edge scalars (beyond five: d/d scalars on the matrix cores).  `_edge_contract_dz`
+               (EGNN_NATIVE_BACKWARD=dz) is the first native backward -- egnn_edge_bwd_dz_f32 writes dz and a, reductions / library
+               GEMMs read them;
+             * the node-level products -- d/d feats, d/d edge_mlp.0, node_mlp -- on the forward's split-f16 GEMM (`_ops.grad_nn / grad_tn`).
            `_backward_recompute` (everything else, and the native path's reference in the tests): the whole layer re-evaluated
            a few graphs at a time as a differentiable chain of ATen ops over the neighbour list the HIP kernel selected,
            factorised like the forward, and differentiated by autograd.
@@ -587,11 +588,11 @@ def _node_mlp_backward(layer, w, f, m_i, g_out, grads_by_id, drop=None, row0=0):
 
 def _backward_native(ctx, g_node, g_coors):
     """The backward on the HIP kernels (module docstring), per chunk of graphs:
-       1. behind u = ctx.u_pre (edge_mlp's second Linear, written by the forward kernel): node_norm / node_mlp / residual through
-          autograd from the pooled messages; the per-edge chain in closed form on egnn_edge_tail_bwd_f32 (m_dim > 16 or a wider
-          coors_mlp: through autograd, `layer_tail`)  ->  gU = d loss / d u, d loss / d (x_i - x_j), those modules' parameter gradients;
+       1. behind u = ctx.u_pre (edge_mlp's second Linear, written by the forward kernel): the pooled messages (egnn_edge_pool_f32), node_mlp
+          on the split-f16 GEMMs (`_node_mlp_backward`; node_norm through autograd); the per-edge chain in closed form on
+          egnn_edge_tail_bwd_f32, which also sums its parameter gradients (on the CPU, in the tests: through autograd, `layer_tail`)  ->  gU = d loss / d u, d loss / d (x_i - x_j), those modules' parameter gradients;
        2. the E x H work on egnn_edge_bwd_pass_f32 (`_edge_contract_fused`: by source and by destination, everything recomputed
-          and contracted in registers) or, beyond 5 per-edge scalars, egnn_edge_bwd_dz_f32 + reductions (`_edge_contract_dz`)
+          and contracted in registers; EGNN_NATIVE_BACKWARD=dz: egnn_edge_bwd_dz_f32 + reductions, `_edge_contract_dz`)
           ->  d/d P_i, d/d P_j per node, d/d W_s, d/d scalars, d/d W_2;
        3. node-level products: d/d feats, d/d W_i, W_j, b_1 from the per-node sums and feats; d/d scalars -> coordinates (closed
           form when the distance is the only scalar, the scalars' own small graph otherwise) and edge features.
