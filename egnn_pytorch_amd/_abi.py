@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -72,7 +72,7 @@ class EdgeBwdArgs(Structure):
         ("dW2_part", c_void_p), ("dWs_part", c_void_p), ("ds_part", c_void_p),
         ("WsTh", c_void_p), ("wst_inv_scale", c_float),
         ("drop_thr", c_uint32), ("drop_seed", c_uint32), ("drop_inv_keep", c_float), ("drop_eid0", c_int64),
-        ("row_pairs", c_int32), ("work", c_void_p), ("work_bytes", c_int64),
+        ("row_pairs", c_int32), ("rows_amax", c_void_p), ("work", c_void_p), ("work_bytes", c_int64),
     ]
 
 

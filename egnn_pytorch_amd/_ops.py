@@ -682,7 +682,7 @@ ROUNDS_PER_SLAB = int(os.environ.get("EGNN_BWD_ROUNDS_PER_SLAB", "8"))
 
 
 def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, ws_nat=None, want_w2=False, n_slabs=None, row_pairs=False,
-                  drop=None, eid0=0):
+                  drop=None, eid0=0, want_amax=False):
     """One pass of egnn_edge_bwd_pass_f32 (include/egnn_hip.h) over the entry list ent (autograd.entry_list).  proj = (B*N, 2 Hp)
     fp32 P_i | P_j rows.  Returns a dict: rows (L / 16, Hp) partial rows, one per tile; with want_w2: w2 = d/d W_2 (16, Hp); with ws_nat (the
     natural-units scalar weights (Hp, S)): ws = d/d W_s (Hp, S) and scal = d/d scalars (E, S) -- the partial arrays of the
@@ -709,6 +709,10 @@ def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, w
     a.scal = scal.data_ptr()
     a.part_rows, a.ld_rows = rows.data_ptr(), hp
     a.row_pairs = int(row_pairs)
+    amax_bits = None
+    if want_amax and (s_in == 1 or ws_nat is None):           # (by-product of the fp32 tile sums: max |rows|)
+        amax_bits = torch.empty(1, dtype=torch.int32, device=dev)
+        a.rows_amax = amax_bits.data_ptr()
     if drop is not None:                                      # training-mode dropout in edge_mlp: the forward's hash mask (p, seed)
         from . import _dropout
         a.drop_thr, a.drop_seed, a.drop_inv_keep, a.drop_eid0 = _dropout.threshold(drop[0]), int(drop[1]), 1.0 / (1.0 - drop[0]), int(eid0)
@@ -735,7 +739,7 @@ def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, w
     with _timed("edge_bwd_by_dest" if by_dest else "edge_bwd_by_src"):
         rc = lib.egnn_edge_bwd_pass_f32(byref(a), _stream())
     _abi.check(rc, "egnn_edge_bwd_pass_f32")
-    out = {"rows": rows[:n_rows]}
+    out = {"rows": rows[:n_rows], "amax_bits": amax_bits}
     if want_w2:
         out["w2"] = dw2.sum(dim=0)
     if ws_nat is not None:

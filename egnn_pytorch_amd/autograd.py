@@ -508,10 +508,12 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
     # by source every node has ceil(K / 16) tiles: two (16 < K <= 32) are summed inside the kernel, one IS the node's row -- no gather-sum
     pairs = 16 < k <= 32 and s_first and not want_w2_first
     o = _ops.edge_bwd_pass(w, proj, i32, gu16, gu_scale, sc2, ent, bc, n, k, by_dest=False, ws_nat=w_s if s_first else None,
-                           want_w2=want_w2_first, row_pairs=pairs, drop=drop, eid0=eid0)
+                           want_w2=want_w2_first, row_pairs=pairs, drop=drop, eid0=eid0, want_amax=(pairs or k <= 16) and dev.type == "cuda")
     g_ws, g_scal, g_w2 = o.get("ws"), o.get("scal"), o.get("w2")
     if pairs or k <= 16:
         gz_i = o["rows"][:bc * n]
+        if o.get("amax_bits") is not None:
+            gz_i.amax_bits = o["amax_bits"]                  # (max |d/d P_i| as a by-product of the pass)
     else:
         ident = torch.arange(o["rows"].shape[0], device=dev)
         gz_i = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n)
@@ -833,8 +835,9 @@ def _backward_native(ctx, g_node, g_coors):
             gw1 = grads_by_id[id(lin0.weight)]
             if f2d.is_cuda and _GRAD_GEMM:
                 # (each matrix: one absmax, one read for its plain and transposed images; feats^T split once for both weight gradients)
-                jb = getattr(gz_j, "amax_bits", None)
-                op_i, op_j = _ops.GradOperand(gz_i), _ops.GradOperand(gz_j, amax=None if jb is None else _ops.bits_to_floats(jb)[0])
+                ib, jb = getattr(gz_i, "amax_bits", None), getattr(gz_j, "amax_bits", None)
+                op_i = _ops.GradOperand(gz_i, amax=None if ib is None else _ops.bits_to_floats(ib)[0])
+                op_j = _ops.GradOperand(gz_j, amax=None if jb is None else _ops.bits_to_floats(jb)[0])
                 t = _ops.grad_nn(op_i, w["WiT_split"], dim, name="bwd_dfeats")
                 t = _ops.grad_nn(op_j, w["WjT_split"], dim, residual=t, name="bwd_dfeats")
                 g_feats[lo:hi_] += t.view(bc, n, dim)

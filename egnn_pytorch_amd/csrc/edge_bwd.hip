@@ -327,6 +327,7 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
 #pragma unroll
     for (int bl = 0; bl < (MW ? 2 * CH : 1); ++bl) dWsm[bl] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    uint32_t rows_max = 0u;                      // max |partial row value| (rows_amax: the rows are final node rows with one or two tiles per node)
     const int64_t rounds_total = p.L / 128;
     const int64_t per_slab = (rounds_total + p.n_slabs - 1) / p.n_slabs;
     const int64_t rd0 = (int64_t)slab * per_slab;
@@ -535,9 +536,17 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
                         float tsum = egnn_column_sum4_reg((dz4[0] + dz4[1]) + (dz4[2] + dz4[3]));
                         if constexpr (PAIR) {
                             if (t == 0) dPc[0] = tsum;
-                            else buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)q0 >> 5) * row_bytes) + (hoff + 16 * hb) * 4, (dPc[0] + tsum) * rows_scale);
+                            else {
+                                const float rv = (dPc[0] + tsum) * rows_scale;
+                                buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)q0 >> 5) * row_bytes) + (hoff + 16 * hb) * 4, rv);
+                                const uint32_t rb = egnn_abs_bits(rv);
+                                rows_max = rows_max > rb ? rows_max : rb;
+                            }
                         } else {
-                            buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)(q0 + 16 * t) >> 4) * row_bytes) + (hoff + 16 * hb) * 4, tsum * rows_scale);
+                            const float rv = tsum * rows_scale;
+                            buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)(q0 + 16 * t) >> 4) * row_bytes) + (hoff + 16 * hb) * 4, rv);
+                            const uint32_t rb = egnn_abs_bits(rv);
+                            rows_max = rows_max > rb ? rows_max : rb;
                         }
                     }
                     // (hi, lo) halves: hi = RNE pair conversion, lo = product - hi as ONE v_fma_mix_f32 per value (the f16 operand read in place)
@@ -655,6 +664,12 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
         }
     }
 
+    if constexpr (!(WANT_S && ST > 1) && EGNN_BWD_VALU_TILE_SUM) {
+        if (p.rows_amax) {
+            __shared__ uint32_t amax_slot;
+            egnn_block_absmax_commit(rows_max, &amax_slot, p.rows_amax);
+        }
+    }
     // The all-edge partials: one per WORKGROUP for d/d W_2 and (S = 1) d/d W_s -- the four waves' accumulators (and the four lane
     // groups' of d/d W_s) are added up through LDS in a fixed order (wave 0 .. 3, lane group 0 .. 3): 4x / 16x smaller partial
     // arrays for the host's final sum (1.1 GB -> 0.27 GB at the north-star shape).
@@ -724,6 +739,10 @@ int launch_v(const egnn_edge_bwd_args& a, hipStream_t s)
     constexpr bool S1 = SS && ST == 1;
     if (!a.work || a.work_bytes < (int64_t)prep_bytes(a.L, NM, W2, S1)) return EGNN_E_SHAPE;
     const BwdPrep w = prep_carve(a.work, a.L, NM, W2, S1);
+    if (a.rows_amax) {
+        if ((SS && ST > 1) || !EGNN_BWD_VALU_TILE_SUM) return EGNN_E_UNSUPPORTED;          // (the by-product exists where the tile sums are fp32 adds)
+        if (hipMemsetAsync(a.rows_amax, 0, sizeof(uint32_t), s) != hipSuccess) return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL((edge_bwd_prep_kernel<NM>), dim3((unsigned)((a.L + 255) / 256)), dim3(256), 0, s, a, w);
     hipLaunchKernelGGL((edge_bwd_kernel<NM, ST, W2, SS, CH, PAIR, DROP, DSM>), grid, dim3(BW_THREADS), lds, s, a, w);
     return egnn_launch_status();

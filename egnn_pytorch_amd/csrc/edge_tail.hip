@@ -321,6 +321,8 @@ __device__ __forceinline__ void tail_split4(const f32x4 v, h16x4& hi, h16x4& lo)
 
 constexpr int GLD = 68;      // floats per row of a tile's g_hid / a3 staging (64 columns + 4: rows 16 banks apart for the 16-byte writes)
 
+// DROP: training-mode dropout in coors_mlp (its own instantiation: the keep bits and the hash cost the plain one a wave per SIMD)
+template <bool DROP>
 __global__ __launch_bounds__(256) void edge_tail_mfma_kernel(const egnn_edge_tail_args p)
 {
     __shared__ uint2 fragA[4][2][64];            // W3 rows: [t block][hi | lo][lane (g, m)] = W3[16 tb + m][4g .. 4g+3] x s3
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(256) void edge_tail_mfma_kernel(const egnn_edge_tai
         float wpartial = 0.f;
         uint32_t kbits = 0xffffu;
         const uint32_t ckey = egnn_drop_base(p.drop_seed, EGNN_DROP_SITE_COORS, (uint32_t)(e + p.drop_eid0));
-        if (p.drop_thr) kbits = 0u;
+        if constexpr (DROP) kbits = 0u;
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb) {
             const h16x4 ah = __builtin_bit_cast(h16x4, fragA[tb][0][lane]), al = __builtin_bit_cast(h16x4, fragA[tb][1][lane]);
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(256) void edge_tail_mfma_kernel(const egnn_edge_tai
             for (int r = 0; r < 4; ++r) {
                 const int t = 16 * tb + 4 * g + r;
                 float h = __builtin_fmaf(d[r], inv_s3, sb3[t]);
-                if (p.drop_thr) {
+                if constexpr (DROP) {
                     const bool keep = egnn_drop_hash(ckey, (uint32_t)t) >= p.drop_thr;
                     h = keep ? h * p.drop_inv_keep : 0.f;
                     kbits |= keep ? (1u << (4 * tb + r)) : 0u;
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(256) void edge_tail_mfma_kernel(const egnn_edge_tai
             for (int r = 0; r < 4; ++r) {
                 const float h = hid[tb][r], sg = sgh4[tb][r];
                 q[r] = sW4[16 * tb + 4 * g + r] * (sg * (1.0f + h * (1.0f - sg)));
-                if (p.drop_thr) q[r] = ((kbits >> (4 * tb + r)) & 1u) ? q[r] * p.drop_inv_keep : 0.f;       // d (dropped hid) / d hid
+                if constexpr (DROP) q[r] = ((kbits >> (4 * tb + r)) & 1u) ? q[r] * p.drop_inv_keep : 0.f;       // d (dropped hid) / d hid
                 ghv[r] = g_w * q[r];
                 a3v[r] = h * sg;
             }
@@ -598,7 +600,8 @@ extern "C" int egnn_edge_tail_bwd_f32(const egnn_edge_tail_args* args, void* str
     // (EGNN_TAIL_SCALAR=1: the reduce variant with coors_mlp as per-lane FMAs, for A/B and debugging)
     static const bool scalar_tail = [] { const char* v = getenv("EGNN_TAIL_SCALAR"); return v && v[0] == '1'; }();
     if (a.drop_thr && (!a.part || scalar_tail)) return EGNN_E_UNSUPPORTED;       // (dropout: the matrix-core variant only)
-    if (a.part && !scalar_tail) hipLaunchKernelGGL(edge_tail_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (a.part && !scalar_tail && a.drop_thr) hipLaunchKernelGGL(edge_tail_mfma_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else if (a.part && !scalar_tail) hipLaunchKernelGGL(edge_tail_mfma_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     else if (a.part) hipLaunchKernelGGL(edge_tail_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     else hipLaunchKernelGGL(edge_tail_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return egnn_launch_status();

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 27
+#define EGNN_ABI_VERSION 28
 
 enum {
     EGNN_OK = 0,
@@ -378,6 +378,8 @@ typedef struct egnn_edge_bwd_args {
     int64_t drop_eid0;          /*   global id of this call's first edge (the forward numbered the whole batch's edges) */
     int row_pairs;              /* 1 (by source with d/d W_s, 16 < K <= 32, the list = 32 entries per node): the two tiles of a node are summed */
                                 /*   in the kernel -- part_rows (L / 32 + 1, ld_rows) holds one row per NODE and no gather-sum is needed */
+    uint32_t* rows_amax;        /* out or NULL: the bit pattern of max |part_rows| (egnn_absmax_f32's contract; S = 1 or without dWs_part) -- with */
+                                /*   row_pairs / one tile per node the rows ARE d/d P_i and this is the scale of its gradient GEMM operands */
     void* work;                 /* scratch, 16-byte aligned: the pass's per-entry records (other endpoint's row, fp16 fragments of gU and of */
     int64_t work_bytes;         /*   the scalars' first-layer terms, in list order), written by a first launch, read once per column chunk */
 } egnn_edge_bwd_args;

@@ -643,7 +643,7 @@ def _emulated_backward(layer, feats, coors, mask, idx, rank, radius, g_node, g_c
         return (proj[src, :hp] + proj[dst, hp:] + scal @ w["Ws"]) / nl2e
 
     def bwd_pass(w_, proj, idx32, gu16, gu_scale, scal, ent, b_, n_, k_, by_dest, ws_nat=None, want_w2=False, n_slabs=None, row_pairs=False,
-                 drop=None, eid0=0):
+                 drop=None, eid0=0, want_amax=False):
         assert drop is None
         z = z_of(proj, idx32, scal, b_, n_, k_)
         sg = torch.sigmoid(z)
