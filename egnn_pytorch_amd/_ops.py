@@ -460,7 +460,7 @@ class GradOperand:
         self.scale = grad_scale(absmax(g2d) if amax is None else amax)
         self.zero = self.scale is None
         self.plain = self.t = None
-        if not self.zero:
+        if not self.zero and self.scale is not NONFINITE:
             self.plain, self.t = split_scaled_both(g2d, self.scale)
 
 
@@ -486,11 +486,16 @@ def unsplit_words_(table, cols):
     return table
 
 
+NONFINITE = "nonfinite"          # grad_scale of an operand that holds a NaN / inf: its products are NaN, like any fp32 product would be
+
+
 def grad_scale(amax):
     """The power of two that brings max |x| into [2^12, 2^13) (fp16 hi halves well inside the range, lo halves off the subnormals);
-    None for 0 / NaN / inf: the caller returns zeros (or lets the NaN through)."""
+    None for an all-zero operand (the product is zero), NONFINITE for one that holds a NaN or an inf (the product is NaN)."""
     from . import _weights
-    if not (amax > 0.0) or amax != amax or amax == float("inf"):
+    if amax != amax or amax == float("inf"):
+        return NONFINITE
+    if not (amax > 0.0):
         return None
     return _weights.pow2_scale(amax) * 4096.0
 
@@ -504,7 +509,9 @@ def grad_nn(g2d, wsplit_t, n, residual=None, name="grad_nn", amax=None):
         scale, a, rows, dev = op.scale, op.plain, op.shape[0], (residual.device if residual is not None else wsplit_t[0].device)
     else:
         scale, rows, dev = grad_scale(absmax(g2d) if amax is None else amax), g2d.shape[0], g2d.device
-        a = None if scale is None else split_scaled(g2d, scale)[0]      # max |scale * g| in [2^12, 2^13)
+        a = None if (scale is None or scale is NONFINITE) else split_scaled(g2d, scale)[0]      # max |scale * g| in [2^12, 2^13)
+    if scale is NONFINITE:
+        return torch.full((rows, n), float("nan"), dtype=torch.float32, device=dev)
     if scale is None:
         out = torch.zeros(rows, n, dtype=torch.float32, device=dev)
         return out if residual is None else out + residual
@@ -516,8 +523,8 @@ def grad_tn_operand(x2d, amax=None):
     """The right-hand operand of grad_tn, prepared once for several products with the same x2d: (packed image of (s x2d)^T, rows, s)
     or None when x2d is all zero / not finite.  amax: max |x2d| if the caller has it."""
     sx = grad_scale(absmax(x2d) if amax is None else amax)
-    if sx is None:
-        return None
+    if sx is None or sx is NONFINITE:
+        return sx
     w, w_rows = split_scaled(x2d, sx, transposed=True, w_image=True)  # (n rows, K = r)
     return w, w_rows, sx
 
@@ -531,6 +538,8 @@ def grad_tn(g2d, x2d, k_splits=None, name="grad_tn", amax=None, x_operand=None):
     sg = op.scale if op is not None else grad_scale(absmax(g2d) if amax is None else amax)
     if x_operand is None:
         x_operand = grad_tn_operand(x2d)
+    if sg is NONFINITE or x_operand is NONFINITE:
+        return torch.full((m, n), float("nan"), dtype=torch.float32, device=x2d.device)
     if sg is None or x_operand is None:
         return torch.zeros(m, n, dtype=torch.float32, device=x2d.device)
     w, w_rows, sx = x_operand

@@ -508,6 +508,8 @@ def test_gradient_gemms_match_float64(r, m, n):
         assert float((alt.double() - want_tn).abs().max()) <= 3e-6 * float(want_tn.abs().max())
     zero = _ops.grad_tn(torch.zeros_like(grad), x)
     assert float(zero.abs().max()) == 0.0
+    bad = grad.clone(); bad[3, 1] = float("nan")                                  # a NaN in an operand: NaN products, like fp32 (not zeros)
+    assert bool(torch.isnan(_ops.grad_tn(bad, x)).all()) and bool(torch.isnan(_ops.grad_nn(bad, _weights.split_f16(w.t().contiguous()), n)).all())
     # the shared pieces (one absmax per matrix, feats^T split once) give the same bits as the stand-alone calls
     op = _ops.grad_tn_operand(x)
     assert torch.equal(_ops.grad_tn(grad, x, amax=_ops.absmax(grad), x_operand=op), got_tn)
