@@ -845,3 +845,38 @@ def test_recompute_backward_with_inputs_of_another_dtype_and_with_no_neighbours(
     node = layer.node_mlp(torch.cat((layer.node_norm(f), torch.zeros(b, n, layer.m_dim)), dim=-1)) + f
     want0 = torch.autograd.grad([node.sum()], [f])[0]
     assert float((out0[4].float() - want0).abs().max()) <= 1e-5 * float(want0.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frozen", [("node_mlp",), ("node_mlp", "edge_mlp", "coors_mlp", "node_norm", "coors_norm", "edge_gate"), ("edge_mlp.0", "coors_mlp.3")])
+def test_native_backward_on_the_device_with_frozen_parameters(frozen):
+    """The device-side native backward (node_mlp on the split-f16 GEMMs, the tail kernel's in-kernel sums) with frozen parameters:
+    the input gradients equal those of the unfrozen module, frozen parameters get no gradient, the others the same ones."""
+    from egnn_pytorch_amd import EGNN
+    kw = dict(dim=32, num_nearest_neighbors=20, soft_edges=True, norm_coors=True, norm_feats=True)
+    torch.manual_seed(9)
+    layer = EGNN(**kw).cuda()
+    g = torch.Generator().manual_seed(2)
+    feats, coors = torch.randn(2, 50, 32, generator=g).cuda(), torch.randn(2, 50, 3, generator=g).cuda()
+    gn, gc = torch.randn(2, 50, 32, generator=g).cuda(), torch.randn(2, 50, 3, generator=g).cuda()
+
+    def run():
+        f, c = feats.clone().requires_grad_(True), coors.clone().requires_grad_(True)
+        node, co = layer(f, c)
+        layer.zero_grad()
+        ((node * gn).sum() + (co * gc).sum()).backward()
+        return f.grad.clone(), c.grad.clone(), {k: (None if p.grad is None else p.grad.clone()) for k, p in layer.named_parameters()}
+
+    f0, c0, p0 = run()
+    for name, p in layer.named_parameters():
+        if any(name.startswith(fr) for fr in frozen):
+            p.requires_grad_(False)
+    for p in layer.parameters():
+        p.grad = None
+    f1, c1, p1 = run()
+    assert torch.equal(f0, f1) and torch.equal(c0, c1)
+    for name, p in layer.named_parameters():
+        if p.requires_grad:
+            assert torch.equal(p0[name], p1[name]), name
+        else:
+            assert p1[name] is None, name
