@@ -880,3 +880,22 @@ def test_native_backward_on_the_device_with_frozen_parameters(frozen):
             assert torch.equal(p0[name], p1[name]), name
         else:
             assert p1[name] is None, name
+
+
+@pytest.mark.gpu
+def test_backward_twice_over_a_retained_graph_gives_the_same_gradients():
+    """The backward decodes the forward's projection table in place, once: a second backward over the retained graph must find it
+    decoded (same gradients, bit for bit), and so must torch.autograd.grad called for different inputs."""
+    from egnn_pytorch_amd import EGNN
+    torch.manual_seed(3)
+    layer = EGNN(dim=64, num_nearest_neighbors=32).cuda()
+    g = torch.Generator().manual_seed(8)
+    f = torch.randn(2, 96, 64, generator=g).cuda().requires_grad_(True)
+    c = torch.randn(2, 96, 3, generator=g).cuda().requires_grad_(True)
+    node, co = layer(f, c)
+    loss = node.square().mean() + co.square().mean()
+    g1 = torch.autograd.grad(loss, [f, c] + list(layer.parameters()), retain_graph=True)
+    g2 = torch.autograd.grad(loss, [f, c] + list(layer.parameters()), retain_graph=True)
+    g3 = torch.autograd.grad(loss, [c])
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))
+    assert torch.equal(g1[1], g3[0])
