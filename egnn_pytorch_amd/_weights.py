@@ -153,6 +153,14 @@ def pack(layer) -> dict:
     """Build the kernel-side weight set of one EGNN layer.  All outputs are fp32, contiguous, on the
     parameters' device.  On the GPU the seven GEMM weight images come from split_f16_device and every maximum the scales are
     chosen from is read in one transfer (an optimizer step invalidates the cache: this runs once per layer and training step)."""
+    dev0 = layer.edge_mlp[0].weight.device
+    if dev0.type == "cuda":
+        with torch.cuda.device(dev0):                             # (the packing kernels launch on the parameters' device)
+            return _pack(layer)
+    return _pack(layer)
+
+
+def _pack(layer) -> dict:
     w1 = layer.edge_mlp[0].weight.detach().float()
     b1 = layer.edge_mlp[0].bias.detach().float()
     w2 = layer.edge_mlp[3].weight.detach().float()
