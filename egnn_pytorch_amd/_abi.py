@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -56,6 +56,7 @@ class EdgeArgs(Structure):
         ("edges_by_k", c_int32),
         ("slots", c_void_p),
         ("drop_thr", ctypes.c_uint32), ("drop_seed", ctypes.c_uint32), ("drop_inv_keep", c_float),
+        ("algo", c_int32),
     ]
 
 

@@ -24,6 +24,12 @@ def threshold(p: float) -> int:
     return max(1, min(_M32, int(round(p * 4294967296.0))))
 
 
+def inv_keep(p: float) -> float:
+    """1 / (1 - p), the scale of a kept unit.  p = 1 (nn.Dropout(1.0) is legal upstream and outputs zeros): every unit is dropped
+    -- threshold() keeps one with probability 2^-32 -- and the scale of that unit stays finite (1) instead of dividing by zero."""
+    return 1.0 / (1.0 - p) if p < 1.0 else 1.0
+
+
 def draw_seed() -> int:
     """A fresh 31-bit seed from torch's default CPU generator (no device synchronisation)."""
     return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
@@ -51,4 +57,4 @@ def apply(z: torch.Tensor, seed: int, site: int, rows: torch.Tensor, p: float) -
     """dropout of z (..., C) whose leading dimensions flatten to `rows` (R,): z * keep / (1 - p)."""
     c = z.shape[-1]
     keep = keep_mask(seed, site, rows.reshape(-1), torch.arange(c, device=z.device), p).view(z.shape)
-    return torch.where(keep, z * (1.0 / (1.0 - p)), torch.zeros_like(z))
+    return torch.where(keep, z * inv_keep(p), torch.zeros_like(z))

@@ -317,7 +317,7 @@ def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32
             rc = _abi.load().egnn_linear_hl_drop_f32(_ptr(a.hi), _ptr(a.lo), _ptr(whi), _ptr(wlo), float(inv), _ptr(bias),
                                                      _ptr(residual), ldr, _ptr(c), n, _ptr(out.hi) if out else None,
                                                      _ptr(out.lo) if out else None, kp_out, m, n, kp, w_rows, act, int(split_cols),
-                                                     _dropout.threshold(p_drop), int(seed), 1.0 / (1.0 - p_drop),
+                                                     _dropout.threshold(p_drop), int(seed), _dropout.inv_keep(p_drop),
                                                      _ptr(status_word(dev).dev), _stream())
     _abi.check(rc, "egnn_linear_hl_f32")
     if out_f32 and out_hl:
@@ -446,7 +446,7 @@ def silu_bwd_(z, g, drop=None, row0=0):
         else:
             from . import _dropout
             rc = _abi.load().egnn_silu_bwd_drop_f32(_ptr(z), _ptr(g), _ptr(z), _ptr(g), z.numel(), _ptr(bits), _dropout.threshold(drop[0]),
-                                                    int(drop[1]), 1.0 / (1.0 - drop[0]), int(row0), z.shape[-1], _stream())
+                                                    int(drop[1]), _dropout.inv_keep(drop[0]), int(row0), z.shape[-1], _stream())
     _abi.check(rc, "egnn_silu_bwd_f32")
     return z, g, bits
 
@@ -497,7 +497,10 @@ def grad_scale(amax):
         return NONFINITE
     if not (amax > 0.0):
         return None
-    return _weights.pow2_scale(amax) * 4096.0
+    # (clamped: for max |x| below ~2^-88 the scale -- a C float in the ABI -- and the inverse scales built from it would leave fp32's
+    # normal range; such an operand is split with 2^100 instead, its values then sit in fp16's subnormals or flush to zero, which is
+    # what the fp32 product they replace would have given at that magnitude: ~0)
+    return min(_weights.pow2_scale(amax) * 4096.0, 2.0 ** 100)
 
 
 def grad_nn(g2d, wsplit_t, n, residual=None, name="grad_nn", amax=None):
@@ -650,7 +653,7 @@ def edge_tail_bwd(u16, coors, idx32, pair_mask, g_coors_out, g_msum16, w3p, b3p,
         a.amax_gu = gu_bits.data_ptr()
         if drop is not None:                                  # training-mode dropout in coors_mlp: the forward's hash mask (p, seed), edges numbered from eid0
             from . import _dropout
-            a.drop_thr, a.drop_seed, a.drop_inv_keep, a.drop_eid0 = _dropout.threshold(drop[0]), int(drop[1]), 1.0 / (1.0 - drop[0]), int(eid0)
+            a.drop_thr, a.drop_seed, a.drop_inv_keep, a.drop_eid0 = _dropout.threshold(drop[0]), int(drop[1]), _dropout.inv_keep(drop[0]), int(eid0)
         if gate is not None:
             a.gate_w, a.gate_b = gate[0].data_ptr(), gate[1].data_ptr()
         rel = dist = None
@@ -724,7 +727,7 @@ def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, w
         a.rows_amax = amax_bits.data_ptr()
     if drop is not None:                                      # training-mode dropout in edge_mlp: the forward's hash mask (p, seed)
         from . import _dropout
-        a.drop_thr, a.drop_seed, a.drop_inv_keep, a.drop_eid0 = _dropout.threshold(drop[0]), int(drop[1]), 1.0 / (1.0 - drop[0]), int(eid0)
+        a.drop_thr, a.drop_seed, a.drop_inv_keep, a.drop_eid0 = _dropout.threshold(drop[0]), int(drop[1]), _dropout.inv_keep(drop[0]), int(eid0)
     if want_w2:
         dw2 = empty(n_slabs, 16, hp, dtype=torch.float32, device=dev)
         a.dW2_part = dw2.data_ptr()

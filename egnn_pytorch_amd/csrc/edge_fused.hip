@@ -40,6 +40,7 @@
 //   * blocks are remapped so that each XCD works on a contiguous range of graphs (Pj rows of a graph stay
 //     in that XCD's L2; measured hit rate 85 %).
 #include "egnn_common.h"
+#include "egnn_lds_dma.h"
 
 namespace {
 
@@ -141,49 +142,6 @@ __device__ __forceinline__ uint32_t pack_h2(_Float16 a, _Float16 b)
 {
     const f16x2 v = {a, b};
     return __builtin_bit_cast(uint32_t, v);
-}
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
-
-// One LDS-DMA instruction: lane l's 16 bytes at `g` (per-lane address) land at lds_base + 16 l (lds_base wave-uniform).
-// Issued from inline asm on purpose, see the staging ring in edge_body.
-__device__ __forceinline__ void lds_dma16(const char* g, char* lds_base)
-{
-#if defined(EGNN_EDGE_DMA_BUILTIN) && EGNN_EDGE_DMA_BUILTIN
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
-#else
-    const uint32_t m0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(m0) : "memory", "m0");
-#endif
-}
-
-__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff)
-{
-    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-    return __builtin_bit_cast(f32x4, (u32x4v)__builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
-}
-__device__ __forceinline__ uint32_t buf_load1(__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff)
-{
-    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0);
-}
-
-// One gather instruction of the LDS-DMA path: lane l's 16 bytes at (descriptor base + voff + soff) land at lds_addr + 16 l
-// (lds_addr, soff wave-uniform).  Inline asm for the same reason as lds_dma16.
-typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void gather_dma16(u32x4s rsrc, uint32_t voff, uint32_t soff, uint32_t lds_addr)
-{
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory", "m0");
-}
-__device__ __forceinline__ u32x4s make_rsrc_words(const void* base, uint32_t bytes)
-{
-    const uint64_t a = (uint64_t)(size_t)base;
-    u32x4s r;
-    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
-    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
-    r[2] = __builtin_amdgcn_readfirstlane(bytes);
-    r[3] = 0x00020000u;
-    return r;
 }
 
 // NM: chained first-layer MFMAs (4 split terms each, 3 terms per per-edge scalar); HCT: hidden columns per LDS chunk;
@@ -1263,9 +1221,14 @@ extern "C" int egnn_edge_mfmas(int S) { return S <= 1 ? 1 : (S <= 4 ? 3 : (S <= 
 
 #endif
 
-// internal: the two compilations of this file (coordinate dimension 3 / generic)
+// internal: the two compilations of this file (coordinate dimension 3 / generic), and the persistent wave-per-node kernel of the
+// K % 32 == 0 inference layers (edge_pw.hip; EGNN_E_UNSUPPORTED = not its shape)
 int egnn_edge_fused_c3(const egnn_edge_args* args, void* stream);
 int egnn_edge_fused_generic_c(const egnn_edge_args* args, void* stream);
+int egnn_edge_pw_launch(const egnn_edge_args* args, void* stream);
+#ifndef EGNN_EDGE_PW
+#define EGNN_EDGE_PW 1
+#endif
 
 #ifndef EGNN_EDGE_GENERIC_C
 extern "C" int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream)
@@ -1336,6 +1299,14 @@ int EGNN_EDGE_ENTRY(const egnn_edge_args* args, void* stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     // NM = ceil(3 S / 4) first-layer MFMAs, rounded up to an instantiated value; Wst must be laid out for that NM
     if (a.wst_terms != 4 * egnn_edge_mfmas(a.S)) return EGNN_E_SHAPE;
+#if !defined(EGNN_EDGE_GENERIC_C) && EGNN_EDGE_PW
+    if (a.algo == 0) {
+        const int rc = egnn_edge_pw_launch(args, stream);
+        if (rc != EGNN_E_UNSUPPORTED) return rc;
+    } else if (a.algo != 1) {
+        return EGNN_E_SHAPE;
+    }
+#endif
     if (a.S == 1) return dispatch_tpi<1, HC>(a, s);
 #ifndef EGNN_EDGE_TUNING_BUILD
     if (a.S <= 4) return dispatch_tpi<3, 128>(a, s);

@@ -1,0 +1,530 @@
+// The edge pass of the k-NN layers as a PERSISTENT kernel with one wave per node (reference: egnn_pytorch/egnn_pytorch.py:262-333).
+//
+// Same arithmetic, same operand layouts and -- for K <= 128 -- the same bits as edge_fused.hip's general kernel, for the shape every
+// k-NN configuration of BASELINE.json has: K % 32 == 0 neighbours, squared distance as the only per-edge scalar (no fourier
+// features, no edge features), m_dim <= 16, 3-D coordinates, the per-slot records of egnn_slot_prep_f32, inference.  What differs is
+// everything AROUND the hidden loop, which at 32 neighbours is 16 % of the general kernel's VALU instructions at dim 512 and 40 % at
+// dim 128 (505 M issued against 426 M in the loop, profiles/r03_final):
+//   * the grid is 5 workgroups per CU, once; a workgroup walks its node groups itself (XCD x takes a contiguous eighth of the node
+//     groups, its workgroups interleave over it: the working set of an XCD's L2 is the same ~160 consecutive groups as with one
+//     launch per group).  No workgroup launch / LDS allocation / argument load per 4 nodes, and the W2 / W_s staging ring never
+//     drains: the first chunk of the next node is in flight while the current node's epilogue runs.
+//   * one wave owns one node: its 32 k-slots per round are the wave's two MFMA tiles, rounds (K / 32) run back to back in the same
+//     wave and the per-node sums stay in registers (DPP butterfly over a tile's 16 edges) -- no cross-wave reduction, no LDS
+//     accumulators, no workgroup barrier outside the staging ring's one per chunk.
+//   * the next round's 32 slot records (512 B) are fetched by LDS-DMA into a wave-private buffer while the current round computes: the
+//     setup has no dependent global loads left; the epilogue re-reads x_i - x_j from the same LDS copy.
+//   * the setup is written for this shape only (the general kernel carries fourier / edge-feature / dense / ragged-K paths as
+//     run-time branches through every tile).
+//   * the residual of the hidden value's hi/lo split runs as v_mfma_f32_4x4x4_16B_f16 (lane-local: D = C - B with A = -I4, two
+//     passes on the matrix pipe) instead of v_mfma_f32_16x16x16_f16 (four): bit-identical, half the matrix-pipe time.
+#include "egnn_common.h"
+#include "egnn_lds_dma.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+
+#ifndef EGNN_PW_WGS
+#define EGNN_PW_WGS 5                        // workgroups per CU the register allocation must allow
+#endif
+#ifndef EGNN_PW_RESID4
+#define EGNN_PW_RESID4 1                     // residual of the split on v_mfma_f32_4x4x4_16B_f16 (0: v_mfma_f32_16x16x16_f16)
+#endif
+
+constexpr int PW_THREADS = 256;
+constexpr int PW_WAVES = 4;
+constexpr int PW_HC = 64;                    // hidden columns per slot of the staging ring (two steps of 32)
+constexpr int PW_XLD = 32;                   // floats per row of the gather exchange buffer (one 128-byte line, chunk-swizzled)
+// LDS (31 KB: five workgroups per CU):  W2 fragments, two ring slots | first-layer A fragments, two ring slots |
+// per-wave gather exchange rows (32 slots x 128 B) | per-wave slot records, two buffers of 32 x 16 B | per-wave 64-float scratch
+constexpr int PW_W2S = 0;
+constexpr int PW_WST = PW_W2S + 2 * PW_HC * 64;
+constexpr int PW_XCH = PW_WST + 2 * PW_HC * 16;
+constexpr int PW_REC = PW_XCH + PW_WAVES * 32 * PW_XLD * 4;
+constexpr int PW_SCR = PW_REC + PW_WAVES * 2 * 512;
+constexpr int PW_LDS = PW_SCR + PW_WAVES * 256;
+
+__device__ __forceinline__ uint32_t pw_pack_h2(_Float16 a, _Float16 b)
+{
+    const f16x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// A wave-uniform value the optimiser must treat as changed at this point: keeps per-lane addresses that depend only on kernel
+// arguments (epilogue constants, output offsets) from being hoisted out of the persistent loop, where they would sit in -- or be
+// spilled from -- vector registers across the hidden loop.
+template <typename T>
+__device__ __forceinline__ T pw_opaque(T v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p)
+{
+    return __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)(char*)p);
+}
+
+__global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const egnn_edge_args p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[PW_LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int e = lane & 15;
+    const int g = lane >> 4;
+    const int N = p.N, K = p.K;
+    const int R = K >> 5;                                     // rounds of 32 k-slots per node
+    const int T = p.B * N;                                    // nodes (B N K 16 < 2^32, checked by the launcher)
+
+    // ---- the workgroup's node groups (4 nodes, one per wave): XCD x owns groups [gstart, gstart + gcount), its workgroups interleave
+    const int ngroups = (T + PW_WAVES - 1) / PW_WAVES;
+    const int nper = (int)(gridDim.x >> 3);
+    const int xcd = (int)(blockIdx.x & 7), wi = (int)(blockIdx.x >> 3);
+    const int gq = ngroups >> 3, grem = ngroups & 7;
+    const int gstart = xcd * gq + (xcd < grem ? xcd : grem);
+    const int gcount = gq + (xcd < grem ? 1 : 0);
+    if (wi >= gcount) return;                                 // (the whole workgroup)
+    const int mygroups = (gcount - wi + nper - 1) / nper;
+    const int total_rounds = mygroups * R;
+
+    _Float16* const w2s = reinterpret_cast<_Float16*>(smem + PW_W2S);
+    char* const wst = smem + PW_WST;
+    float* const xch = reinterpret_cast<float*>(smem + PW_XCH) + wave * (32 * PW_XLD);
+    char* const recb = smem + PW_REC + wave * 1024;
+    float* const scr = reinterpret_cast<float*>(smem + PW_SCR) + wave * 64;
+    const uint32_t xch_lds = lds_addr_of(xch);
+    const uint32_t rec_lds = lds_addr_of(recb);
+
+    const bool has_mask = p.mask != nullptr;
+    const int Hp = p.Hp;
+    const int nchunks = (Hp + PW_HC - 1) / PW_HC;
+    const uint32_t prow_bytes = (uint32_t)((size_t)N * p.ldp * 4);
+    const u32x4s slot_words = make_rsrc_words(p.slots, (uint32_t)((size_t)T * K * 16));
+
+    // ---- staging ring: chunk c of the hidden dimension (PW_HC columns of W2 fragments + first-layer A fragments) -> slot
+    auto stage = [&](int c, int slot) {
+        const int c0s = c * PW_HC;
+        const int hcs = (Hp - c0s) < PW_HC ? (Hp - c0s) : PW_HC;
+        const char* src = reinterpret_cast<const char*>(p.W2h) + (size_t)c0s * 64 + lane * 16;
+        char* dst = reinterpret_cast<char*>(w2s) + slot * (PW_HC * 64);
+        for (int pc = wave; pc < hcs / 16; pc += PW_WAVES) lds_dma16(src + pc * 1024, dst + pc * 1024);
+        if (wave == 0) {
+            const int tbytes = hcs * 16;                                   // one 16-byte row of four terms per hidden unit
+            const char* tsrc = reinterpret_cast<const char*>(p.Wst) + (size_t)c0s * 16 + lane * 16;
+            if (lane * 16 < tbytes) lds_dma16(tsrc, wst + slot * (PW_HC * 16));
+        }
+    };
+    // the 32 slot records of round r of node tau -> record buffer `buf` (lanes 0 .. 31: 512 bytes)
+    auto rec_dma = [&](int tau, int r, int buf) {
+        const uint32_t soff = ((uint32_t)tau * (uint32_t)K + 32u * (uint32_t)r) * 16u;
+        if (lane < 32) gather_dma16(slot_words, (uint32_t)lane * 16u, soff, rec_lds + (uint32_t)buf * 512u);
+    };
+    // node of this wave in the workgroup's kg-th group (a wave past the last node repeats the last one and stores nothing)
+    auto node_of = [&](int kg) { return (gstart + wi + kg * nper) * PW_WAVES + wave; };
+    // its feature row i = order[tau], requested a whole round before it is needed: the load is made to look per-lane (an opaque zero in
+    // the address) so that it stays an ordinary vector load whose wait sits at the first use -- as a uniform load the compiler reads
+    // it back into a scalar register, and waits for it, on the spot
+    int zero_v = 0;
+    asm volatile("" : "+v"(zero_v));
+    auto row_of = [&](int tau) { return p.order ? p.order[tau + zero_v] : tau % N; };
+
+    // ---- lane constants
+    // pick-up: lane (e, g) reads hidden rows 16 hb + 4 g .. + 3 of slot 16 t + e; the swizzle depends on e only
+    const float* xr[2];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) xr[hb] = xch + e * PW_XLD + 4 * ((4 * hb + g) ^ ((e >> 1) & 7));
+    // first-layer A fragments: row (hidden unit) e of the 16-block, split term g
+    const char* const tl = wst + (e * 4 + g) * 4;
+    constexpr int tstep = 16 * 4 * 4;                                      // bytes per 16 hidden units
+#if EGNN_PW_RESID4
+    f16x4 neg_identity;                                                    // A operand of the 4x4x4 residual MFMA: row (lane & 3) of -I4
+#pragma unroll
+    for (int u = 0; u < 4; ++u) neg_identity[u] = ((lane & 3) == u) ? (_Float16)-1.f : (_Float16)0.f;
+#else
+    f16x4 neg_identity;                                                    // -I16: row e, K-slots 4g .. 4g+3
+#pragma unroll
+    for (int u = 0; u < 4; ++u) neg_identity[u] = (e == 4 * g + u) ? (_Float16)-1.f : (_Float16)0.f;
+#endif
+    // swizzled chunk this lane fetches in gather instruction qq (the DMA drops lane l's 16 bytes at position l & 7 of row 8 qq + (l >> 3))
+    uint32_t gchunk4[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) gchunk4[qq] = (uint32_t)(((lane & 7) ^ ((4 * qq + (lane >> 4)) & 7)) * 16);
+
+    // ---- prologue: first chunk of the ring, first records
+    stage(0, 0);
+    int tau_next = node_of(0);
+    bool live_next = tau_next < T;
+    if (!live_next) tau_next = T - 1;
+    rec_dma(tau_next, 0, 0);
+    int i_next_v = row_of(tau_next);
+    int ring = 0;                                                          // chunks staged so far - 1 = index of the chunk the loop consumes next
+
+    f32x4 nms = f32x4{0.f, 0.f, 0.f, 0.f};                                 // the node's message sums, channels 4g .. 4g+3 (every lane of row g)
+    float ncs[4] = {0.f, 0.f, 0.f, 0.f};                                   // coordinate update (3) and edge count
+
+    int kg = 0, r = 0;
+    for (int rho = 0; rho < total_rounds; ++rho) {
+        // ------------------------------------------------------------------ round setup
+        const int tau = tau_next;
+        const bool live = live_next;
+        const int b = tau / N;
+        const size_t bN = (size_t)b * N;
+        const int i = __builtin_amdgcn_readfirstlane(i_next_v);
+        const __amdgpu_buffer_rsrc_t pi_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Pi + bN * p.ldp), 0, prow_bytes, 0x00020000);
+        const u32x4s pj_words = make_rsrc_words(p.Pj + bN * p.ldp, prow_bytes);
+        const int cur = rho & 1;
+        const char* const rb = recb + cur * 512;
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this round's records have landed
+        __builtin_amdgcn_wave_barrier();
+        uint32_t goff[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const uint32_t j2 = *reinterpret_cast<const uint32_t*>(rb + (8 * qq + (lane >> 3)) * 16) & 0x7fffffffu;
+            goff[qq] = (uint32_t)((size_t)j2 * p.ldp * 4) + gchunk4[qq];
+        }
+        u32x4v rec[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) rec[t] = *reinterpret_cast<const u32x4v*>(rb + (16 * t + e) * 16);
+        // the first step's gathered lines and P_i words
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) gather_dma16(pj_words, goff[qq], 0u, xch_lds + qq * 1024);
+        const uint32_t piw = (uint32_t)(((size_t)i * p.ldp + e) * 4);
+        uint32_t piv[2];
+        piv[0] = buf_load1(pi_rsrc, piw, 0);
+        piv[1] = buf_load1(pi_rsrc, piw, 64);
+        // the records (and, for a new node, the feature row) of the round after this one
+        if (rho + 1 < total_rounds) {
+            if (r + 1 == R) {
+                tau_next = node_of(kg + 1);
+                live_next = tau_next < T;
+                if (!live_next) tau_next = T - 1;
+                i_next_v = row_of(tau_next);
+                rec_dma(tau_next, 0, cur ^ 1);
+            } else {
+                rec_dma(tau, r + 1, cur ^ 1);
+            }
+        }
+
+        u32x2 bq[2];                                                        // B fragments of the first-layer MFMA
+        bool fm[2];                                                         // edge contributes (unmasked)
+        // lane-group masks, rebuilt every round (three registers that need not live through the hidden loop) and applied with bitwise
+        // operations: as selects on g the compiler turns the split below into divergent branches
+        const int gq_ = g + pw_opaque(0);
+        const uint32_t gm0 = gq_ == 0 ? 0xffffffffu : 0u, gm1 = gq_ == 1 ? 0xffffffffu : 0u, gm2 = gq_ == 2 ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t r0 = rec[t][0], r1 = rec[t][1], r2 = rec[t][2], r3 = rec[t][3];   // (by value: see edge_fused.hip)
+            const float d = egnn_sqdist_rel(__uint_as_float(r1), __uint_as_float(r2), __uint_as_float(r3));
+            // d' = d / ws_scale = 2^10 s1 + r_hi + r_lo: lane group g carries split term g in K-slots 4g+2, 4g+3
+            float val = d * p.ws_inv_scale;
+            egnn_flag_range(p.status, live && fabsf(val) >= 6.0e7f && fabsf(val) < __builtin_inff(), EGNN_RANGE_SCALAR);
+            if (fabsf(val) >= 6.0e7f) val = __builtin_nanf("");
+            const _Float16 s1 = (_Float16)(val * (1.0f / 1024.0f));
+            const float rem = val - (float)s1 * 1024.0f;
+            const _Float16 rh = (_Float16)rem;
+            const _Float16 rl = (_Float16)(rem - (float)rh);
+            u32x2 bw;
+            bw[0] = 0x3c003c00u & gm0;                                           // (1, 1) x (P_i hi, P_i lo), lane group 0 only
+            bw[1] = (pw_pack_h2(s1, s1) & gm0) | (pw_pack_h2(rh, rh) & gm1) | (pw_pack_h2(rl, (_Float16)0.f) & gm2);
+            bq[t] = bw;
+            fm[t] = live && (r0 >> 31) != 0u;                                    // mask_i & mask_j & (rank <= radius), or 1 without a mask
+        }
+
+        f32x4 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ------------------------------------------------------------------ hidden loop
+        const bool last_round = rho + 1 == total_rounds;
+        for (int c = 0; c < nchunks; ++c, ++ring) {
+            const int slot = ring & 1;
+            const int c0 = c * PW_HC;
+            const int hc = (Hp - c0) < PW_HC ? (Hp - c0) : PW_HC;
+            // chunk `ring` was requested one chunk ago; the only other loads in flight are the gathers of the coming step
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                 // every wave's pieces have landed, and every wave has left the other slot
+            const _Float16* w2c = w2s + slot * (PW_HC * 32);
+            const char* tlc = tl + slot * (PW_HC * 16);
+            const int nst = hc >> 5;
+            for (int st = 0; st < nst; ++st) {
+                const int hoff = c0 + st * 32;
+                const bool more = hoff + 32 < Hp;
+                const int hnext = more ? hoff + 32 : hoff;                       // last step: harmless re-read of the P_i words
+                f32x4 x[2][2];
+                uint32_t pivn[2];
+                // the lines of this step were requested a step ago and land in the wave's exchange rows by themselves
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    x[t][0] = *reinterpret_cast<const f32x4*>(xr[0] + t * 16 * PW_XLD);
+                    x[t][1] = *reinterpret_cast<const f32x4*>(xr[1] + t * 16 * PW_XLD);
+                }
+                // the rows are in registers before the next step's lines may overwrite them
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0)
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                pivn[0] = buf_load1(pi_rsrc, piw, hnext * 4);
+                pivn[1] = buf_load1(pi_rsrc, piw, hnext * 4 + 64);
+                if (st == 0) {
+                    // the next chunk of the ring: the next one of this round, or -- the ring never drains -- the first one of the round
+                    // that follows (its setup and this round's epilogue run with the chunk in flight)
+                    if (c + 1 < nchunks) stage(c + 1, slot ^ 1);
+                    else if (!last_round) stage(0, slot ^ 1);
+                }
+                if (more) {
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) gather_dma16(pj_words, goff[qq], (uint32_t)(hnext * 4), xch_lds + qq * 1024);
+                }
+
+                u32x2 a0[2];
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+                    a0[hb] = u32x2{piv[hb], *reinterpret_cast<const uint32_t*>(tlc + st * 2 * tstep + hb * tstep)};
+                const f16x8 whi = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 0) * 64 + lane) * 8);
+                const f16x8 wlo = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 1) * 64 + lane) * 8);
+                piv[0] = pivn[0];
+                piv[1] = pivn[1];
+                // first Linear of edge_mlp on the matrix cores: x += [P_i | W_s] x [1 | split d]
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb)
+                        x[t][hb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a0[hb]), __builtin_bit_cast(f16x4, bq[t]), x[t][hb], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    // x holds y = -log2(e) * (pre-activation); a = y / (1 + 2^y) = SiLU(pre) / (-ln 2); hi = fp16(a) (IEEE: beyond 65504 ->
+                    // inf, never a silently saturated number); lo32 = a - hi exactly, on the matrix cores
+                    f16x8 bhi, blo;
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {
+                        f32x4 a4;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float y = x[t][hb][u];
+                            float h = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
+                            asm("" : "+v"(h));           // keeps the products scalar (v_pk_mul_f32 costs 9.3 cycles per pair against 2 x 2.8)
+                            a4[u] = h;
+                        }
+                        const f16x2 h01 = __builtin_convertvector((f32x2v){a4[0], a4[1]}, f16x2);
+                        const f16x2 h23 = __builtin_convertvector((f32x2v){a4[2], a4[3]}, f16x2);
+                        const f16x4 hi4 = {h01[0], h01[1], h23[0], h23[1]};
+#if EGNN_PW_RESID4
+                        const f32x4 l4 = __builtin_amdgcn_mfma_f32_4x4x4f16(neg_identity, hi4, a4, 0, 0, 0);
+#else
+                        const f32x4 l4 = __builtin_amdgcn_mfma_f32_16x16x16f16(neg_identity, hi4, a4, 0, 0, 0);
+#endif
+                        const f16x2 l01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l4[0], l4[1]));
+                        const f16x2 l23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l4[2], l4[3]));
+                        bhi[4 * hb + 0] = h01[0]; bhi[4 * hb + 1] = h01[1]; bhi[4 * hb + 2] = h23[0]; bhi[4 * hb + 3] = h23[1];
+                        blo[4 * hb + 0] = l01[0]; blo[4 * hb + 1] = l01[1]; blo[4 * hb + 2] = l23[0]; blo[4 * hb + 3] = l23[1];
+                    }
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bhi, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, bhi, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, blo, acc[t], 0, 0, 0);
+                }
+            }
+        }
+
+        // ------------------------------------------------------------------ per-edge epilogue (registers; channel of (lane group g, register u) = 4 g + u)
+        f32x4 b2r, gwr = f32x4{0.f, 0.f, 0.f, 0.f};
+        float gb = 0.f;
+        const int g4 = pw_opaque(4) * g;                                     // (opaque: see pw_opaque)
+        b2r = *reinterpret_cast<const f32x4*>(p.b2 + g4);
+        if (p.gate_w) {
+            gwr = *reinterpret_cast<const f32x4*>(p.gate_w + g4);
+            gb = p.gate_b[0];
+        }
+        float cscale = 0.f;
+        if (p.coors_scale) cscale = p.coors_scale[0];
+
+        float cw[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 m;
+            bool bad = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                bad = bad || !(fabsf(acc[t][u]) < __builtin_inff());
+                m[u] = egnn_silu(acc[t][u] * p.w2_inv_scale + b2r[u]);
+            }
+            float part = gwr[0] * m[0] + gwr[1] * m[1] + gwr[2] * m[2] + gwr[3] * m[3];
+            egnn_flag_range(p.status, bad && fm[t], EGNN_RANGE_HIDDEN);
+            if (p.gate_w) {                                                      // soft_edges (:289-290)
+                part = egnn_column_sum4(part, scr, lane);
+                const float gt = egnn_sigmoid(part + gb);
+                m *= gt;
+            }
+            acc[t] = m;
+            cw[t] = 0.f;
+        }
+
+        if (p.W3h) {
+            // coors_mlp (:203-208): first Linear (16 -> 64) on the matrix cores, split-f16: lane (e, g) holds channels 4g .. 4g+3 of its
+            // edge = the B fragment of v_mfma_f32_16x16x16_f16; A = rows 16 blk + e of W3
+            float part[2] = {0.f, 0.f};
+            f16x4 mhi[2], mlo[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bool bad = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bad = bad || egnn_beyond_f16(acc[t][u]);
+                egnn_flag_range(p.status, bad && fm[t], EGNN_RANGE_MESSAGE);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const _Float16 h = (_Float16)acc[t][u];
+                    mhi[t][u] = h;
+                    mlo[t][u] = (_Float16)(acc[t][u] - (float)h);
+                }
+            }
+            const _Float16* w3h = static_cast<const _Float16*>(p.W3h);
+            constexpr int W3LD = 16, W3IMG = 64 * 16;
+            const int w3o = e * W3LD + g4;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                const f32x4 b3 = *reinterpret_cast<const f32x4*>(p.b3 + 16 * blk + g4);
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.W4 + 16 * blk + g4);
+                const f16x4 w3hi = *reinterpret_cast<const f16x4*>(w3h + 16 * blk * W3LD + w3o);
+                const f16x4 w3lo = *reinterpret_cast<const f16x4*>(w3h + W3IMG + 16 * blk * W3LD + w3o);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x16f16(w3hi, mhi[t], a2, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x16f16(w3lo, mhi[t], a2, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x16f16(w3hi, mlo[t], a2, 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) part[t] += w4[u] * egnn_silu(a2[u] * p.w3_inv_scale + b3[u]);
+                }
+            }
+            const float b4 = p.b4[0];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float s = egnn_column_sum4(part[t], scr, lane);
+                s += b4;
+                if (has_mask && !fm[t]) s = 0.f;                                 // :308-309
+                if (p.clamp >= 0.f) s = fminf(fmaxf(s, -p.clamp), p.clamp);      // :311-313
+                if (!fm[t] && !has_mask) s = 0.f;                                // a wave past the last node
+                cw[t] = s;
+            }
+        }
+
+        // x_i - x_j again, from the wave's LDS copy of the records
+        float rn[2][3], keep[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32x4v rc = *reinterpret_cast<const u32x4v*>(rb + (16 * t + e) * 16);
+            const uint32_t rw[3] = {rc[1], rc[2], rc[3]};
+            float rel[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rel[c] = __uint_as_float(rw[c]);
+            keep[t] = fm[t] ? 1.f : 0.f;
+            float inv = 1.f;
+            if (p.coors_scale) {                                                 // CoorsNorm, egnn_pytorch.py:67-77
+                float n2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) n2 += rel[c] * rel[c];
+                inv = cscale / fmaxf(sqrtf(n2), 1e-8f);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rn[t][c] = rel[c] * inv;
+        }
+        // the round's 32 edges belong to this wave's node: sum them in registers (DPP butterfly over the 16 edges of a tile, fixed order)
+        const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 ms = (fm[0] ? acc[0] : zero4) + (fm[1] ? acc[1] : zero4);          // select: masked_fill semantics (:322)
+        float cs[4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) cs[c] = cw[0] * rn[0][c] + cw[1] * rn[1][c];
+        cs[3] = keep[0] + keep[1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ms[u] = egnn_row16_sum(ms[u]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cs[c] = egnn_row16_sum(cs[c]);
+        // rounds in ascending order, each added to a running sum that starts at +0 (the order -- and the bits -- of the general kernel's
+        // cross-wave reduction for K <= 128)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nms[u] += ms[u];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ncs[c] += cs[c];
+
+        // ------------------------------------------------------------------ node outputs (after the node's last round)
+        if (r + 1 == R) {
+            if (live) {
+                const size_t row = bN + i;
+                if (e == 0) {
+                    const int gch = pw_opaque(4) * g;                            // (opaque: the packed offsets below are not loop invariants)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ch = gch + u;
+                        float val = 0.f + nms[u];
+                        if (ch < p.m_dim && (p.m_i || p.node_hi)) {
+                            if (p.pool_mean) {
+                                if (has_mask) {                                  // safe_div, egnn_pytorch.py:13-16
+                                    const float cnt = 0.f + ncs[3];
+                                    val = (cnt == 0.f) ? 0.f : val / fmaxf(cnt, 1e-8f);
+                                } else {
+                                    val = val / (float)K;                        // :330
+                                }
+                            }
+                            if (p.m_i) p.m_i[row * p.m_dim + ch] = val;
+                            if (p.node_hi) {                                     // straight into the node_mlp input, as a (hi, lo) pair
+                                egnn_flag_range(p.status, egnn_beyond_f16(val), EGNN_RANGE_MESSAGE);
+                                const _Float16 h = (_Float16)val;
+                                const size_t off = egnn_pk_off((int64_t)row, p.dim + ch, p.node_kp / 16);
+                                static_cast<_Float16*>(p.node_hi)[off] = h;
+                                static_cast<_Float16*>(p.node_lo)[off] = (_Float16)(val - (float)h);
+                            }
+                        }
+                    }
+                }
+                if (lane < 3 && p.coors_out) {
+                    const float val = 0.f + (lane == 0 ? ncs[0] : (lane == 1 ? ncs[1] : ncs[2]));
+                    p.coors_out[row * 3 + lane] = p.coors[row * 3 + lane] + val;
+                }
+            }
+            nms = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ncs[c] = 0.f;
+            r = 0;
+            ++kg;
+        } else {
+            ++r;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // no DMA may land after the LDS is released
+}
+
+}  // namespace
+
+// internal (called by egnn_edge_fused_f32's dispatcher, edge_fused.hip): EGNN_E_UNSUPPORTED = "not this kernel's shape, use the general one"
+int egnn_edge_pw_launch(const egnn_edge_args* args, void* stream)
+{
+    const egnn_edge_args& a = *args;
+    if (a.coor_dim != 3 || a.K < 32 || (a.K % 32) != 0 || a.K > 4096) return EGNN_E_UNSUPPORTED;
+    if (a.S != 1 || a.fourier != 0 || a.edge_dim != 0 || a.m_dim > 16 || a.wst_terms != 4) return EGNN_E_UNSUPPORTED;
+    if (!a.slots || !a.idx || !a.pi_split) return EGNN_E_UNSUPPORTED;
+    if (a.drop_thr || a.U_out) return EGNN_E_UNSUPPORTED;                 // inference only: the training forward keeps the general kernel
+    if ((int64_t)a.B * a.N * a.K * 16 > 0xffffffffLL) return EGNN_E_UNSUPPORTED;       // slot records behind one 32-bit buffer resource
+    if ((int64_t)a.N * a.ldp * 4 > 0xffffffffLL) return EGNN_E_UNSUPPORTED;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return (int)hipGetLastError();
+    const int64_t T = (int64_t)a.B * a.N;
+    const int64_t ngroups = (T + PW_WAVES - 1) / PW_WAVES;
+    int64_t grid = (int64_t)cus * EGNN_PW_WGS;
+    if (grid > ngroups) grid = ngroups;
+    grid = (grid + 7) / 8 * 8;                                             // eight XCDs; surplus workgroups return at once
+    hipLaunchKernelGGL(edge_pw_kernel, dim3((unsigned)grid), dim3(PW_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    return egnn_launch_status();
+}

@@ -146,12 +146,15 @@ extern "C" int egnn_dest_lists_i32(const int32_t* idx, int B, int N, int K, int3
     if ((int64_t)B * N * K > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;       // edge ids are int32 in the entry list
     if (ent_capacity < egnn_dest_lists_capacity(B, N, K)) return EGNN_E_SHAPE;
     // as many waves per graph as histograms fit in LDS (16, 8 or 4): one workgroup per graph is all the parallelism there is
+    // (large graphs -- N beyond ~8000 -- trade waves for histogram space: 2 waves up to N = 13 500, 1 wave up to N = 20 400; the
+    // forward's k-NN select stops at 8192 nodes per graph, dense graphs reach the int32 edge-id limit long before)
     int waves = 16;
     auto lds_for = [&](int w) { return ((size_t)w * N + 2 * (size_t)w * 64 + 2 + N) * sizeof(int); };
     while (waves > 4 && lds_for(waves) > 96 * 1024) waves >>= 1;
+    while (waves > 1 && lds_for(waves) > 160 * 1024) waves >>= 1;
     const size_t lds = lds_for(waves);
     const int EL_THREADS = waves * 64;
-    if (lds > 160 * 1024) return EGNN_E_UNSUPPORTED;                        // N <= ~8000 destinations per graph
+    if (lds > 160 * 1024) return EGNN_E_UNSUPPORTED;                        // N <= 20 415 destinations per graph
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dest_totals_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -30,7 +30,10 @@ struct DropArgs { uint32_t thr, seed; float inv_keep; };
 
 constexpr int BK = 16;                       // one v_mfma_f32_32x32x16_f16 step per K-tile
 constexpr int ROWB = BK * 2;                 // bytes per LDS row (32)
-constexpr int GROUP_M = 8;
+#ifndef EGNN_HL_GROUP_M
+#define EGNN_HL_GROUP_M 8
+#endif
+constexpr int GROUP_M = EGNN_HL_GROUP_M;
 
 // Tile configurations (BM x BN output tile, K-tile 16, every wave owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles):
 //   0: 128 x 128, 4 waves (2 x 2), 4-deep ring of 16 KB  -> 64 KB LDS, two workgroups per CU

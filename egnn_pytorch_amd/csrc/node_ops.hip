@@ -329,7 +329,7 @@ extern "C" int egnn_split_scaled_both_f16(const float* X, int64_t ldx, int64_t r
                                           void* hiT, void* loT, int KpT, int32_t* status, void* stream)
 {
     if (!X || !hi || !lo || !hiT || !loT) return EGNN_E_NULLPTR;
-    if (rows <= 0 || cols <= 0 || ldx < cols || Kp < cols || (Kp % 32) != 0 || KpT < rows || (KpT % 32) != 0 || !(scale > 0.f)) return EGNN_E_SHAPE;
+    if (rows <= 0 || cols <= 0 || ldx < cols || Kp < cols || (Kp % 32) != 0 || KpT < rows || (KpT % 32) != 0 || !(scale > 0.f) || !(scale < __builtin_inff())) return EGNN_E_SHAPE;
     // the grid covers both padded images: X rows up to max(rows | 32, KpT), X columns up to max(Kp, cols | 32)
     const int64_t rows32 = (rows + 31) / 32 * 32, cols32 = ((int64_t)cols + 31) / 32 * 32;
     const int64_t rows_cover = rows32 > KpT ? rows32 : KpT, cols_cover = Kp > cols32 ? Kp : cols32;

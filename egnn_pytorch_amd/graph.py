@@ -22,6 +22,12 @@ def graphed(module, *example_inputs, warmup: int = 2, range_check: str | None = 
     range_check: how the range status word is examined after a replay -- None = the process setting (EGNN_RANGE_CHECK),
     "deferred" = copied to pinned memory behind the replay and looked at by the next call (keeps the replay asynchronous),
     "sync" = one blocking 4-byte read per replay, "off"."""
+    # training-mode dropout draws its mask seed on the host (egnn_pytorch_amd/_dropout.py) and the seed is a kernel ARGUMENT: a captured
+    # graph would replay the same mask every step, silently (torch's own graph-safe RNG advances a device-side Philox offset instead)
+    for m in module.modules():
+        if callable(getattr(m, "dropout_active", None)) and m.dropout_active():
+            raise NotImplementedError("graphed(): a layer has training-mode dropout active; its mask seed would be frozen into the graph "
+                                      "(call .eval(), or run the module eagerly)")
     args = [a.clone() if torch.is_tensor(a) else a for a in example_inputs]
     kwargs = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_kwargs.items()}
     dev = next(a for a in list(args) + list(kwargs.values()) if torch.is_tensor(a)).device

@@ -24,6 +24,9 @@ from .attention import GlobalLinearAttention
 _SPATIAL_ORDER = os.environ.get("EGNN_SPATIAL_ORDER", "1") != "0"     # scheduling knob only; results do not depend on it
 _SLOT_PREP = os.environ.get("EGNN_SLOT_PREP", "1") != "0"             # per-slot records for the edge pass's setup (same results)
 _SIDE_STREAM = os.environ.get("EGNN_SIDE_STREAM", "1") != "0"         # neighbour selection beside the projection GEMM
+# egnn_edge_args.algo: 0 = the library chooses (persistent wave-per-node kernel where it applies), 1 = the general edge kernel always
+# (A/B measurements; tests/test_gpu_kernels.py checks the two against each other)
+_EDGE_ALGO = int(os.environ.get("EGNN_EDGE_ALGO", "0"))
 # The kernels compute in fp32-class arithmetic (split-f16 products, fp32 accumulation: DESIGN.md §2).  Other floating dtypes
 # -- the reference is dtype-generic and its own tests run in float64 -- are accepted at the boundary: inputs are converted to
 # fp32, outputs back to the callers' dtype.  For bf16 / fp16 that is at least the reference's precision; for float64 it is
@@ -212,7 +215,7 @@ class EGNN(nn.Module):
         idx = rank = order = slots = None
         if b == 0 or (n == 0 and not use_nearest):
             # empty batch / empty dense graphs: the reference returns empty outputs (N = 0 on the k-NN path: topk's error)
-            return torch.empty_like(feats), torch.empty_like(coors), None, None, None, valid_radius, None
+            return torch.empty_like(feats), torch.empty_like(coors), None, None, None, valid_radius, None, None
         if use_nearest:
             if adj_mat is not None and self.only_sparse_neighbors:
                 num_nearest = _ops.adj_max_degree(adj_mat)                # host sync, as upstream (:249)
@@ -312,10 +315,11 @@ class EGNN(nn.Module):
             if self.node_mlp is not None:
                 a.node_hi, a.node_lo, a.node_kp = node_in.hi.data_ptr(), node_in.lo.data_ptr(), node_in.kp
             if drop is not None:                                  # training-mode dropout: the mask is a hash, see _dropout.py
-                a.drop_thr, a.drop_seed, a.drop_inv_keep = _dropout.threshold(drop[0]), int(drop[1]), 1.0 / (1.0 - drop[0])
+                a.drop_thr, a.drop_seed, a.drop_inv_keep = _dropout.threshold(drop[0]), int(drop[1]), _dropout.inv_keep(drop[0])
             if want_u and self.m_dim <= 16:
                 u_pre = _ops.empty(b * n * k, 16, dtype=torch.float32, device=feats.device)
                 a.U_out = u_pre.data_ptr()
+            a.algo = _EDGE_ALGO
             _ops.edge_fused(a, feats.device)
             if u_pre is not None:
                 proj_kept = (proj, pi_split)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 28
+#define EGNN_ABI_VERSION 29
 
 enum {
     EGNN_OK = 0,
@@ -100,7 +100,7 @@ int egnn_spatial_order_f32(const float* coors, int B, int N, int32_t* order_out,
  *         tiles [tile_seg[n], tile_seg[n+1]) -- and -1 behind the last tile: the entry list of egnn_edge_bwd_pass_f32 (by_dest = 1),
  *         of which the caller uses the first (tile_seg[B N] * 16 rounded up to 128) entries
  * ent_capacity >= egnn_dest_lists_capacity(B, N, K) entries; tiles_per_graph: (B) int64 scratch.  Counting sort per graph (the
- * destinations of one source row are distinct), two launches, deterministic.  Limits: B N K < 2^31, N <= ~8000. */
+ * destinations of one source row are distinct), two launches, deterministic.  Limits: B N K < 2^31, N <= 20 415 (the per-wave histograms live in LDS). */
 size_t egnn_dest_lists_capacity(int B, int N, int K);
 int egnn_dest_lists_i32(const int32_t* idx, int B, int N, int K, int32_t* ent, size_t ent_capacity, int64_t* tile_seg,
                         int64_t* csr_order, int64_t* csr_seg, int64_t* tiles_per_graph, void* stream);
@@ -302,6 +302,10 @@ typedef struct egnn_edge_args {
     uint32_t drop_thr;          /* round(p * 2^32), p in (0, 1) */
     uint32_t drop_seed;
     float drop_inv_keep;
+    /* Kernel selection.  0 = automatic: inference calls with K % 32 == 0, S = 1 (squared distance only), m_dim <= 16, coor_dim = 3 and
+     * slot records run the persistent wave-per-node kernel (csrc/edge_pw.hip), everything else the general kernel (csrc/edge_fused.hip).
+     * 1 = the general kernel always (A/B measurements, and the tests that check the two against each other: same bits for K <= 128). */
+    int32_t algo;
 } egnn_edge_args;
 
 int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream);
