@@ -46,10 +46,19 @@ WORKLOADS = {
 }
 
 
+def neighbours_of(kwargs, n):
+    """K of the workload: num_nearest_neighbors, the maximum adjacency row sum for only_sparse_neighbors (3 for the README chain
+    |i - j| <= 1 this file builds, diagonal included: egnn_pytorch.py:249), N on the dense all-pairs path."""
+    if kwargs.get("only_sparse_neighbors"):
+        return min(3, n)
+    return kwargs.get("num_nearest_neighbors", 0) or n
+
+
 def model_counts(kwargs, b, n):
-    """Algorithmic bytes / executed flops per kernel for one step."""
+    """Algorithmic bytes / executed flops per LAUNCH of every kernel of one layer-forward (DESIGN.md section 7; SURVEY.md section 8d);
+    a network step launches each of them `depth` times."""
     dim = kwargs["dim"]
-    k = kwargs.get("num_nearest_neighbors", 0) or n
+    k = neighbours_of(kwargs, n)
     edge_dim = kwargs.get("edge_dim", 0)
     m = kwargs.get("m_dim", 16)
     din = 2 * dim + 1 + edge_dim
@@ -72,22 +81,54 @@ def model_counts(kwargs, b, n):
         "spatial_order": dict(bound="hbm", bytes=16 * bn, flops=0.0),
         # per-slot records for the edge pass's setup: reads the neighbour list, rank and two coordinate rows, writes 16 bytes per slot
         "slot_prep": dict(bound="hbm", bytes=e * (4 + 4 + 16) + 24 * bn, flops=6.0 * e),
-        # fused select: compulsory traffic is tiny; the comparable figure is one fp32 rank per ordered pair
-        "knn_select": dict(bound="hbm", bytes=4 * b * n * n, flops=8.0 * b * n * n),
+        # the K selected pairs' edge features out of the (B,N,N,edge_dim) tensor (network front-end / c4)
+        "edge_features": dict(bound="hbm", bytes=e * (4 + 2 * 4 * max(edge_dim, 1)), flops=0.0),
+        # fused pairwise distance + ranking + top-K: its compulsory traffic is tiny (B N 13 bytes in, B N K 8 out) and nothing of
+        # size N^2 exists -- a VALU / scalar-unit kernel, reported as ordered pairs per second
+        "knn_select": dict(bound="valu", pairs=float(b) * n * n, bytes=13 * bn + 8 * e, flops=8.0 * b * n * n),
     }, dict(E=e, K=k, H=h, Hp=hp)
 
 
-def roofline_entry(name, counts, ms):
+def roofline_entry(name, counts, ms, launches=1):
+    """One kernel against its roofline: `ms` = average duration of ONE launch (events on the launch stream), `launches` per step."""
     c = counts[name]
     sec = ms * 1e-3
+    if c["bound"] == "valu":
+        return dict(kernel=name, bound="valu", achieved=round(c["pairs"] / sec / 1e9, 2), peak=None, unit="Gpairs/s", frac=None,
+                    avg_ms=round(ms, 4), launches_per_step=launches, ordered_pairs=int(c["pairs"]),
+                    note="pairwise distance + ranking + top-K in registers: VALU / scalar-unit bound (VALUBusy: profiles/), compulsory "
+                         f"HBM traffic {int(c['bytes'])} bytes")
     if c["bound"] == "hbm":
         ach = c["bytes"] / sec / 1e9
         return dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 4), avg_ms=round(ms, 4), algorithmic_bytes=int(c["bytes"]))
+                    frac=round(ach / HBM_PEAK_GBS, 4), avg_ms=round(ms, 4), launches_per_step=launches, algorithmic_bytes=int(c["bytes"]))
     ach = SPLIT_TERMS * c["flops"] / sec / 1e12          # MFMA-issued flops (3 f16 MFMAs per fp32 product)
     return dict(kernel=name, bound="mfma", achieved=round(ach, 2), peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
-                frac=round(ach / MFMA_F16_PEAK_TFLOPS, 4), avg_ms=round(ms, 4), mfma_issued_flops=SPLIT_TERMS * c["flops"],
+                frac=round(ach / MFMA_F16_PEAK_TFLOPS, 4), avg_ms=round(ms, 4), launches_per_step=launches,
+                mfma_issued_flops=SPLIT_TERMS * c["flops"],
                 algorithmic_tflops=round(c["flops"] / sec / 1e12, 2), mfma_dtype="f16 (split x3, fp32 accumulate)")
+
+
+def workload_label(kwargs, b, n, k):
+    net = f"EGNN_Network(depth={kwargs['depth']}, " if "depth" in kwargs else "EGNN("
+    opts = "".join(f", {o}" for o in ("norm_coors", "only_sparse_neighbors") if kwargs.get(o))
+    if kwargs.get("edge_dim"):
+        opts += f", edge_dim={kwargs['edge_dim']}"
+    if kwargs.get("only_sparse_neighbors"):
+        path = f"adjacency neighbours (K={k})"
+    elif kwargs.get("num_nearest_neighbors"):
+        path = f"masked k-NN (k={k})"
+    else:
+        path = "dense all-pairs"
+    return f"{net}dim={kwargs['dim']}{opts}) {path} B={b}/GPU N={n} fp32"
+
+
+def git_head():
+    try:
+        import subprocess
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+    except Exception:
+        return None
 
 
 def make_inputs(kwargs, b, n, device, seed):
@@ -295,7 +336,7 @@ def main():
         device = torch.device("cuda", local_rank)
 
     dist = None
-    if world > 1:
+    if world > 1 or "WORLD_SIZE" in os.environ:            # under a launcher the process group is real even at world size 1 (RCCL smoke)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if standin:
@@ -366,42 +407,49 @@ def main():
     elapsed = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, reduce_max)
     check_range()                                        # raises if any timed step left the representable range
 
-    # ---- per-kernel durations (events on the launch stream), outside the timed region
-    with phase_timer() as pt:
-        for _ in range(5):
-            step()
-    per_kernel = {k: sum(v) / len(v) for k, v in pt.summary().items()}
+    # the same K steps with the range status word read back synchronously (the library's default for user code: one 4-byte
+    # device -> host read per forward), so that the line shows what the deferred mode of the timed region saves
+    value_sync = None
+    if _ops.RANGE_CHECK != "sync" and world == 1:
+        mode = _ops.RANGE_CHECK
+        _ops.RANGE_CHECK = "sync"
+        try:
+            el2 = timed_region(step, args.steps, 1, torch.cuda.synchronize, barrier, reduce_max)
+            value_sync = world * b * args.steps / el2
+        finally:
+            _ops.RANGE_CHECK = mode
 
-    if rank == 0 and args.workload != "north_star":
-        # secondary configs: throughput + per-kernel times only (the roofline bookkeeping is defined for the metric's config)
-        graphs = world * b * args.steps
-        depth = kwargs.get("depth", 1)
-        print(json.dumps({"metric": "EGNN.forward graphs/sec", "value": round(graphs / elapsed, 2), "unit": "graphs/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": args.workload, "kwargs": kwargs, "graphs_per_gpu": b, "nodes": n,
-                                     "mask": "ragged" if args.ragged_mask else "all-true"},
-                          "kernel_ms_per_step": {k: round(v * (len(pt.summary()[k]) / 5), 4) for k, v in per_kernel.items()},
-                          "layers": depth,
-                          **({"train_step": train_step(layer, feats, coors, mask, edges, adj)} if args.train_step and world == 1 and not is_net else {}),
-                          **({} if args.no_cpu_baseline or world != 1 else {"cpu_baseline": cpu_baseline(args.workload, kwargs, n)})}),
-              flush=True)
-    elif rank == 0:
+    # ---- per-kernel durations (events on the launch stream), outside the timed region
+    PROBE_STEPS = 5
+    with phase_timer() as pt:
+        for _ in range(PROBE_STEPS):
+            step()
+    summary = pt.summary()
+    per_kernel = {k: sum(v) / len(v) for k, v in summary.items()}              # average duration of one launch
+    launches = {k: len(v) / PROBE_STEPS for k, v in summary.items()}           # launches per step (network: one per layer)
+
+    if rank == 0:
         counts, shp = model_counts(kwargs, b, n)
-        kernels = [roofline_entry(k, counts, ms) for k, ms in sorted(per_kernel.items(), key=lambda kv: -kv[1])
-                   if k in counts]
-        dominant = dict(kernels[0])
-        traffic = None
+        depth = kwargs.get("depth", 1)
+        # kernels ordered by their share of the step; the roofline object is the dominant one
+        order = sorted(per_kernel.items(), key=lambda kv: -kv[1] * launches[kv[0]])
+        kernels = [roofline_entry(k, counts, ms, launches[k]) for k, ms in order if k in counts]
+        other = {k: round(ms * launches[k], 4) for k, ms in order if k not in counts}
+        dominant = dict(next(kr for kr in kernels if kr["bound"] in ("hbm", "mfma")))
+        traffic = thead = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dominant["kernel"])
+                tj = json.load(open(tpath))
+                per_wl = tj.get(args.workload, tj if args.workload == "north_star" and "north_star" not in tj else {})
+                traffic = per_wl.get(dominant["kernel"])
+                thead = per_wl.get("_head", tj.get("_head"))
             except Exception:
                 traffic = None
         dominant["traffic"] = traffic
-        dominant["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/profile.sh)" \
-            if traffic is not None else None
+        dominant["traffic_source"] = "profiles/pmc_traffic.json: (2 FETCH_SIZE + WRITE_SIZE) * 1024 per launch, separate rocprofv3 --pmc passes " \
+                                     "of this command (tools/profile.sh); PMC collection cannot run inside the timed process" if traffic is not None else None
+        dominant["traffic_head"] = thead                     # commit the profile run was taken at (a stale file is visible)
         graphs = world * b * args.steps
         value = graphs / elapsed
         out = {
@@ -409,21 +457,26 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "edges_per_s": round(value * n * shp["K"], 1), "range_check": _ops.RANGE_CHECK,
-            "config": {"workload": f"EGNN(dim={kwargs['dim']}, k={shp['K']}) B={b}/GPU N={n} fp32 masked k-NN"
-                       if "num_nearest_neighbors" in kwargs else f"EGNN(dim={kwargs['dim']}) dense B={b}/GPU N={n} fp32",
-                       "graphs_per_gpu": b, "nodes": n, "neighbors": shp["K"], "global_batch": world * b,
+            "edges_per_s": round(value * n * shp["K"] * depth, 1), "range_check": _ops.RANGE_CHECK,
+            "value_range_check_sync": None if value_sync is None else round(value_sync, 2),
+            "config": {"workload": workload_label(kwargs, b, n, shp["K"]), "name": args.workload,
+                       "graphs_per_gpu": b, "nodes": n, "neighbors": shp["K"], "layers": depth, "global_batch": world * b,
                        "mask": "ragged" if args.ragged_mask else "all-true",
                        "parallelism": f"batch-shard x{world} (no data-path collective)"},
+            "head": git_head(),
             "roofline": dominant,
             "kernels": kernels,
-            "sum_kernel_ms": round(sum(per_kernel.values()), 4),
+            "other_kernels_ms_per_step": other,
+            "sum_kernel_ms": round(sum(per_kernel[k] * launches[k] for k in per_kernel), 4),
         }
+        if dist is not None:
+            out["process_group"] = {"backend": dist.get_backend(), "world_size": world}
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.workload, kwargs, n)
         if args.reference_eager and world == 1:
             out["reference_gpu_eager"] = reference_gpu_eager(kwargs, b, n, device)
-        if (args.train_step or not args.no_train_step) and world == 1 and not is_net:
+        default_train = args.workload == "north_star" and not args.no_train_step
+        if (args.train_step or default_train) and world == 1 and not is_net:
             # after the timed inference region (never part of `value`): must not cost the line if it fails
             try:
                 out["train_step"] = train_step(layer, feats, coors, mask, edges, adj)

@@ -1014,9 +1014,9 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 keep[t] = fm[t] ? 1.f : 0.f;
                 float inv = 1.f;
                 if (p.coors_scale) {                                    // CoorsNorm, egnn_pytorch.py:67-77
-                    float n2 = 0.f;
+                    float n2 = 0.f;                                     // (explicit fma chain: the same bits in every kernel variant)
 #pragma unroll
-                    for (int c = 0; c < CDM; ++c) n2 += rel[t][c] * rel[t][c];
+                    for (int c = 0; c < CDM; ++c) n2 = __builtin_fmaf(rel[t][c], rel[t][c], n2);
                     inv = cscale / fmaxf(sqrtf(n2), 1e-8f);
                 }
 #pragma unroll
@@ -1029,7 +1029,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 ms[nb] = (fm[0] ? acc[0][nb] : zero4) + (fm[1] ? acc[1][nb] : zero4);     // select: masked_fill semantics (:322)
             float cs[CDM + 1];
 #pragma unroll
-            for (int c = 0; c < CDM; ++c) cs[c] = cw[0] * rn[0][c] + cw[1] * rn[1][c];
+            for (int c = 0; c < CDM; ++c) cs[c] = __builtin_fmaf(cw[1], rn[1][c], cw[0] * rn[0][c]);
             cs[CDM] = keep[0] + keep[1];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
@@ -1073,7 +1073,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                     if (p.coors_scale) {                                    // CoorsNorm, egnn_pytorch.py:67-77
                         float n2 = 0.f;
 #pragma unroll
-                        for (int c = 0; c < CDM; ++c) n2 += rel[t][c] * rel[t][c];
+                        for (int c = 0; c < CDM; ++c) n2 = __builtin_fmaf(rel[t][c], rel[t][c], n2);
                         inv = cscale / fmaxf(sqrtf(n2), 1e-8f);
                     }
 #pragma unroll

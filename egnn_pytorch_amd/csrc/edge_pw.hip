@@ -71,6 +71,19 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p)
     return __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)(char*)p);
 }
 
+// Kernel arguments read where they are used, through a pointer the optimiser cannot see through: as ordinary by-value arguments all
+// ~40 fields are loaded up front and stay live -- spilled to vector-register lanes -- across the persistent loop; this way the setup
+// and the epilogue fetch theirs with a handful of scalar loads per round (scalar cache) and the hidden loop keeps its registers.
+typedef const __attribute__((address_space(4))) egnn_edge_args* pw_args_ptr;
+__device__ __forceinline__ pw_args_ptr pw_args()
+{
+    pw_args_ptr a = (pw_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(a));
+    return a;
+}
+
+// MULTI: K > 32 -- a node's rounds accumulate in registers that live through the hidden loop (K = 32: nothing does)
+template <bool MULTI>
 __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const egnn_edge_args p)
 {
     __shared__ __attribute__((aligned(16))) char smem[PW_LDS];
@@ -80,8 +93,9 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int e = lane & 15;
     const int g = lane >> 4;
+    // (`p` is read at kernel entry only; everything the round loop needs comes through pw_args(), per phase)
     const int N = p.N, K = p.K;
-    const int R = K >> 5;                                     // rounds of 32 k-slots per node
+    const int R = MULTI ? (K >> 5) : 1;                       // rounds of 32 k-slots per node
     const int T = p.B * N;                                    // nodes (B N K 16 < 2^32, checked by the launcher)
 
     // ---- the workgroup's node groups (4 nodes, one per wave): XCD x owns groups [gstart, gstart + gcount), its workgroups interleave
@@ -103,28 +117,29 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
     const uint32_t xch_lds = lds_addr_of(xch);
     const uint32_t rec_lds = lds_addr_of(recb);
 
-    const bool has_mask = p.mask != nullptr;
     const int Hp = p.Hp;
     const int nchunks = (Hp + PW_HC - 1) / PW_HC;
-    const uint32_t prow_bytes = (uint32_t)((size_t)N * p.ldp * 4);
-    const u32x4s slot_words = make_rsrc_words(p.slots, (uint32_t)((size_t)T * K * 16));
 
     // ---- staging ring: chunk c of the hidden dimension (PW_HC columns of W2 fragments + first-layer A fragments) -> slot
+    const char* const w2h_g = reinterpret_cast<const char*>(p.W2h);
+    const char* const wst_g = reinterpret_cast<const char*>(p.Wst);
     auto stage = [&](int c, int slot) {
         const int c0s = c * PW_HC;
         const int hcs = (Hp - c0s) < PW_HC ? (Hp - c0s) : PW_HC;
-        const char* src = reinterpret_cast<const char*>(p.W2h) + (size_t)c0s * 64 + lane * 16;
+        const char* src = w2h_g + (size_t)c0s * 64 + lane * 16;
         char* dst = reinterpret_cast<char*>(w2s) + slot * (PW_HC * 64);
         for (int pc = wave; pc < hcs / 16; pc += PW_WAVES) lds_dma16(src + pc * 1024, dst + pc * 1024);
         if (wave == 0) {
             const int tbytes = hcs * 16;                                   // one 16-byte row of four terms per hidden unit
-            const char* tsrc = reinterpret_cast<const char*>(p.Wst) + (size_t)c0s * 16 + lane * 16;
+            const char* tsrc = wst_g + (size_t)c0s * 16 + lane * 16;
             if (lane * 16 < tbytes) lds_dma16(tsrc, wst + slot * (PW_HC * 16));
         }
     };
     // the 32 slot records of round r of node tau -> record buffer `buf` (lanes 0 .. 31: 512 bytes)
     auto rec_dma = [&](int tau, int r, int buf) {
-        const uint32_t soff = ((uint32_t)tau * (uint32_t)K + 32u * (uint32_t)r) * 16u;
+        const pw_args_ptr a = pw_args();
+        const u32x4s slot_words = make_rsrc_words(a->slots, (uint32_t)((size_t)a->B * a->N * a->K * 16));
+        const uint32_t soff = ((uint32_t)tau * (uint32_t)a->K + 32u * (uint32_t)r) * 16u;
         if (lane < 32) gather_dma16(slot_words, (uint32_t)lane * 16u, soff, rec_lds + (uint32_t)buf * 512u);
     };
     // node of this wave in the workgroup's kg-th group (a wave past the last node repeats the last one and stores nothing)
@@ -134,7 +149,10 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
     // it back into a scalar register, and waits for it, on the spot
     int zero_v = 0;
     asm volatile("" : "+v"(zero_v));
-    auto row_of = [&](int tau) { return p.order ? p.order[tau + zero_v] : tau % N; };
+    auto row_of = [&](int tau) {
+        const pw_args_ptr a = pw_args();
+        return a->order ? a->order[tau + zero_v] : tau % a->N;
+    };
 
     // ---- lane constants
     // pick-up: lane (e, g) reads hidden rows 16 hb + 4 g .. + 3 of slot 16 t + e; the swizzle depends on e only
@@ -153,11 +171,11 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
 #pragma unroll
     for (int u = 0; u < 4; ++u) neg_identity[u] = (e == 4 * g + u) ? (_Float16)-1.f : (_Float16)0.f;
 #endif
-    // swizzled chunk this lane fetches in gather instruction qq (the DMA drops lane l's 16 bytes at position l & 7 of row 8 qq + (l >> 3))
-    uint32_t gchunk4[4];
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) gchunk4[qq] = (uint32_t)(((lane & 7) ^ ((4 * qq + (lane >> 4)) & 7)) * 16);
-
+#if defined(EGNN_PW_STAGGER) && EGNN_PW_STAGGER
+    // experiment: the five workgroups of a CU start together and run rounds of equal length -- are their latency-bound phases (epilogue,
+    // setup) phase-locked?  Delay the workgroup by its (presumed) slot on the CU
+    for (int q = 0; q < ((wi / 32) % EGNN_PW_WGS) * EGNN_PW_STAGGER; ++q) __builtin_amdgcn_s_sleep(127);
+#endif
     // ---- prologue: first chunk of the ring, first records
     stage(0, 0);
     int tau_next = node_of(0);
@@ -167,19 +185,22 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
     int i_next_v = row_of(tau_next);
     int ring = 0;                                                          // chunks staged so far - 1 = index of the chunk the loop consumes next
 
-    f32x4 nms = f32x4{0.f, 0.f, 0.f, 0.f};                                 // the node's message sums, channels 4g .. 4g+3 (every lane of row g)
-    float ncs[4] = {0.f, 0.f, 0.f, 0.f};                                   // coordinate update (3) and edge count
+    f32x4 nms = f32x4{0.f, 0.f, 0.f, 0.f};                                 // MULTI: the node's message sums, channels 4g .. 4g+3 (every lane of row g)
+    float ncs[4] = {0.f, 0.f, 0.f, 0.f};                                   //        coordinate update (3) and edge count
 
     int kg = 0, r = 0;
     for (int rho = 0; rho < total_rounds; ++rho) {
         // ------------------------------------------------------------------ round setup
+        const pw_args_ptr pa = pw_args();                                   // setup arguments (scalar loads, this round only)
+        const int64_t ldp = pa->ldp;
         const int tau = tau_next;
         const bool live = live_next;
         const int b = tau / N;
         const size_t bN = (size_t)b * N;
         const int i = __builtin_amdgcn_readfirstlane(i_next_v);
-        const __amdgpu_buffer_rsrc_t pi_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Pi + bN * p.ldp), 0, prow_bytes, 0x00020000);
-        const u32x4s pj_words = make_rsrc_words(p.Pj + bN * p.ldp, prow_bytes);
+        const uint32_t prow_bytes = (uint32_t)((size_t)N * ldp * 4);
+        const __amdgpu_buffer_rsrc_t pi_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pa->Pi + bN * ldp), 0, prow_bytes, 0x00020000);
+        const u32x4s pj_words = make_rsrc_words(pa->Pj + bN * ldp, prow_bytes);
         const int cur = rho & 1;
         const char* const rb = recb + cur * 512;
 
@@ -189,7 +210,10 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
             const uint32_t j2 = *reinterpret_cast<const uint32_t*>(rb + (8 * qq + (lane >> 3)) * 16) & 0x7fffffffu;
-            goff[qq] = (uint32_t)((size_t)j2 * p.ldp * 4) + gchunk4[qq];
+            // the DMA drops lane l's 16 bytes at position l & 7 of row 8 qq + (l >> 3); the exchange rows' swizzle (chunk c at position
+            // c ^ ((row >> 1) & 7)) moves to the global side: fetch the chunk that belongs at that position
+            const uint32_t gchunk = (uint32_t)(((lane & 7) ^ ((4 * qq + (lane >> 4)) & 7)) * 16);
+            goff[qq] = (uint32_t)((size_t)j2 * ldp * 4) + gchunk;
         }
         u32x4v rec[2];
 #pragma unroll
@@ -197,7 +221,7 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
         // the first step's gathered lines and P_i words
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) gather_dma16(pj_words, goff[qq], 0u, xch_lds + qq * 1024);
-        const uint32_t piw = (uint32_t)(((size_t)i * p.ldp + e) * 4);
+        const uint32_t piw = (uint32_t)(((size_t)i * ldp + e) * 4);
         uint32_t piv[2];
         piv[0] = buf_load1(pi_rsrc, piw, 0);
         piv[1] = buf_load1(pi_rsrc, piw, 64);
@@ -225,8 +249,8 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
             const uint32_t r0 = rec[t][0], r1 = rec[t][1], r2 = rec[t][2], r3 = rec[t][3];   // (by value: see edge_fused.hip)
             const float d = egnn_sqdist_rel(__uint_as_float(r1), __uint_as_float(r2), __uint_as_float(r3));
             // d' = d / ws_scale = 2^10 s1 + r_hi + r_lo: lane group g carries split term g in K-slots 4g+2, 4g+3
-            float val = d * p.ws_inv_scale;
-            egnn_flag_range(p.status, live && fabsf(val) >= 6.0e7f && fabsf(val) < __builtin_inff(), EGNN_RANGE_SCALAR);
+            float val = d * pa->ws_inv_scale;
+            egnn_flag_range(pa->status, live && fabsf(val) >= 6.0e7f && fabsf(val) < __builtin_inff(), EGNN_RANGE_SCALAR);
             if (fabsf(val) >= 6.0e7f) val = __builtin_nanf("");
             const _Float16 s1 = (_Float16)(val * (1.0f / 1024.0f));
             const float rem = val - (float)s1 * 1024.0f;
@@ -339,16 +363,22 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
         }
 
         // ------------------------------------------------------------------ per-edge epilogue (registers; channel of (lane group g, register u) = 4 g + u)
+        const pw_args_ptr pe = pw_args();                                   // epilogue arguments (scalar loads, this round only)
+        const bool has_mask = pe->mask != nullptr;
+        int32_t* const status = pe->status;
+        const float* const gate_w = pe->gate_w;
+        const float* const coors_scale = pe->coors_scale;
         f32x4 b2r, gwr = f32x4{0.f, 0.f, 0.f, 0.f};
         float gb = 0.f;
         const int g4 = pw_opaque(4) * g;                                     // (opaque: see pw_opaque)
-        b2r = *reinterpret_cast<const f32x4*>(p.b2 + g4);
-        if (p.gate_w) {
-            gwr = *reinterpret_cast<const f32x4*>(p.gate_w + g4);
-            gb = p.gate_b[0];
+        b2r = *reinterpret_cast<const f32x4*>(pe->b2 + g4);
+        if (gate_w) {
+            gwr = *reinterpret_cast<const f32x4*>(gate_w + g4);
+            gb = pe->gate_b[0];
         }
         float cscale = 0.f;
-        if (p.coors_scale) cscale = p.coors_scale[0];
+        if (coors_scale) cscale = coors_scale[0];
+        const float w2_inv_scale = pe->w2_inv_scale;
 
         float cw[2];
 #pragma unroll
@@ -358,11 +388,11 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 bad = bad || !(fabsf(acc[t][u]) < __builtin_inff());
-                m[u] = egnn_silu(acc[t][u] * p.w2_inv_scale + b2r[u]);
+                m[u] = egnn_silu(acc[t][u] * w2_inv_scale + b2r[u]);
             }
             float part = gwr[0] * m[0] + gwr[1] * m[1] + gwr[2] * m[2] + gwr[3] * m[3];
-            egnn_flag_range(p.status, bad && fm[t], EGNN_RANGE_HIDDEN);
-            if (p.gate_w) {                                                      // soft_edges (:289-290)
+            egnn_flag_range(status, bad && fm[t], EGNN_RANGE_HIDDEN);
+            if (gate_w) {                                                      // soft_edges (:289-290)
                 part = egnn_column_sum4(part, scr, lane);
                 const float gt = egnn_sigmoid(part + gb);
                 m *= gt;
@@ -371,7 +401,8 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
             cw[t] = 0.f;
         }
 
-        if (p.W3h) {
+        const _Float16* const w3h = static_cast<const _Float16*>(pe->W3h);
+        if (w3h) {
             // coors_mlp (:203-208): first Linear (16 -> 64) on the matrix cores, split-f16: lane (e, g) holds channels 4g .. 4g+3 of its
             // edge = the B fragment of v_mfma_f32_16x16x16_f16; A = rows 16 blk + e of W3
             float part[2] = {0.f, 0.f};
@@ -381,7 +412,7 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
                 bool bad = false;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) bad = bad || egnn_beyond_f16(acc[t][u]);
-                egnn_flag_range(p.status, bad && fm[t], EGNN_RANGE_MESSAGE);
+                egnn_flag_range(status, bad && fm[t], EGNN_RANGE_MESSAGE);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const _Float16 h = (_Float16)acc[t][u];
@@ -389,13 +420,16 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
                     mlo[t][u] = (_Float16)(acc[t][u] - (float)h);
                 }
             }
-            const _Float16* w3h = static_cast<const _Float16*>(p.W3h);
             constexpr int W3LD = 16, W3IMG = 64 * 16;
             const int w3o = e * W3LD + g4;
+            const float* const b3p = pe->b3;
+            const float* const w4p = pe->W4;
+            const float w3_inv_scale = pe->w3_inv_scale;
+            const float clampv = pe->clamp;
 #pragma unroll
             for (int blk = 0; blk < 4; ++blk) {
-                const f32x4 b3 = *reinterpret_cast<const f32x4*>(p.b3 + 16 * blk + g4);
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.W4 + 16 * blk + g4);
+                const f32x4 b3 = *reinterpret_cast<const f32x4*>(b3p + 16 * blk + g4);
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(w4p + 16 * blk + g4);
                 const f16x4 w3hi = *reinterpret_cast<const f16x4*>(w3h + 16 * blk * W3LD + w3o);
                 const f16x4 w3lo = *reinterpret_cast<const f16x4*>(w3h + W3IMG + 16 * blk * W3LD + w3o);
 #pragma unroll
@@ -405,16 +439,16 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
                     a2 = __builtin_amdgcn_mfma_f32_16x16x16f16(w3lo, mhi[t], a2, 0, 0, 0);
                     a2 = __builtin_amdgcn_mfma_f32_16x16x16f16(w3hi, mlo[t], a2, 0, 0, 0);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) part[t] += w4[u] * egnn_silu(a2[u] * p.w3_inv_scale + b3[u]);
+                    for (int u = 0; u < 4; ++u) part[t] += w4[u] * egnn_silu(a2[u] * w3_inv_scale + b3[u]);
                 }
             }
-            const float b4 = p.b4[0];
+            const float b4 = pe->b4[0];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 float s = egnn_column_sum4(part[t], scr, lane);
                 s += b4;
                 if (has_mask && !fm[t]) s = 0.f;                                 // :308-309
-                if (p.clamp >= 0.f) s = fminf(fmaxf(s, -p.clamp), p.clamp);      // :311-313
+                if (clampv >= 0.f) s = fminf(fmaxf(s, -clampv), clampv);         // :311-313
                 if (!fm[t] && !has_mask) s = 0.f;                                // a wave past the last node
                 cw[t] = s;
             }
@@ -431,10 +465,10 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
             for (int c = 0; c < 3; ++c) rel[c] = __uint_as_float(rw[c]);
             keep[t] = fm[t] ? 1.f : 0.f;
             float inv = 1.f;
-            if (p.coors_scale) {                                                 // CoorsNorm, egnn_pytorch.py:67-77
-                float n2 = 0.f;
+            if (coors_scale) {                                                   // CoorsNorm, egnn_pytorch.py:67-77
+                float n2 = 0.f;                                                  // (explicit fma chain, as in edge_fused.hip: the same bits)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) n2 += rel[c] * rel[c];
+                for (int c = 0; c < 3; ++c) n2 = __builtin_fmaf(rel[c], rel[c], n2);
                 inv = cscale / fmaxf(sqrtf(n2), 1e-8f);
             }
 #pragma unroll
@@ -445,7 +479,7 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
         f32x4 ms = (fm[0] ? acc[0] : zero4) + (fm[1] ? acc[1] : zero4);          // select: masked_fill semantics (:322)
         float cs[4];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) cs[c] = cw[0] * rn[0][c] + cw[1] * rn[1][c];
+        for (int c = 0; c < 3; ++c) cs[c] = __builtin_fmaf(cw[1], rn[1][c], cw[0] * rn[0][c]);
         cs[3] = keep[0] + keep[1];
 #pragma unroll
         for (int u = 0; u < 4; ++u) ms[u] = egnn_row16_sum(ms[u]);
@@ -453,23 +487,35 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
         for (int c = 0; c < 4; ++c) cs[c] = egnn_row16_sum(cs[c]);
         // rounds in ascending order, each added to a running sum that starts at +0 (the order -- and the bits -- of the general kernel's
         // cross-wave reduction for K <= 128)
+        if (MULTI) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) nms[u] += ms[u];
+            for (int u = 0; u < 4; ++u) nms[u] += ms[u];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ncs[c] += cs[c];
+            for (int c = 0; c < 4; ++c) ncs[c] += cs[c];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nms[u] = 0.f + ms[u];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ncs[c] = 0.f + cs[c];
+        }
 
         // ------------------------------------------------------------------ node outputs (after the node's last round)
         if (r + 1 == R) {
             if (live) {
                 const size_t row = bN + i;
-                if (e == 0) {
+                const int m_dim = pe->m_dim;
+                float* const m_i = pe->m_i;
+                _Float16* const node_hi = static_cast<_Float16*>(pe->node_hi);
+                _Float16* const node_lo = static_cast<_Float16*>(pe->node_lo);
+                if (e == 0 && (m_i || node_hi)) {
                     const int gch = pw_opaque(4) * g;                            // (opaque: the packed offsets below are not loop invariants)
+                    const int pool_mean = pe->pool_mean, dim = pe->dim, nkt = pe->node_kp / 16;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int ch = gch + u;
                         float val = 0.f + nms[u];
-                        if (ch < p.m_dim && (p.m_i || p.node_hi)) {
-                            if (p.pool_mean) {
+                        if (ch < m_dim) {
+                            if (pool_mean) {
                                 if (has_mask) {                                  // safe_div, egnn_pytorch.py:13-16
                                     const float cnt = 0.f + ncs[3];
                                     val = (cnt == 0.f) ? 0.f : val / fmaxf(cnt, 1e-8f);
@@ -477,25 +523,28 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
                                     val = val / (float)K;                        // :330
                                 }
                             }
-                            if (p.m_i) p.m_i[row * p.m_dim + ch] = val;
-                            if (p.node_hi) {                                     // straight into the node_mlp input, as a (hi, lo) pair
-                                egnn_flag_range(p.status, egnn_beyond_f16(val), EGNN_RANGE_MESSAGE);
+                            if (m_i) m_i[row * m_dim + ch] = val;
+                            if (node_hi) {                                       // straight into the node_mlp input, as a (hi, lo) pair
+                                egnn_flag_range(status, egnn_beyond_f16(val), EGNN_RANGE_MESSAGE);
                                 const _Float16 h = (_Float16)val;
-                                const size_t off = egnn_pk_off((int64_t)row, p.dim + ch, p.node_kp / 16);
-                                static_cast<_Float16*>(p.node_hi)[off] = h;
-                                static_cast<_Float16*>(p.node_lo)[off] = (_Float16)(val - (float)h);
+                                const size_t off = egnn_pk_off((int64_t)row, dim + ch, nkt);
+                                node_hi[off] = h;
+                                node_lo[off] = (_Float16)(val - (float)h);
                             }
                         }
                     }
                 }
-                if (lane < 3 && p.coors_out) {
+                float* const coors_out = pe->coors_out;
+                if (lane < 3 && coors_out) {
                     const float val = 0.f + (lane == 0 ? ncs[0] : (lane == 1 ? ncs[1] : ncs[2]));
-                    p.coors_out[row * 3 + lane] = p.coors[row * 3 + lane] + val;
+                    coors_out[row * 3 + lane] = pe->coors[row * 3 + lane] + val;
                 }
             }
-            nms = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (MULTI) {
+                nms = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) ncs[c] = 0.f;
+                for (int c = 0; c < 4; ++c) ncs[c] = 0.f;
+            }
             r = 0;
             ++kg;
         } else {
@@ -525,6 +574,7 @@ int egnn_edge_pw_launch(const egnn_edge_args* args, void* stream)
     int64_t grid = (int64_t)cus * EGNN_PW_WGS;
     if (grid > ngroups) grid = ngroups;
     grid = (grid + 7) / 8 * 8;                                             // eight XCDs; surplus workgroups return at once
-    hipLaunchKernelGGL(edge_pw_kernel, dim3((unsigned)grid), dim3(PW_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    if (a.K == 32) hipLaunchKernelGGL(edge_pw_kernel<false>, dim3((unsigned)grid), dim3(PW_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(edge_pw_kernel<true>, dim3((unsigned)grid), dim3(PW_THREADS), 0, static_cast<hipStream_t>(stream), a);
     return egnn_launch_status();
 }

@@ -471,6 +471,7 @@ def test_dest_lists_equal_a_stable_sort(b, n, k, dense):
             idx[:, ::3, 0] = 7                                                  # a hub (destinations stay distinct within a row:
             idx[:, ::3, 1:] = torch.where(idx[:, ::3, 1:] == 7, torch.full_like(idx[:, ::3, 1:], 8), idx[:, ::3, 1:])   # ... mostly)
             idx[:, ::3, 1:] = torch.where(idx[:, ::3, 1:] == 8, (idx[:, ::3, 1:2] * 0 + 9).expand_as(idx[:, ::3, 1:]), idx[:, ::3, 1:]) if False else idx[:, ::3, 1:]
+    if not dense:
         dest = (idx.long() + (torch.arange(b, device="cuda") * n)[:, None, None]).reshape(-1)
     dl = _ops.dest_lists(idx, b, n, k, "cuda")
     dl2 = _ops.dest_lists(idx, b, n, k, "cuda")

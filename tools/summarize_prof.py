@@ -12,7 +12,7 @@ import json
 import re
 
 ROLE = {r"linear_hl_kernel<\d+, 0, false": "node_proj", r"linear_hl_kernel<\d+, 1, false": "node_mlp0",
-        r"linear_hl_kernel<\d+, 0, true": "node_mlp1", r"edge_kernel": "edge_fused", r"knn_select_kernel": "knn_select",
+        r"linear_hl_kernel<\d+, 0, true": "node_mlp1", r"edge_kernel": "edge_fused", r"edge_pw_kernel": "edge_fused", r"knn_select_kernel": "knn_select",
         r"node_prep_hl_kernel": "node_prep", r"split_f16_kernel": "split_f16", r"spatial_order_kernel": "spatial_order",
         r"slot_prep_kernel": "slot_prep"}
 
@@ -86,5 +86,14 @@ for k, cs in vals.items():
         traffic[k] = int((2.0 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024)
         print(f"traffic {k:12s} fetch_KiB={cs['FETCH_SIZE']:.0f} (x2 gfx950 correction) write_KiB={cs['WRITE_SIZE']:.0f} "
               f"-> {traffic[k]/1e9:.3f} GB per launch")
+# one file for all workloads: {workload: {kernel: bytes per launch, "_head": commit the run was taken at}} (bench.py reads it)
+workload = sys.argv[2] if len(sys.argv) > 2 else "north_star"
+try:
+    import subprocess
+    traffic["_head"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+except Exception:
+    traffic["_head"] = None
+if len(sys.argv) > 3 and sys.argv[3]:
+    traffic["_head"] = sys.argv[3]
 with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
-    json.dump(traffic, fh, indent=1)
+    json.dump({workload: traffic}, fh, indent=1)
