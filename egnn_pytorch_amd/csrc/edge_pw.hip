@@ -18,6 +18,7 @@
 //     run-time branches through every tile).
 //   * the residual of the hidden value's hi/lo split runs as v_mfma_f32_4x4x4_16B_f16 (lane-local: D = C - B with A = -I4, two
 //     passes on the matrix pipe) instead of v_mfma_f32_16x16x16_f16 (four): bit-identical, half the matrix-pipe time.
+#include <type_traits>
 #include "egnn_common.h"
 #include "egnn_lds_dma.h"
 
@@ -119,6 +120,11 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
 
     const int Hp = p.Hp;
     const int nchunks = (Hp + PW_HC - 1) / PW_HC;
+#if defined(EGNN_PW_NO_HALF_TAIL) && EGNN_PW_NO_HALF_TAIL
+    const bool half_tail = false;
+#else
+    const bool half_tail = Hp - p.H >= 16;                    // the last step's upper 16 units are padding (exact zeros)
+#endif
 
     // ---- staging ring: chunk c of the hidden dimension (PW_HC columns of W2 fragments + first-layer A fragments) -> slot
     const char* const w2h_g = reinterpret_cast<const char*>(p.W2h);
@@ -269,6 +275,98 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
 
         // ------------------------------------------------------------------ hidden loop
         const bool last_round = rho + 1 == total_rounds;
+        // One step of 32 hidden units for the wave's 32 edges.  HALF: the layer's last step when at most 16 of its units are real
+        // (H = 2 (2 dim + 1 + ...) leaves TWO units in the last step whenever dim % 8 == 0 -- every BASELINE.json configuration): the
+        // upper 16-unit block is padding -- P, W_s and W2 are exactly zero there, so y = 0, a = 0 / (1 + 1) = 0, hi = lo = 0 -- and its
+        // pick-up reads, first-layer MFMAs, 32 SiLU evaluations, conversions and residual MFMAs are skipped: the same bits, 40 VALU
+        // instructions instead of 86 in that step (1 step of 17 at dim 128, of 33 at dim 256, of 65 at dim 512).
+        auto step = [&](auto half_tag, const int c, const int st, const int slot, const int hoff, const _Float16* w2c, const char* tlc) {
+            constexpr bool HALF = decltype(half_tag)::value;
+            constexpr int NHB = HALF ? 1 : 2;
+            const bool more = hoff + 32 < Hp;
+            const int hnext = more ? hoff + 32 : hoff;                       // last step: harmless re-read of the P_i words
+            f32x4 x[2][2];
+            uint32_t pivn[2];
+            // the lines of this step were requested a step ago and land in the wave's exchange rows by themselves
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int hb = 0; hb < NHB; ++hb) x[t][hb] = *reinterpret_cast<const f32x4*>(xr[hb] + t * 16 * PW_XLD);
+            // the rows are in registers before the next step's lines may overwrite them
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (!HALF) {
+                pivn[0] = buf_load1(pi_rsrc, piw, hnext * 4);
+                pivn[1] = buf_load1(pi_rsrc, piw, hnext * 4 + 64);
+            }
+            if (st == 0) {
+                // the next chunk of the ring: the next one of this round, or -- the ring does not drain between the rounds of a
+                // workgroup -- the first one of the round that follows (its setup and this round's epilogue run with the chunk in flight)
+                if (c + 1 < nchunks) stage(c + 1, slot ^ 1);
+                else if (!last_round) stage(0, slot ^ 1);
+            }
+            if (more) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) gather_dma16(pj_words, goff[qq], (uint32_t)(hnext * 4), xch_lds + qq * 1024);
+            }
+
+            u32x2 a0[2];
+#pragma unroll
+            for (int hb = 0; hb < NHB; ++hb)
+                a0[hb] = u32x2{piv[hb], *reinterpret_cast<const uint32_t*>(tlc + st * 2 * tstep + hb * tstep)};
+            const f16x8 whi = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 0) * 64 + lane) * 8);
+            const f16x8 wlo = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 1) * 64 + lane) * 8);
+            if (!HALF) {
+                piv[0] = pivn[0];
+                piv[1] = pivn[1];
+            }
+            // first Linear of edge_mlp on the matrix cores: x += [P_i | W_s] x [1 | split d]
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int hb = 0; hb < NHB; ++hb)
+                    x[t][hb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a0[hb]), __builtin_bit_cast(f16x4, bq[t]), x[t][hb], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                // x holds y = -log2(e) * (pre-activation); a = y / (1 + 2^y) = SiLU(pre) / (-ln 2); hi = fp16(a) (IEEE: beyond 65504 ->
+                // inf, never a silently saturated number); lo32 = a - hi exactly, on the matrix cores
+                f16x8 bhi, blo;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { bhi[u] = (_Float16)0.f; blo[u] = (_Float16)0.f; }
+#pragma unroll
+                for (int hb = 0; hb < NHB; ++hb) {
+                    f32x4 a4;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float y = x[t][hb][u];
+                        float h = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
+                        asm("" : "+v"(h));           // keeps the products scalar (v_pk_mul_f32 costs 9.3 cycles per pair against 2 x 2.8)
+                        a4[u] = h;
+                    }
+                    const f16x2 h01 = __builtin_convertvector((f32x2v){a4[0], a4[1]}, f16x2);
+                    const f16x2 h23 = __builtin_convertvector((f32x2v){a4[2], a4[3]}, f16x2);
+                    const f16x4 hi4 = {h01[0], h01[1], h23[0], h23[1]};
+#if EGNN_PW_RESID4
+                    const f32x4 l4 = __builtin_amdgcn_mfma_f32_4x4x4f16(neg_identity, hi4, a4, 0, 0, 0);
+#else
+                    const f32x4 l4 = __builtin_amdgcn_mfma_f32_16x16x16f16(neg_identity, hi4, a4, 0, 0, 0);
+#endif
+                    const f16x2 l01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l4[0], l4[1]));
+                    const f16x2 l23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l4[2], l4[3]));
+                    bhi[4 * hb + 0] = h01[0]; bhi[4 * hb + 1] = h01[1]; bhi[4 * hb + 2] = h23[0]; bhi[4 * hb + 3] = h23[1];
+                    blo[4 * hb + 0] = l01[0]; blo[4 * hb + 1] = l01[1]; blo[4 * hb + 2] = l23[0]; blo[4 * hb + 3] = l23[1];
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bhi, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, bhi, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, blo, acc[t], 0, 0, 0);
+            }
+        };
         for (int c = 0; c < nchunks; ++c, ++ring) {
             const int slot = ring & 1;
             const int c0 = c * PW_HC;
@@ -281,84 +379,8 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
             const int nst = hc >> 5;
             for (int st = 0; st < nst; ++st) {
                 const int hoff = c0 + st * 32;
-                const bool more = hoff + 32 < Hp;
-                const int hnext = more ? hoff + 32 : hoff;                       // last step: harmless re-read of the P_i words
-                f32x4 x[2][2];
-                uint32_t pivn[2];
-                // the lines of this step were requested a step ago and land in the wave's exchange rows by themselves
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    x[t][0] = *reinterpret_cast<const f32x4*>(xr[0] + t * 16 * PW_XLD);
-                    x[t][1] = *reinterpret_cast<const f32x4*>(xr[1] + t * 16 * PW_XLD);
-                }
-                // the rows are in registers before the next step's lines may overwrite them
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0)
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                pivn[0] = buf_load1(pi_rsrc, piw, hnext * 4);
-                pivn[1] = buf_load1(pi_rsrc, piw, hnext * 4 + 64);
-                if (st == 0) {
-                    // the next chunk of the ring: the next one of this round, or -- the ring never drains -- the first one of the round
-                    // that follows (its setup and this round's epilogue run with the chunk in flight)
-                    if (c + 1 < nchunks) stage(c + 1, slot ^ 1);
-                    else if (!last_round) stage(0, slot ^ 1);
-                }
-                if (more) {
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) gather_dma16(pj_words, goff[qq], (uint32_t)(hnext * 4), xch_lds + qq * 1024);
-                }
-
-                u32x2 a0[2];
-#pragma unroll
-                for (int hb = 0; hb < 2; ++hb)
-                    a0[hb] = u32x2{piv[hb], *reinterpret_cast<const uint32_t*>(tlc + st * 2 * tstep + hb * tstep)};
-                const f16x8 whi = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 0) * 64 + lane) * 8);
-                const f16x8 wlo = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 1) * 64 + lane) * 8);
-                piv[0] = pivn[0];
-                piv[1] = pivn[1];
-                // first Linear of edge_mlp on the matrix cores: x += [P_i | W_s] x [1 | split d]
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int hb = 0; hb < 2; ++hb)
-                        x[t][hb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a0[hb]), __builtin_bit_cast(f16x4, bq[t]), x[t][hb], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    // x holds y = -log2(e) * (pre-activation); a = y / (1 + 2^y) = SiLU(pre) / (-ln 2); hi = fp16(a) (IEEE: beyond 65504 ->
-                    // inf, never a silently saturated number); lo32 = a - hi exactly, on the matrix cores
-                    f16x8 bhi, blo;
-#pragma unroll
-                    for (int hb = 0; hb < 2; ++hb) {
-                        f32x4 a4;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const float y = x[t][hb][u];
-                            float h = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
-                            asm("" : "+v"(h));           // keeps the products scalar (v_pk_mul_f32 costs 9.3 cycles per pair against 2 x 2.8)
-                            a4[u] = h;
-                        }
-                        const f16x2 h01 = __builtin_convertvector((f32x2v){a4[0], a4[1]}, f16x2);
-                        const f16x2 h23 = __builtin_convertvector((f32x2v){a4[2], a4[3]}, f16x2);
-                        const f16x4 hi4 = {h01[0], h01[1], h23[0], h23[1]};
-#if EGNN_PW_RESID4
-                        const f32x4 l4 = __builtin_amdgcn_mfma_f32_4x4x4f16(neg_identity, hi4, a4, 0, 0, 0);
-#else
-                        const f32x4 l4 = __builtin_amdgcn_mfma_f32_16x16x16f16(neg_identity, hi4, a4, 0, 0, 0);
-#endif
-                        const f16x2 l01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l4[0], l4[1]));
-                        const f16x2 l23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l4[2], l4[3]));
-                        bhi[4 * hb + 0] = h01[0]; bhi[4 * hb + 1] = h01[1]; bhi[4 * hb + 2] = h23[0]; bhi[4 * hb + 3] = h23[1];
-                        blo[4 * hb + 0] = l01[0]; blo[4 * hb + 1] = l01[1]; blo[4 * hb + 2] = l23[0]; blo[4 * hb + 3] = l23[1];
-                    }
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bhi, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, bhi, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, blo, acc[t], 0, 0, 0);
-                }
+                if (half_tail && hoff + 32 >= Hp) step(std::true_type{}, c, st, slot, hoff, w2c, tlc);
+                else step(std::false_type{}, c, st, slot, hoff, w2c, tlc);
             }
         }
 
@@ -571,8 +593,17 @@ int egnn_edge_pw_launch(const egnn_edge_args* args, void* stream)
         return (int)hipGetLastError();
     const int64_t T = (int64_t)a.B * a.N;
     const int64_t ngroups = (T + PW_WAVES - 1) / PW_WAVES;
-    int64_t grid = (int64_t)cus * EGNN_PW_WGS;
+    // One workgroup per node group by default.  The kernel can walk several groups per workgroup (a grid of EGNN_PW_GRID_MULT x 5
+    // workgroups per CU; 1 = fully persistent) -- measured on the north-star shape / c3, same box: persistent 1.54 / 0.484 ms, two
+    // workgroups per slot 1.45 / 0.463, four 1.40 / 0.446, one workgroup per group 1.39 / 0.443 (profiles/r04_experiments/): with equal
+    // shares fixed at launch the five workgroups of a CU stay in step -- their latency-bound setups and epilogues coincide instead of
+    // hiding under each other's hidden loops -- and dynamic dispatch is what de-phases them.
+#if defined(EGNN_PW_GRID_MULT)
+    int64_t grid = (int64_t)cus * EGNN_PW_WGS * EGNN_PW_GRID_MULT;
     if (grid > ngroups) grid = ngroups;
+#else
+    int64_t grid = ngroups;
+#endif
     grid = (grid + 7) / 8 * 8;                                             // eight XCDs; surplus workgroups return at once
     if (a.K == 32) hipLaunchKernelGGL(edge_pw_kernel<false>, dim3((unsigned)grid), dim3(PW_THREADS), 0, static_cast<hipStream_t>(stream), a);
     else hipLaunchKernelGGL(edge_pw_kernel<true>, dim3((unsigned)grid), dim3(PW_THREADS), 0, static_cast<hipStream_t>(stream), a);
