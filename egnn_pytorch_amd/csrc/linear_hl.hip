@@ -238,6 +238,128 @@ __device__ __forceinline__ void linear_hl_body(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the dummy DMAs before the LDS is released
 
+#if defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 16)
+    {                                                                  // ablation: no epilogue at all (keeps the accumulators alive)
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 12345.678f && C) C[0] = sacc;
+        return;
+    }
+#endif
+#ifndef EGNN_HL_STAGED
+#define EGNN_HL_STAGED 1
+#endif
+#if EGNN_HL_STAGED
+    // ---- epilogue of a full tile, staged through LDS (the ring is free now).  The MFMA leaves a lane one COLUMN of its 64 x 64
+    // sub-tile: storing from there means 64 scalar store instructions per wave (two 128-byte row pieces each; 2-byte scatters for the
+    // packed (hi, lo) output) behind ~18 VALU instructions of addressing / bounds / range checks per element -- measured (ablations,
+    // profiles/r04_experiments/gemm_ablations.txt): the epilogue was 19 % of the projection GEMM and 30 - 37 % of the two node_mlp
+    // GEMMs, almost all of it the stores.  Here each wave transposes 32 rows at a time through a private 8.5 KB strip: transformed
+    // values go in as the MFMA holds them (conflict-free ds_write_b32), come out row-major (ds_read_b128) and leave as 16-byte stores
+    // that fill whole lines -- fp32 rows: 4 rows x 256 B per instruction; packed (hi, lo) images: one contiguous 1 KB (row block, K-tile)
+    // piece per instruction.  Same arithmetic per element, same bits.  Partial tiles (M or N edge) keep the per-element path below.
+    if (m0 + BM <= M && n0 + BN <= N && (ldc & 3) == 0 && (ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(R) & 15) == 0 && (split_cols & 3) == 0) {
+        static_assert(TJ == 2, "the staged epilogue reads 64-column strips");
+        __syncthreads();                                               // every wave has left the ring (no DMA in flight: vmcnt(0) above)
+        const int LD = Chi ? 68 : 64;                                  // strip row stride in dwords (packed output: rows spread over banks)
+        float* const stg = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+        const int c = lane & 31, q4 = 4 * (lane >> 5);
+        const int nw0 = n0 + wn * (TJ * 32);                           // first column / row of this wave's sub-tile
+        const int64_t mw0 = m0 + wm * (TI * 32);
+        float bv[TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) bv[j] = bias ? bias[nw0 + 32 * j + c] : 0.f;
+        bool bad_p = false, bad_a = false;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            // 1. transform, in the accumulator layout: lane = column c of block j, register r = row (r&3) + 8 (r>>2) + 4 (lane>>5)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + q4;
+                    float x = acc[i][j][r] * out_scale + bv[j];
+                    if constexpr (DROP)
+                        x = egnn_drop_hash(egnn_drop_base(drop.seed, EGNN_DROP_SITE_NODE, (uint32_t)(mw0 + i * 32 + row)), (uint32_t)(nw0 + 32 * j + c)) >= drop.thr
+                                ? x * drop.inv_keep : 0.f;
+                    if (ACT == 1) x = egnn_silu(x);
+                    if (ACT == 2) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+                    stg[row * LD + 32 * j + c] = x;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            // 2a. fp32 rows: lane -> 4 consecutive columns of row (lane >> 4) + 4 k
+            if (C) {
+                const int col4 = 4 * (lane & 15);
+                const int gn = nw0 + col4;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int row = (lane >> 4) + 4 * k;
+                    const int64_t gm = mw0 + i * 32 + row;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * LD + col4);
+                    if (HAS_RES) v += *reinterpret_cast<const f32x4*>(R + gm * ldr + gn);
+                    if (gn < split_cols) {                               // these columns as (fp16 hi, fp16 lo) words
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float x = v[u];
+                            bad_p = bad_p || egnn_beyond_f16(x);
+                            const _Float16 h = (_Float16)x;
+                            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                            const f16x2 w = {h, (_Float16)(x - (float)h)};
+                            v[u] = __builtin_bit_cast(float, w);
+                        }
+                    }
+#if !(defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 1))
+                    *reinterpret_cast<f32x4*>(C + gm * ldc + gn) = v;
+#else
+                    if (v[0] == 123.456f) *reinterpret_cast<f32x4*>(C + gm * ldc + gn) = v;
+#endif
+                }
+            }
+            // 2b. packed (hi, lo) images: one 1 KB (row block, K-tile) piece per instruction -- lane l = bytes [16 l, 16 l + 16) of the
+            // piece = row l >> 1, physical chunk l & 1 (logical chunk XOR-swizzled by (row >> 3) & 1, egnn_pk_off)
+            if (Chi) {
+                const int row = lane >> 1;
+                const int ck = (lane & 1) ^ ((row >> 3) & 1);
+                const int64_t gm = mw0 + i * 32 + row;
+                const int64_t rbg = (mw0 + i * 32) >> 5;
+#pragma unroll
+                for (int kt = 0; kt < TJ * 2; ++kt) {
+                    const int cc = 16 * kt + 8 * ck;
+                    f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * LD + cc);
+                    f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * LD + cc + 4);
+                    if (HAS_RES) {
+                        v0 += *reinterpret_cast<const f32x4*>(R + gm * ldr + nw0 + cc);
+                        v1 += *reinterpret_cast<const f32x4*>(R + gm * ldr + nw0 + cc + 4);
+                    }
+                    f16x8 h8, l8;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float x = u < 4 ? v0[u & 3] : v1[u & 3];
+                        bad_a = bad_a || egnn_beyond_f16(x);
+                        const _Float16 h = (_Float16)x;
+                        h8[u] = h;
+                        l8[u] = (_Float16)(x - (float)h);
+                    }
+                    const size_t o = (size_t)((rbg * nkt_out + (nw0 >> 4) + kt) * 512 + lane * 8);
+                    *reinterpret_cast<f16x8*>(Chi + o) = h8;
+                    *reinterpret_cast<f16x8*>(Clo + o) = l8;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the strip is read before the next 32 rows overwrite it
+            __builtin_amdgcn_wave_barrier();
+        }
+        egnn_flag_range(status, bad_p, EGNN_RANGE_PROJ);
+        egnn_flag_range(status, bad_a, EGNN_RANGE_A_OPERAND);
+        return;
+    }
+#endif
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = lane & 31;
     const int rbase = 4 * (lane >> 5);
