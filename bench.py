@@ -124,9 +124,17 @@ def workload_label(kwargs, b, n, k):
 
 
 def git_head():
+    """Commit of the tree that printed the line: `git rev-parse`, or -- the GPU boxes get a snapshot without .git -- the file `.head`
+    that tools/stamp_head.sh writes before a gpurun call."""
     try:
         import subprocess
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+        h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip()
+        if h:
+            return h
+    except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, ".head")).read().strip() or None
     except Exception:
         return None
 

@@ -40,7 +40,10 @@ typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int PW_THREADS = 256;
 constexpr int PW_WAVES = 4;
-constexpr int PW_HC = 64;                    // hidden columns per slot of the staging ring (two steps of 32)
+#ifndef EGNN_PW_HC
+#define EGNN_PW_HC 64
+#endif
+constexpr int PW_HC = EGNN_PW_HC;            // hidden columns per slot of the staging ring (64: two steps of 32)
 constexpr int PW_XLD = 32;                   // floats per row of the gather exchange buffer (one 128-byte line, chunk-swizzled)
 // LDS (31 KB: five workgroups per CU):  W2 fragments, two ring slots | first-layer A fragments, two ring slots |
 // per-wave gather exchange rows (32 slots x 128 B) | per-wave slot records, two buffers of 32 x 16 B | per-wave 64-float scratch
@@ -129,16 +132,17 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
     // ---- staging ring: chunk c of the hidden dimension (PW_HC columns of W2 fragments + first-layer A fragments) -> slot
     const char* const w2h_g = reinterpret_cast<const char*>(p.W2h);
     const char* const wst_g = reinterpret_cast<const char*>(p.Wst);
+    const uint32_t lane16 = (uint32_t)lane * 16u;
     auto stage = [&](int c, int slot) {
         const int c0s = c * PW_HC;
         const int hcs = (Hp - c0s) < PW_HC ? (Hp - c0s) : PW_HC;
-        const char* src = w2h_g + (size_t)c0s * 64 + lane * 16;
+        // (wave-uniform base + per-lane 32-bit offset: no vector address arithmetic per piece)
+        const char* src = w2h_g + (size_t)c0s * 64;
         char* dst = reinterpret_cast<char*>(w2s) + slot * (PW_HC * 64);
-        for (int pc = wave; pc < hcs / 16; pc += PW_WAVES) lds_dma16(src + pc * 1024, dst + pc * 1024);
+        for (int pc = wave; pc < hcs / 16; pc += PW_WAVES) lds_dma16_s(src + pc * 1024, lane16, dst + pc * 1024);
         if (wave == 0) {
             const int tbytes = hcs * 16;                                   // one 16-byte row of four terms per hidden unit
-            const char* tsrc = wst_g + (size_t)c0s * 16 + lane * 16;
-            if (lane * 16 < tbytes) lds_dma16(tsrc, wst + slot * (PW_HC * 16));
+            if ((int)lane16 < tbytes) lds_dma16_s(wst_g + (size_t)c0s * 16, lane16, wst + slot * (PW_HC * 16));
         }
     };
     // the 32 slot records of round r of node tau -> record buffer `buf` (lanes 0 .. 31: 512 bytes)
@@ -529,9 +533,42 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
                 float* const m_i = pe->m_i;
                 _Float16* const node_hi = static_cast<_Float16*>(pe->node_hi);
                 _Float16* const node_lo = static_cast<_Float16*>(pe->node_lo);
-                if (e == 0 && (m_i || node_hi)) {
+                const int dim = pe->dim;
+                if (e == 0 && node_hi && !m_i && (dim & 3) == 0 && m_dim == 16) {
+                    // the common case (the layer's own launch sequence, m_dim = 16, dim % 4 == 0): the lane's four channels are four
+                    // consecutive halves of one 16-byte chunk of the packed images -- one 8-byte store per image instead of four
+                    // per-channel rounds of offset arithmetic
+                    const int gch = pw_opaque(4) * g;
+                    const int pool_mean = pe->pool_mean, nkt = pe->node_kp / 16;
+                    f32x4 val;
+                    bool bad = false;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        float v = 0.f + nms[u];
+                        if (pool_mean) {
+                            if (has_mask) {                                      // safe_div, egnn_pytorch.py:13-16
+                                const float cnt = 0.f + ncs[3];
+                                v = (cnt == 0.f) ? 0.f : v / fmaxf(cnt, 1e-8f);
+                            } else {
+                                v = v / (float)K;                                // :330
+                            }
+                        }
+                        bad = bad || egnn_beyond_f16(v);
+                        val[u] = v;
+                    }
+                    egnn_flag_range(status, bad, EGNN_RANGE_MESSAGE);
+                    f16x4 h4, l4;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        h4[u] = (_Float16)val[u];
+                        l4[u] = (_Float16)(val[u] - (float)h4[u]);
+                    }
+                    const size_t off = egnn_pk_off((int64_t)row, dim + gch, nkt);
+                    *reinterpret_cast<f16x4*>(node_hi + off) = h4;
+                    *reinterpret_cast<f16x4*>(node_lo + off) = l4;
+                } else if (e == 0 && (m_i || node_hi)) {
                     const int gch = pw_opaque(4) * g;                            // (opaque: the packed offsets below are not loop invariants)
-                    const int pool_mean = pe->pool_mean, dim = pe->dim, nkt = pe->node_kp / 16;
+                    const int pool_mean = pe->pool_mean, nkt = pe->node_kp / 16;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int ch = gch + u;

@@ -20,6 +20,14 @@ __device__ __forceinline__ void lds_dma16(const char* g, char* lds_base)
 #endif
 }
 
+// The same with a wave-uniform base (scalar register pair) and a 32-bit per-lane byte offset: no 64-bit vector address arithmetic
+// per instruction (the staging loops of the edge kernels issue a handful per chunk of the hidden dimension).
+__device__ __forceinline__ void lds_dma16_s(const char* sbase, uint32_t voff, char* lds_base)
+{
+    const uint32_t m0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds_base);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(m0) : "memory", "m0");
+}
+
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff)
 {
     typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));

@@ -24,5 +24,15 @@ python bench.py --workload c4_sparse --no-cpu-baseline --train-step > $OUT/bench
 python tools/train_step_probe.py 3 > $OUT/train_step_kernels.txt 2>&1; tail -2 $OUT/train_step_kernels.txt | cut -c1-400
 EGNN_PROBE_PHASES=1 python tools/net_train_probe.py > $OUT/net_train_step.txt 2>&1; grep "^c[35]" $OUT/net_train_step.txt
 bash tools/train_trace.sh $TAG > $OUT/train_trace.log 2>&1; cp gpurun_out/train_$TAG/kernels.txt $OUT/train_step_kernel_trace.txt; tail -1 $OUT/train_trace.log
-bash tools/profile.sh $TAG 2>&1 | tail -70
-rm -f $OUT/trace/*kernel_trace.csv $OUT/trace/*/*kernel_trace.csv $OUT/pmc*/*/*kernel_trace.csv $OUT/pmc*/*kernel_trace.csv 2>/dev/null
+HEAD_="$(cat .head 2>/dev/null)"
+for w in north_star c3_network c5_shard c2_dense c4_sparse; do
+  bash tools/profile.sh $TAG $w "$HEAD_" 2>&1 | tail -25
+done
+python - <<PY
+import json, glob, os
+merged = {}
+for f in sorted(glob.glob("$OUT/*/pmc_traffic.json")):
+    merged.update(json.load(open(f)))
+json.dump(merged, open("$OUT/pmc_traffic.json", "w"), indent=1)
+PY
+find $OUT -name "*kernel_trace.csv" -delete 2>/dev/null
