@@ -27,7 +27,7 @@ SYMBOLS = (
     "egnn_edge_fused_f32", "egnn_spatial_order_f32", "egnn_linear_hl_f32", "egnn_split_f16", "egnn_node_prep_hl",
     "egnn_packed_halves", "egnn_adj_expand_u8", "egnn_adj_expand_workspace_bytes", "egnn_edge_mfmas",
     "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32",
-    "egnn_edge_bwd_dz_f32", "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_bwd_work_bytes", "egnn_edge_tail_bwd_f32", "egnn_edge_tail_part_floats", "egnn_edge_pool_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
+    "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_bwd_work_bytes", "egnn_edge_tail_bwd_f32", "egnn_edge_tail_part_floats", "egnn_edge_pool_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
     "egnn_induced_attn_f32", "egnn_token_attn_f32", "egnn_slot_prep_f32", "egnn_struct_bytes",
     "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32", "egnn_split_scaled_both_f16", "egnn_silu_bwd_f32", "egnn_silu_bwd_drop_f32",
     "egnn_linear_hl_drop_f32",
@@ -51,8 +51,7 @@ class EdgeArgs(Structure):
         ("m_i", c_void_p), ("coors_out", c_void_p),
         ("node_hi", c_void_p), ("node_lo", c_void_p), ("node_kp", c_int32),
         ("status", c_void_p),
-        ("U_out", c_void_p), ("W2Th", c_void_p), ("gU", c_void_p), ("gu_scale", c_float), ("bwd_inv_scale", c_float),
-        ("dZ", c_void_p), ("A_out", c_void_p), ("ldz", c_int64),
+        ("U_out", c_void_p),
         ("edges_by_k", c_int32),
         ("slots", c_void_p),
         ("drop_thr", ctypes.c_uint32), ("drop_seed", ctypes.c_uint32), ("drop_inv_keep", c_float),
@@ -242,8 +241,6 @@ def load():
     lib.egnn_edge_mfmas.argtypes = [c_int]
     lib.egnn_edge_fused_f32.restype = c_int
     lib.egnn_edge_fused_f32.argtypes = [POINTER(EdgeArgs), c_void_p]
-    lib.egnn_edge_bwd_dz_f32.restype = c_int
-    lib.egnn_edge_bwd_dz_f32.argtypes = [POINTER(EdgeArgs), c_void_p]
     lib.egnn_edge_bwd_pass_f32.restype = c_int
     lib.egnn_edge_bwd_pass_f32.argtypes = [POINTER(EdgeBwdArgs), c_void_p]
     lib.egnn_edge_tail_bwd_f32.restype = c_int

@@ -229,7 +229,7 @@ def _pack(layer) -> dict:
         out["WiT_split"] = split_f16(wit)
         out["WjT_split"] = split_f16(wjt)
     if nb == 1:
-        # backward (egnn_edge_bwd_dz_f32): W2^T in natural units as A fragments of v_mfma_f32_16x16x16_f16,
+        # backward (egnn_edge_bwd_pass_f32): W2^T in natural units as A fragments of v_mfma_f32_16x16x16_f16,
         # [step][hb][hi|lo][lane = 16 g + r][u] = W2[4 g + u][32 step + 16 hb + r]
         w2t = z(hp, 16)
         w2t[:h, :m] = w2.t()

@@ -14,9 +14,7 @@ Backward = `_backward_native` (fp32, coordinate dimension 3, m_dim <= 16):
                egnn_edge_bwd_pass_f32 (csrc/edge_bwd.hip; `_edge_contract_fused`): one pass over the edges grouped by source node
                (d/d P_i, d/d W_s, d/d scalars) and one over the edges sorted by destination (d/d P_j, d/d W_2), everything
                recomputed and contracted in registers: nothing of size E x H reaches memory (8 GiB peak where the first native
-               backward needed 27); up to 16 per-edge scalars (beyond five: d/d scalars on the matrix cores).  `_edge_contract_dz`
-               (EGNN_NATIVE_BACKWARD=dz) is the first native backward -- egnn_edge_bwd_dz_f32 writes dz and a, reductions / library
-               GEMMs read them;
+               backward needed 27); up to 16 per-edge scalars (beyond five: d/d scalars on the matrix cores);
              * the node-level products -- d/d feats, d/d edge_mlp.0, node_mlp -- on the forward's split-f16 GEMM (`_ops.grad_nn / grad_tn`).
            `_backward_recompute` (everything else, and the native path's reference in the tests): the whole layer re-evaluated
            a few graphs at a time as a differentiable chain of ATen ops over the neighbour list the HIP kernel selected,
@@ -37,7 +35,6 @@ import torch
 from torch import nn
 
 # EGNN_NATIVE_BACKWARD=0: always the pure-ATen recompute (the reference implementation of the backward)
-# EGNN_NATIVE_BACKWARD=dz: the first native backward (egnn_edge_bwd_dz_f32: dz and SiLU(z) through HBM, library reductions)
 _NATIVE_MODE = os.environ.get("EGNN_NATIVE_BACKWARD", "1")
 _NATIVE = _NATIVE_MODE != "0"
 # which pass of the fused backward carries d/d W_2: "dest" (default), "both" = the by-source pass carries everything (tuning knob)
@@ -47,7 +44,6 @@ _GRAD_GEMM = os.environ.get("EGNN_BWD_GRAD_GEMM", "1") != "0"          # 0: the 
 _TAIL_REDUCE = os.environ.get("EGNN_BWD_TAIL_REDUCE", "1") != "0"      # 0: the tail kernel writes its E x 64 factors out for library reductions
 _KEEP_PROJ = os.environ.get("EGNN_BWD_KEEP_PROJ", "1") != "0"          # 0: the backward recomputes the P_i | P_j table (B N x 2 Hp fp32 less to keep)
 _FUSED_MAX_GRAPHS = 0                 # tests: force the chunking over graphs that very large batches need (0 = by size only)
-_NATIVE_BUDGET_BYTES = 24 << 30                      # dZ + SiLU(z), 2 x E x Hp fp32, per chunk of graphs
 
 # activations of the recompute per edge: a few E x H tensors (pre-activation, activation, gradients); 16 GB of the 288 GB
 _BYTES_PER_EDGE_FACTOR = 5.0
@@ -316,7 +312,7 @@ def _dropout_native_ok(layer):
     """Training-mode dropout on the native backward: the kernels that re-evaluate the forward's hash masks are built for the standard
     layer with up to five per-edge scalars (egnn_edge_bwd_pass_f32 with drop_thr, the matrix-core tail kernel,
     egnn_silu_bwd_drop_f32); everything else differentiates the masked layer on the recompute path."""
-    return (_NATIVE_MODE != "dz" and _TAIL_KERNEL and _TAIL_REDUCE and _GRAD_GEMM and _FUSED_SPLIT == "dest"
+    return (_TAIL_KERNEL and _TAIL_REDUCE and _GRAD_GEMM and _FUSED_SPLIT == "dest"
             and 2 * layer.fourier_features + 1 + layer.edge_dim <= 5 and layer.m_dim <= 16
             and layer.coors_mlp is not None and layer.node_mlp is not None and layer.dim % 2 == 0
             and os.environ.get("EGNN_TAIL_SCALAR", "0") != "1" and os.environ.get("EGNN_BWD_DROP_NATIVE", "1") != "0")
@@ -419,51 +415,6 @@ def _edge_tables(layer, w, f2d, pi_split):
     return _ops.linear_hl(feats_hl, w["Wcat_split"], 2 * hp, w["bcat"], name="bwd_node_proj", split_cols=hp if pi_split else 0)
 
 
-def _edge_contract_dz(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists=None, proj=None):
-    """egnn_edge_bwd_dz_f32 writes dz and a = SiLU(z) (2 x E x Hp fp32); reductions / library GEMMs over them.
-    Returns d/d P_i (rows, Hp), d/d P_j (rows, Hp), d/d W_s (Hp, S), d/d scalars (E, S), d/d W_2 (16, Hp)."""
-    from . import _abi, _ops
-    h, hp, s_in = w["H"], w["Hp"], w["S"]
-    dev = f2d.device
-    ec = bc * n * k
-    proj = _edge_tables(layer, w, f2d, pi_split)
-    # (one spare row each: where the kernel's padding slots store, include/egnn_hip.h)
-    dz_buf = _ops.empty(ec + 1, hp, dtype=torch.float32, device=dev)
-    act_buf = _ops.empty(ec + 1, hp, dtype=torch.float32, device=dev)
-    dz, act = dz_buf[:ec], act_buf[:ec]
-    a = _abi.EdgeArgs()
-    a.B, a.N, a.K, a.dim, a.m_dim = bc, n, k, layer.dim, layer.m_dim
-    a.H, a.Hp = h, hp
-    a.fourier, a.edge_dim, a.S, a.pi_split = layer.fourier_features, layer.edge_dim, s_in, int(pi_split)
-    a.Pi, a.Pj, a.ldp = proj.data_ptr(), proj.data_ptr() + 4 * hp, 2 * hp
-    a.Wst, a.wst_terms, a.ws_inv_scale = w["Wst"].data_ptr(), w["Wst"].shape[1], w["ws_inv_scale"]
-    a.coors, a.coor_dim = c0.data_ptr(), 3
-    a.edges = _ops._ptr(e0)
-    a.idx = _ops._ptr(i32)
-    a.W2Th = w["W2Th"].data_ptr()
-    a.gU, a.gu_scale = gu16.data_ptr(), gu_scale
-    a.bwd_inv_scale = 1.0 / (gu_scale * w["w2t_scale"])
-    a.dZ, a.A_out, a.ldz = dz.data_ptr(), act.data_ptr(), hp
-    with _ops._timed("edge_bwd_dz"):
-        rc = _abi.load().egnn_edge_bwd_dz_f32(_ops.byref(a), _ops._stream())
-    _abi.check(rc, "egnn_edge_bwd_dz_f32")
-    del proj
-    dz4 = dz.view(bc, n, k, hp)
-    gz_i = dz4.sum(dim=2).view(bc * n, hp)                                 # d loss / d P_i (pad columns are 0)
-    if i32 is None:
-        gz_j = dz4.sum(dim=1).view(bc * n, hp)                             # dense: neighbour k IS node j
-    else:
-        # scatter by neighbour as a fixed-order gather over the transposed neighbour list (edges sorted stably by
-        # destination, egnn_dest_lists_i32): no float atomics, bit-reproducible
-        if dest_lists is None:
-            dest_lists = _ops.dest_lists(i32, bc, n, k, dev)
-        gz_j = _ops.rows_gather_sum(dz, dest_lists.order, dest_lists.seg, bc * n)
-    g_ws = dz.t() @ sc2
-    g_scal = dz @ w_s
-    g_w2 = gu16.t() @ act
-    return gz_i, gz_j, g_ws, g_scal, g_w2
-
-
 def entry_list(eids, keys, n_keys):
     """The entry list of one egnn_edge_bwd_pass_f32 call (include/egnn_hip.h): edge ids `eids` (E,) ordered so that their keys
     `keys` (E,) -- the node each entry is grouped by -- are non-decreasing (None: E / n_keys consecutive entries per node).  Every
@@ -494,7 +445,8 @@ def entry_list(eids, keys, n_keys):
 
 def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists=None, proj=None, drop=None, eid0=0):
     """egnn_edge_bwd_pass_f32 (csrc/edge_bwd.hip) twice -- entries grouped by source node, then by neighbour: z, SiLU(z) and dz
-    are recomputed and contracted in registers, nothing of size E x H reaches memory.  Same returns as _edge_contract_dz."""
+    are recomputed and contracted in registers, nothing of size E x H reaches memory.
+    Returns d/d P_i (rows, Hp), d/d P_j (rows, Hp), d/d W_s (Hp, S), d/d scalars (E, S), d/d W_2 (16, Hp)."""
     from . import _ops
     dev = f2d.device
     ec = bc * n * k
@@ -594,12 +546,11 @@ def _backward_native(ctx, g_node, g_coors):
           on the split-f16 GEMMs (`_node_mlp_backward`; node_norm through autograd); the per-edge chain in closed form on
           egnn_edge_tail_bwd_f32, which also sums its parameter gradients (on the CPU, in the tests: through autograd, `layer_tail`)  ->  gU = d loss / d u, d loss / d (x_i - x_j), those modules' parameter gradients;
        2. the E x H work on egnn_edge_bwd_pass_f32 (`_edge_contract_fused`: by source and by destination, everything recomputed
-          and contracted in registers; EGNN_NATIVE_BACKWARD=dz: egnn_edge_bwd_dz_f32 + reductions, `_edge_contract_dz`)
+          and contracted in registers)
           ->  d/d P_i, d/d P_j per node, d/d W_s, d/d scalars, d/d W_2;
        3. node-level products: d/d feats, d/d W_i, W_j, b_1 from the per-node sums and feats; d/d scalars -> coordinates (closed
           form when the distance is the only scalar, the scalars' own small graph otherwise) and edge features.
-    Every sum over edges has a fixed order.  Chunks: the kernels' tables stay below 2 GB (signed 32-bit offsets); the dz version
-    keeps dz and a (2 x E x Hp fp32) inside a fixed budget."""
+    Every sum over edges has a fixed order.  Chunks: the kernels' tables stay below 2 GB (signed 32-bit offsets)."""
     from . import _abi, _ops, _weights
     w = ctx.layer.packed_weights()
     orig_params = list(ctx.layer.parameters())
@@ -632,23 +583,22 @@ def _backward_native(ctx, g_node, g_coors):
     drop = getattr(ctx, "drop", None)                    # (p, seed) of a training-mode forward (_dropout_native_ok), else None
     reduce = False
     # (egnn_edge_bwd_pass_f32: up to 16 per-edge scalars -- beyond five with the all-edge contractions split over the two passes)
-    fused = _NATIVE_MODE != "dz" and (s_in <= 5 or (s_in <= 16 and _FUSED_SPLIT == "dest" and "WsTh" in w))
+    fused = (s_in <= 5 or (s_in <= 16 and _FUSED_SPLIT == "dest" and "WsTh" in w))
+    if not fused:
+        raise NotImplementedError("the native backward carries more than five per-edge scalars only with EGNN_BWD_SPLIT=dest (the default)")
     proj_all = None
     if len(ctx.saved_tensors) > 7 and ctx.saved_tensors[7].numel() and fused:
         proj_all = ctx.saved_tensors[7]                                   # (B N, 2 Hp): what the forward's edge pass read
         if ctx.proj_words:
             _ops.unsplit_words_(proj_all, hp)
             ctx.proj_words = False
-    if fused:
+    if True:
         # nothing of size E x H: graphs are only chunked to keep the P table below 4 GB (32-bit buffer offsets) and E below 2^31
         # (the kernel addresses both with signed 32-bit scalar offsets)
         step = max(1, min(b, int(((1 << 31) - 1) // (n * 2 * hp * 4)), int(((1 << 31) - 1) // (n * k)),
                           int(((1 << 31) - 1) // ((n * k // 16 + n + 16) * hp * 4))))         # (... and the partial rows)
         if _FUSED_MAX_GRAPHS > 0:
             step = min(step, _FUSED_MAX_GRAPHS)
-    else:
-        per_graph = 2.0 * n * k * hp * 4
-        step = max(1, min(b, int(_NATIVE_BUDGET_BYTES // per_graph)))
     # the first Linear's blocks, zero padded to the kernel's hidden width Hp: everything below works on the contiguous
     # (E, Hp) buffers the kernel wrote (slicing [:, :H] first would copy 17 GB per use at the north-star shape)
     w1p = torch.zeros(hp, lin0.weight.shape[1], dtype=torch.float32, device=feats.device)
@@ -821,7 +771,7 @@ def _backward_native(ctx, g_node, g_coors):
         with torch.no_grad():
             f2d = f0.view(bc * n, dim)
             sc2 = scal.detach().reshape(ec, s_in).contiguous()
-            contract = _edge_contract_fused if fused else _edge_contract_dz
+            contract = _edge_contract_fused
             proj = None if proj_all is None else proj_all[lo * n:hi_ * n]
             if drop is not None:
                 assert fused and tail_kernel and reduce                                # (_dropout_native_ok: nothing else keeps u)

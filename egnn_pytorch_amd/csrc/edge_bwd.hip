@@ -6,7 +6,7 @@
 // values are contractions -- over the hidden index (d/d s = dz W_s) or over edges:
 //     d/d P_i[n] = sum of dz over the edges that leave n,      d/d P_j[n] = sum of dz over the edges that arrive at n,
 //     d/d W_2    = gU^T a,                                      d/d W_s    = dz^T s.
-// The first backward kernel (egnn_edge_bwd_dz_f32) wrote dz and a to HBM (35 GB at the north-star shape) for library
+// The first backward kernel (round 2, since removed) wrote dz and a to HBM (35 GB at the north-star shape) for library
 // reductions to read back five times: traffic-bound at 45 + 87 GB.  This one recomputes z and contracts in registers.
 //
 // Layout.  The forward kernel holds z as (hidden rows) x (edge columns) in the MFMA accumulator layout; contracting over

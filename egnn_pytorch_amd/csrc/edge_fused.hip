@@ -65,9 +65,6 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 #ifndef EGNN_EDGE_PRIO
 #define EGNN_EDGE_PRIO 0
 #endif
-#ifndef EGNN_EDGE_BWD_NT
-#define EGNN_EDGE_BWD_NT 1
-#endif
 // Gathered P_j lines go straight from L2 into the wave's exchange rows by LDS-DMA (`buffer_load_dwordx4 ... lds`): no VGPR
 // round trip, no ds_write_b128 parking stores (4 KB of LDS-pipe traffic and 16 registers per wave and step)
 #ifndef EGNN_EDGE_GDMA
@@ -120,12 +117,11 @@ constexpr int edge_min_blocks(int nm, int tpi, int nb)
     if (CDM == 3 && tpi == 2) return EGNN_EDGE_MINW;
     return (CDM == 3 && tpi >= 1) ? 4 : 3;
 }
-// (the training forward also writes u and keeps the edge index: one workgroup fewer; the dz-through-HBM backward: at most 4)
+// (the training forward also writes u and keeps the edge index: one workgroup fewer)
 constexpr int edge_launch_blocks(int nm, int tpi, int nb, int mode)
 {
     const int mb = edge_min_blocks(nm, tpi, nb);
     if (mode == 1 || mode == 3) return mb > 1 ? mb - 1 : mb;
-    if (mode == 2) return mb > 4 ? 4 : mb;
     return mb;
 }
 // staging chunk of the five-workgroup kernel
@@ -151,19 +147,14 @@ __device__ __forceinline__ uint32_t pack_h2(_Float16 a, _Float16 b)
 // lane on the VALU.
 // (The body is a device function of the block index so that a dispatcher kernel can give a workgroup slot either an edge
 // group or a GEMM tile: tools/ubench/mix_probe.hip.)
-// MODE = 2: the backward companion (egnn_edge_bwd_dz_f32).  Same slot setup, same gathers, same first-layer MFMAs -- the
-// pre-activation x is RECOMPUTED, nothing of size E x H was kept by the forward -- but instead of SiLU + the H -> m_dim
-// contraction each step evaluates   ga = W2^T gU  (v_mfma_f32_16x16x16_f16 against W2^T fragments: the result lands in x's
-// own layout),   a = SiLU(x),   dz = ga * SiLU'(x)   and streams a and dz to HBM (fp32, natural units).  No epilogue.
 template <int NM, int HCT, int TPI, int NB, int MODE = 0>
 __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, const int gpg, char* smem, const int bid, const int nblk)
 {
     // MODE 0: inference forward.  1: forward that also writes u (args.U_out) for the backward -- its own instantiation, the
-    // inference kernels sit at the register limit of 4 workgroups per CU.  2: backward (egnn_edge_bwd_dz_f32).
-    constexpr bool BWD = MODE == 2;
+    // inference kernels sit at the register limit.  3: training-mode dropout.
     constexpr bool DROP = MODE == 3;                         // training-mode dropout (args.drop_thr); writes u like MODE 1 if asked
     constexpr bool WRITE_U = MODE == 1 || MODE == 3;
-    constexpr bool GDMA = EGNN_EDGE_GDMA && EGNN_EDGE_RING && !BWD;   // gathers by LDS-DMA (the backward keeps its counted store waits)
+    constexpr bool GDMA = EGNN_EDGE_GDMA && EGNN_EDGE_RING;           // gathers by LDS-DMA
     constexpr int HC = EGNN_EDGE_RING ? HCT / 2 : HCT;     // columns per staged chunk (ring: two slots of HCT / 2)
     constexpr int NCH = nch_of(NB);
     constexpr int W2B = 64 * NB;                           // bytes of W2 fragments per hidden column: NB blocks x (hi | lo) x 16 channels
@@ -192,7 +183,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
     // per-slot records of egnn_slot_prep_f32 (neighbour path, C = 3): {j | pair_ok << 31, x_i - x_j} in consumption order -- the
     // setup then has no dependent loads (order -> idx -> coors -> mask / rank), just one coalesced 16-byte load per slot
     typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
-    const u32x4v* slot_rec = (CDM == 3 && !BWD && p.idx) ? static_cast<const u32x4v*>(p.slots) : nullptr;
+    const u32x4v* slot_rec = (CDM == 3 && p.idx) ? static_cast<const u32x4v*>(p.slots) : nullptr;
     const size_t bN = (size_t)b * N;
     // Buffer resources over this graph's rows of P_j / P_i: the gathers are `buffer_load ... offen` with a 32-bit per-lane
     // byte offset (one address register per stream) and the hidden-unit offset of the step in the SCALAR offset operand --
@@ -214,9 +205,6 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                                                              // epilogue instead of living in 2 x CDM registers across the hidden loop
         bool fm[TILES];                                      // edge contributes (valid slot and unmasked)
         uint32_t ekey[DROP ? TILES : 1] = {};                // DROP: mask row key of this lane's edge (+ the lane's unit offset)
-        int64_t erow[TILES];                                 // BWD: global edge index (b, i, k) of this lane's edge; padding slots
-                                                             // write to the spare row B*N*K of dZ / A_out
-        f16x4 guhi[TILES], gulo[TILES];                      // BWD: d loss / d u of this lane's edge (B fragments)
 
         // TPI == 2 (K % 32 == 0): the 32 slots of a wave belong to ONE node -> node index and first k are wave-uniform
         const int qwave = round * SLOTS_PER_ROUND + wave * SLOTS_PER_WAVE;
@@ -265,19 +253,6 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             ei[t] = i; ej[t] = j;
             if constexpr (DROP)                                   // the edge's mask row (csrc/egnn_common.h), + this lane's 4 g of the unit index
                 ekey[t] = egnn_drop_base(p.drop_seed, EGNN_DROP_SITE_EDGE, (uint32_t)((bN + i) * (size_t)K + k)) + (uint32_t)(4 * g) * 0x85EBCA77u;
-            if (BWD) erow[t] = valid ? (int64_t)((bN + i) * (size_t)K + k) : (int64_t)((size_t)p.B * N * K);
-            if (BWD) {
-                // B fragment of the W2^T product: channels 4g .. 4g+3 of this edge's d loss / d u, as a split-f16 pair
-                f32x4 gu = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (valid) gu = *reinterpret_cast<const f32x4*>(p.gU + erow[t] * 16 + 4 * g);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float v = gu[u] * p.gu_scale;
-                    const _Float16 h = (_Float16)v;
-                    guhi[t][u] = h;
-                    gulo[t][u] = (_Float16)(v - (float)h);
-                }
-            }
 
             // Per-edge scalars [sin(d/2^f)..., cos(d/2^f)..., d, edges...] (egnn_pytorch.py:34-41, 282-285) as B
             // fragments of v_mfma_f32_16x16x16_f16: lane group g of MFMA m carries split term tau = 4 m + g of scalar
@@ -450,7 +425,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
         // W2 fragments: (Hp/32, 2, 64, 8) halves = 2048 bytes per step; scalar table: NM * 16 bytes per hidden unit.
         auto stage = [&](int c0s, int slot) {
             const int hcs = (p.Hp - c0s) < HC ? (p.Hp - c0s) : HC;
-            const char* src = reinterpret_cast<const char*>(BWD ? p.W2Th : p.W2h) + (size_t)c0s * W2B + lane * 16;
+            const char* src = reinterpret_cast<const char*>(p.W2h) + (size_t)c0s * W2B + lane * 16;
             char* dst = reinterpret_cast<char*>(w2s) + slot * (HC * W2B);
             for (int pc = wave; pc < hcs * NB / 16; pc += EDGE_WAVES) lds_dma16(src + pc * 1024, dst + pc * 1024);
             const int tbytes = hcs * NM * 16;
@@ -460,27 +435,12 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 if (pc * 1024 + lane * 16 < tbytes) lds_dma16(tsrc + pc * 1024, tdst + pc * 1024);
         };
         stage(0, 0);               // (the barrier that ended the previous round freed both slots)
-        if constexpr (BWD) {
-            // The step's gathers are followed by its 2 x TILES x 2 stores on the same in-order counter.  Entering the loop the
-            // compiler merges "no store behind the gathers" (from here) with "8 stores behind them" (the back edge) into the
-            // stricter wait -- vmcnt(3): every step would sit out the full latency of the stores it has just issued.  The same
-            // number of stores here (zeros into the spare row) makes both paths agree on vmcnt(11): a store has a whole step
-            // to retire.  Issued behind the first DMA, like every later DMA has a chunk's steps behind it (the wait below).
-            const size_t o = (size_t)p.B * N * K * p.ldz + 4 * g;
-#pragma unroll
-            for (int q = 0; q < 2 * TILES; ++q) {
-                *reinterpret_cast<f32x4*>(p.A_out + o + 16 * q) = f32x4{0.f, 0.f, 0.f, 0.f};      // (distinct addresses: none is dead)
-                *reinterpret_cast<f32x4*>(p.dZ + o + 16 * q) = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
         int slot = 0;
         for (int c0 = 0; c0 < HpLoop; c0 += HC, slot ^= 1) {
             const int hc = (p.Hp - c0) < HC ? (p.Hp - c0) : HC;
             // chunk c0 was requested one chunk ago; the only other loads in flight are the gathers of the coming step, which
-            // the step consumes first thing anyway -> waiting for everything costs nothing extra.  (BWD: everything but the
-            // 2 x TILES x 2 stores issued last -- a step's, or the spare-row ones above -- which are younger than the DMA.)
-            if constexpr (BWD) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the step consumes first thing anyway -> waiting for everything costs nothing extra
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if !(defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 64))                         // (ablation 64: no chunk barrier -- timing only)
             __syncthreads();       // every wave's pieces have landed, and every wave has left the other slot
 #endif
@@ -500,7 +460,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             {
                 // LDS-DMA, 1 KB (64 lanes x 16 B) per instruction: no VGPR round trip, no VALU address loop.
                 // W2 fragments: (Hp/32, 2, 64, 8) halves = 2048 bytes per step; scalar table: NM * 16 bytes per hidden unit.
-                const char* src = reinterpret_cast<const char*>(BWD ? p.W2Th : p.W2h) + (size_t)c0 * W2B + lane * 16;
+                const char* src = reinterpret_cast<const char*>(p.W2h) + (size_t)c0 * W2B + lane * 16;
                 for (int pc = wave; pc < hc * NB / 16; pc += EDGE_WAVES)
                     __builtin_amdgcn_global_load_lds((glb_void*)(src + pc * 1024),
                                                      (lds_void*)(reinterpret_cast<char*>(w2s) + pc * 1024), 16, 0, 0);
@@ -656,43 +616,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 #if EGNN_EDGE_PRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
-                if constexpr (BWD) {
-                    // W2^T fragments of this step: [hb][hi|lo][lane = 16 g + r][4 halves]: row 16 hb + r, channels 4g .. 4g+3
-                    const f16x4* wt = reinterpret_cast<const f16x4*>(w2c + (size_t)st * (W2B / 2) * 32);
-#pragma unroll
-                    for (int hb = 0; hb < 2; ++hb) {
-                        const f16x4 wthi = wt[(hb * 2 + 0) * 64 + lane], wtlo = wt[(hb * 2 + 1) * 64 + lane];
-#pragma unroll
-                        for (int t = 0; t < TILES; ++t) {
-                            f32x4 ga = f32x4{0.f, 0.f, 0.f, 0.f};
-                            ga = __builtin_amdgcn_mfma_f32_16x16x16f16(wthi, guhi[t], ga, 0, 0, 0);
-                            ga = __builtin_amdgcn_mfma_f32_16x16x16f16(wtlo, guhi[t], ga, 0, 0, 0);
-                            ga = __builtin_amdgcn_mfma_f32_16x16x16f16(wthi, gulo[t], ga, 0, 0, 0);
-                            f32x4 av4, dz4;
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                // y = -log2(e) x;  sigma(x) = 1 / (1 + 2^y);  SiLU(x) = x sigma;  SiLU'(x) = sigma (1 + x (1 - sigma))
-                                const float y = x[t][hb][u];
-                                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
-                                const float xn = y * -0.6931471805599453f;
-                                av4[u] = xn * r;
-                                dz4[u] = ga[u] * p.bwd_inv_scale * (r * (1.0f + xn * (1.0f - r)));
-                            }
-                            // unconditional (padding slots own the spare row): behind a branch the compiler cannot count the
-                            // stores and makes the next step's wait for its gathers a wait for every store as well
-                            const size_t o = (size_t)erow[t] * p.ldz + hoff + 16 * hb + 4 * g;
-#if EGNN_EDGE_BWD_NT
-                            // streaming stores: 35 GB of dz / a passing through L2 as ordinary lines evict the P_j rows the gathers
-                            // live on (read hit rate 52 % against the forward's 85 %); measured 9.3 -> 8.4 ms per 45 graphs
-                            __builtin_nontemporal_store(av4, reinterpret_cast<f32x4*>(p.A_out + o));
-                            __builtin_nontemporal_store(dz4, reinterpret_cast<f32x4*>(p.dZ + o));
-#else
-                            *reinterpret_cast<f32x4*>(p.A_out + o) = av4;
-                            *reinterpret_cast<f32x4*>(p.dZ + o) = dz4;
-#endif
-                        }
-                    }
-                } else {
+                {
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
                     // x holds y = -log2(e) * (pre-activation); hv = y / (1 + 2^y) = SiLU(pre) / (-ln 2)
@@ -823,10 +747,6 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 }
                 }
             }
-        }
-        if constexpr (BWD) {
-            __syncthreads();                                 // (multi-round groups: both staging slots free again)
-            continue;
         }
         if constexpr (GDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may land in rows the epilogue reuses
 #if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 512)
@@ -1099,7 +1019,6 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
     }
     __syncthreads();
 
-    if constexpr (BWD) return;
     // ---------------------------------------------------------------------- node outputs
     for (int o = tid; o < G * NCH; o += EDGE_THREADS) {
         const int nl = o / NCH, ch = o - nl * NCH;
@@ -1184,14 +1103,6 @@ int dispatch_tpi_nb(const egnn_edge_args& a, hipStream_t s)
     return launch_edge<NM, HCT, 0, NB, MODE>(a, s);
 }
 
-template <int NM, int HCT>
-int dispatch_bwd(const egnn_edge_args& a, hipStream_t s)
-{
-    if (a.K % 32 == 0) return launch_edge<NM, HCT, 2, 1, 2>(a, s);
-    if (a.K >= 6) return launch_edge<NM, HCT, 1, 1, 2>(a, s);
-    return launch_edge<NM, HCT, 0, 1, 2>(a, s);
-}
-
 // m_dim <= 16: one accumulator tile per edge tile (every BASELINE config); 17..32: two; 33..64: four, with the staged
 // chunk shrunk so that the W2 fragments keep their LDS footprint (HCT * 64 NB bytes)
 template <int NM, int HCT>
@@ -1235,38 +1146,9 @@ extern "C" int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream)
 {
     if (!args) return EGNN_E_NULLPTR;
     if (args->coor_dim < 1 || args->coor_dim > 8) return EGNN_E_UNSUPPORTED;
-    if (args->gU || args->dZ || args->A_out) return EGNN_E_SHAPE;          // backward fields belong to egnn_edge_bwd_dz_f32
     return args->coor_dim == 3 ? egnn_edge_fused_c3(args, stream) : egnn_edge_fused_generic_c(args, stream);
 }
 
-extern "C" int egnn_edge_bwd_dz_f32(const egnn_edge_args* args, void* stream)
-{
-    if (!args) return EGNN_E_NULLPTR;
-    const egnn_edge_args& a = *args;
-    if (!a.Pi || !a.Pj || !a.Wst || !a.W2Th || !a.coors || !a.gU || !a.dZ || !a.A_out) return EGNN_E_NULLPTR;
-    if (a.coor_dim != 3 || a.m_dim < 1 || a.m_dim > 16) return EGNN_E_UNSUPPORTED;   // the fast-path shapes only
-    if (a.B <= 0 || a.N <= 0 || a.K <= 0 || a.H <= 0) return EGNN_E_SHAPE;
-    if (a.Hp != egnn_padded_hidden(a.H) || a.ldp < a.Hp || (a.ldp % 4) != 0 || a.ldz < a.Hp || (a.ldz % 4) != 0) return EGNN_E_SHAPE;
-    if (a.S != 2 * a.fourier + 1 + a.edge_dim || a.S > 16 || a.wst_terms != 4 * egnn_edge_mfmas(a.S)) return EGNN_E_SHAPE;
-    if (!(a.ws_inv_scale > 0.f) || !(a.gu_scale > 0.f) || !(a.bwd_inv_scale > 0.f)) return EGNN_E_SHAPE;
-    if ((a.pi_split != 0) != (a.K >= 6)) return EGNN_E_SHAPE;
-    if (a.edge_dim > 0 && !a.edges) return EGNN_E_NULLPTR;
-    if (a.idx == nullptr && a.K != a.N) return EGNN_E_SHAPE;
-    if ((reinterpret_cast<uintptr_t>(a.Pi) & 15) || (reinterpret_cast<uintptr_t>(a.Pj) & 15) || (reinterpret_cast<uintptr_t>(a.Wst) & 15) ||
-        (reinterpret_cast<uintptr_t>(a.W2Th) & 15) || (reinterpret_cast<uintptr_t>(a.gU) & 15) || (reinterpret_cast<uintptr_t>(a.dZ) & 15) ||
-        (reinterpret_cast<uintptr_t>(a.A_out) & 15))
-        return EGNN_E_ALIGN;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (a.S == 1) return dispatch_bwd<1, HC>(a, s);
-#ifndef EGNN_EDGE_TUNING_BUILD
-    if (a.S <= 4) return dispatch_bwd<3, 128>(a, s);
-    if (a.S <= 5) return dispatch_bwd<4, 128>(a, s);
-    if (a.S <= 8) return dispatch_bwd<6, 64>(a, s);
-    return dispatch_bwd<12, 64>(a, s);
-#else
-    return EGNN_E_UNSUPPORTED;
-#endif
-}
 #endif
 
 int EGNN_EDGE_ENTRY(const egnn_edge_args* args, void* stream)

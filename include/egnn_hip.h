@@ -280,18 +280,10 @@ typedef struct egnn_edge_args {
     void* node_lo;              /*   egnn_node_prep_hl(m_i = NULL); the pooled messages are written into its columns  */
     int32_t node_kp;            /*   [dim, dim + m_dim) (both or neither; node_kp % 32 == 0, >= dim + m_dim)          */
     int32_t* status;            /* optional range status word (EGNN_RANGE_SCALAR / _HIDDEN / _MESSAGE), see the enum above */
-    /* autograd support (all NULL / 0 for plain inference) */
+    /* autograd support (NULL for plain inference) */
     float* U_out;               /* forward, optional, m_dim <= 16: (B*N*K, 16) fp32 u = edge_mlp.3(SiLU(edge_mlp.0(.))) before the second
-                                   SiLU (egnn_pytorch.py:181-183), one row per edge (b, i, k), pad channels 0 */
-    const void* W2Th;           /* backward: (Hp/32, 2, 2, 64, 4) fp16: w2t_scale * edge_mlp.3.weight^T (natural units) as A fragments
-                                   of v_mfma_f32_16x16x16_f16: [step][hb][hi|lo][lane = 16 g + r][u] = W2[4 g + u][32 step + 16 hb + r] */
-    const float* gU;            /* backward: (B*N*K, 16) fp32 d loss / d u */
-    float gu_scale;             /* power of two the kernel multiplies gU by before the fp16 split */
-    float bwd_inv_scale;        /* 1 / (w2t_scale * gu_scale) */
-    float* dZ;                  /* backward out: (B*N*K + 1, ldz) fp32 d loss / d z, z = pre-activation of the first SiLU (natural units);
-                                   the last row is scratch (padding slots of the kernel's tiles store there) */
-    float* A_out;               /* backward out: (B*N*K + 1, ldz) fp32 SiLU(z), last row scratch */
-    int64_t ldz;                /* >= Hp, multiple of 4 */
+                                   SiLU (egnn_pytorch.py:181-183), one row per edge (b, i, k), pad channels 0: what the backward
+                                   (egnn_edge_tail_bwd_f32 / egnn_edge_bwd_pass_f32) differentiates from */
     int32_t edges_by_k;         /* 0: `edges` is (B,N,N,edge_dim), read at [b,i,j];  1: `edges` is (B,N,K,edge_dim), the features of the
                                    selected pairs in neighbour-list order (egnn_edge_features_gather_f32), read at [b,i,k] */
     const void* slots;          /* optional (idx != NULL, coor_dim == 3): the records of egnn_slot_prep_f32 for the SAME idx / rank / mask /
@@ -318,17 +310,6 @@ int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream);
 int egnn_edge_features_gather_f32(const float* edges, const int64_t* edge_tok, const float* edge_tok_emb, int d1,
                                   const uint8_t* adj_deg, const float* adj_deg_emb, int d2, const int32_t* idx,
                                   int B, int N, int K, float* out, void* stream);
-
-/* Backward companion of the edge pass (autograd of egnn_pytorch.py:279-287).  Recomputes the pre-activation
- * z of edge_mlp's first SiLU exactly as the forward does (gathers of P_j, first-layer MFMAs) and, from gU = d loss / d u
- * (u = the second Linear's output, args->U_out of the forward), writes per edge
- *     A_out = SiLU(z)                  (what d loss / d edge_mlp.3.weight = gU^T A_out needs)
- *     dZ    = (W2^T gU) * SiLU'(z)     (d loss / d z: summed over a node's edges -> d/d P_i, scattered by neighbour -> d/d P_j,
- *                                        times the per-edge scalars -> d/d W_s, times W_s -> d/d scalars)
- * in fp32, natural units.  Nothing of size E x H is read: 2 E Hp floats are written (both arrays need one spare row behind the
- * B*N*K edge rows: the padding slots of the kernel's tiles store there, so that every store is unconditional).  Shapes: coor_dim 3, m_dim <= 16;
- * fields used: shapes, Pi / Pj / ldp / pi_split, Wst & scales, coors, edges, idx, order and the backward fields. */
-int egnn_edge_bwd_dz_f32(const egnn_edge_args* args, void* stream);
 
 /* Backward of the edge pass without anything of size E x H in memory (autograd of egnn_pytorch.py:279-287;
  * csrc/edge_bwd.hip).  One call = one pass over a list of L entries (edges) grouped by a key node: by the source node i

@@ -336,8 +336,8 @@ def test_rows_gather_sum_fixed_order():
                                                  (1, 48, 32, 64, False, dict(edge_dim=3, fourier_features=2)), (2, 40, 8, 32, True, dict(edge_dim=12)),
                                                  (1, 40, 16, 32, False, dict(edge_dim=5, fourier_features=5))])
 def test_edge_bwd_pass_contractions_match_float64(b, n, k, dim, hub, extra):
-    """egnn_edge_bwd_pass_f32 (nothing of size E x H in memory: z, SiLU(z), dz recomputed and contracted in registers) and
-    egnn_edge_bwd_dz_f32 (dz / SiLU(z) through HBM + library reductions) against the same contractions in float64:
+    """egnn_edge_bwd_pass_f32 (nothing of size E x H in memory: z, SiLU(z), dz recomputed and contracted in registers) against the
+    same contractions in float64:
     d/d P_i, d/d P_j (per node), d/d W_s, d/d scalars, d/d W_2.  K below / equal / above a 16-entry tile, and `hub` = a few nodes
     with very large in-degree (one key over many tiles) next to nodes nobody points to."""
     from egnn_pytorch_amd import EGNN, _weights, autograd
@@ -374,7 +374,7 @@ def test_edge_bwd_pass_contractions_match_float64(b, n, k, dim, hub, extra):
     w_s[:h] = w1[:, 2 * dim:]
     f2d = feats.view(b * n, dim)
     outs = {}
-    for name, fn in (("fused", autograd._edge_contract_fused), ("dz", autograd._edge_contract_dz)):
+    for name, fn in (("fused", autograd._edge_contract_fused),):
         with torch.no_grad():
             outs[name] = fn(layer, w, f2d, coors, edges, scal, idx32, gu16, gu_scale, w_s, b, n, k, k >= 6)
     with torch.no_grad():
