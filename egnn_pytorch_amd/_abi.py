@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 29
+ABI_VERSION = 30
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -31,6 +31,7 @@ SYMBOLS = (
     "egnn_induced_attn_f32", "egnn_token_attn_f32", "egnn_slot_prep_f32", "egnn_struct_bytes",
     "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32", "egnn_split_scaled_both_f16", "egnn_silu_bwd_f32", "egnn_silu_bwd_drop_f32",
     "egnn_linear_hl_drop_f32",
+    "egnn_linear_f32", "egnn_node_prep_f32", "egnn_edge_exact_f32", "egnn_edge_exact_workspace_bytes",
 )
 
 
@@ -56,6 +57,20 @@ class EdgeArgs(Structure):
         ("slots", c_void_p),
         ("drop_thr", ctypes.c_uint32), ("drop_seed", ctypes.c_uint32), ("drop_inv_keep", c_float),
         ("algo", c_int32),
+    ]
+
+
+class EdgeExactArgs(Structure):
+    """Mirror of `struct egnn_edge_exact_args` (include/egnn_hip.h): the edge pass in plain fp32 (wide-range path)."""
+    _fields_ = [
+        ("B", c_int32), ("N", c_int32), ("K", c_int32), ("m_dim", c_int32), ("H", c_int32), ("fourier", c_int32),
+        ("edge_dim", c_int32), ("coor_dim", c_int32), ("pool_mean", c_int32), ("edges_by_k", c_int32),
+        ("Pi", c_void_p), ("Pj", c_void_p), ("ldp", c_int64), ("Ws", c_void_p), ("ldws", c_int64),
+        ("W2", c_void_p), ("b2", c_void_p), ("gate_w", c_void_p), ("gate_b", c_void_p),
+        ("W3", c_void_p), ("b3", c_void_p), ("W4", c_void_p), ("b4", c_void_p), ("coors_scale", c_void_p),
+        ("coors", c_void_p), ("edges", c_void_p), ("mask", c_void_p), ("idx", c_void_p), ("rank", c_void_p),
+        ("valid_radius", c_float), ("clamp", c_float),
+        ("m_i", c_void_p), ("coors_out", c_void_p), ("edge_ws", c_void_p),
     ]
 
 
@@ -276,11 +291,20 @@ def load():
                                            c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                            c_void_p, c_void_p]
 
+    lib.egnn_linear_f32.restype = c_int
+    lib.egnn_linear_f32.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                    c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]
+    lib.egnn_node_prep_f32.restype = c_int
+    lib.egnn_node_prep_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]
+    lib.egnn_edge_exact_f32.restype = c_int
+    lib.egnn_edge_exact_f32.argtypes = [POINTER(EdgeExactArgs), c_void_p]
+    lib.egnn_edge_exact_workspace_bytes.restype = c_size_t
+    lib.egnn_edge_exact_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, c_int]
     if lib.egnn_abi_version() != ABI_VERSION:
         raise EGNNHipError(f"{path}: ABI version {lib.egnn_abi_version()} != {ABI_VERSION}; rebuild it")
     lib.egnn_struct_bytes.restype = c_int64
     lib.egnn_struct_bytes.argtypes = [c_int]
-    for which, mirror in enumerate((EdgeArgs, EdgeBwdArgs, EdgeTailArgs, LayerDesc, PackedInfo)):
+    for which, mirror in enumerate((EdgeArgs, EdgeBwdArgs, EdgeTailArgs, LayerDesc, PackedInfo, EdgeExactArgs)):
         if lib.egnn_struct_bytes(which) != ctypes.sizeof(mirror):
             raise EGNNHipError(f"{path}: sizeof({mirror.__name__}) = {ctypes.sizeof(mirror)} here, {lib.egnn_struct_bytes(which)} in the "
                                f"library: the ctypes mirror in _abi.py and include/egnn_hip.h disagree")

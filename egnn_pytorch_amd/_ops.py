@@ -325,6 +325,49 @@ def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32
     return out if out_hl else c
 
 
+# ---- the wide-range path: the same layer in plain fp32 (include/egnn_hip.h, "The wide-range path")
+def linear_f32(a, w, n, k, bias=None, residual=None, act=0, out=None, name="linear_f32"):
+    """act(a @ w[:n, :k].T + bias) (+ residual) in exact fp32 (v_mfma_f32_32x32x2_f32) -- egnn_linear_f32.  a (M, >= k) and w
+    (>= n rows, row stride w.stride(0)) may be column slices of wider tensors (unit column stride); `out` likewise (M, >= n)."""
+    m = a.shape[0]
+    assert a.stride(1) == 1 and w.stride(1) == 1 and a.dtype == torch.float32 and w.dtype == torch.float32
+    if out is None:
+        out = empty(m, n, dtype=torch.float32, device=a.device)
+    assert out.stride(1) == 1 and out.shape[0] == m
+    ldr = 0
+    if residual is not None:
+        assert residual.stride(1) == 1 and residual.shape[0] == m
+        ldr = residual.stride(0)
+    with _timed(name):
+        rc = _abi.load().egnn_linear_f32(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(residual), ldr,
+                                         _ptr(out), out.stride(0), m, n, k, act, _stream())
+    _abi.check(rc, "egnn_linear_f32")
+    return out
+
+
+def node_prep_f32(feats2d, m_i, gamma, beta, eps, m_dim):
+    """[LayerNorm(feats) | m_i] as a plain fp32 (rows, dim + m_dim) matrix -- egnn_node_prep_f32."""
+    rows, dim = feats2d.shape
+    out = empty(rows, dim + m_dim, dtype=torch.float32, device=feats2d.device)
+    with _timed("node_prep_f32"):
+        rc = _abi.load().egnn_node_prep_f32(_ptr(feats2d), _ptr(m_i), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), rows, dim, m_dim,
+                                            _stream())
+    _abi.check(rc, "egnn_node_prep_f32")
+    return out
+
+
+def edge_exact(args: "_abi.EdgeExactArgs", device):
+    """egnn_edge_exact_f32; allocates the per-edge workspace the entry asks for."""
+    lib = _abi.load()
+    nbytes = lib.egnn_edge_exact_workspace_bytes(args.B, args.N, args.K, args.m_dim, args.coor_dim)
+    ws = empty(max(1, nbytes // 4), dtype=torch.float32, device=device)
+    args.edge_ws = ws.data_ptr()
+    with _timed("edge_exact"):
+        rc = lib.egnn_edge_exact_f32(byref(args), _stream())
+    _abi.check(rc, "egnn_edge_exact_f32")
+    return ws
+
+
 def node_prep_hl(feats2d, m_i, gamma, beta, eps, m_dim, with_raw=False):
     """[LayerNorm(feats) | m_i] as a packed fp16 (hi, lo) pair -- egnn_node_prep_hl.  m_i None: those columns are
     zero (the edge pass writes them in place).  with_raw: also return feats itself as a packed pair (the projection's

@@ -56,8 +56,10 @@ class GlobalLinearAttention(nn.Module):
         self.ff = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, dim * 4), nn.GELU(), nn.Linear(dim * 4, dim))
 
     def forward(self, x, queries, mask=None):
+        from . import layer as _layer
         if x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.float32 and queries.dtype == torch.float32 \
-                and queries.shape[1] <= 8 and self.attn1.to_q.weight.shape[0] // self.attn1.heads <= 256:
+                and queries.shape[1] <= 8 and self.attn1.to_q.weight.shape[0] // self.attn1.heads <= 256 \
+                and not _layer.exact_active():                    # (plain-fp32 mode: the differentiable module below, in fp32)
             return self._forward_hip(x, queries, mask)
         seq, tok = self.norm_seq(x), self.norm_queries(queries)
         induced = self.attn1(tok, seq, mask=mask)

@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -Wno-inline-a
 rm -rf "$HERE/obj"
 mkdir -p "$HERE/obj"
 pids=()
-for f in knn_select spatial_order adj_expand linear_hl edge_fused edge_pw edge_bwd edge_tail node_ops layer_api segment_sum entry_lists global_attn linear_f32 linear_split node_prep_ref; do
+for f in knn_select spatial_order adj_expand linear_hl edge_fused edge_pw edge_exact edge_bwd edge_tail node_ops layer_api segment_sum entry_lists global_attn linear_f32 node_prep_f32 linear_split; do
   EXTRA=""
   # the ranking kernel must reproduce the reference's un-fused ((dx*dx+dy*dy)+dz*dz) bit for bit
   [ "$f" = knn_select ] && EXTRA="-ffp-contract=off"
@@ -47,7 +47,7 @@ for res in "$HERE"/obj/*.res; do
   fi
 done
 # the product library, and -- separately -- the test-only reference kernels (include/egnn_hip_ref.h; loaded by tests/_reflib.py)
-REF_OBJS=("$HERE/obj/linear_f32.o" "$HERE/obj/linear_split.o" "$HERE/obj/node_prep_ref.o")
+REF_OBJS=("$HERE/obj/linear_split.o")
 PROD_OBJS=()
 for o in "$HERE"/obj/*.o; do
   case " ${REF_OBJS[*]} " in *" $o "*) ;; *) PROD_OBJS+=("$o") ;; esac

@@ -40,6 +40,9 @@ typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int PW_THREADS = 256;
 constexpr int PW_WAVES = 4;
+#ifndef EGNN_PW_EARLY_W
+#define EGNN_PW_EARLY_W 1
+#endif
 #ifndef EGNN_PW_HC
 #define EGNN_PW_HC 64
 #endif
@@ -291,6 +294,16 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
             const int hnext = more ? hoff + 32 : hoff;                       // last step: harmless re-read of the P_i words
             f32x4 x[2][2];
             uint32_t pivn[2];
+#if EGNN_PW_EARLY_W
+            // this step's staged operands first (in LDS since the chunk's barrier): their LDS latency runs under the wait for the
+            // gathered lines instead of after it
+            u32x2 a0[2];
+#pragma unroll
+            for (int hb = 0; hb < NHB; ++hb)
+                a0[hb] = u32x2{0u, *reinterpret_cast<const uint32_t*>(tlc + st * 2 * tstep + hb * tstep)};
+            const f16x8 whi = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 0) * 64 + lane) * 8);
+            const f16x8 wlo = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 1) * 64 + lane) * 8);
+#endif
             // the lines of this step were requested a step ago and land in the wave's exchange rows by themselves
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
@@ -320,12 +333,17 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
                 for (int qq = 0; qq < 4; ++qq) gather_dma16(pj_words, goff[qq], (uint32_t)(hnext * 4), xch_lds + qq * 1024);
             }
 
+#if EGNN_PW_EARLY_W
+#pragma unroll
+            for (int hb = 0; hb < NHB; ++hb) a0[hb][0] = piv[hb];
+#else
             u32x2 a0[2];
 #pragma unroll
             for (int hb = 0; hb < NHB; ++hb)
                 a0[hb] = u32x2{piv[hb], *reinterpret_cast<const uint32_t*>(tlc + st * 2 * tstep + hb * tstep)};
             const f16x8 whi = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 0) * 64 + lane) * 8);
             const f16x8 wlo = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 1) * 64 + lane) * 8);
+#endif
             if (!HALF) {
                 piv[0] = pivn[0];
                 piv[1] = pivn[1];

@@ -14,7 +14,6 @@
 // Block -> tile map: XCD-contiguous (block b runs on XCD b % 8; each XCD gets a contiguous range of
 // tiles) and grouped over M (8 M-tiles share each W panel while it is L2-hot).
 #include "egnn_common.h"
-#include "../../include/egnn_hip_ref.h"       // TEST-ONLY library (tests/libegnn_hip_ref.so)
 
 namespace {
 

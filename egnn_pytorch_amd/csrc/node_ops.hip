@@ -403,6 +403,7 @@ extern "C" int64_t egnn_struct_bytes(int which)
     case 2: return (int64_t)sizeof(egnn_edge_tail_args);
     case 3: return (int64_t)sizeof(egnn_layer_desc);
     case 4: return (int64_t)sizeof(egnn_packed_info);
+    case 5: return (int64_t)sizeof(egnn_edge_exact_args);
     default: return -1;
     }
 }

@@ -1,9 +1,8 @@
-// TEST-ONLY (include/egnn_hip_ref.h, tests/libegnn_hip_ref.so): node_norm + concat with fp32 output,
+// node_norm + concat with fp32 output (the wide-range path, include/egnn_hip.h: egnn_node_prep_f32),
 //     out[r] = [ LayerNorm(feats[r]) (or feats[r]) | m_i[r] ]        (egnn_pytorch/egnn_pytorch.py:335-336)
 // One wavefront per row; row statistics by DPP reductions (two-pass: mean, then centred variance, as torch's LayerNorm).
-// The production path writes the packed fp16 (hi, lo) pair instead (node_ops.hip); this is its A/B reference.
+// The fast path writes the packed fp16 (hi, lo) pair instead (node_ops.hip); this kernel is also its A/B reference in the tests.
 #include "egnn_common.h"
-#include "../../include/egnn_hip_ref.h"
 
 namespace {
 

@@ -12,6 +12,7 @@ a few graphs at a time (egnn_pytorch_amd/autograd.py).
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import warnings
 
@@ -27,6 +28,38 @@ _SIDE_STREAM = os.environ.get("EGNN_SIDE_STREAM", "1") != "0"         # neighbou
 # egnn_edge_args.algo: 0 = the library chooses (persistent wave-per-node kernel where it applies), 1 = the general edge kernel always
 # (A/B measurements; tests/test_gpu_kernels.py checks the two against each other)
 _EDGE_ALGO = int(os.environ.get("EGNN_EDGE_ALGO", "0"))
+# Arithmetic.  "fast" (default): split-fp16 products on the matrix cores (fp32-class accuracy, values up to fp16's 65504 at the cast
+# sites); a call that leaves that range is re-run automatically in plain fp32 -- the reference's arithmetic class, several times
+# slower -- when the range status word is read synchronously (EGNN_RANGE_CHECK=sync, the default) and no graph is being recorded;
+# otherwise it raises EGNNRangeError.  "exact": always the plain-fp32 kernels (inference only).
+_PRECISION = os.environ.get("EGNN_PRECISION", "fast")
+_exact_now = False
+
+
+@contextlib.contextmanager
+def exact_arithmetic():
+    """Run the enclosed forwards on the plain-fp32 (wide-range) kernels: include/egnn_hip.h, "The wide-range path"."""
+    global _exact_now
+    prev, _exact_now = _exact_now, True
+    try:
+        yield
+    finally:
+        _exact_now = prev
+
+
+def exact_active():
+    return _exact_now or _PRECISION == "exact"
+
+
+def _rerun_exact_ok(module, *tensors):
+    """A forward that tripped the range status word may be re-run in plain fp32: the word was read for THIS call (sync mode),
+    nothing is being recorded for a backward (the native backward has the same fp16 cast sites), and no stream capture is going on."""
+    if _ops.RANGE_CHECK != "sync" or exact_active():
+        return False
+    if torch.is_grad_enabled() and (any(p.requires_grad for p in module.parameters()) or
+                                    any(torch.is_tensor(t) and t.is_floating_point() and t.requires_grad for t in tensors)):
+        return False
+    return not torch.cuda.is_current_stream_capturing()
 # The kernels compute in fp32-class arithmetic (split-f16 products, fp32 accumulation: DESIGN.md §2).  Other floating dtypes
 # -- the reference is dtype-generic and its own tests run in float64 -- are accepted at the boundary: inputs are converted to
 # fp32, outputs back to the callers' dtype.  For bf16 / fp16 that is at least the reference's precision; for float64 it is
@@ -150,8 +183,14 @@ class EGNN(nn.Module):
             raise ValueError(f"mask shape {tuple(mask.shape)} != {(b, n)}")
 
     def forward(self, feats, coors, edges=None, mask=None, adj_mat=None):
-        out = self._call(feats, coors, edges, mask, adj_mat, None)[:2]
-        _ops.range_check_after_forward(feats.device)                # EGNN_RANGE_CHECK: sync (default) | deferred | off
+        try:
+            out = self._call(feats, coors, edges, mask, adj_mat, None)[:2]
+            _ops.range_check_after_forward(feats.device)            # EGNN_RANGE_CHECK: sync (default) | deferred | off
+        except _abi.EGNNRangeError:
+            if not _rerun_exact_ok(self, feats, coors, edges):
+                raise
+            with exact_arithmetic():                                # reference-legal inputs beyond the fp16 cast sites: plain fp32
+                out = self._call(feats, coors, edges, mask, adj_mat, None)[:2]
         return out
 
     def _call(self, feats, coors, edges, mask, adj_mat, order_hint):
@@ -196,6 +235,10 @@ class EGNN(nn.Module):
         return out
 
     def _forward_hip(self, feats, coors, edges, mask, adj_mat, order_hint=None, want_u=False, drop=None):
+        if exact_active():
+            if want_u or drop is not None:
+                raise NotImplementedError("the plain-fp32 (wide-range) kernels are inference-only: no backward, no training-mode dropout")
+            return self._forward_exact(feats, coors, edges, mask, adj_mat)
         b, n, dim = feats.shape
         w = self.packed_weights()
         feats = feats.contiguous()
@@ -335,6 +378,92 @@ class EGNN(nn.Module):
         return node_out, coors_out, order, idx, rank, valid_radius, u_pre, proj_kept
 
 
+    def _forward_exact(self, feats, coors, edges, mask, adj_mat):
+        """The layer on the plain-fp32 kernels (include/egnn_hip.h, "The wide-range path"): exact-fp32 GEMMs, fp32 node_norm, the edge
+        pass as fp32 VALU arithmetic on the module's own weight tensors.  Same neighbour selection, same return tuple as _forward_hip."""
+        b, n, dim = feats.shape
+        feats = feats.contiguous()
+        coors = coors.contiguous()
+        feats2d = feats.view(b * n, dim)
+        lookup = edges if isinstance(edges, EdgeLookup) else None
+        if lookup is not None:
+            edges = lookup.edges
+        elif edges is not None:
+            edges = edges.contiguous().float()
+        mask8 = _ops._u8(mask)
+        num_nearest, valid_radius = self.num_nearest_neighbors, self.valid_radius
+        use_nearest = num_nearest > 0 or self.only_sparse_neighbors
+        idx = rank = None
+        if b == 0 or (n == 0 and not use_nearest):
+            return torch.empty_like(feats), torch.empty_like(coors), None, None, None, valid_radius, None, None
+        if use_nearest:
+            if adj_mat is not None and self.only_sparse_neighbors:
+                num_nearest = _ops.adj_max_degree(adj_mat)
+                valid_radius = 0.0
+            k = num_nearest
+            if k > n:
+                raise RuntimeError("selected index k out of range")
+            if k > 0:
+                idx, rank = _ops.knn_select(coors, mask, adj_mat, k)
+        else:
+            k = n
+        f32 = lambda t: t.detach().float().contiguous()
+        node_out, coors_out, m_i = feats, coors, None
+        if k > 0:
+            lin0, lin3 = self.edge_mlp[0], self.edge_mlp[3]
+            w1 = f32(lin0.weight)                                        # (H, Din): [W_i | W_j | scalar columns]
+            h, din = w1.shape
+            hq = (h + 3) // 4 * 4
+            proj = _ops.empty(b * n, 2 * hq, dtype=torch.float32, device=feats.device)
+            _ops.linear_f32(feats2d, w1, h, dim, bias=f32(lin0.bias), out=proj[:, :h], name="node_proj_f32")
+            _ops.linear_f32(feats2d, w1[:, dim:], h, dim, out=proj[:, hq:hq + h], name="node_proj_f32")
+            a = _abi.EdgeExactArgs()
+            a.B, a.N, a.K, a.m_dim, a.H = b, n, k, self.m_dim, h
+            a.fourier, a.edge_dim, a.coor_dim = self.fourier_features, self.edge_dim, coors.shape[-1]
+            a.pool_mean = int(self.m_pool_method == "mean")
+            a.Pi, a.Pj, a.ldp = proj.data_ptr(), proj.data_ptr() + 4 * hq, 2 * hq
+            a.Ws, a.ldws = w1.data_ptr() + 4 * 2 * dim, din
+            keep = [w1, f32(lin3.weight), f32(lin3.bias)]
+            a.W2, a.b2 = keep[1].data_ptr(), keep[2].data_ptr()
+            if self.edge_gate is not None:
+                keep += [f32(self.edge_gate[0].weight).view(-1), f32(self.edge_gate[0].bias)]
+                a.gate_w, a.gate_b = keep[-2].data_ptr(), keep[-1].data_ptr()
+            if self.coors_mlp is not None:
+                c0, c3 = self.coors_mlp[0], self.coors_mlp[3]
+                keep += [f32(c0.weight), f32(c0.bias), f32(c3.weight).view(-1), f32(c3.bias)]
+                a.W3, a.b3, a.W4, a.b4 = (t.data_ptr() for t in keep[-4:])
+                coors_out = _ops.empty(*coors.shape, dtype=torch.float32, device=coors.device)
+                a.coors_out = coors_out.data_ptr()
+            if self.norm_coors:
+                keep.append(f32(self.coors_norm.scale))
+                a.coors_scale = keep[-1].data_ptr()
+            a.coors = coors.data_ptr()
+            if lookup is not None:
+                edges = _ops.edge_features_gather(lookup, idx, b, n, k)
+                a.edges_by_k = 1
+            a.edges, a.mask = _ops._ptr(edges), _ops._ptr(mask8)
+            a.idx, a.rank = _ops._ptr(idx), _ops._ptr(rank)
+            a.valid_radius = float(min(valid_radius, 3.0e38))
+            cv = self.coor_weights_clamp_value
+            a.clamp = -1.0 if cv is None else float(cv)
+            if self.node_mlp is not None:
+                m_i = _ops.empty(b * n, self.m_dim, dtype=torch.float32, device=feats.device)
+                a.m_i = m_i.data_ptr()
+            _ops.edge_exact(a, feats.device)
+            del proj, keep
+        elif self.node_mlp is not None:
+            m_i = torch.zeros(b * n, self.m_dim, dtype=torch.float32, device=feats.device)        # K == 0: no messages
+        if self.node_mlp is not None:
+            ln = self.node_norm if isinstance(self.node_norm, nn.LayerNorm) else None
+            node_in = _ops.node_prep_f32(feats2d, m_i, f32(ln.weight) if ln is not None else None,
+                                         f32(ln.bias) if ln is not None else None, ln.eps if ln is not None else 1e-5, self.m_dim)
+            n0, n3 = self.node_mlp[0], self.node_mlp[3]
+            hid = _ops.linear_f32(node_in, f32(n0.weight), 2 * dim, dim + self.m_dim, bias=f32(n0.bias), act=1, name="node_mlp0_f32")
+            node_out = _ops.linear_f32(hid, f32(n3.weight), dim, 2 * dim, bias=f32(n3.bias), residual=feats2d,
+                                       name="node_mlp1_f32").view(b, n, dim)
+        return node_out, coors_out, None, idx, rank, valid_radius, None, None
+
+
 _FP64_WARNED = False
 
 
@@ -394,9 +523,15 @@ class EGNN_Network(nn.Module):
         grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
                                             any(torch.is_tensor(t) and t.is_floating_point() and t.requires_grad
                                                 for t in (feats, coors, edges)))
-        with torch.enable_grad() if grad else torch.no_grad():
-            out = self._forward(feats, coors, adj_mat, edges, mask, return_coor_changes)
-        _ops.range_check_after_forward(coors.device)                # once per network forward, not per layer
+        try:
+            with torch.enable_grad() if grad else torch.no_grad():
+                out = self._forward(feats, coors, adj_mat, edges, mask, return_coor_changes)
+            _ops.range_check_after_forward(coors.device)            # once per network forward, not per layer
+        except _abi.EGNNRangeError:
+            if grad or not _rerun_exact_ok(self, feats, coors, edges):
+                raise
+            with exact_arithmetic(), torch.no_grad():               # the whole stack again, in plain fp32
+                out = self._forward(feats, coors, adj_mat, edges, mask, return_coor_changes)
         return out
 
     def _forward(self, feats, coors, adj_mat, edges, mask, return_coor_changes):

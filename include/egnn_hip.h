@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 29
+#define EGNN_ABI_VERSION 30
 
 enum {
     EGNN_OK = 0,
@@ -54,7 +54,7 @@ enum {
 
 int egnn_abi_version(void);
 /* sizeof of the argument structs as this library was compiled -- 0: egnn_edge_args, 1: egnn_edge_bwd_args, 2: egnn_edge_tail_args,
- * 3: egnn_layer_desc, 4: the packed-weights info struct; -1 otherwise -- so that a binding that mirrors them (ctypes, cgo, JNI) can verify its
+ * 3: egnn_layer_desc, 4: the packed-weights info struct, 5: egnn_edge_exact_args; -1 otherwise -- so that a binding that mirrors them (ctypes, cgo, JNI) can verify its
  * layout at load time instead of corrupting a call. */
 int64_t egnn_struct_bytes(int which);
 const char* egnn_error_string(int code);
@@ -518,6 +518,76 @@ int egnn_layer_forward_f32(const egnn_layer_desc* desc, const egnn_packed_info* 
                            const uint8_t* adj, int64_t adj_batch_stride, int B, int N, int K, int coor_dim,
                            float* feats_out, float* coors_out, void* workspace, size_t workspace_bytes,
                            int32_t* status, void* stream);
+
+
+/* =============================================================================================
+ * The wide-range path: the same layer in plain fp32 (no split-fp16 products, no re-laid-out weights).
+ *
+ * The fast kernels above carry every product as a split-fp16 pair: a finite activation beyond fp16's 65504 at one of their cast
+ * sites sets a bit of the range status word instead of producing a number (EGNN_RANGE_*).  The reference computes in plain fp32
+ * (egnn_pytorch.py:232-233, 287) and has no such limit.  A binding re-runs a call that tripped a bit on the entries below (the shipped
+ * binding does so automatically, egnn_pytorch_amd/layer.py): exact-fp32 GEMMs (v_mfma_f32_32x32x2_f32 = an fmaf chain), fp32
+ * node_norm, and the edge pass as fp32 VALU arithmetic on the module's own weight tensors -- the reference's arithmetic class,
+ * overflowing only where fp32 itself does.  Several times slower than the fast path; never what bench.py times.
+ * ============================================================================================= */
+/*  * Dense layer, exact-fp32 variant (v_mfma_f32_32x32x2_f32): C = act(A * W^T + bias) (+ residual).
+ * Used for (a) the node-level projections P = feats * [W_i ; W_j]^T + [b1 ; 0] that replace the
+ * per-edge first Linear of edge_mlp (egnn_pytorch.py:178-179, 279-287: Linear(cat(h_i,h_j,d,e)) =
+ * W_i h_i + W_j h_j + w_d d + W_e e + b), and (b) node_mlp (egnn_pytorch.py:196-201, 336-337).
+ *   A (M,K) lda;  W (N,K) ldw (nn.Linear weight layout);  bias (N) or NULL;
+ *   residual (M,N) ldr or NULL;  C (M,N) ldc;  act: 0 = identity, 1 = SiLU.
+ * v_mfma_f32_32x32x2_f32: exact fp32 products/accumulation.
+ */
+int egnn_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                    const float* residual, int64_t ldr, float* C, int64_t ldc,
+                    int64_t M, int N, int K, int act, void* stream);
+
+
+/* node_norm + concat (egnn_pytorch.py:335-336): out[r] = [ LayerNorm(feats[r]) | m_i[r] ].
+ * gamma/beta NULL -> Identity (norm_feats=False).  out: (rows, dim + m_dim). */
+int egnn_node_prep_f32(const float* feats, const float* m_i, const float* gamma, const float* beta,
+                       float eps, float* out, int64_t rows, int dim, int m_dim, void* stream);
+
+
+/* The edge pass of egnn_pytorch.py:262-333 in fp32.  Weights are the module's own tensors:
+ *   Pi, Pj   (B*N, ldp) fp32, natural units: Pi = feats W_i^T + b1, Pj = feats W_j^T with W_i = edge_mlp.0.weight[:, :dim],
+ *            W_j = edge_mlp.0.weight[:, dim:2dim] (two egnn_linear_f32 calls with ldw = Din);
+ *   Ws       = edge_mlp.0.weight + 2 dim: row h holds the S = 2 fourier + 1 + edge_dim scalar columns, ldws = Din;
+ *   W2, b2   edge_mlp.3 (m_dim, H), (m_dim);  gate_w (m_dim), gate_b (1) or NULL;
+ *   W3 (4 m_dim, m_dim), b3 (4 m_dim), W4 (4 m_dim), b4 (1): coors_mlp, or NULL (update_coors=False);  coors_scale (1) or NULL;
+ *   coors (B,N,coor_dim), 1 <= coor_dim <= 8;  edges / edges_by_k / mask / idx / rank / valid_radius / clamp / pool_mean as in egnn_edge_args;
+ *   m_i (B*N, m_dim) and / or coors_out (B,N,coor_dim);  edge_ws: egnn_edge_exact_workspace_bytes() of scratch (per-edge rows,
+ *   summed per node in k order: deterministic).
+ * Limits: m_dim <= 64, at most 64 per-edge scalars. */
+typedef struct egnn_edge_exact_args {
+    int32_t B, N, K, m_dim, H, fourier, edge_dim, coor_dim, pool_mean, edges_by_k;
+    const float* Pi;
+    const float* Pj;
+    int64_t ldp;
+    const float* Ws;
+    int64_t ldws;
+    const float* W2;
+    const float* b2;
+    const float* gate_w;
+    const float* gate_b;
+    const float* W3;
+    const float* b3;
+    const float* W4;
+    const float* b4;
+    const float* coors_scale;
+    const float* coors;
+    const float* edges;
+    const uint8_t* mask;
+    const int32_t* idx;
+    const float* rank;
+    float valid_radius, clamp;
+    float* m_i;
+    float* coors_out;
+    float* edge_ws;
+} egnn_edge_exact_args;
+
+size_t egnn_edge_exact_workspace_bytes(int B, int N, int K, int m_dim, int coor_dim);
+int egnn_edge_exact_f32(const egnn_edge_exact_args* args, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
-/* egnn_hip_ref.h -- TEST-ONLY companion of egnn_hip.h: reference implementations the shipped library does not contain.
+/* egnn_hip_ref.h -- TEST-ONLY companion of egnn_hip.h: a reference implementation the shipped library does not contain.
  *
  * Built into tests/libegnn_hip_ref.so by egnn_pytorch_amd/csrc/build.sh and loaded only by tests/_reflib.py (A/B checks of
- * the production kernels: exact fp32 products, operands split on the fly, fp32 node_norm + concat).  Nothing under
+ * the production kernels: operands split on the fly).  Nothing under
  * egnn_pytorch_amd/ binds these symbols.  Same conventions as egnn_hip.h (device pointers, stream, return codes).
  */
 #ifndef EGNN_HIP_REF_H
@@ -14,19 +14,7 @@ extern "C" {
 #endif
 
 /* ---------------------------------------------------------------------------------------------
- * Dense layer, exact-fp32 variant (v_mfma_f32_32x32x2_f32): C = act(A * W^T + bias) (+ residual).
- * Used for (a) the node-level projections P = feats * [W_i ; W_j]^T + [b1 ; 0] that replace the
- * per-edge first Linear of edge_mlp (egnn_pytorch.py:178-179, 279-287: Linear(cat(h_i,h_j,d,e)) =
- * W_i h_i + W_j h_j + w_d d + W_e e + b), and (b) node_mlp (egnn_pytorch.py:196-201, 336-337).
- *   A (M,K) lda;  W (N,K) ldw (nn.Linear weight layout);  bias (N) or NULL;
- *   residual (M,N) ldr or NULL;  C (M,N) ldc;  act: 0 = identity, 1 = SiLU.
- * v_mfma_f32_32x32x2_f32: exact fp32 products/accumulation.
- */
-int egnn_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
-                    const float* residual, int64_t ldr, float* C, int64_t ldc,
-                    int64_t M, int N, int K, int act, void* stream);
-
-/* The same operation on the matrix cores with A split on the fly (predecessor of egnn_linear_hl_f32): fp32 in / fp32 out, every product evaluated as
+ * The same operation on the matrix cores with A split on the fly (predecessor of egnn_linear_hl_f32): fp32 in / fp32 out, every product evaluated as
  * a 3-term split-f16 product with fp32 accumulation on v_mfma_f32_32x32x16_f16
  * (a = a_hi + a_lo, w = w_hi + w_lo;  a_hi w_hi + a_lo w_hi + a_hi w_lo;  dropped term <= 2^-22 |a w|: fp32-class
  * accuracy at 3/16 of the f32-MFMA cost -- on gfx950 the f32-input MFMA runs at vector rate on the vector datapath).
@@ -38,11 +26,6 @@ int egnn_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, co
 int egnn_linear_split_f32(const float* A, int64_t lda, const void* W_hi, const void* W_lo, int64_t ldw,
                           float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
                           float* C, int64_t ldc, int64_t M, int N, int K, int act, void* stream);
-
-/* node_norm + concat (egnn_pytorch.py:335-336): out[r] = [ LayerNorm(feats[r]) | m_i[r] ].
- * gamma/beta NULL -> Identity (norm_feats=False).  out: (rows, dim + m_dim). */
-int egnn_node_prep_f32(const float* feats, const float* m_i, const float* gamma, const float* beta,
-                       float eps, float* out, int64_t rows, int dim, int m_dim, void* stream);
 
 #ifdef __cplusplus
 }

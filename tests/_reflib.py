@@ -1,6 +1,6 @@
-"""ctypes binding of tests/libegnn_hip_ref.so (include/egnn_hip_ref.h): TEST-ONLY reference kernels -- exact fp32 GEMM,
-GEMM with A split on the fly, fp32 node_norm + concat -- used for A/B checks of the production kernels.  Not part of the
-product: nothing under egnn_pytorch_amd/ imports this."""
+"""ctypes binding of tests/libegnn_hip_ref.so (include/egnn_hip_ref.h): the TEST-ONLY reference kernel -- the GEMM with A split
+on the fly -- plus test-side wrappers of the product library's plain-fp32 kernels (exact fp32 GEMM, fp32 node_norm + concat:
+the wide-range path, which doubles as the A/B reference of the split-f16 kernels).  Nothing under egnn_pytorch_amd/ imports this."""
 import ctypes
 import math
 import os
@@ -20,15 +20,9 @@ def load():
     if _lib is None:
         _abi.load()                                        # the HIP runtime torch initialised, then ours
         lib = ctypes.CDLL(_PATH)
-        lib.egnn_linear_f32.restype = c_int
-        lib.egnn_linear_f32.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
-                                        c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]
         lib.egnn_linear_split_f32.restype = c_int
         lib.egnn_linear_split_f32.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p,
                                               c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]
-        lib.egnn_node_prep_f32.restype = c_int
-        lib.egnn_node_prep_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
-                                           c_int, c_int, c_void_p]
         _lib = lib
     return _lib
 
@@ -57,7 +51,7 @@ def linear(a, w, bias=None, residual=None, act=0, name="linear"):
         assert residual.shape == (m, n) and residual.is_contiguous()
         ldr = n
     with _timed(name):
-        rc = load().egnn_linear_f32(_ptr(a), k, _ptr(w), k, _ptr(bias), _ptr(residual), ldr,
+        rc = _abi.load().egnn_linear_f32(_ptr(a), k, _ptr(w), k, _ptr(bias), _ptr(residual), ldr,
                                          _ptr(c), n, m, n, k, act, _stream())
     _abi.check(rc, "egnn_linear_f32")
     return c
@@ -85,7 +79,7 @@ def node_prep(feats2d, m_i, gamma, beta, eps, m_dim):
     rows, dim = feats2d.shape
     out = empty(rows, dim + m_dim, dtype=torch.float32, device=feats2d.device)
     with _timed("node_prep"):
-        rc = load().egnn_node_prep_f32(_ptr(feats2d), _ptr(m_i), _ptr(gamma), _ptr(beta), float(eps),
+        rc = _abi.load().egnn_node_prep_f32(_ptr(feats2d), _ptr(m_i), _ptr(gamma), _ptr(beta), float(eps),
                                             _ptr(out), rows, dim, m_dim, _stream())
     _abi.check(rc, "egnn_node_prep_f32")
     return out

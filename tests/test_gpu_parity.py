@@ -481,10 +481,12 @@ def test_large_but_representable_inputs_match_at_scale():
 
 
 @pytest.mark.parametrize("what,bit", [("feats", 1), ("coors", 4), ("edges", 4)])
-def test_out_of_range_inputs_raise_instead_of_saturating(what, bit):
+def test_out_of_range_inputs_match_the_reference_through_the_wide_range_path(what, bit):
     """feats x 1e6 (|x| >= 65504 entering the fp16 split), coordinates x 1e5 (dist^2 ~ 1e10) and edge features x 1e9: the
-    reference computes these in plain fp32; the gfx950 path cannot -- it must say so (EGNNRangeError naming the cause) and
-    leave non-finite outputs, never silently clamped ones."""
+    reference computes these in plain fp32 (egnn_pytorch.py:232-233, 287).  The split-fp16 kernels cannot carry them: they set a range
+    status bit -- never a silently clamped number -- and the module re-runs the call on the plain-fp32 kernels (csrc/edge_exact.hip,
+    egnn_linear_f32): the result matches the oracle at 1e-4 of the output's scale.  Where the word cannot be read for the call itself
+    (deferred mode) the old contract holds: non-finite outputs, EGNNRangeError naming the cause at the next check."""
     from egnn_pytorch_amd import EGNNRangeError, _ops
     kw = dict(dim=32, num_nearest_neighbors=8, edge_dim=2)
     cfg, params, net = _range_layer(kw)
@@ -500,9 +502,21 @@ def test_out_of_range_inputs_raise_instead_of_saturating(what, bit):
     else:
         edges *= 1e9
     args = (_dev(feats), _dev(coors), _dev(edges))
-    with pytest.raises(EGNNRangeError) as err:
-        net(*args)
-    assert _abi_bits(str(err.value)) & bit
+    # sync mode (the default): the fast path trips the word, the call is answered by the wide-range path
+    with _ops.phase_timer() as pt:
+        node, co = net(*args)
+    launched = set(pt.summary())
+    assert "edge_fused" in launched and "edge_exact" in launched, launched          # the fast attempt, then the re-run
+    ref_node, ref_co = O.egnn_forward(cfg, params, feats, coors, edges, None, None)
+    ref64 = O.egnn_forward(cfg, {k: v.astype(np.float64) for k, v in params.items()}, feats.astype(np.float64), coors.astype(np.float64),
+                           edges.astype(np.float64), None, None)
+    for got, ref, r64 in ((node, ref_node, ref64[0]), (co, ref_co, ref64[1])):
+        assert np.isfinite(ref).all()                            # (fp32 itself does not overflow on these inputs)
+        scale = float(np.abs(ref).max())
+        assert np.isfinite(got.cpu().numpy()).all()
+        # against the fp32 oracle at 1e-4 of the output's scale, and no further from float64 than 1e-4 of it either
+        np.testing.assert_allclose(got.cpu().numpy(), ref, atol=ATOL * max(1.0, scale), rtol=0)
+        np.testing.assert_allclose(got.cpu().numpy().astype(np.float64), r64, atol=ATOL * max(1.0, scale), rtol=0)
     # deferred mode: the call returns (non-finite outputs), the next check raises
     old = _ops.RANGE_CHECK
     _ops.RANGE_CHECK = "deferred"
@@ -510,14 +524,61 @@ def test_out_of_range_inputs_raise_instead_of_saturating(what, bit):
         node, co = net(*args)
         torch.cuda.synchronize()
         assert not (torch.isfinite(node).all() and torch.isfinite(co).all())
-        with pytest.raises(EGNNRangeError):
+        with pytest.raises(EGNNRangeError) as err:
             _ops.check_range()
+        assert _abi_bits(str(err.value)) & bit
         _ops.check_range()                                   # the word was cleared
     finally:
         _ops.RANGE_CHECK = old
-    # and the module keeps working afterwards
-    small = net(_dev(feats * 0 + 1), _dev(rng.standard_normal((b, n, 3)).astype(np.float32)), _dev(edges * 0))
-    assert torch.isfinite(small[0]).all()
+    # under autograd the native backward has the same cast sites: it raises instead of re-running
+    with torch.enable_grad():
+        f = args[0].clone().requires_grad_(True)
+        with pytest.raises(EGNNRangeError):
+            net(f, args[1], args[2])
+    # and the module keeps working afterwards, on the fast path
+    with _ops.phase_timer() as pt:
+        small = net(_dev(feats * 0 + 1), _dev(rng.standard_normal((b, n, 3)).astype(np.float32)), _dev(edges * 0))
+    assert torch.isfinite(small[0]).all() and "edge_exact" not in pt.summary()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_on_the_plain_fp32_kernels(name):
+    """Every golden case of the reference through `exact_arithmetic()` -- exact-fp32 GEMMs, fp32 node_norm, csrc/edge_exact.hip: all
+    layer options (fourier, edge features, dense / k-NN / adjacency, gates, CoorsNorm, clamps, mean pooling, coordinate dimensions,
+    networks with their front-end and attention blocks)."""
+    from egnn_pytorch_amd import exact_arithmetic, _ops
+    meta, params, d = load_golden(name)
+    net = _module(meta["kind"], meta["kwargs"], params)
+    feats, coors = _dev(d["feats"]), _dev(d["coors"])
+    edges, mask, adj = _dev(d.get("edges")), _dev(d.get("mask")), _dev(d.get("adj_mat"))
+    with exact_arithmetic(), _ops.phase_timer() as pt:
+        if meta["kind"] == "layer":
+            node, co = net(feats, coors, edges, mask, adj)
+        else:
+            node, co = net(feats, coors, adj_mat=adj, edges=edges, mask=mask)
+    launched = set(pt.summary())
+    assert not launched & {"edge_fused", "node_proj", "node_mlp0", "node_mlp1"}, launched      # nothing of the split-fp16 path ran
+    np.testing.assert_allclose(node.cpu().numpy(), d["node_out"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(co.cpu().numpy(), d["coors_out"], atol=ATOL, rtol=0)
+
+
+def test_plain_fp32_kernels_agree_with_the_fast_path_at_the_north_star_width():
+    """dim 512, k 32, ragged mask: the two arithmetic classes on the same inputs -- both within 1e-4 of the oracle, and of each other."""
+    from egnn_pytorch_amd import exact_arithmetic
+    kw = dict(dim=512, num_nearest_neighbors=32)
+    cfg, params, net = _range_layer(kw, seed=17)
+    rng = np.random.default_rng(99)
+    b, n = 2, 160
+    feats = rng.standard_normal((b, n, 512)).astype(np.float32)
+    coors = rng.standard_normal((b, n, 3)).astype(np.float32)
+    mask = np.arange(n)[None, :] < np.array([[n], [n - 31]])
+    fast = net(_dev(feats), _dev(coors), mask=_dev(mask))
+    with exact_arithmetic():
+        exact = net(_dev(feats), _dev(coors), mask=_dev(mask))
+    ref = O.egnn_forward(cfg, params, feats, coors, None, mask, None)
+    for f, e, r in zip(fast, exact, ref):
+        np.testing.assert_allclose(e.cpu().numpy(), r, atol=ATOL, rtol=0)
+        np.testing.assert_allclose(e.cpu().numpy(), f.cpu().numpy(), atol=ATOL, rtol=0)
 
 
 def _abi_bits(message):
