@@ -232,6 +232,135 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
     }
 }
 
+// ---- large graphs (N beyond what a wave keeps in registers: 8192 nodes with 3-D coordinates, 4096 otherwise).  One WORKGROUP per
+// query row: the row's N ranking keys (the same bit-exact values) live in LDS -- up to 32 768 -- instead of registers; the K-th
+// smallest key by the same 32-step radix descent (per-thread counts over a contiguous slice, wave sums, one cross-wave sum per step),
+// the index-ordered pick among the ties with the K-th value through a block-wide exclusive scan, rank-by-counting on (value, index).
+// Coordinates are read from global memory (a graph's 12 N bytes are L2-resident).  Deterministic, same tie policy; ~10 us per row,
+// rows spread over the chip: a rarely used path (the reference's topk has no size limit, egnn_pytorch.py:258), not a fast one.
+template <int CDM>
+__global__ __launch_bounds__(KNN_THREADS) void knn_select_large_kernel(
+    const float* __restrict__ coors, const uint8_t* __restrict__ mask, const uint8_t* __restrict__ adj,
+    int64_t adj_bstride, int N, int K, int Cdim, int32_t* __restrict__ idx_out, float* __restrict__ rank_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* keys = reinterpret_cast<uint32_t*>(smem);                  // [N]
+    uint64_t* sel = reinterpret_cast<uint64_t*>(smem + ((size_t)N * 4 + 7) / 8 * 8);     // [K]
+    int* red = reinterpret_cast<int*>(sel + K);                          // [2 * KNN_WAVES + 2]
+    const int C = (CDM == 3) ? 3 : Cdim;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, i = blockIdx.x;
+    const float* cb = coors + (size_t)b * N * C;
+    const uint8_t* mb = mask ? mask + (size_t)b * N : nullptr;
+    const bool mi = mb ? mb[i] != 0 : true;
+    const uint8_t* adjrow = adj ? adj + (size_t)b * adj_bstride + (size_t)i * N : nullptr;
+    const size_t obase = ((size_t)b * N + i) * K;
+    if (!mi && !adjrow) {                                                // a masked row: all keys 1e5, the first K indices (see above)
+        for (int k = tid; k < K; k += KNN_THREADS) { idx_out[obase + k] = k; rank_out[obase + k] = 1e5f; }
+        return;
+    }
+    float ci[CDM];
+#pragma unroll
+    for (int c = 0; c < CDM; ++c) ci[c] = c < C ? cb[(size_t)i * C + c] : 0.f;
+    for (int j = tid; j < N; j += KNN_THREADS) {
+        float rk;
+        if (CDM == 3) {
+            float dx, dy, dz;
+            rk = egnn_sqdist(ci[0], ci[1], ci[2], cb[(size_t)j * 3], cb[(size_t)j * 3 + 1], cb[(size_t)j * 3 + 2], dx, dy, dz);
+        } else {
+            float cj[CDM], rel[CDM];
+#pragma unroll
+            for (int c = 0; c < CDM; ++c) cj[c] = c < C ? cb[(size_t)j * C + c] : 0.f;
+            rk = egnn_sqdist_n<CDM>(ci, cj, C, rel);
+        }
+        if (!(mi && (mb ? mb[j] != 0 : true))) rk = 1e5f;                // :240-242
+        if (adjrow) {
+            if (j == i) rk = -1.0f;                                      // :255
+            else if (adjrow[j]) rk = 0.0f;                               // :256
+        }
+        keys[j] = f2key(rk);
+    }
+    __syncthreads();
+
+    // block-wide sum of a per-thread count (every thread gets it)
+    auto block_sum = [&](int v, int slot) {
+        v = egnn_wave_sum(v);
+        if (lane == 0) red[slot * KNN_WAVES + wave] = v;
+        __syncthreads();
+        int t = 0;
+#pragma unroll
+        for (int w = 0; w < KNN_WAVES; ++w) t += red[slot * KNN_WAVES + w];
+        return t;
+    };
+    // contiguous slice of candidate indices per thread (index order = thread order: the tie pick below relies on it)
+    const int per = (N + KNN_THREADS - 1) / KNN_THREADS;
+    const int j0 = tid * per, j1 = (j0 + per) < N ? (j0 + per) : N;
+
+    // ---- exact K-th smallest key T by bitwise radix descent
+    uint32_t T = 0;
+    int below = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t want = T >> bit;
+        int cnt = 0;
+        for (int j = j0; j < j1; ++j) cnt += (keys[j] >> bit) == want ? 1 : 0;
+        cnt = block_sum(cnt, bit & 1);                                   // (alternating slots: one barrier per step)
+        if (below + cnt < K) {
+            below += cnt;
+            T |= (1u << bit);
+        }
+    }
+    // ---- pick: everything below T, then the lowest-index `need` candidates equal to T
+    const int need = K - below;
+    int nless = 0, neq = 0;
+    for (int j = j0; j < j1; ++j) {
+        nless += keys[j] < T ? 1 : 0;
+        neq += keys[j] == T ? 1 : 0;
+    }
+    // exclusive scans over the threads (wave scan + cross-wave offsets)
+    __syncthreads();
+    const int il = egnn_wave_inclusive_scan(nless), ie = egnn_wave_inclusive_scan(neq);
+    if (lane == 63) { red[wave] = il; red[KNN_WAVES + wave] = ie; }
+    __syncthreads();
+    int offl = il - nless, offe = ie - neq;
+    for (int w = 0; w < wave; ++w) { offl += red[w]; offe += red[KNN_WAVES + w]; }
+    // selected entries: the `below` smaller ones first (any order), then the ties in index order
+    int pl = offl, pe = offe;
+    for (int j = j0; j < j1; ++j) {
+        const uint32_t kj = keys[j];
+        if (kj < T) sel[pl++] = ((uint64_t)kj << 32) | (uint32_t)j;
+        else if (kj == T) {
+            if (pe < need) sel[below + pe] = ((uint64_t)kj << 32) | (uint32_t)j;
+            ++pe;
+        }
+    }
+    __syncthreads();
+    // ---- sort the K selected by (value, index): rank by counting
+    for (int t = tid; t < K; t += KNN_THREADS) {
+        const uint64_t mine = sel[t];
+        int rnk = 0;
+        for (int u = 0; u < K; ++u) rnk += (sel[u] < mine) ? 1 : 0;
+        idx_out[obase + rnk] = (int32_t)(uint32_t)(mine & 0xFFFFFFFFull);
+        rank_out[obase + rnk] = key2f((uint32_t)(mine >> 32));
+    }
+}
+
+template <int CDM>
+int launch_knn_large(const float* coors, const uint8_t* mask, const uint8_t* adj, int64_t adj_bstride, int B, int N,
+                     int K, int C, int32_t* idx_out, float* rank_out, hipStream_t s)
+{
+    const size_t lds = ((size_t)N * 4 + 7) / 8 * 8 + (size_t)K * 8 + (2 * KNN_WAVES + 2) * sizeof(int);
+    if (lds > 160 * 1024) return EGNN_E_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_select_large_kernel<CDM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((knn_select_large_kernel<CDM>), dim3(N, B), dim3(KNN_THREADS), lds, s, coors, mask, adj, adj_bstride, N, K, C,
+                       idx_out, rank_out);
+    return egnn_launch_status();
+}
+
 __global__ __launch_bounds__(256) void adj_max_degree_kernel(const uint8_t* __restrict__ adj, int64_t rows,
                                                               int N, int32_t* __restrict__ out)
 {
@@ -291,11 +420,15 @@ extern "C" int egnn_knn_select_f32(const float* coors, const uint8_t* mask, cons
     if (coor_dim < 1 || coor_dim > 8) return EGNN_E_UNSUPPORTED;
     const int C = coor_dim;
     if (K > N) return EGNN_E_K_GT_N;
-    // candidate keys live in registers (ceil(N / 64) per lane) and the graph's coordinates in LDS: N <= 8192 for 3-D coordinates
-    // (128 keys per lane, 104 KB), N <= 4096 otherwise
-    if (N > (C == 3 ? 8192 : 4096) || K > 1024) return EGNN_E_UNSUPPORTED;
-    if (B > 65535) return EGNN_E_UNSUPPORTED;
+    if (K > 1024 || B > 65535) return EGNN_E_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // candidate keys live in registers (ceil(N / 64) per lane) and the graph's coordinates in LDS: N <= 8192 for 3-D coordinates
+    // (128 keys per lane, 104 KB), N <= 4096 otherwise; larger graphs: one workgroup per row with the keys in LDS, up to 32 768 nodes
+    if (N > (C == 3 ? 8192 : 4096)) {
+        if (N > 32768) return EGNN_E_UNSUPPORTED;
+        return C == 3 ? launch_knn_large<3>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s)
+                      : launch_knn_large<8>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
+    }
     if (N <= 64) return launch_knn<1>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
     if (N <= 128) return launch_knn<2>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);
     if (N <= 256) return launch_knn<4>(coors, mask, adj, adj_batch_stride, B, N, K, C, idx_out, rank_out, s);

@@ -235,7 +235,9 @@ class EGNN(nn.Module):
         return out
 
     def _forward_hip(self, feats, coors, edges, mask, adj_mat, order_hint=None, want_u=False, drop=None):
-        if exact_active():
+        # more per-edge scalars than the split-fp16 edge kernels carry (2 fourier + 1 + edge_dim > 16, up to 64): the plain-fp32 kernels
+        wide_shape = 16 < 2 * self.fourier_features + 1 + self.edge_dim <= 64
+        if exact_active() or (wide_shape and not want_u and drop is None):
             if want_u or drop is not None:
                 raise NotImplementedError("the plain-fp32 (wide-range) kernels are inference-only: no backward, no training-mode dropout")
             return self._forward_exact(feats, coors, edges, mask, adj_mat)

@@ -76,7 +76,8 @@ int egnn_padded_hidden(int H);
  *          The diagonal is ignored (the reference clears it, :254).
  *   idx_out  (B,N,K) int32   neighbour indices, ascending rank; ties broken by ascending index
  *   rank_out (B,N,K) fp32    the ranking values of the selected neighbours (reference `nbhd_ranking`)
- * Limits: 1 <= K <= min(N, 1024), N <= 8192 for 3-D coordinates (the candidate keys of a row live in registers), N <= 4096 otherwise.
+ * Limits: 1 <= K <= min(N, 1024), N <= 32 768 (up to 8192 nodes with 3-D coordinates, 4096 otherwise, a wave keeps a row's candidate
+ * keys in registers; beyond that one workgroup per row keeps them in LDS: ~10 us per row).
  */
 int egnn_knn_select_f32(const float* coors, const uint8_t* mask, const uint8_t* adj,
                         int64_t adj_batch_stride, int B, int N, int K, int coor_dim,

@@ -29,6 +29,9 @@ def _dev(x):
     (16, 4, False, None), (64, 8, True, None), (100, 7, True, None), (256, 32, True, None),
     (1024, 32, True, None), (2048, 16, False, None), (300, 40, True, "random"), (64, 8, True, "chain"),
     (4096, 8, False, None), (33, 33, True, None), (1024, 100, True, None), (6000, 16, True, None), (8192, 32, False, None),
+    # beyond what a wave keeps in registers: one workgroup per row, keys in LDS; the second case has fewer valid
+    # nodes than K in its row set (ties at 1e5 straddle the K boundary: index-ordered pick)
+    (9000, 32, False, None), (8300, 700, True, None),
 ])
 def test_knn_select_bit_exact(n, k, use_mask, adj_kind):
     from egnn_pytorch_amd import _ops
@@ -37,7 +40,7 @@ def test_knn_select_bit_exact(n, k, use_mask, adj_kind):
     coors = rng.standard_normal((b, n, 3)).astype(np.float32)
     mask = None
     if use_mask:
-        lens = rng.integers(max(k, n // 2), n + 1, size=b)
+        lens = rng.integers(max(k, n // 2) if n != 8300 else 500, (n + 1) if n != 8300 else 600, size=b)
         mask = np.arange(n)[None, :] < lens[:, None]
     adj = None
     if adj_kind == "chain":
@@ -59,6 +62,22 @@ def test_knn_select_bit_exact(n, k, use_mask, adj_kind):
     # oracle and kernel share the tie policy (ascending index): everything must be identical
     np.testing.assert_array_equal(ref_val.view(np.uint32), rank.view(np.uint32))
     np.testing.assert_array_equal(ref_idx.astype(np.int32), idx)
+
+
+def test_knn_select_large_graph_other_coordinate_dimensions():
+    """N = 4500 with 5-D coordinates (a wave keeps at most 4096 such candidates): the workgroup-per-row kernel with the reference's
+    summation order for C = 5 (s0, s4, s1, s2, s3)."""
+    from egnn_pytorch_amd import _ops
+    rng = np.random.default_rng(45)
+    n, k = 4500, 24
+    coors = rng.standard_normal((1, n, 5)).astype(np.float32)
+    mask = (np.arange(n)[None, :] < 4100)
+    _, dist = O.pairwise(coors)
+    ranking, _ = O.build_ranking(dist, mask, None)
+    ref_val, ref_idx = O.topk_smallest(ranking, k)
+    idx, rank = _ops.knn_select(_dev(coors), _dev(mask), None, k)
+    np.testing.assert_array_equal(ref_val.view(np.uint32), rank.cpu().numpy().view(np.uint32))
+    np.testing.assert_array_equal(ref_idx.astype(np.int32), idx.cpu().numpy())
 
 
 @pytest.mark.parametrize("name", [g for g in golden_names()])

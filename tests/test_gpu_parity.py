@@ -562,6 +562,26 @@ def test_golden_on_the_plain_fp32_kernels(name):
     np.testing.assert_allclose(co.cpu().numpy(), d["coors_out"], atol=ATOL, rtol=0)
 
 
+def test_more_than_16_per_edge_scalars_run_on_the_plain_fp32_kernels():
+    """fourier_features = 8, edge_dim = 5: 22 per-edge scalars -- more than the split-fp16 edge kernels carry (16): inference goes to
+    csrc/edge_exact.hip (up to 64) instead of raising."""
+    from egnn_pytorch_amd import _ops
+    kw = dict(dim=24, fourier_features=8, edge_dim=5, num_nearest_neighbors=12, soft_edges=True, norm_coors=True)
+    cfg, params, net = _range_layer(kw, seed=23)
+    rng = np.random.default_rng(5)
+    b, n = 2, 40
+    feats = rng.standard_normal((b, n, 24)).astype(np.float32)
+    coors = rng.standard_normal((b, n, 3)).astype(np.float32)
+    edges = rng.standard_normal((b, n, n, 5)).astype(np.float32)
+    mask = np.arange(n)[None, :] < np.array([[n], [n - 7]])
+    with _ops.phase_timer() as pt:
+        node, co = net(_dev(feats), _dev(coors), _dev(edges), _dev(mask))
+    assert "edge_exact" in pt.summary() and "edge_fused" not in pt.summary()
+    ref = O.egnn_forward(cfg, params, feats, coors, edges, mask, None)
+    np.testing.assert_allclose(node.cpu().numpy(), ref[0], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(co.cpu().numpy(), ref[1], atol=ATOL, rtol=0)
+
+
 def test_plain_fp32_kernels_agree_with_the_fast_path_at_the_north_star_width():
     """dim 512, k 32, ragged mask: the two arithmetic classes on the same inputs -- both within 1e-4 of the oracle, and of each other."""
     from egnn_pytorch_amd import exact_arithmetic
