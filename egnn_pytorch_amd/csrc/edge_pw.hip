@@ -1,23 +1,33 @@
-// The edge pass of the k-NN layers as a PERSISTENT kernel with one wave per node (reference: egnn_pytorch/egnn_pytorch.py:262-333).
+// The edge pass of the k-NN layers with ONE WAVE PER NODE (reference: egnn_pytorch/egnn_pytorch.py:262-333).
 //
 // Same arithmetic, same operand layouts and -- for K <= 128 -- the same bits as edge_fused.hip's general kernel, for the shape every
 // k-NN configuration of BASELINE.json has: K % 32 == 0 neighbours, squared distance as the only per-edge scalar (no fourier
-// features, no edge features), m_dim <= 16, 3-D coordinates, the per-slot records of egnn_slot_prep_f32, inference.  What differs is
-// everything AROUND the hidden loop, which at 32 neighbours is 16 % of the general kernel's VALU instructions at dim 512 and 40 % at
-// dim 128 (505 M issued against 426 M in the loop, profiles/r03_final):
-//   * the grid is 5 workgroups per CU, once; a workgroup walks its node groups itself (XCD x takes a contiguous eighth of the node
-//     groups, its workgroups interleave over it: the working set of an XCD's L2 is the same ~160 consecutive groups as with one
-//     launch per group).  No workgroup launch / LDS allocation / argument load per 4 nodes, and the W2 / W_s staging ring never
-//     drains: the first chunk of the next node is in flight while the current node's epilogue runs.
+// features, no edge features), m_dim <= 16, 3-D coordinates, the per-slot records of egnn_slot_prep_f32, no training-mode dropout
+// (inference, and the forward under autograd: args.U_out).  The hidden loop is the general kernel's; what differs is everything
+// AROUND it, which at 32 neighbours was 16 % of the general kernel's VALU instructions at dim 512 and 40 % at dim 128 (505 M issued
+// against 426 M in the loop, profiles/r03_final) -- here 483 M / 159 M against 505 M / 173 M (profiles/r04_final):
 //   * one wave owns one node: its 32 k-slots per round are the wave's two MFMA tiles, rounds (K / 32) run back to back in the same
 //     wave and the per-node sums stay in registers (DPP butterfly over a tile's 16 edges) -- no cross-wave reduction, no LDS
-//     accumulators, no workgroup barrier outside the staging ring's one per chunk.
-//   * the next round's 32 slot records (512 B) are fetched by LDS-DMA into a wave-private buffer while the current round computes: the
-//     setup has no dependent global loads left; the epilogue re-reads x_i - x_j from the same LDS copy.
+//     accumulators, no workgroup barrier outside the staging ring's one per chunk of 64 hidden units;
 //   * the setup is written for this shape only (the general kernel carries fourier / edge-feature / dense / ragged-K paths as
-//     run-time branches through every tile).
+//     run-time branches through every tile); a round's 32 slot records (512 B) arrive by LDS-DMA in a wave-private buffer -- the next
+//     round's while the current one computes -- and the epilogue re-reads x_i - x_j from the same LDS copy;
+//   * kernel arguments are read per phase through a pointer the optimiser cannot see through (pw_args): nothing of the ~40 fields
+//     stays live -- or spilled -- across the hidden loop; per-lane addresses of the epilogue constants are not hoisted (pw_opaque);
+//     the staging ring's LDS-DMA uses a scalar base + 32-bit lane offset (no 64-bit vector address arithmetic per chunk);
 //   * the residual of the hidden value's hi/lo split runs as v_mfma_f32_4x4x4_16B_f16 (lane-local: D = C - B with A = -I4, two
-//     passes on the matrix pipe) instead of v_mfma_f32_16x16x16_f16 (four): bit-identical, half the matrix-pipe time.
+//     passes on the matrix pipe) instead of v_mfma_f32_16x16x16_f16 (four): bit-identical, half the matrix-pipe time (-2 %);
+//   * the layer's last step, of which only 2 hidden units are real whenever dim % 8 == 0, skips its padding block (-2 %);
+//   * the node's 16 message channels leave as one 8-byte store per packed image.
+// Scheduling: one workgroup (4 waves = 4 Morton-adjacent nodes) per node group, dispatched dynamically.  The kernel CAN walk several
+// groups per workgroup (EGNN_PW_GRID_MULT; ring and record prefetch continue across groups) and was first built fully persistent --
+// 5 workgroups per CU, equal static shares: 10 % SLOWER (1.54 vs 1.39 ms at the north-star shape, same box): with equal shares
+// fixed at launch the five workgroups of a CU stay in step, their latency-bound setups and epilogues coincide instead of hiding under
+// each other's hidden loops, and it is the dispatcher's staggered refill that de-phases them (egnn_edge_pw_launch below).
+// Also measured and not kept (profiles/r04_experiments/): W2 / W_s fragments straight from global memory instead of the LDS ring
+// (no barriers, but +2.5 KB of vector-memory traffic per wave-step: +22 %); a 32-column ring at six workgroups per CU (a barrier per
+// step: +3 %); the first Linear as one v_mfma_f32_32x32x16_f16 per (tile, 64 hidden units) (+8 %: a tile at a time leaves the wave
+// nothing to issue under the MFMA's latency).
 #include <type_traits>
 #include "egnn_common.h"
 #include "egnn_lds_dma.h"
@@ -423,17 +433,22 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
         float cscale = 0.f;
         if (coors_scale) cscale = coors_scale[0];
         const float w2_inv_scale = pe->w2_inv_scale;
+        float* const u_out = pe->U_out;
 
         float cw[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 m;
             bool bad = false;
+            f32x4 uu;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 bad = bad || !(fabsf(acc[t][u]) < __builtin_inff());
-                m[u] = egnn_silu(acc[t][u] * w2_inv_scale + b2r[u]);
+                uu[u] = acc[t][u] * w2_inv_scale + b2r[u];
+                m[u] = egnn_silu(uu[u]);
             }
+            // forward under autograd: u = W2 SiLU(x) + b2, what the backward differentiates from (one 16-float row per edge (b, i, k))
+            if (u_out && live) *reinterpret_cast<f32x4*>(u_out + ((bN + i) * (size_t)K + 32 * r + 16 * t + e) * 16 + g4) = uu;
             float part = gwr[0] * m[0] + gwr[1] * m[1] + gwr[2] * m[2] + gwr[3] * m[3];
             egnn_flag_range(status, bad && fm[t], EGNN_RANGE_HIDDEN);
             if (gate_w) {                                                      // soft_edges (:289-290)
@@ -640,7 +655,7 @@ int egnn_edge_pw_launch(const egnn_edge_args* args, void* stream)
     if (a.coor_dim != 3 || a.K < 32 || (a.K % 32) != 0 || a.K > 4096) return EGNN_E_UNSUPPORTED;
     if (a.S != 1 || a.fourier != 0 || a.edge_dim != 0 || a.m_dim > 16 || a.wst_terms != 4) return EGNN_E_UNSUPPORTED;
     if (!a.slots || !a.idx || !a.pi_split) return EGNN_E_UNSUPPORTED;
-    if (a.drop_thr || a.U_out) return EGNN_E_UNSUPPORTED;                 // inference only: the training forward keeps the general kernel
+    if (a.drop_thr) return EGNN_E_UNSUPPORTED;                            // training-mode dropout keeps the general kernel (its MODE 3)
     if ((int64_t)a.B * a.N * a.K * 16 > 0xffffffffLL) return EGNN_E_UNSUPPORTED;       // slot records behind one 32-bit buffer resource
     if ((int64_t)a.N * a.ldp * 4 > 0xffffffffLL) return EGNN_E_UNSUPPORTED;
     int dev = 0, cus = 0;

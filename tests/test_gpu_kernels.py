@@ -678,3 +678,31 @@ def test_persistent_edge_kernel_equals_the_general_one(b, n, k, dim, kw, ragged)
     assert torch.equal(new[0], again[0]) and torch.equal(new[1], again[1])
     assert torch.equal(new[0], ref[0]), float((new[0] - ref[0]).abs().max())
     assert torch.equal(new[1], ref[1]), float((new[1] - ref[1]).abs().max())
+
+
+@pytest.mark.parametrize("b,n,k,dim,ragged", [(2, 150, 32, 64, True), (1, 80, 64, 32, False)])
+def test_wave_per_node_kernel_writes_the_same_u_for_the_backward(b, n, k, dim, ragged):
+    """The forward under autograd keeps u = edge_mlp.3(SiLU(edge_mlp.0(.))) (E x 16), written by the edge kernel on the side
+    (egnn_edge_args.U_out): the wave-per-node kernel's against the general kernel's, bit for bit, outputs included."""
+    from egnn_pytorch_amd import EGNN, layer as L
+    g = torch.Generator().manual_seed(n + k)
+    layer = EGNN(dim=dim, num_nearest_neighbors=k)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.xavier_normal_(m.weight, generator=g)
+    layer = layer.cuda().eval()
+    feats = torch.randn(b, n, dim, generator=g).cuda()
+    coors = torch.randn(b, n, 3, generator=g).cuda()
+    mask = (torch.arange(n)[None] < torch.randint(max(k, n // 2), n + 1, (b, 1), generator=g)).cuda() if ragged else None
+    old = L._EDGE_ALGO
+    res = {}
+    try:
+        for algo in (1, 0):
+            L._EDGE_ALGO = algo
+            out = layer._forward_hip_checked(feats, coors, None, mask, None, None, want_u=True)
+            res[algo] = (out[0], out[1], out[6])
+    finally:
+        L._EDGE_ALGO = old
+    assert res[0][2] is not None and res[0][2].shape == (b * n * k, 16)
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y)
