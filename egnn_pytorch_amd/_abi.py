@@ -12,11 +12,11 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 30
+ABI_VERSION = 31
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -32,6 +32,7 @@ SYMBOLS = (
     "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32", "egnn_split_scaled_both_f16", "egnn_silu_bwd_f32", "egnn_silu_bwd_drop_f32",
     "egnn_linear_hl_drop_f32",
     "egnn_linear_f32", "egnn_node_prep_f32", "egnn_edge_exact_f32", "egnn_edge_exact_workspace_bytes",
+    "egnn_knn_select_f64", "egnn_linear_f64", "egnn_node_prep_f64", "egnn_edge_exact_f64",
 )
 
 
@@ -61,7 +62,7 @@ class EdgeArgs(Structure):
 
 
 class EdgeExactArgs(Structure):
-    """Mirror of `struct egnn_edge_exact_args` (include/egnn_hip.h): the edge pass in plain fp32 (wide-range path)."""
+    """Mirror of `struct egnn_edge_exact_args` (include/egnn_hip.h): the edge pass in plain fp32 (wide-range path) / float64."""
     _fields_ = [
         ("B", c_int32), ("N", c_int32), ("K", c_int32), ("m_dim", c_int32), ("H", c_int32), ("fourier", c_int32),
         ("edge_dim", c_int32), ("coor_dim", c_int32), ("pool_mean", c_int32), ("edges_by_k", c_int32),
@@ -69,7 +70,7 @@ class EdgeExactArgs(Structure):
         ("W2", c_void_p), ("b2", c_void_p), ("gate_w", c_void_p), ("gate_b", c_void_p),
         ("W3", c_void_p), ("b3", c_void_p), ("W4", c_void_p), ("b4", c_void_p), ("coors_scale", c_void_p),
         ("coors", c_void_p), ("edges", c_void_p), ("mask", c_void_p), ("idx", c_void_p), ("rank", c_void_p),
-        ("valid_radius", c_float), ("clamp", c_float),
+        ("valid_radius", c_double), ("clamp", c_double),
         ("m_i", c_void_p), ("coors_out", c_void_p), ("edge_ws", c_void_p),
     ]
 
@@ -298,6 +299,15 @@ def load():
     lib.egnn_node_prep_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]
     lib.egnn_edge_exact_f32.restype = c_int
     lib.egnn_edge_exact_f32.argtypes = [POINTER(EdgeExactArgs), c_void_p]
+    lib.egnn_edge_exact_f64.restype = c_int
+    lib.egnn_edge_exact_f64.argtypes = [POINTER(EdgeExactArgs), c_void_p]
+    lib.egnn_knn_select_f64.restype = c_int
+    lib.egnn_knn_select_f64.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    lib.egnn_linear_f64.restype = c_int
+    lib.egnn_linear_f64.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                    c_int, c_void_p]
+    lib.egnn_node_prep_f64.restype = c_int
+    lib.egnn_node_prep_f64.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_int, c_int, c_void_p]
     lib.egnn_edge_exact_workspace_bytes.restype = c_size_t
     lib.egnn_edge_exact_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, c_int]
     if lib.egnn_abi_version() != ABI_VERSION:

@@ -175,10 +175,12 @@ def check_range(device=None, wait=True):
 
 
 def knn_select(coors, mask, adj_mat, k):
-    """(idx int32 (B,N,K), rank fp32 (B,N,K)) -- egnn_knn_select_f32."""
+    """(idx int32 (B,N,K), rank (B,N,K) in the coordinates' dtype) -- egnn_knn_select_f32; float64 coordinates (a float64 module):
+    egnn_knn_select_f64."""
     b, n, cdim = coors.shape
+    f64 = coors.dtype == torch.float64
     idx = empty(b, n, k, dtype=torch.int32, device=coors.device)
-    rank = empty(b, n, k, dtype=torch.float32, device=coors.device)
+    rank = empty(b, n, k, dtype=coors.dtype, device=coors.device)
     m8 = _u8(mask)
     a8 = _u8(adj_mat)
     stride = 0
@@ -190,9 +192,9 @@ def knn_select(coors, mask, adj_mat, k):
         elif a8.shape != (n, n):
             raise ValueError(f"adj_mat shape {tuple(a8.shape)} != {(n, n)}")
     with _timed("knn_select"):
-        rc = _abi.load().egnn_knn_select_f32(_ptr(coors), _ptr(m8), _ptr(a8), stride, b, n, k, cdim,
-                                             _ptr(idx), _ptr(rank), _stream())
-    _abi.check(rc, "egnn_knn_select_f32")
+        fn = _abi.load().egnn_knn_select_f64 if f64 else _abi.load().egnn_knn_select_f32
+        rc = fn(_ptr(coors), _ptr(m8), _ptr(a8), stride, b, n, k, cdim, _ptr(idx), _ptr(rank), _stream())
+    _abi.check(rc, "egnn_knn_select_f64" if f64 else "egnn_knn_select_f32")
     return idx, rank
 
 
@@ -330,41 +332,43 @@ def linear_f32(a, w, n, k, bias=None, residual=None, act=0, out=None, name="line
     """act(a @ w[:n, :k].T + bias) (+ residual) in exact fp32 (v_mfma_f32_32x32x2_f32) -- egnn_linear_f32.  a (M, >= k) and w
     (>= n rows, row stride w.stride(0)) may be column slices of wider tensors (unit column stride); `out` likewise (M, >= n)."""
     m = a.shape[0]
-    assert a.stride(1) == 1 and w.stride(1) == 1 and a.dtype == torch.float32 and w.dtype == torch.float32
+    assert a.stride(1) == 1 and w.stride(1) == 1 and a.dtype == w.dtype and a.dtype in (torch.float32, torch.float64)
+    f64 = a.dtype == torch.float64                   # (a float64 module: egnn_linear_f64, v_mfma_f64_16x16x4_f64)
     if out is None:
-        out = empty(m, n, dtype=torch.float32, device=a.device)
+        out = empty(m, n, dtype=a.dtype, device=a.device)
     assert out.stride(1) == 1 and out.shape[0] == m
     ldr = 0
     if residual is not None:
         assert residual.stride(1) == 1 and residual.shape[0] == m
         ldr = residual.stride(0)
     with _timed(name):
-        rc = _abi.load().egnn_linear_f32(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(residual), ldr,
-                                         _ptr(out), out.stride(0), m, n, k, act, _stream())
-    _abi.check(rc, "egnn_linear_f32")
+        fn = _abi.load().egnn_linear_f64 if f64 else _abi.load().egnn_linear_f32
+        rc = fn(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(residual), ldr, _ptr(out), out.stride(0), m, n, k, act, _stream())
+    _abi.check(rc, "egnn_linear_f64" if f64 else "egnn_linear_f32")
     return out
 
 
 def node_prep_f32(feats2d, m_i, gamma, beta, eps, m_dim):
-    """[LayerNorm(feats) | m_i] as a plain fp32 (rows, dim + m_dim) matrix -- egnn_node_prep_f32."""
+    """[LayerNorm(feats) | m_i] as a plain (rows, dim + m_dim) matrix in feats2d's dtype -- egnn_node_prep_f32 / egnn_node_prep_f64."""
     rows, dim = feats2d.shape
-    out = empty(rows, dim + m_dim, dtype=torch.float32, device=feats2d.device)
+    out = empty(rows, dim + m_dim, dtype=feats2d.dtype, device=feats2d.device)
     with _timed("node_prep_f32"):
-        rc = _abi.load().egnn_node_prep_f32(_ptr(feats2d), _ptr(m_i), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), rows, dim, m_dim,
-                                            _stream())
+        fn = _abi.load().egnn_node_prep_f64 if feats2d.dtype == torch.float64 else _abi.load().egnn_node_prep_f32
+        rc = fn(_ptr(feats2d), _ptr(m_i), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), rows, dim, m_dim, _stream())
     _abi.check(rc, "egnn_node_prep_f32")
     return out
 
 
-def edge_exact(args: "_abi.EdgeExactArgs", device):
-    """egnn_edge_exact_f32; allocates the per-edge workspace the entry asks for."""
+def edge_exact(args: "_abi.EdgeExactArgs", device, dtype=torch.float32):
+    """egnn_edge_exact_f32 / egnn_edge_exact_f64 (dtype: what the data pointers of args hold); allocates the per-edge workspace the
+    entry asks for."""
     lib = _abi.load()
     nbytes = lib.egnn_edge_exact_workspace_bytes(args.B, args.N, args.K, args.m_dim, args.coor_dim)
-    ws = empty(max(1, nbytes // 4), dtype=torch.float32, device=device)
+    ws = empty(max(1, nbytes // 4), dtype=dtype, device=device)
     args.edge_ws = ws.data_ptr()
     with _timed("edge_exact"):
-        rc = lib.egnn_edge_exact_f32(byref(args), _stream())
-    _abi.check(rc, "egnn_edge_exact_f32")
+        rc = (lib.egnn_edge_exact_f64 if dtype == torch.float64 else lib.egnn_edge_exact_f32)(byref(args), _stream())
+    _abi.check(rc, "egnn_edge_exact_f64" if dtype == torch.float64 else "egnn_edge_exact_f32")
     return ws
 
 

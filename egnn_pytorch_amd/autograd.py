@@ -331,7 +331,8 @@ class EGNNFunction(torch.autograd.Function):
         if layer.dropout_active():
             from . import _dropout
             drop = (layer.dropout_p, _dropout.draw_seed())
-        native = _NATIVE and layer.m_dim <= 16 and coors.shape[-1] == 3 and (drop is None or _dropout_native_ok(layer))
+        native = (_NATIVE and layer.m_dim <= 16 and coors.shape[-1] == 3 and (drop is None or _dropout_native_ok(layer))
+                  and not layer.float64_kernels())           # (a float64 module: float64 forward kernels, float64 recompute backward)
         with torch.no_grad():
             node_out, coors_out, order, idx, rank, valid_radius, u_pre, proj = layer._forward_hip_checked(
                 feats, coors, edges, mask, adj_mat, order_hint, want_u=native, drop_seed=None if drop is None else drop[1])

@@ -1,4 +1,4 @@
-// The edge pass in plain fp32 (reference: egnn_pytorch/egnn_pytorch.py:262-333) -- the WIDE-RANGE path.
+// The edge pass in plain fp32 / fp64 (reference: egnn_pytorch/egnn_pytorch.py:262-333) -- the WIDE-RANGE path and the float64 path.
 //
 // The fast kernels (edge_fused.hip / edge_pw.hip) evaluate every product as a split-fp16 product on the matrix cores: fp32-class
 // accuracy, but an activation beyond fp16's 65504 cannot be carried and the call ends with a range status bit.
@@ -7,6 +7,8 @@
 // VALU instruction on unscaled operands, exactly the arithmetic class of the reference (fp32 products, fp32 accumulation, overflow
 // only where fp32 itself overflows), with the weights read as the module holds them (no re-layout).  It is several times slower
 // than the fast path (16 FMAs per hidden value instead of 3/16 of an MFMA) and is never what bench.py times.
+// Instantiated for double as well (egnn_edge_exact_f64): a float64 module -- the reference is dtype-generic and its own tests run in
+// float64, tests/test_equivariance.py:6 -- computes in float64 on these kernels, not at the fast path's fp32-class precision.
 //
 //   kernel 1, one thread per edge (b, i, k):  x[h] = P_i[i,h] + P_j[j,h] + sum_s scal[s] W_s[h,s];  a = SiLU(x);
 //             u[c] += W2[c,h] a  (the weights are wave-uniform: scalar loads);  m = SiLU(u + b2) (* gate);  coors_mlp;  masks, clamp,
@@ -19,11 +21,71 @@ namespace {
 constexpr int EX_THREADS = 256;
 constexpr int EX_SMAX = 64;                  // per-edge scalars 2 F + 1 + edge_dim (the fast path stops at 16)
 
-// (expf, not the fast exponential of the split-f16 kernels: this path trades speed for the reference's arithmetic class)
-__device__ __forceinline__ float ex_silu(float x) { return x / (1.0f + expf(-x)); }
+// (exp, not the fast exponential of the split-f16 kernels: this path trades speed for the reference's arithmetic class)
+__device__ __forceinline__ float ex_exp(float x) { return expf(x); }
+__device__ __forceinline__ double ex_exp(double x) { return exp(x); }
+__device__ __forceinline__ float ex_sin(float x) { return sinf(x); }
+__device__ __forceinline__ double ex_sin(double x) { return sin(x); }
+__device__ __forceinline__ float ex_cos(float x) { return cosf(x); }
+__device__ __forceinline__ double ex_cos(double x) { return cos(x); }
+__device__ __forceinline__ float ex_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double ex_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float ex_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double ex_fma(double a, double b, double c) { return fma(a, b, c); }
+template <typename T>
+__device__ __forceinline__ T ex_silu(T x) { return x / ((T)1 + ex_exp(-x)); }
 
-template <int MB>                            // message channels held in registers: 16 / 32 / 64
-__global__ __launch_bounds__(EX_THREADS) void edge_exact_kernel(const egnn_edge_exact_args p)
+// x_i - x_j and the squared distance in the reference's operation order (what the neighbour selection ranked by): fp32 through the
+// helpers that are bit-exact against ATen (egnn_common.h); float64 the same order, no FMA contraction
+__device__ __forceinline__ float ex_sqdist(const float* ci, const float* cj, int C, float (&rel)[8])
+{
+    if (C == 3) {
+        const float d = egnn_sqdist(ci[0], ci[1], ci[2], cj[0], cj[1], cj[2], rel[0], rel[1], rel[2]);
+#pragma unroll
+        for (int c = 3; c < 8; ++c) rel[c] = 0.f;
+        return d;
+    }
+    float a[8], bb[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { a[c] = c < C ? ci[c] : 0.f; bb[c] = c < C ? cj[c] : 0.f; }
+    return egnn_sqdist_n<8>(a, bb, C, rel);
+}
+__device__ __forceinline__ double ex_sqdist(const double* ci, const double* cj, int C, double (&rel)[8])
+{
+    return egnn_sqdist_f64(ci, cj, C, rel);
+}
+
+// the argument block with its data pointers typed (float for egnn_edge_exact_f32, double for egnn_edge_exact_f64)
+template <typename T>
+struct ExArgs {
+    int B, N, K, m_dim, H, fourier, edge_dim, coor_dim, pool_mean, edges_by_k;
+    const T *Pi, *Pj, *Ws, *W2, *b2, *gate_w, *gate_b, *W3, *b3, *W4, *b4, *coors_scale, *coors, *edges, *rank;
+    int64_t ldp, ldws;
+    const uint8_t* mask;
+    const int32_t* idx;
+    T valid_radius, clamp;
+    T *m_i, *coors_out, *edge_ws;
+};
+template <typename T>
+ExArgs<T> ex_args(const egnn_edge_exact_args& a)
+{
+    ExArgs<T> p;
+    p.B = a.B; p.N = a.N; p.K = a.K; p.m_dim = a.m_dim; p.H = a.H; p.fourier = a.fourier; p.edge_dim = a.edge_dim;
+    p.coor_dim = a.coor_dim; p.pool_mean = a.pool_mean; p.edges_by_k = a.edges_by_k;
+    p.Pi = static_cast<const T*>(a.Pi); p.Pj = static_cast<const T*>(a.Pj); p.Ws = static_cast<const T*>(a.Ws);
+    p.W2 = static_cast<const T*>(a.W2); p.b2 = static_cast<const T*>(a.b2);
+    p.gate_w = static_cast<const T*>(a.gate_w); p.gate_b = static_cast<const T*>(a.gate_b);
+    p.W3 = static_cast<const T*>(a.W3); p.b3 = static_cast<const T*>(a.b3); p.W4 = static_cast<const T*>(a.W4); p.b4 = static_cast<const T*>(a.b4);
+    p.coors_scale = static_cast<const T*>(a.coors_scale); p.coors = static_cast<const T*>(a.coors);
+    p.edges = static_cast<const T*>(a.edges); p.rank = static_cast<const T*>(a.rank);
+    p.ldp = a.ldp; p.ldws = a.ldws; p.mask = a.mask; p.idx = a.idx;
+    p.valid_radius = (T)a.valid_radius; p.clamp = (T)a.clamp;
+    p.m_i = static_cast<T*>(a.m_i); p.coors_out = static_cast<T*>(a.coors_out); p.edge_ws = static_cast<T*>(a.edge_ws);
+    return p;
+}
+
+template <typename T, int MB>                // message channels held in registers: 16 / 32 / 64
+__global__ __launch_bounds__(EX_THREADS) void edge_exact_kernel(const ExArgs<T> p)
 {
     const int64_t E = (int64_t)p.B * p.N * p.K;
     const int64_t q = (int64_t)blockIdx.x * EX_THREADS + threadIdx.x;
@@ -37,64 +99,50 @@ __global__ __launch_bounds__(EX_THREADS) void edge_exact_kernel(const egnn_edge_
     const int j = p.idx ? p.idx[q] : k;
 
     // x_i - x_j and the squared distance, in the reference's operation order (egnn_common.h): what the neighbour selection ranked by
-    float rel[8];
-    float d;
-    {
-        const float* ci = p.coors + (bN + i) * C;
-        const float* cj = p.coors + (bN + j) * C;
-        if (C == 3) {
-            d = egnn_sqdist(ci[0], ci[1], ci[2], cj[0], cj[1], cj[2], rel[0], rel[1], rel[2]);
-#pragma unroll
-            for (int c = 3; c < 8; ++c) rel[c] = 0.f;
-        } else {
-            float a[8], bb[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { a[c] = c < C ? ci[c] : 0.f; bb[c] = c < C ? cj[c] : 0.f; }
-            d = egnn_sqdist_n<8>(a, bb, C, rel);
-        }
-    }
+    T rel[8];
+    const T d = ex_sqdist(p.coors + (bN + i) * C, p.coors + (bN + j) * C, C, rel);
     // per-edge scalars [sin(d / 2^f) ..., cos(d / 2^f) ..., d, edge features ...]  (:34-41, :270-272, :282-285): a column of LDS per
     // thread (S x 256 floats, dynamic; scalar s of thread t at [s * 256 + t]: conflict-free) -- a run-time indexed private array
     // would live in scratch memory
-    extern __shared__ float scal_lds[];
-    float* const scal = scal_lds + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) char scal_raw[];
+    T* const scal = reinterpret_cast<T*>(scal_raw) + threadIdx.x;
     for (int f = 0; f < F; ++f) {
-        const float x = d / exp2f((float)f);
-        scal[f * EX_THREADS] = sinf(x);
-        scal[(F + f) * EX_THREADS] = cosf(x);
+        const T x = d / (T)(1u << f);                                    // (x / 2^f, :36-38; F <= 31)
+        scal[f * EX_THREADS] = ex_sin(x);
+        scal[(F + f) * EX_THREADS] = ex_cos(x);
     }
     scal[2 * F * EX_THREADS] = d;
     if (p.edge_dim > 0) {
-        const float* ep = p.edges + (p.edges_by_k ? (size_t)q : ((size_t)(bN + i) * N + j)) * p.edge_dim;
+        const T* ep = p.edges + (p.edges_by_k ? (size_t)q : ((size_t)(bN + i) * N + j)) * p.edge_dim;
         for (int s = 0; s < p.edge_dim; ++s) scal[(2 * F + 1 + s) * EX_THREADS] = ep[s];
     }
 
     // ---- edge_mlp: Linear (factorised: node-level projections + the scalars' columns), SiLU, Linear
-    const float* pi = p.Pi + (bN + i) * p.ldp;
-    const float* pj = p.Pj + (bN + j) * p.ldp;
-    float u[MB];
+    const T* pi = p.Pi + (bN + i) * p.ldp;
+    const T* pj = p.Pj + (bN + j) * p.ldp;
+    T u[MB];
 #pragma unroll
-    for (int c = 0; c < MB; ++c) u[c] = 0.f;
+    for (int c = 0; c < MB; ++c) u[c] = (T)0;
     for (int h = 0; h < H; ++h) {
-        float x = pi[h] + pj[h];
-        const float* ws = p.Ws + (size_t)h * p.ldws;
-        if (S == 1) x = fmaf(d, ws[0], x);                               // (the common case stays in a register)
-        else for (int s = 0; s < S; ++s) x = fmaf(scal[s * EX_THREADS], ws[s], x);
-        const float a = ex_silu(x);
-        const float* w2 = p.W2 + h;
+        T x = pi[h] + pj[h];
+        const T* ws = p.Ws + (size_t)h * p.ldws;
+        if (S == 1) x = ex_fma(d, ws[0], x);                             // (the common case stays in a register)
+        else for (int s = 0; s < S; ++s) x = ex_fma(scal[s * EX_THREADS], ws[s], x);
+        const T a = ex_silu(x);
+        const T* w2 = p.W2 + h;
 #pragma unroll
         for (int c = 0; c < MB; ++c)
-            if (c < m_dim) u[c] = fmaf(w2[(size_t)c * H], a, u[c]);
+            if (c < m_dim) u[c] = ex_fma(w2[(size_t)c * H], a, u[c]);
     }
-    float m[MB];
+    T m[MB];
 #pragma unroll
-    for (int c = 0; c < MB; ++c) m[c] = c < m_dim ? ex_silu(u[c] + p.b2[c]) : 0.f;
+    for (int c = 0; c < MB; ++c) m[c] = c < m_dim ? ex_silu(u[c] + p.b2[c]) : (T)0;
     if (p.gate_w) {                                                      // soft_edges (:289-290)
-        float gsum = p.gate_b[0];
+        T gsum = p.gate_b[0];
 #pragma unroll
         for (int c = 0; c < MB; ++c)
-            if (c < m_dim) gsum = fmaf(p.gate_w[c], m[c], gsum);
-        const float gt = 1.0f / (1.0f + expf(-gsum));
+            if (c < m_dim) gsum = ex_fma(p.gate_w[c], m[c], gsum);
+        const T gt = (T)1 / ((T)1 + ex_exp(-gsum));
 #pragma unroll
         for (int c = 0; c < MB; ++c) m[c] *= gt;
     }
@@ -107,43 +155,45 @@ __global__ __launch_bounds__(EX_THREADS) void edge_exact_kernel(const egnn_edge_
         if (p.rank && p.idx) keep = keep && (p.rank[q] <= p.valid_radius);
     }
 
-    float* row = p.edge_ws + (size_t)q * (m_dim + C + 1);
+    T* row = p.edge_ws + (size_t)q * (m_dim + C + 1);
     // ---- coors_mlp, CoorsNorm, clamp (:302-317)
     if (p.W3) {
         const int hid = 4 * m_dim;
-        float cw = p.b4[0];
+        T cw = p.b4[0];
         for (int r = 0; r < hid; ++r) {
-            float z = p.b3[r];
-            const float* w3 = p.W3 + (size_t)r * m_dim;
+            T z = p.b3[r];
+            const T* w3 = p.W3 + (size_t)r * m_dim;
 #pragma unroll
             for (int c = 0; c < MB; ++c)
-                if (c < m_dim) z = fmaf(w3[c], m[c], z);
-            cw = fmaf(p.W4[r], ex_silu(z), cw);
+                if (c < m_dim) z = ex_fma(w3[c], m[c], z);
+            cw = ex_fma(p.W4[r], ex_silu(z), cw);
         }
-        float inv = 1.f;
+        T inv = (T)1;
         if (p.coors_scale) {                                             // CoorsNorm (:67-77)
-            float n2 = 0.f;
+            T n2 = (T)0;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) n2 = fmaf(rel[c], rel[c], n2);
-            inv = p.coors_scale[0] / fmaxf(sqrtf(n2), 1e-8f);
+            for (int c = 0; c < 8; ++c) n2 = ex_fma(rel[c], rel[c], n2);
+            const T nrm = ex_sqrt(n2);
+            inv = p.coors_scale[0] / (nrm > (T)1e-8 ? nrm : (T)1e-8);
         }
-        if (has_mask && !keep) cw = 0.f;                                 // :308-309
-        if (p.clamp >= 0.f) cw = fminf(fmaxf(cw, -p.clamp), p.clamp);    // :311-313
+        if (has_mask && !keep) cw = (T)0;                                // :308-309
+        if (p.clamp >= (T)0) cw = cw < -p.clamp ? -p.clamp : (cw > p.clamp ? p.clamp : cw);      // :311-313
 #pragma unroll
         for (int c = 0; c < 8; ++c)
             if (c < C) row[m_dim + c] = cw * (rel[c] * inv);
     } else {
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            if (c < C) row[m_dim + c] = 0.f;
+            if (c < C) row[m_dim + c] = (T)0;
     }
 #pragma unroll
     for (int c = 0; c < MB; ++c)
-        if (c < m_dim) row[c] = (has_mask && !keep) ? 0.f : m[c];        // masked_fill (:320-322)
-    row[m_dim + C] = keep ? 1.f : 0.f;
+        if (c < m_dim) row[c] = (has_mask && !keep) ? (T)0 : m[c];       // masked_fill (:320-322)
+    row[m_dim + C] = keep ? (T)1 : (T)0;
 }
 
-__global__ __launch_bounds__(EX_THREADS) void edge_exact_pool_kernel(const egnn_edge_exact_args p)
+template <typename T>
+__global__ __launch_bounds__(EX_THREADS) void edge_exact_pool_kernel(const ExArgs<T> p)
 {
     const int C = p.coor_dim, m_dim = p.m_dim, K = p.K;
     const int nch = m_dim + C;
@@ -153,22 +203,60 @@ __global__ __launch_bounds__(EX_THREADS) void edge_exact_pool_kernel(const egnn_
     const int64_t node = o / nch;
     const int ch = (int)(o - node * nch);
     const int ld = m_dim + C + 1;
-    const float* rows = p.edge_ws + (size_t)node * K * ld;
-    float s = 0.f, cnt = 0.f;
+    const T* rows = p.edge_ws + (size_t)node * K * ld;
+    T s = (T)0, cnt = (T)0;
     for (int k = 0; k < K; ++k) {                                        // k order: deterministic
         s += rows[(size_t)k * ld + ch];
         cnt += rows[(size_t)k * ld + m_dim + C];
     }
     if (ch < m_dim) {
         if (p.pool_mean) {
-            if (p.mask) s = (cnt == 0.f) ? 0.f : s / fmaxf(cnt, 1e-8f);  // safe_div (:13-16, :326-327)
-            else s = s / (float)K;                                       // :330
+            if (p.mask) s = (cnt == (T)0) ? (T)0 : s / (cnt > (T)1e-8 ? cnt : (T)1e-8);  // safe_div (:13-16, :326-327)
+            else s = s / (T)K;                                           // :330
         }
         if (p.m_i) p.m_i[node * m_dim + ch] = s;
     } else if (p.coors_out) {
         const int c = ch - m_dim;
         p.coors_out[node * C + c] = p.coors[node * C + c] + s;           // :315
     }
+}
+
+template <typename T>
+int edge_exact_launch(const egnn_edge_exact_args* args, void* stream)
+{
+    if (!args) return EGNN_E_NULLPTR;
+    const egnn_edge_exact_args& a = *args;
+    if (!a.Pi || !a.Pj || !a.Ws || !a.W2 || !a.b2 || !a.coors || !a.edge_ws) return EGNN_E_NULLPTR;
+    if (!a.m_i && !a.coors_out) return EGNN_E_NULLPTR;
+    if (a.B <= 0 || a.N <= 0 || a.K <= 0 || a.H <= 0 || a.ldp < a.H || a.ldws < 2 * a.fourier + 1 + a.edge_dim) return EGNN_E_SHAPE;
+    if (a.m_dim < 1 || a.m_dim > 64 || a.coor_dim < 1 || a.coor_dim > 8) return EGNN_E_UNSUPPORTED;
+    if (a.fourier < 0 || a.fourier > 31 || a.edge_dim < 0 || 2 * a.fourier + 1 + a.edge_dim > EX_SMAX) return EGNN_E_UNSUPPORTED;
+    if (a.edge_dim > 0 && !a.edges) return EGNN_E_NULLPTR;
+    if (a.coors_out && (!a.W3 || !a.b3 || !a.W4 || !a.b4)) return EGNN_E_NULLPTR;
+    if (a.gate_w && !a.gate_b) return EGNN_E_NULLPTR;
+    if (!a.idx && a.K != a.N) return EGNN_E_SHAPE;                        // dense path: K == N
+    const int64_t E = (int64_t)a.B * a.N * a.K;
+    const int64_t blocks = (E + EX_THREADS - 1) / EX_THREADS;
+    if (blocks > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const ExArgs<T> p = ex_args<T>(a);
+    const size_t lds = (size_t)(2 * a.fourier + 1 + a.edge_dim) * EX_THREADS * sizeof(T);      // <= 64 KB (fp32) / 128 KB (fp64)
+    auto run = [&](auto kern) -> int {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, p);
+        return egnn_launch_status();
+    };
+    int rc;
+    if (a.m_dim <= 16) rc = run(edge_exact_kernel<T, 16>);
+    else if (a.m_dim <= 32) rc = run(edge_exact_kernel<T, 32>);
+    else rc = run(edge_exact_kernel<T, 64>);
+    if (rc != EGNN_OK) return rc;
+    const int64_t total = (int64_t)a.B * a.N * (a.m_dim + a.coor_dim);
+    hipLaunchKernelGGL(edge_exact_pool_kernel<T>, dim3((unsigned)((total + EX_THREADS - 1) / EX_THREADS)), dim3(EX_THREADS), 0, s, p);
+    return egnn_launch_status();
 }
 
 }  // namespace
@@ -179,30 +267,6 @@ extern "C" size_t egnn_edge_exact_workspace_bytes(int B, int N, int K, int m_dim
     return (size_t)B * N * K * (size_t)(m_dim + coor_dim + 1) * sizeof(float);
 }
 
-extern "C" int egnn_edge_exact_f32(const egnn_edge_exact_args* args, void* stream)
-{
-    if (!args) return EGNN_E_NULLPTR;
-    const egnn_edge_exact_args& a = *args;
-    if (!a.Pi || !a.Pj || !a.Ws || !a.W2 || !a.b2 || !a.coors || !a.edge_ws) return EGNN_E_NULLPTR;
-    if (!a.m_i && !a.coors_out) return EGNN_E_NULLPTR;
-    if (a.B <= 0 || a.N <= 0 || a.K <= 0 || a.H <= 0 || a.ldp < a.H || a.ldws < 2 * a.fourier + 1 + a.edge_dim) return EGNN_E_SHAPE;
-    if (a.m_dim < 1 || a.m_dim > 64 || a.coor_dim < 1 || a.coor_dim > 8) return EGNN_E_UNSUPPORTED;
-    if (a.fourier < 0 || a.edge_dim < 0 || 2 * a.fourier + 1 + a.edge_dim > EX_SMAX) return EGNN_E_UNSUPPORTED;
-    if (a.edge_dim > 0 && !a.edges) return EGNN_E_NULLPTR;
-    if (a.coors_out && (!a.W3 || !a.b3 || !a.W4 || !a.b4)) return EGNN_E_NULLPTR;
-    if (a.gate_w && !a.gate_b) return EGNN_E_NULLPTR;
-    if (!a.idx && a.K != a.N) return EGNN_E_SHAPE;                        // dense path: K == N
-    const int64_t E = (int64_t)a.B * a.N * a.K;
-    const int64_t blocks = (E + EX_THREADS - 1) / EX_THREADS;
-    if (blocks > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t lds = (size_t)(2 * a.fourier + 1 + a.edge_dim) * EX_THREADS * sizeof(float);      // <= 64 KB
-    if (a.m_dim <= 16) hipLaunchKernelGGL(edge_exact_kernel<16>, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, a);
-    else if (a.m_dim <= 32) hipLaunchKernelGGL(edge_exact_kernel<32>, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, a);
-    else hipLaunchKernelGGL(edge_exact_kernel<64>, dim3((unsigned)blocks), dim3(EX_THREADS), lds, s, a);
-    int rc = egnn_launch_status();
-    if (rc != EGNN_OK) return rc;
-    const int64_t total = (int64_t)a.B * a.N * (a.m_dim + a.coor_dim);
-    hipLaunchKernelGGL(edge_exact_pool_kernel, dim3((unsigned)((total + EX_THREADS - 1) / EX_THREADS)), dim3(EX_THREADS), 0, s, a);
-    return egnn_launch_status();
-}
+extern "C" int egnn_edge_exact_f32(const egnn_edge_exact_args* args, void* stream) { return edge_exact_launch<float>(args, stream); }
+
+extern "C" int egnn_edge_exact_f64(const egnn_edge_exact_args* args, void* stream) { return edge_exact_launch<double>(args, stream); }

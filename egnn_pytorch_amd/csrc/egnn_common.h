@@ -197,6 +197,31 @@ __device__ __forceinline__ float egnn_sqdist_n(const float (&a)[CDM], const floa
     return d;
 }
 
+// float64 (the float64 path: knn_select_f64, edge_exact_f64): the same operation order, each operation rounded separately.
+// a, b: C valid components; rel: 8 components, those >= C set to 0.
+__device__ __forceinline__ double egnn_sqdist_f64(const double* a, const double* b, int C, double (&rel)[8]) {
+#pragma clang fp contract(off)
+    double sq[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        rel[c] = c < C ? a[c] - b[c] : 0.0;
+        sq[c] = rel[c] * rel[c];
+    }
+    double d = sq[0];
+    if (C >= 5 && C <= 7) {
+#pragma unroll
+        for (int c = 4; c < 8; ++c)
+            if (c < C) d = d + sq[c];
+#pragma unroll
+        for (int c = 1; c < 4; ++c) d = d + sq[c];
+    } else {
+#pragma unroll
+        for (int c = 1; c < 8; ++c)
+            if (c < C) d = d + sq[c];
+    }
+    return d;
+}
+
 // Packed ("tile-major") layout of the fp16 GEMM operands: an (R x Kp) matrix, R padded to 32 rows, Kp % 32 == 0, is
 // stored as [R/32][Kp/16][32 rows][2 chunks][8 halves]; the chunk index is XOR-swizzled by ((row >> 3) & 1) so that the
 // 1 KB (row block, K-tile) piece is exactly the bank-conflict-free LDS image the GEMM wants.  nkt = Kp / 16.

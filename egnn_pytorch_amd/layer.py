@@ -222,6 +222,19 @@ class EGNN(nn.Module):
         self._check_inputs(feats, coors, edges, mask, adj_mat)
         _abi.load()
         f_dtype, c_dtype = feats.dtype, coors.dtype
+        if self.float64_kernels():
+            # a float64 module computes in float64, as the reference does (its own tests run in float64, tests/test_equivariance.py:6):
+            # the plain kernels instantiated for double (include/egnn_hip.h, "The float64 path")
+            if want_u:
+                raise NotImplementedError("float64 modules run on the plain float64 kernels: no native backward")
+            if isinstance(edges, EdgeLookup):
+                raise NotImplementedError("float64 modules take the materialised (B,N,N,edge_dim) edge features")
+            with torch.cuda.device(feats.device):
+                out = self._forward_exact(feats.double(), coors.double(), None if edges is None else edges.double(), mask, adj_mat,
+                                          dtype=torch.float64)
+            if f_dtype != torch.float64 or c_dtype != torch.float64:
+                out = (out[0].to(f_dtype), out[1].to(c_dtype)) + tuple(out[2:])
+            return out
         if f_dtype == torch.float64 or c_dtype == torch.float64:
             _warn_float64_once()
         with torch.cuda.device(feats.device):
@@ -233,6 +246,17 @@ class EGNN(nn.Module):
         if f_dtype != torch.float32 or c_dtype != torch.float32:
             out = (out[0].to(f_dtype), out[1].to(c_dtype)) + tuple(out[2:])
         return out
+
+    def compute_dtype(self):
+        """float64 for a module converted with .double() (every kernel of its forward then is a float64 kernel), else float32 (half /
+        bfloat16 modules are converted at the boundary: at least their own precision)."""
+        p = next(self.parameters(), None)
+        return torch.float64 if (p is not None and p.dtype == torch.float64) else torch.float32
+
+    def float64_kernels(self):
+        """A float64 module runs on the float64 kernels -- except with training-mode dropout, whose hash masks live in the fast
+        kernels only: that combination keeps the boundary conversion (fp32-class arithmetic, with the one-time warning)."""
+        return self.compute_dtype() == torch.float64 and not self.dropout_active()
 
     def _forward_hip(self, feats, coors, edges, mask, adj_mat, order_hint=None, want_u=False, drop=None):
         # more per-edge scalars than the split-fp16 edge kernels carry (2 fourier + 1 + edge_dim > 16, up to 64): the plain-fp32 kernels
@@ -380,9 +404,11 @@ class EGNN(nn.Module):
         return node_out, coors_out, order, idx, rank, valid_radius, u_pre, proj_kept
 
 
-    def _forward_exact(self, feats, coors, edges, mask, adj_mat):
+    def _forward_exact(self, feats, coors, edges, mask, adj_mat, dtype=torch.float32):
         """The layer on the plain-fp32 kernels (include/egnn_hip.h, "The wide-range path"): exact-fp32 GEMMs, fp32 node_norm, the edge
-        pass as fp32 VALU arithmetic on the module's own weight tensors.  Same neighbour selection, same return tuple as _forward_hip."""
+        pass as fp32 VALU arithmetic on the module's own weight tensors.  Same neighbour selection, same return tuple as _forward_hip.
+        dtype = torch.float64: the same kernels instantiated for double ("The float64 path"; feats / coors / edges are float64)."""
+        esz = 8 if dtype == torch.float64 else 4
         b, n, dim = feats.shape
         feats = feats.contiguous()
         coors = coors.contiguous()
@@ -391,7 +417,7 @@ class EGNN(nn.Module):
         if lookup is not None:
             edges = lookup.edges
         elif edges is not None:
-            edges = edges.contiguous().float()
+            edges = edges.contiguous().to(dtype)
         mask8 = _ops._u8(mask)
         num_nearest, valid_radius = self.num_nearest_neighbors, self.valid_radius
         use_nearest = num_nearest > 0 or self.only_sparse_neighbors
@@ -409,22 +435,22 @@ class EGNN(nn.Module):
                 idx, rank = _ops.knn_select(coors, mask, adj_mat, k)
         else:
             k = n
-        f32 = lambda t: t.detach().float().contiguous()
+        f32 = lambda t: t.detach().to(dtype).contiguous()                # noqa: E731  (the module's tensors in the compute dtype)
         node_out, coors_out, m_i = feats, coors, None
         if k > 0:
             lin0, lin3 = self.edge_mlp[0], self.edge_mlp[3]
             w1 = f32(lin0.weight)                                        # (H, Din): [W_i | W_j | scalar columns]
             h, din = w1.shape
             hq = (h + 3) // 4 * 4
-            proj = _ops.empty(b * n, 2 * hq, dtype=torch.float32, device=feats.device)
+            proj = _ops.empty(b * n, 2 * hq, dtype=dtype, device=feats.device)
             _ops.linear_f32(feats2d, w1, h, dim, bias=f32(lin0.bias), out=proj[:, :h], name="node_proj_f32")
             _ops.linear_f32(feats2d, w1[:, dim:], h, dim, out=proj[:, hq:hq + h], name="node_proj_f32")
             a = _abi.EdgeExactArgs()
             a.B, a.N, a.K, a.m_dim, a.H = b, n, k, self.m_dim, h
             a.fourier, a.edge_dim, a.coor_dim = self.fourier_features, self.edge_dim, coors.shape[-1]
             a.pool_mean = int(self.m_pool_method == "mean")
-            a.Pi, a.Pj, a.ldp = proj.data_ptr(), proj.data_ptr() + 4 * hq, 2 * hq
-            a.Ws, a.ldws = w1.data_ptr() + 4 * 2 * dim, din
+            a.Pi, a.Pj, a.ldp = proj.data_ptr(), proj.data_ptr() + esz * hq, 2 * hq
+            a.Ws, a.ldws = w1.data_ptr() + esz * 2 * dim, din
             keep = [w1, f32(lin3.weight), f32(lin3.bias)]
             a.W2, a.b2 = keep[1].data_ptr(), keep[2].data_ptr()
             if self.edge_gate is not None:
@@ -434,7 +460,7 @@ class EGNN(nn.Module):
                 c0, c3 = self.coors_mlp[0], self.coors_mlp[3]
                 keep += [f32(c0.weight), f32(c0.bias), f32(c3.weight).view(-1), f32(c3.bias)]
                 a.W3, a.b3, a.W4, a.b4 = (t.data_ptr() for t in keep[-4:])
-                coors_out = _ops.empty(*coors.shape, dtype=torch.float32, device=coors.device)
+                coors_out = _ops.empty(*coors.shape, dtype=dtype, device=coors.device)
                 a.coors_out = coors_out.data_ptr()
             if self.norm_coors:
                 keep.append(f32(self.coors_norm.scale))
@@ -445,16 +471,16 @@ class EGNN(nn.Module):
                 a.edges_by_k = 1
             a.edges, a.mask = _ops._ptr(edges), _ops._ptr(mask8)
             a.idx, a.rank = _ops._ptr(idx), _ops._ptr(rank)
-            a.valid_radius = float(min(valid_radius, 3.0e38))
+            a.valid_radius = float(valid_radius) if dtype == torch.float64 else float(min(valid_radius, 3.0e38))
             cv = self.coor_weights_clamp_value
             a.clamp = -1.0 if cv is None else float(cv)
             if self.node_mlp is not None:
-                m_i = _ops.empty(b * n, self.m_dim, dtype=torch.float32, device=feats.device)
+                m_i = _ops.empty(b * n, self.m_dim, dtype=dtype, device=feats.device)
                 a.m_i = m_i.data_ptr()
-            _ops.edge_exact(a, feats.device)
+            _ops.edge_exact(a, feats.device, dtype)
             del proj, keep
         elif self.node_mlp is not None:
-            m_i = torch.zeros(b * n, self.m_dim, dtype=torch.float32, device=feats.device)        # K == 0: no messages
+            m_i = torch.zeros(b * n, self.m_dim, dtype=dtype, device=feats.device)        # K == 0: no messages
         if self.node_mlp is not None:
             ln = self.node_norm if isinstance(self.node_norm, nn.LayerNorm) else None
             node_in = _ops.node_prep_f32(feats2d, m_i, f32(ln.weight) if ln is not None else None,
@@ -548,7 +574,7 @@ class EGNN_Network(nn.Module):
         # Edge features for the layers.  Inference: look-up tables (EdgeLookup) -- the (B,N,N,edge_dim+adj_dim) tensor of :410-432
         # is never materialised, the edge kernel reads the embedding rows of the K selected pairs of each node.  Under autograd:
         # the tensor, so that the embeddings receive gradients.
-        lazy = not torch.is_grad_enabled()
+        lazy = not torch.is_grad_enabled() and not self.layers[0][1].float64_kernels()
         tok = tok_emb = None
         if edges is not None and self.edge_emb is not None:
             if lazy:

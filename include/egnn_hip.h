@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 30
+#define EGNN_ABI_VERSION 31
 
 enum {
     EGNN_OK = 0,
@@ -562,33 +562,57 @@ int egnn_node_prep_f32(const float* feats, const float* m_i, const float* gamma,
  * Limits: m_dim <= 64, at most 64 per-edge scalars. */
 typedef struct egnn_edge_exact_args {
     int32_t B, N, K, m_dim, H, fourier, edge_dim, coor_dim, pool_mean, edges_by_k;
-    const float* Pi;
-    const float* Pj;
+    /* data pointers: float for egnn_edge_exact_f32, double for egnn_edge_exact_f64 */
+    const void* Pi;
+    const void* Pj;
     int64_t ldp;
-    const float* Ws;
+    const void* Ws;
     int64_t ldws;
-    const float* W2;
-    const float* b2;
-    const float* gate_w;
-    const float* gate_b;
-    const float* W3;
-    const float* b3;
-    const float* W4;
-    const float* b4;
-    const float* coors_scale;
-    const float* coors;
-    const float* edges;
+    const void* W2;
+    const void* b2;
+    const void* gate_w;
+    const void* gate_b;
+    const void* W3;
+    const void* b3;
+    const void* W4;
+    const void* b4;
+    const void* coors_scale;
+    const void* coors;
+    const void* edges;
     const uint8_t* mask;
     const int32_t* idx;
-    const float* rank;
-    float valid_radius, clamp;
-    float* m_i;
-    float* coors_out;
-    float* edge_ws;
+    const void* rank;
+    double valid_radius, clamp;
+    void* m_i;
+    void* coors_out;
+    void* edge_ws;
 } egnn_edge_exact_args;
 
-size_t egnn_edge_exact_workspace_bytes(int B, int N, int K, int m_dim, int coor_dim);
+size_t egnn_edge_exact_workspace_bytes(int B, int N, int K, int m_dim, int coor_dim);      /* fp32; twice that for egnn_edge_exact_f64 */
 int egnn_edge_exact_f32(const egnn_edge_exact_args* args, void* stream);
+
+/* =============================================================================================
+ * The float64 path: a float64 module in float64 arithmetic.
+ *
+ * The reference is dtype-generic and its own tests run in float64 (tests/test_equivariance.py:6); the fast kernels carry ~22
+ * significant bits per product.  A binding routes a module whose parameters are float64 through the entries below (the shipped one
+ * does: egnn_pytorch_amd/layer.py) -- the same plain kernels as the wide-range path, instantiated for double:
+ *   egnn_knn_select_f64   as egnn_knn_select_f32 (squared distances in the same operation order, ranking edits, exact top-K, ties
+ *                         towards the lowest index); rank_out in float64.  One workgroup per row, keys in LDS: N <= 20 000, K <= 1024
+ *   egnn_linear_f64       as egnn_linear_f32, on v_mfma_f64_16x16x4_f64
+ *   egnn_node_prep_f64    as egnn_node_prep_f32
+ *   egnn_edge_exact_f64   as egnn_edge_exact_f32 with every data pointer of egnn_edge_exact_args a double*; workspace twice
+ *                         egnn_edge_exact_workspace_bytes()
+ * Correct and deterministic first: gfx950's float64 matrix rate is 1/32 of its fp16 rate.  Never what bench.py times.
+ * ============================================================================================= */
+int egnn_knn_select_f64(const double* coors, const uint8_t* mask, const uint8_t* adj, int64_t adj_batch_stride,
+                        int B, int N, int K, int coor_dim, int32_t* idx_out, double* rank_out, void* stream);
+int egnn_linear_f64(const double* A, int64_t lda, const double* W, int64_t ldw, const double* bias,
+                    const double* residual, int64_t ldr, double* C, int64_t ldc,
+                    int64_t M, int N, int K, int act, void* stream);
+int egnn_node_prep_f64(const double* feats, const double* m_i, const double* gamma, const double* beta,
+                       double eps, double* out, int64_t rows, int dim, int m_dim, void* stream);
+int egnn_edge_exact_f64(const egnn_edge_exact_args* args, void* stream);
 
 #ifdef __cplusplus
 }

@@ -792,8 +792,9 @@ def test_native_backward_with_frozen_parameters(frozen):
 
 
 def test_native_backward_of_a_float64_module_goes_through_the_fp32_boundary():
-    """VERDICT r2 missing #1: a float64 module (the reference's own tests and training script run in float64) used to fall to the
-    ATen recompute; now the native backward differentiates an fp32 shadow and returns every gradient in float64."""
+    """The native backward of a module that is not fp32 differentiates an fp32 shadow of it and returns every gradient in the
+    module's dtype: half / bfloat16 modules, and a float64 module with training-mode dropout (which keeps the boundary conversion;
+    without dropout a float64 module runs on the float64 kernels and the float64 recompute, tests/test_float64_property_suite.py)."""
     from egnn_pytorch_amd import autograd as A
     kw = dict(dim=8, num_nearest_neighbors=6, norm_feats=True)
     layer, feats, coors, idx, rank, gn, gc = _emulated_case(kw, dtype=torch.float64)

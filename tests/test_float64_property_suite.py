@@ -1,12 +1,20 @@
-"""The reference's own four dense-layer property tests (/root/reference/tests/test_equivariance.py:8-102) run as upstream runs
-them -- float64 module, float64 inputs, default init, unseeded-style random inputs, atol 1e-6 -- against the drop-in layer on
-the MI355X (VERDICT r2 missing #7 / next #7).  The gfx950 path converts float64 at the boundary and computes with fp32-class
-arithmetic (a RuntimeWarning says so once); these tests pin that the reference's float64 assertions still hold under it."""
+"""float64 modules compute in float64 (VERDICT r3 missing #2 / next #8).
+
+The reference is dtype-generic and its own tests run in float64 (/root/reference/tests/test_equivariance.py:6-102, atol 1e-6).  A
+module converted with .double() runs on the float64 kernels of libegnn_hip.so (include/egnn_hip.h, "The float64 path":
+egnn_knn_select_f64, egnn_linear_f64 on v_mfma_f64_16x16x4_f64, egnn_node_prep_f64, egnn_edge_exact_f64).  Checked here:
+  * the reference's four property tests as upstream runs them, but at XAVIER-scale weights, where fp32-class arithmetic fails the
+    1e-6 bars (with upstream's default init, std 1e-3, any arithmetic passes);
+  * the layer and the network against the numpy oracle evaluated in float64 at 1e-10 of the output's scale;
+  * the kernels on their own against torch's float64 operators."""
 import math
 import warnings
 
+import numpy as np
 import pytest
 import torch
+
+from oracle import egnn_oracle as O
 
 pytestmark = pytest.mark.gpu
 
@@ -14,10 +22,19 @@ pytestmark = pytest.mark.gpu
 def _rotation(g):
     """a proper rotation of R^3 from three random Euler angles (what egnn_pytorch/utils.py::rot builds)"""
     a, b, c = (float(x) * 2.0 * math.pi for x in torch.rand(3, generator=g))
-    rz = torch.tensor([[math.cos(a), -math.sin(a), 0.0], [math.sin(a), math.cos(a), 0.0], [0.0, 0.0, 1.0]])
-    ry = torch.tensor([[math.cos(b), 0.0, math.sin(b)], [0.0, 1.0, 0.0], [-math.sin(b), 0.0, math.cos(b)]])
-    rz2 = torch.tensor([[math.cos(c), -math.sin(c), 0.0], [math.sin(c), math.cos(c), 0.0], [0.0, 0.0, 1.0]])
-    return (rz @ ry @ rz2).double()
+    f64 = torch.float64                         # (built in float64: a float32 rotation is orthogonal to 1e-7 only)
+    rz = torch.tensor([[math.cos(a), -math.sin(a), 0.0], [math.sin(a), math.cos(a), 0.0], [0.0, 0.0, 1.0]], dtype=f64)
+    ry = torch.tensor([[math.cos(b), 0.0, math.sin(b)], [0.0, 1.0, 0.0], [-math.sin(b), 0.0, math.cos(b)]], dtype=f64)
+    rz2 = torch.tensor([[math.cos(c), -math.sin(c), 0.0], [math.sin(c), math.cos(c), 0.0], [0.0, 0.0, 1.0]], dtype=f64)
+    return rz @ ry @ rz2
+
+
+def _xavier_(module, g):
+    """weights of every Linear ~ N(0, 1 / fan_in): activations of order one all the way through (upstream's default is std 1e-3)"""
+    with torch.no_grad():
+        for mod in module.modules():
+            if type(mod) is torch.nn.Linear:
+                mod.weight.copy_(torch.randn(mod.weight.shape, generator=g, dtype=torch.float64) / math.sqrt(mod.weight.shape[1]))
 
 
 @pytest.mark.parametrize("kwargs,n,edge_dim", [
@@ -25,11 +42,15 @@ def _rotation(g):
     (dict(dim=512, edge_dim=1, num_nearest_neighbors=8), 256, 1),                # ..._with_nearest_neighbors (:47-73)
     (dict(dim=512, edge_dim=1, num_nearest_neighbors=8, norm_coors=True), 256, 1),   # ..._with_coord_norm (:76-102)
 ])
-def test_reference_float64_assertions_hold(kwargs, n, edge_dim):
+@pytest.mark.parametrize("init", ["default", "xavier"])
+def test_reference_float64_assertions_hold(kwargs, n, edge_dim, init):
     from egnn_pytorch_amd import EGNN
     g = torch.Generator().manual_seed(n + edge_dim)
     torch.manual_seed(17)
-    layer = EGNN(**kwargs).double().cuda()                                       # default init, float64 -- as upstream
+    layer = EGNN(**kwargs).double()
+    if init == "xavier":
+        _xavier_(layer, g)
+    layer = layer.cuda()
     rot, shift = _rotation(g).cuda(), torch.randn(1, 1, 3, generator=g).double().cuda()
     feats = torch.randn(1, n, 512, generator=g).double().cuda()
     coors = torch.randn(1, n, 3, generator=g).double().cuda()
@@ -38,7 +59,7 @@ def test_reference_float64_assertions_hold(kwargs, n, edge_dim):
     swapped = feats.clone()
     swapped[:, 0], swapped[:, 1] = feats[:, 1], feats[:, 0]
     with warnings.catch_warnings():
-        warnings.simplefilter("ignore", RuntimeWarning)
+        warnings.simplefilter("error")                                           # (no "fp32-class arithmetic" warning any more)
         with torch.no_grad():
             f_moved, c_moved = layer(feats, coors @ rot + shift, edges, mask=mask)
             f_plain, c_plain = layer(feats, coors, edges, mask=mask)
@@ -47,6 +68,9 @@ def test_reference_float64_assertions_hold(kwargs, n, edge_dim):
     assert torch.allclose(f_moved, f_plain, atol=1e-6), "type 0 features are invariant"
     assert torch.allclose(c_moved, c_plain @ rot + shift, atol=1e-6), "type 1 features are equivariant"
     assert not torch.allclose(f_moved, f_swapped, atol=1e-6), "the layer must see a permutation of the node features"
+    if init == "xavier":
+        # far beyond what 22-bit products give at this scale: the invariance holds to float64 rounding
+        assert float((f_moved - f_plain).abs().max()) <= 1e-10 * max(1.0, float(f_plain.abs().max()))
 
 
 def test_five_dimensional_coordinates_run_in_float64():
@@ -56,17 +80,17 @@ def test_five_dimensional_coordinates_run_in_float64():
     g = torch.Generator().manual_seed(5)
     feats, coors = torch.randn(1, 16, 512, generator=g).double().cuda(), torch.randn(1, 16, 5, generator=g).double().cuda()
     edges = torch.randn(1, 16, 16, 4, generator=g).double().cuda()
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", RuntimeWarning)
-        with torch.no_grad():
-            f, c = layer(feats, coors, edges, mask=torch.ones(1, 16, dtype=torch.bool).cuda())
+    with torch.no_grad():
+        f, c = layer(feats, coors, edges, mask=torch.ones(1, 16, dtype=torch.bool).cuda())
     assert f.shape == feats.shape and c.shape == coors.shape and f.dtype == torch.float64 and torch.isfinite(f).all()
 
 
-def test_float64_callers_are_told_about_the_precision_once():
+def test_float64_inputs_of_a_float32_module_are_told_about_the_precision_once():
+    """float64 INPUTS to an fp32 module (the reference raises a dtype mismatch there) are converted at the boundary, with a warning;
+    a float64 MODULE does not warn: it computes in float64."""
     from egnn_pytorch_amd import EGNN, layer as L
     L._FP64_WARNED = False
-    mod = EGNN(dim=16, num_nearest_neighbors=4).double().cuda()
+    mod = EGNN(dim=16, num_nearest_neighbors=4).cuda()
     f, c = torch.randn(1, 12, 16).double().cuda(), torch.randn(1, 12, 3).double().cuda()
     with torch.no_grad():
         with pytest.warns(RuntimeWarning, match="fp32-class"):
@@ -74,3 +98,169 @@ def test_float64_callers_are_told_about_the_precision_once():
         with warnings.catch_warnings():
             warnings.simplefilter("error")
             mod(f, c)                                                            # once per process
+            mod.double()(f, c)                                                   # the float64 kernels: nothing to warn about
+
+
+def _dev(x):
+    return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+LAYER_CASES = [
+    ("knn_fourier_edges", dict(dim=48, num_nearest_neighbors=11, fourier_features=2, edge_dim=3), 3, 77, dict(mask=True, edges=True)),
+    ("dense_mask", dict(dim=40, edge_dim=1), 2, 37, dict(mask=True, edges=True)),
+    ("normcoors_normfeats_clamp", dict(dim=64, num_nearest_neighbors=32, norm_feats=True, norm_coors=True, coor_weights_clamp_value=0.3),
+     2, 96, dict(mask=True)),
+    ("soft_edges_mean_radius", dict(dim=32, num_nearest_neighbors=8, soft_edges=True, m_pool_method="mean", valid_radius=1.5), 2, 50,
+     dict(mask=True)),
+    ("five_dims_m32", dict(dim=32, m_dim=32, num_nearest_neighbors=6), 2, 40, dict(cdim=5)),
+    ("sparse_adjacency", dict(dim=32, edge_dim=2, only_sparse_neighbors=True), 2, 48, dict(mask=True, edges=True, adj=True)),
+    ("no_coors_update", dict(dim=32, update_coors=False, num_nearest_neighbors=5), 1, 30, dict()),
+    ("ns_width", dict(dim=512, num_nearest_neighbors=32), 1, 128, dict(mask=True)),
+]
+
+
+@pytest.mark.parametrize("name,kwargs,b,n,opt", LAYER_CASES, ids=[c[0] for c in LAYER_CASES])
+def test_float64_layer_matches_the_float64_oracle(name, kwargs, b, n, opt):
+    from egnn_pytorch_amd import EGNN
+    cfg = O.EGNNConfig(**kwargs)
+    params = O.random_params(cfg, seed=11, dtype=np.float64)
+    rng = np.random.default_rng(len(name))
+    cdim = opt.get("cdim", 3)
+    feats, coors = rng.standard_normal((b, n, kwargs["dim"])), rng.standard_normal((b, n, cdim))
+    edges = rng.standard_normal((b, n, n, kwargs["edge_dim"])) if opt.get("edges") else None
+    mask = (np.arange(n)[None] < rng.integers(n // 2, n + 1, (b, 1))) if opt.get("mask") else None
+    i = np.arange(n)
+    adj = (np.abs(i[:, None] - i[None, :]) <= 1) if opt.get("adj") else None
+    want_n, want_c = O.egnn_forward(cfg, params, feats, coors, edges=edges, mask=mask, adj_mat=adj)
+    assert want_n.dtype == np.float64
+    net = EGNN(**kwargs).double()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        node, co = net(_dev(feats), _dev(coors), _dev(edges), _dev(mask), _dev(adj))
+    assert node.dtype == torch.float64 and co.dtype == torch.float64
+    for got, want, what in ((node, want_n, "feats"), (co, want_c, "coors")):
+        scale = max(1.0, float(np.abs(want).max()))
+        err = float(np.abs(got.cpu().numpy() - want).max())
+        assert err <= 1e-10 * scale, (name, what, err, scale)
+
+
+def test_float64_network_matches_the_float64_oracle():
+    """EGNN_Network in float64: embeddings, N-degree adjacency, the induced-set attention block (ATen in float64) and three layers."""
+    from egnn_pytorch_amd import EGNN_Network
+    kw = dict(depth=3, dim=32, num_tokens=12, num_edge_tokens=5, edge_dim=4, num_adj_degrees=2, adj_dim=3, num_nearest_neighbors=8,
+              global_linear_attn_every=2, global_linear_attn_heads=2, global_linear_attn_dim_head=8, norm_coors=True)
+    torch.manual_seed(9)
+    net = EGNN_Network(**kw).double()
+    g = torch.Generator().manual_seed(2)
+    _xavier_(net, g)
+    net = net.cuda().eval()
+    b, n = 2, 40
+    seq = torch.randint(0, 12, (b, n), generator=g)
+    coors = torch.randn(b, n, 3, generator=g, dtype=torch.float64)
+    etok = torch.randint(0, 5, (b, n, n), generator=g)
+    i = torch.arange(n)
+    adj = (i[:, None] - i[None, :]).abs() <= 1
+    mask = torch.arange(n)[None] < torch.tensor([[n], [n - 9]])
+    params = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    cfg = O.EGNNConfig(dim=32, edge_dim=4 + 3, num_nearest_neighbors=8, norm_feats=True, norm_coors=True)
+    want_n, want_c = O.egnn_network_forward(3, cfg, params, seq.numpy(), coors.numpy(), adj_mat=adj.numpy(), edges=etok.numpy(),
+                                            mask=mask.numpy(), num_adj_degrees=2, global_linear_attn_every=2, global_linear_attn_heads=2)[:2]
+    with torch.no_grad():
+        node, co = net(seq.cuda(), coors.cuda(), adj_mat=adj.cuda(), edges=etok.cuda(), mask=mask.cuda())
+    assert node.dtype == torch.float64
+    for got, want in ((node, want_n), (co, want_c)):
+        scale = max(1.0, float(np.abs(want).max()))
+        assert float(np.abs(got.cpu().numpy() - want).max()) <= 1e-9 * scale
+
+
+def test_float64_module_trains_through_the_float64_recompute_backward():
+    """Under autograd a float64 module's forward is the float64 kernels and its backward the chunked recompute in float64: gradients
+    equal float64 autograd of the restated layer over the same neighbour list."""
+    from egnn_pytorch_amd import EGNN
+    from egnn_pytorch_amd import autograd as A
+    g = torch.Generator().manual_seed(4)
+    layer = EGNN(dim=24, num_nearest_neighbors=6, norm_feats=True).double()
+    _xavier_(layer, g)
+    layer = layer.cuda()
+    feats = torch.randn(2, 30, 24, generator=g, dtype=torch.float64).cuda().requires_grad_(True)
+    coors = torch.randn(2, 30, 3, generator=g, dtype=torch.float64).cuda().requires_grad_(True)
+    with torch.enable_grad():
+        f, c = layer(feats, coors)
+        assert f.dtype == torch.float64 and f.requires_grad
+        (f.square().sum() + c.square().sum()).backward()
+    got = [feats.grad.clone(), coors.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+    feats.grad = coors.grad = None
+    layer.zero_grad()
+    with torch.no_grad():
+        idx, rank = layer._forward_with_hint(feats.detach(), coors.detach(), None, None, None, None)[3:5]
+    with torch.enable_grad():
+        f2, c2 = A.layer_given_neighbors(layer, feats, coors, None, None, idx.long(), rank, layer.valid_radius)
+        (f2.square().sum() + c2.square().sum()).backward()
+    want = [feats.grad, coors.grad] + [p.grad for p in layer.parameters()]
+    for a, b_ in zip(got, want):
+        assert float((a - b_).abs().max()) <= 1e-9 * max(1.0, float(b_.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------ the kernels on their own
+@pytest.mark.parametrize("m,n,k,act,res", [(300, 70, 33, 0, False), (64, 64, 16, 1, True), (1000, 130, 515, 0, True), (5, 3, 2, 1, False)])
+def test_linear_f64_kernel(m, n, k, act, res):
+    from egnn_pytorch_amd import _ops
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k + 3, generator=g, dtype=torch.float64).cuda()[:, :k]            # (a column slice of a wider matrix)
+    w = torch.randn(n, k, generator=g, dtype=torch.float64).cuda()
+    bias = torch.randn(n, generator=g, dtype=torch.float64).cuda()
+    r = torch.randn(m, n, generator=g, dtype=torch.float64).cuda() if res else None
+    out = _ops.linear_f32(a, w, n, k, bias=bias, residual=r, act=act)
+    want = a @ w.t() + bias
+    if act:
+        want = torch.nn.functional.silu(want)
+    if res:
+        want = want + r
+    assert out.dtype == torch.float64
+    assert float((out - want).abs().max()) <= 1e-12 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("n,k,cdim,use_mask,use_adj", [(64, 8, 3, True, False), (300, 32, 3, True, True), (50, 50, 5, False, False),
+                                                       (1024, 32, 3, True, False), (5000, 17, 2, False, False)])
+def test_knn_select_f64_kernel(n, k, cdim, use_mask, use_adj):
+    from egnn_pytorch_amd import _ops
+    g = torch.Generator().manual_seed(n + k)
+    b = 2
+    coors = torch.randn(b, n, cdim, generator=g, dtype=torch.float64).cuda()
+    coors[:, 3] = coors[:, 2]                                                     # exact ties: lowest index first
+    mask = (torch.arange(n)[None] < torch.tensor([[n], [max(k, n - 5)]])).cuda() if use_mask else None
+    i = torch.arange(n)
+    adj = ((i[:, None] - i[None, :]).abs() <= 2).cuda() if use_adj else None
+    idx, rank = _ops.knn_select(coors, mask, adj, k)
+    rel = coors[:, :, None, :] - coors[:, None, :, :]
+    sq = rel * rel
+    order = list(range(cdim)) if cdim not in (5, 6, 7) else [0] + list(range(4, cdim)) + [1, 2, 3]
+    dist = sq[..., order[0]].clone()
+    for c in order[1:]:
+        dist = dist + sq[..., c]
+    ranking = dist.clone()
+    if mask is not None:
+        ranking.masked_fill_(~(mask[:, :, None] & mask[:, None, :]), 1e5)
+    if adj is not None:
+        eye = torch.eye(n, dtype=torch.bool, device="cuda")
+        ranking.masked_fill_(eye[None], -1.0)
+        ranking.masked_fill_((adj & ~eye)[None].expand(b, -1, -1), 0.0)
+    # (value, index) order = a stable sort by value
+    want_rank, want_idx = torch.sort(ranking, dim=-1, stable=True)
+    assert rank.dtype == torch.float64
+    assert torch.equal(rank, want_rank[..., :k])
+    assert torch.equal(idx.long(), want_idx[..., :k])
+
+
+def test_node_prep_f64_kernel():
+    from egnn_pytorch_amd import _ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(77, 130, generator=g, dtype=torch.float64).cuda() * 3 + 1
+    m = torch.randn(77, 16, generator=g, dtype=torch.float64).cuda()
+    gam, bet = torch.randn(130, generator=g, dtype=torch.float64).cuda(), torch.randn(130, generator=g, dtype=torch.float64).cuda()
+    out = _ops.node_prep_f32(x, m, gam, bet, 1e-5, 16)
+    want = torch.cat((torch.nn.functional.layer_norm(x, (130,), gam, bet, 1e-5), m), dim=-1)
+    assert float((out - want).abs().max()) <= 1e-13 * float(want.abs().max())
+    out = _ops.node_prep_f32(x, None, None, None, 1e-5, 16)
+    assert torch.equal(out[:, :130], x) and not out[:, 130:].any()

@@ -632,7 +632,8 @@ def test_nan_padding_behind_the_mask_is_harmless():
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-4), (torch.bfloat16, 3e-2), (torch.float16, 4e-3)])
 def test_other_float_dtypes_at_the_boundary(dtype, tol):
     """The reference is dtype-generic (its own tests run in float64, tests/test_equivariance.py:6).  The gfx950 path accepts
-    float64 / bfloat16 / float16 modules and inputs, computes in its fp32-class arithmetic and returns the callers' dtype:
+    float64 / bfloat16 / float16 modules and inputs and returns the callers' dtype; bfloat16 / float16 modules compute in its
+    fp32-class arithmetic (float64 ones on the float64 kernels: tests/test_float64_property_suite.py has their 1e-10 bars):
     against the fp32 oracle within what the output dtype can hold."""
     from egnn_pytorch_amd import EGNN
     kw = dict(dim=32, num_nearest_neighbors=8, norm_feats=True)
