@@ -228,17 +228,22 @@ def _pack(layer) -> dict:
         wjt[:, :h] = w_j.t()
         out["WiT_split"] = split_f16(wit)
         out["WjT_split"] = split_f16(wjt)
-    if nb == 1:
+    if True:
         # backward (egnn_edge_bwd_pass_f32): W2^T in natural units as A fragments of v_mfma_f32_16x16x16_f16,
-        # [step][hb][hi|lo][lane = 16 g + r][u] = W2[4 g + u][32 step + 16 hb + r]
-        w2t = z(hp, 16)
+        # [step][hb][hi|lo][lane = 16 g + r][u] = W2[4 g + u][32 step + 16 hb + r] -- one image per block of 16 message channels
+        # (m_dim > 16: the pass is linear in gU, so it runs once per block and the results are added; "W2Th" = block 0)
+        w2t = z(hp, 16 * nb)
         w2t[:h, :m] = w2.t()
         t_scale = pow2_scale((float(w2t.abs().max()) if w2t.numel() else 0.0) if am is None else am["w2"])
-        w2ts = w2t * t_scale
-        t_hi = w2ts.half()
-        t_lo = (w2ts - t_hi.float()).half()
         fragt = lambda t: t.view(hp // 32, 2, 16, 4, 4).permute(0, 1, 3, 2, 4).contiguous().view(hp // 32, 2, 64, 4)
-        out["W2Th"] = torch.stack([fragt(t_hi), fragt(t_lo)], dim=2).contiguous()      # (Hp/32, 2, 2, 64, 4) fp16
+        blocks = []
+        for blk in range(nb):
+            w2ts = w2t[:, 16 * blk:16 * blk + 16].contiguous() * t_scale
+            t_hi = w2ts.half()
+            t_lo = (w2ts - t_hi.float()).half()
+            blocks.append(torch.stack([fragt(t_hi), fragt(t_lo)], dim=2).contiguous())      # (Hp/32, 2, 2, 64, 4) fp16
+        out["W2Th"] = blocks[0]
+        out["W2Th_blocks"] = blocks
         out["w2t_scale"] = t_scale
         if s > 5:
             # backward with more than five per-edge scalars (egnn_edge_bwd_pass_f32, DSM): W_s^T in natural units as A fragments,

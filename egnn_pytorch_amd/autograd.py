@@ -331,7 +331,9 @@ class EGNNFunction(torch.autograd.Function):
         if layer.dropout_active():
             from . import _dropout
             drop = (layer.dropout_p, _dropout.draw_seed())
-        native = (_NATIVE and layer.m_dim <= 16 and coors.shape[-1] == 3 and (drop is None or _dropout_native_ok(layer))
+        # (the E x H work of every shape the forward kernels cover -- m_dim <= 64, coordinate dimension 1 .. 8 -- is native; the per-edge
+        # chain behind u has its closed-form kernel for m_dim <= 16 and 3-D coordinates and goes through autograd on E x m tensors otherwise)
+        native = (_NATIVE and layer.m_dim <= 64 and (drop is None or (_dropout_native_ok(layer) and coors.shape[-1] == 3))
                   and not layer.float64_kernels())           # (a float64 module: float64 forward kernels, float64 recompute backward)
         with torch.no_grad():
             node_out, coors_out, order, idx, rank, valid_radius, u_pre, proj = layer._forward_hip_checked(
@@ -345,7 +347,7 @@ class EGNNFunction(torch.autograd.Function):
             idx = torch.empty(b, n, 0, dtype=torch.int32, device=feats.device)
             rank = torch.empty(b, n, 0, dtype=torch.float32, device=feats.device)
         ctx.layer = layer
-        ctx.has_u = u_pre is not None                    # (E, 16) fp32: E x 16, not E x H
+        ctx.has_u = u_pre is not None                    # (E, 16 ceil(m_dim / 16)) fp32: E x m, not E x H
         ctx.valid_radius = valid_radius
         ctx.has_edges = edges is not None
         none = feats.new_empty(0)
@@ -580,7 +582,8 @@ def _backward_native(ctx, g_node, g_coors):
         g_node = torch.zeros_like(feats)
     if g_coors is None:
         g_coors = torch.zeros_like(coors)
-    u_all = ctx.saved_tensors[6].view(b, n, k, 16)
+    mp = 16 * _weights.m_blocks(m)                       # u rows: whole 16-channel blocks, pad channels 0
+    u_all = ctx.saved_tensors[6].view(b, n, k, mp)
     drop = getattr(ctx, "drop", None)                    # (p, seed) of a training-mode forward (_dropout_native_ok), else None
     reduce = False
     # (egnn_edge_bwd_pass_f32: up to 16 per-edge scalars -- beyond five with the all-edge contractions split over the two passes)
@@ -609,7 +612,7 @@ def _backward_native(ctx, g_node, g_coors):
     # the per-edge chain behind u in closed form on the device (egnn_edge_tail_bwd_f32) where it applies (m_dim <= 16, coors_mlp
     # hidden width <= 64); otherwise that part goes through autograd as well
     tail_kernel = (_TAIL_KERNEL and layer.coors_mlp is not None and layer.node_mlp is not None
-                   and m <= 16 and layer.coors_mlp[0].weight.shape[0] <= 64)
+                   and m <= 16 and layer.coors_mlp[0].weight.shape[0] <= 64 and coors.shape[-1] == 3)
     for lo in range(0, b, step):
         hi_ = min(b, lo + step)
         bc = hi_ - lo
@@ -764,7 +767,7 @@ def _backward_native(ctx, g_node, g_coors):
             for p, g in zip(live_tail, tg[3:]):
                 if g is not None:
                     grads_by_id[id(p)] += g
-            gu16 = torch.zeros(ec, 16, dtype=torch.float32, device=feats.device)
+            gu16 = torch.zeros(ec, mp, dtype=torch.float32, device=feats.device)
             gu16[:, :m] = g_u.reshape(ec, m)
         # ---- 2. the E x H work: d/d P_i, d/d P_j (per node), d/d W_s, d/d scalars, d/d W_2
         amax = _ops.bits_to_floats(gu_bits)[0] if gu_bits is not None else _ops.absmax(gu16)
@@ -778,8 +781,21 @@ def _backward_native(ctx, g_node, g_coors):
                 assert fused and tail_kernel and reduce                                # (_dropout_native_ok: nothing else keeps u)
                 gz_i, gz_j, g_ws, g_scal, g_w2 = contract(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists, proj,
                                                           drop, lo * n * k)
-            else:
+            elif mp == 16:
                 gz_i, gz_j, g_ws, g_scal, g_w2 = contract(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists, proj)
+            else:
+                # m_dim > 16: dz = (W2^T gU) SiLU'(z) and every contraction of it are linear in gU, so the passes run once per block of
+                # 16 message channels (its columns of gU, its rows of W2) and the results are added; d/d W_2 is per block anyway
+                if dest_lists is None and i32 is not None:
+                    dest_lists = _ops.dest_lists(i32, bc, n, k, feats.device)
+                parts = []
+                for blk in range(mp // 16):
+                    wb = dict(w, W2Th=w["W2Th_blocks"][blk], w2_block=blk)
+                    parts.append(contract(layer, wb, f2d, c0, e0, sc2, i32, gu16[:, 16 * blk:16 * blk + 16].contiguous(), gu_scale, w_s, bc, n, k,
+                                          pi_split, dest_lists, proj))
+                gz_i, gz_j, g_ws, g_scal = (sum(p[q] for p in parts[1:]) + parts[0][q] for q in range(4))
+                g_w2 = torch.cat([p[4] for p in parts], dim=0)
+                del parts
             # ---- 3. node-level products: d/d feats = dP_i W_i + dP_j W_j, d/d W_i = dP_i^T feats, d/d W_j = dP_j^T feats.  On the
             # device: the forward's split-f16 matrix-core GEMM (operands pre-scaled by powers of two, the weight gradients split-K
             # over the B N nodes with the parts summed in fixed order) -- the fp32 library GEMMs they replace ran at 60 - 130 TFLOP/s

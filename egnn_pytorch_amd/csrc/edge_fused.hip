@@ -153,7 +153,8 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
     // MODE 0: inference forward.  1: forward that also writes u (args.U_out) for the backward -- its own instantiation, the
     // inference kernels sit at the register limit.  3: training-mode dropout.
     constexpr bool DROP = MODE == 3;                         // training-mode dropout (args.drop_thr); writes u like MODE 1 if asked
-    constexpr bool WRITE_U = MODE == 1 || MODE == 3;
+    // (wide heads -- m_dim > 16 -- and the generic coordinate dimension have no instantiation of their own for it: a run-time branch)
+    constexpr bool WRITE_U = MODE == 1 || MODE == 3 || NB > 1 || CDM != 3;
     constexpr bool GDMA = EGNN_EDGE_GDMA && EGNN_EDGE_RING;           // gathers by LDS-DMA
     constexpr int HC = EGNN_EDGE_RING ? HCT / 2 : HCT;     // columns per staged chunk (ring: two slots of HCT / 2)
     constexpr int NCH = nch_of(NB);
@@ -801,10 +802,13 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 const int nl = (TPI == 2) ? nl_w : q / K;
                 const int kk = (TPI == 2) ? k_w + t * 16 + e : q - nl * K;
                 if (q < slots_total && node0 + nl < N) {
-                    f32x4 uu;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) uu[u] = acc[t][0][u] * p.w2_inv_scale + b2r[0][u];
-                    *reinterpret_cast<f32x4*>(p.U_out + ((bN + ei[t]) * (size_t)K + kk) * 16 + 4 * g) = uu;
+                    for (int nb = 0; nb < NB; ++nb) {          // rows of 16 NB channels (m_dim rounded up to whole accumulator tiles)
+                        f32x4 uu;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) uu[u] = acc[t][nb][u] * p.w2_inv_scale + b2r[nb][u];
+                        *reinterpret_cast<f32x4*>(p.U_out + ((bN + ei[t]) * (size_t)K + kk) * (16 * NB) + 16 * nb + 4 * g) = uu;
+                    }
                 }
             }
             if (p.gate_w) {

@@ -385,8 +385,8 @@ class EGNN(nn.Module):
                 a.node_hi, a.node_lo, a.node_kp = node_in.hi.data_ptr(), node_in.lo.data_ptr(), node_in.kp
             if drop is not None:                                  # training-mode dropout: the mask is a hash, see _dropout.py
                 a.drop_thr, a.drop_seed, a.drop_inv_keep = _dropout.threshold(drop[0]), int(drop[1]), _dropout.inv_keep(drop[0])
-            if want_u and self.m_dim <= 16:
-                u_pre = _ops.empty(b * n * k, 16, dtype=torch.float32, device=feats.device)
+            if want_u:                                            # (rows of whole 16-channel accumulator tiles, pad channels 0)
+                u_pre = _ops.empty(b * n * k, 16 * _weights.m_blocks(self.m_dim), dtype=torch.float32, device=feats.device)
                 a.U_out = u_pre.data_ptr()
             a.algo = _EDGE_ALGO
             _ops.edge_fused(a, feats.device)

@@ -282,7 +282,7 @@ typedef struct egnn_edge_args {
     int32_t node_kp;            /*   [dim, dim + m_dim) (both or neither; node_kp % 32 == 0, >= dim + m_dim)          */
     int32_t* status;            /* optional range status word (EGNN_RANGE_SCALAR / _HIDDEN / _MESSAGE), see the enum above */
     /* autograd support (NULL for plain inference) */
-    float* U_out;               /* forward, optional, m_dim <= 16: (B*N*K, 16) fp32 u = edge_mlp.3(SiLU(edge_mlp.0(.))) before the second
+    float* U_out;               /* forward, optional: (B*N*K, 16 * ceil(m_dim / 16)) fp32 u = edge_mlp.3(SiLU(edge_mlp.0(.))) before the second
                                    SiLU (egnn_pytorch.py:181-183), one row per edge (b, i, k), pad channels 0: what the backward
                                    (egnn_edge_tail_bwd_f32 / egnn_edge_bwd_pass_f32) differentiates from */
     int32_t edges_by_k;         /* 0: `edges` is (B,N,N,edge_dim), read at [b,i,j];  1: `edges` is (B,N,K,edge_dim), the features of the

