@@ -54,6 +54,10 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 #ifndef EGNN_EDGE_HC
 #define EGNN_EDGE_HC 256
 #endif
+// workgroups per CU of the per-lane-P_i variants (K < 6: adjacency neighbours) with 2 .. 5 per-edge scalars
+#ifndef EGNN_EDGE_T0_BLOCKS
+#define EGNN_EDGE_T0_BLOCKS 4
+#endif
 #ifndef EGNN_EDGE_MINW
 #define EGNN_EDGE_MINW 5
 #endif
@@ -113,7 +117,7 @@ constexpr int edge_min_blocks(int nm, int tpi, int nb)
     if (nb == 2) return nm > 4 ? 1 : 2;
     if (nm >= 12) return 1;
     if (nm > 4) return 2;
-    if (nm > 1) return (CDM == 3 && tpi == 2) ? 3 : 2;
+    if (nm > 1) return (CDM == 3 && tpi == 2) ? 3 : ((CDM == 3 && tpi == 0) ? EGNN_EDGE_T0_BLOCKS : 2);
     if (CDM == 3 && tpi == 2) return EGNN_EDGE_MINW;
     return (CDM == 3 && tpi >= 1) ? 4 : 3;
 }

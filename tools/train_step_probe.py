@@ -1,5 +1,6 @@
 """One training step (forward + backward) of the north-star layer, timed, for rocprofv3 --kernel-trace --stats:
-    python tools/train_step_probe.py [steps]"""
+    python tools/train_step_probe.py [steps]
+PROBE_KW='{"dim": 512, "m_dim": 32, "num_nearest_neighbors": 32}' PROBE_B=16 PROBE_C=3: another layer / batch / coordinate dimension."""
 import sys
 import time
 import torch
@@ -10,9 +11,12 @@ from egnn_pytorch_amd import EGNN, _ops
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 torch.manual_seed(0)
 dev = "cuda"
-layer = EGNN(dim=512, num_nearest_neighbors=32).to(dev)
-feats = torch.randn(64, 1024, 512, device=dev, requires_grad=True)
-coors = torch.randn(64, 1024, 3, device=dev, requires_grad=True)
+import json
+kw = json.loads(os.environ.get("PROBE_KW", '{"dim": 512, "num_nearest_neighbors": 32}'))
+B, C = int(os.environ.get("PROBE_B", "64")), int(os.environ.get("PROBE_C", "3"))
+layer = EGNN(**kw).to(dev)
+feats = torch.randn(B, 1024, kw["dim"], device=dev, requires_grad=True)
+coors = torch.randn(B, 1024, C, device=dev, requires_grad=True)
 for it in range(steps + 1):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     f, c = layer(feats, coors)

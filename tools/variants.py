@@ -18,7 +18,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "egnn_pytorch_amd", "csrc")
 VDIR = os.path.join(ROOT, "build_variants")
-PROD = ("knn_select", "spatial_order", "adj_expand", "linear_hl", "node_ops", "edge_fused", "edge_pw", "edge_exact", "linear_f32", "node_prep_f32", "edge_fused_c", "edge_bwd", "edge_tail",
+PROD = ("knn_select", "spatial_order", "adj_expand", "linear_hl", "node_ops", "edge_fused", "edge_pw", "edge_exact", "linear_f32", "node_prep_f32", "fp64", "edge_fused_c", "edge_bwd", "edge_tail",
         "layer_api", "segment_sum", "entry_lists", "global_attn")
 
 TIMER = r'''
@@ -37,6 +37,8 @@ elif shape == "c5":
     layer, B, N, D = EGNN(dim=256, num_nearest_neighbors=32, norm_feats=True, norm_coors=True), 64, 1024, 256
 elif shape == "c2":
     layer, B, N, D = EGNN(dim=512), 8, 256, 512
+elif shape == "c4":
+    layer, B, N, D = EGNN(dim=512, edge_dim=4, only_sparse_neighbors=True), 32, 2048, 512
 else:
     raise SystemExit("unknown shape " + shape)
 for m in layer.modules():
@@ -46,9 +48,14 @@ layer = layer.cuda().eval()
 g = torch.Generator().manual_seed(1)
 feats = torch.randn(B, N, D, generator=g).cuda(); coors = torch.randn(B, N, 3, generator=g).cuda()
 mask = torch.ones(B, N, dtype=torch.bool).cuda()
-for _ in range(3): out = layer(feats, coors, mask=mask)
+kw = dict(mask=mask)
+if shape == "c4":
+    i = torch.arange(N)
+    kw["adj_mat"] = ((i[:, None] - i[None, :]).abs() <= 1).cuda()
+    kw["edges"] = torch.randn(B, N, N, 4, generator=g).cuda()
+for _ in range(3): out = layer(feats, coors, **kw)
 with phase_timer() as pt:
-    for _ in range(reps): out = layer(feats, coors, mask=mask)
+    for _ in range(reps): out = layer(feats, coors, **kw)
 s = pt.summary()
 h = hashlib.sha256()
 for o in out: h.update(o.float().cpu().numpy().tobytes())
