@@ -148,9 +148,15 @@ def range_check_after_forward(device, mode=None):
             st.dev.zero_()
             _raise_range(bits, "this call")
         return
-    st.host.copy_(st.dev, non_blocking=True)            # deferred: examined by the next call / check_range()
-    st.event = torch.cuda.Event()
-    st.event.record()
+    # deferred: examined by the next call / check_range().  The 4-byte copy is a blit kernel: on the side stream, behind this forward's
+    # last kernel, it does not sit between this step and the next one on the launch stream (two launch gaps + 4 us per step)
+    cur = torch.cuda.current_stream(st.dev.device)
+    side = side_stream(st.dev.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        st.host.copy_(st.dev, non_blocking=True)
+        st.event = torch.cuda.Event()
+        st.event.record(side)
 
 
 def check_range(device=None, wait=True):
