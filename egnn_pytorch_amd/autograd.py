@@ -333,7 +333,8 @@ class EGNNFunction(torch.autograd.Function):
             drop = (layer.dropout_p, _dropout.draw_seed())
         # (the E x H work of every shape the forward kernels cover -- m_dim <= 64, coordinate dimension 1 .. 8 -- is native; the per-edge
         # chain behind u has its closed-form kernel for m_dim <= 16 and 3-D coordinates and goes through autograd on E x m tensors otherwise)
-        native = (_NATIVE and layer.m_dim <= 64 and (drop is None or (_dropout_native_ok(layer) and coors.shape[-1] == 3))
+        native = (_NATIVE and layer.m_dim <= 64 and coors.shape[-1] <= 8 and (drop is None or (_dropout_native_ok(layer) and coors.shape[-1] == 3))
+                  and 2 * layer.fourier_features + 1 + layer.edge_dim <= 16
                   and not layer.float64_kernels())           # (a float64 module: float64 forward kernels, float64 recompute backward)
         with torch.no_grad():
             node_out, coors_out, order, idx, rank, valid_radius, u_pre, proj = layer._forward_hip_checked(

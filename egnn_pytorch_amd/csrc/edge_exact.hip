@@ -35,25 +35,17 @@ __device__ __forceinline__ double ex_fma(double a, double b, double c) { return 
 template <typename T>
 __device__ __forceinline__ T ex_silu(T x) { return x / ((T)1 + ex_exp(-x)); }
 
-// x_i - x_j and the squared distance in the reference's operation order (what the neighbour selection ranked by): fp32 through the
-// helpers that are bit-exact against ATen (egnn_common.h); float64 the same order, no FMA contraction
-__device__ __forceinline__ float ex_sqdist(const float* ci, const float* cj, int C, float (&rel)[8])
+// the squared distance in the reference's operation order (what the neighbour selection ranked by): up to 8 coordinates in fp32 through
+// the helpers that are bit-exact against ATen (egnn_common.h), otherwise -- more coordinates, float64 -- the general summation tree
+__device__ __forceinline__ float ex_sqdist(const float* ci, const float* cj, int C)
 {
     if (C == 3) {
-        const float d = egnn_sqdist(ci[0], ci[1], ci[2], cj[0], cj[1], cj[2], rel[0], rel[1], rel[2]);
-#pragma unroll
-        for (int c = 3; c < 8; ++c) rel[c] = 0.f;
-        return d;
+        float dx, dy, dz;
+        return egnn_sqdist(ci[0], ci[1], ci[2], cj[0], cj[1], cj[2], dx, dy, dz);
     }
-    float a[8], bb[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { a[c] = c < C ? ci[c] : 0.f; bb[c] = c < C ? cj[c] : 0.f; }
-    return egnn_sqdist_n<8>(a, bb, C, rel);
+    return egnn_sqdist_any<float, 8>(ci, cj, C);
 }
-__device__ __forceinline__ double ex_sqdist(const double* ci, const double* cj, int C, double (&rel)[8])
-{
-    return egnn_sqdist_f64(ci, cj, C, rel);
-}
+__device__ __forceinline__ double ex_sqdist(const double* ci, const double* cj, int C) { return egnn_sqdist_any<double, 4>(ci, cj, C); }
 
 // the argument block with its data pointers typed (float for egnn_edge_exact_f32, double for egnn_edge_exact_f64)
 template <typename T>
@@ -99,8 +91,9 @@ __global__ __launch_bounds__(EX_THREADS) void edge_exact_kernel(const ExArgs<T> 
     const int j = p.idx ? p.idx[q] : k;
 
     // x_i - x_j and the squared distance, in the reference's operation order (egnn_common.h): what the neighbour selection ranked by
-    T rel[8];
-    const T d = ex_sqdist(p.coors + (bN + i) * C, p.coors + (bN + j) * C, C, rel);
+    const T* const ci = p.coors + (bN + i) * C;
+    const T* const cj = p.coors + (bN + j) * C;
+    const T d = ex_sqdist(ci, cj, C);                                    // (x_i - x_j is re-read per coordinate below: any C)
     // per-edge scalars [sin(d / 2^f) ..., cos(d / 2^f) ..., d, edge features ...]  (:34-41, :270-272, :282-285): a column of LDS per
     // thread (S x 256 floats, dynamic; scalar s of thread t at [s * 256 + t]: conflict-free) -- a run-time indexed private array
     // would live in scratch memory
@@ -171,20 +164,15 @@ __global__ __launch_bounds__(EX_THREADS) void edge_exact_kernel(const ExArgs<T> 
         T inv = (T)1;
         if (p.coors_scale) {                                             // CoorsNorm (:67-77)
             T n2 = (T)0;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) n2 = ex_fma(rel[c], rel[c], n2);
+            for (int c = 0; c < C; ++c) { const T r = ci[c] - cj[c]; n2 = ex_fma(r, r, n2); }
             const T nrm = ex_sqrt(n2);
             inv = p.coors_scale[0] / (nrm > (T)1e-8 ? nrm : (T)1e-8);
         }
         if (has_mask && !keep) cw = (T)0;                                // :308-309
         if (p.clamp >= (T)0) cw = cw < -p.clamp ? -p.clamp : (cw > p.clamp ? p.clamp : cw);      // :311-313
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (c < C) row[m_dim + c] = cw * (rel[c] * inv);
+        for (int c = 0; c < C; ++c) row[m_dim + c] = cw * ((ci[c] - cj[c]) * inv);
     } else {
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (c < C) row[m_dim + c] = (T)0;
+        for (int c = 0; c < C; ++c) row[m_dim + c] = (T)0;
     }
 #pragma unroll
     for (int c = 0; c < MB; ++c)
@@ -229,7 +217,7 @@ int edge_exact_launch(const egnn_edge_exact_args* args, void* stream)
     if (!a.Pi || !a.Pj || !a.Ws || !a.W2 || !a.b2 || !a.coors || !a.edge_ws) return EGNN_E_NULLPTR;
     if (!a.m_i && !a.coors_out) return EGNN_E_NULLPTR;
     if (a.B <= 0 || a.N <= 0 || a.K <= 0 || a.H <= 0 || a.ldp < a.H || a.ldws < 2 * a.fourier + 1 + a.edge_dim) return EGNN_E_SHAPE;
-    if (a.m_dim < 1 || a.m_dim > 64 || a.coor_dim < 1 || a.coor_dim > 8) return EGNN_E_UNSUPPORTED;
+    if (a.m_dim < 1 || a.m_dim > 64 || a.coor_dim < 1 || a.coor_dim > 64) return EGNN_E_UNSUPPORTED;
     if (a.fourier < 0 || a.fourier > 31 || a.edge_dim < 0 || 2 * a.fourier + 1 + a.edge_dim > EX_SMAX) return EGNN_E_UNSUPPORTED;
     if (a.edge_dim > 0 && !a.edges) return EGNN_E_NULLPTR;
     if (a.coors_out && (!a.W3 || !a.b3 || !a.W4 || !a.b4)) return EGNN_E_NULLPTR;

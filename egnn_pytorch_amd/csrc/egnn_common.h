@@ -197,29 +197,65 @@ __device__ __forceinline__ float egnn_sqdist_n(const float (&a)[CDM], const floa
     return d;
 }
 
-// float64 (the float64 path: knn_select_f64, edge_exact_f64): the same operation order, each operation rounded separately.
-// a, b: C valid components; rel: 8 components, those >= C set to 0.
-__device__ __forceinline__ double egnn_sqdist_f64(const double* a, const double* b, int C, double (&rel)[8]) {
+// Any coordinate dimension (C > 8 on the plain kernels; every C in float64): the summation tree of the reference's
+// `(rel_coors ** 2).sum(dim=-1)` on the CPU -- ATen's inner-dimension sum (aten/src/ATen/native/cpu/SumKernel.cpp), restated and
+// checked bit for bit against torch 2.10 for C = 1 .. 513 in float32 and 1 .. 200 in float64 (the tests' CPU checker holds the same
+// statement and is compared with torch itself in tests/).  V = lanes of its vector type: 8 for float32, 4 for float64.
+//   C <  V: four interleaved partial sums p[j] = x[j] + x[4 + j] + ..., the tail x[4 (C / 4) ..] added to p[0], then ((p0 + p1) + p2) + p3;
+//   C >= V: whole vectors v_i = x[V i .. V i + V): four interleaved partial vectors over groups of four, the remaining vectors added to
+//           the first, the four folded into it; then a scalar that starts at 0, takes the tail x[V (C / V) ..] first and the V lanes after.
+// (long rows cascade in blocks of 16 groups: the statement holds for C <= 512 in float32, 256 in float64.)  Every operation rounded
+// separately -- no FMA contraction.  For C <= 8 in float32 it coincides with egnn_sqdist / egnn_sqdist_n above.
+template <typename T, int V>
+__device__ __forceinline__ T egnn_sqdist_any(const T* __restrict__ a, const T* __restrict__ b, int C) {
 #pragma clang fp contract(off)
-    double sq[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        rel[c] = c < C ? a[c] - b[c] : 0.0;
-        sq[c] = rel[c] * rel[c];
+    auto sq = [&](int c) { const T r = a[c] - b[c]; return r * r; };
+    if (C < V) {
+        T p0 = (T)0, p1 = (T)0, p2 = (T)0, p3 = (T)0;
+        const int groups = C >> 2;
+        for (int i = 0; i < groups; ++i) {
+            p0 = p0 + sq(4 * i);
+            p1 = p1 + sq(4 * i + 1);
+            p2 = p2 + sq(4 * i + 2);
+            p3 = p3 + sq(4 * i + 3);
+        }
+        for (int k = 4 * groups; k < C; ++k) p0 = p0 + sq(k);
+        return ((p0 + p1) + p2) + p3;
     }
-    double d = sq[0];
-    if (C >= 5 && C <= 7) {
+    const int nv = C / V, groups = nv >> 2;
+    T p[V];
 #pragma unroll
-        for (int c = 4; c < 8; ++c)
-            if (c < C) d = d + sq[c];
+    for (int k = 0; k < V; ++k) p[k] = (T)0;
+    if (groups > 0) {                                            // (C >= 4 V only: three more partial vectors)
+        T q1[V], q2[V], q3[V];
 #pragma unroll
-        for (int c = 1; c < 4; ++c) d = d + sq[c];
+        for (int k = 0; k < V; ++k) { q1[k] = (T)0; q2[k] = (T)0; q3[k] = (T)0; }
+        for (int i = 0; i < groups; ++i) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                p[k] = p[k] + sq(V * (4 * i) + k);
+                q1[k] = q1[k] + sq(V * (4 * i + 1) + k);
+                q2[k] = q2[k] + sq(V * (4 * i + 2) + k);
+                q3[k] = q3[k] + sq(V * (4 * i + 3) + k);
+            }
+        }
+        for (int i = 4 * groups; i < nv; ++i) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) p[k] = p[k] + sq(V * i + k);
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) p[k] = ((p[k] + q1[k]) + q2[k]) + q3[k];
     } else {
+        for (int i = 0; i < nv; ++i) {
 #pragma unroll
-        for (int c = 1; c < 8; ++c)
-            if (c < C) d = d + sq[c];
+            for (int k = 0; k < V; ++k) p[k] = p[k] + sq(V * i + k);
+        }
     }
-    return d;
+    T acc = (T)0;
+    for (int k = V * nv; k < C; ++k) acc = acc + sq(k);
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc = acc + p[k];
+    return acc;
 }
 
 // Packed ("tile-major") layout of the fp16 GEMM operands: an (R x Kp) matrix, R padded to 32 rows, Kp % 32 == 0, is

@@ -142,52 +142,69 @@ __global__ __launch_bounds__(256) void node_prep_f64_kernel(const double* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ neighbour selection
-// One workgroup per row: the row's N ranking keys (order-preserving 64-bit images of the float64 values) in LDS, the exact K-th
-// smallest by bitwise radix descent, ties at the threshold resolved towards the lowest index, the K selected sorted by
-// (value, index) -- the tie policy of the fp32 kernels (knn_select.hip).
+// One workgroup per row: the row's N ranking keys (order-preserving integer images of the values) in LDS, the exact K-th smallest by
+// bitwise radix descent, ties at the threshold resolved towards the lowest index, the K selected sorted by (value, index) -- the tie
+// policy of the fp32 kernels (knn_select.hip).  Any coordinate dimension: the squared distances follow the
+// reference's summation tree (egnn_common.h::egnn_sqdist_any).  Instantiated for double (egnn_knn_select_f64) and for float with more
+// than 8 coordinates (egnn_knn_select_f32 hands those over: knn_select.hip keeps a row's coordinates in registers up to 8).
 constexpr int KN_THREADS = 256, KN_WAVES = 4;
 
-__device__ __forceinline__ uint64_t d2key(double f)
+__device__ __forceinline__ uint64_t to_key(double f)
 {
     const uint64_t u = (uint64_t)__double_as_longlong(f);
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
-__device__ __forceinline__ double key2d(uint64_t k)
+__device__ __forceinline__ uint32_t to_key(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ double from_key(uint64_t k)
 {
     const uint64_t u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
     return __longlong_as_double((long long)u);
 }
-
-__global__ __launch_bounds__(KN_THREADS) void knn_select_f64_kernel(
-    const double* __restrict__ coors, const uint8_t* __restrict__ mask, const uint8_t* __restrict__ adj, int64_t adj_bstride,
-    int N, int K, int C, int32_t* __restrict__ idx_out, double* __restrict__ rank_out)
+__device__ __forceinline__ float from_key(uint32_t k)
 {
+    const uint32_t u = (k >> 31) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+template <typename T> struct KnnKey;
+template <> struct KnnKey<double> { typedef uint64_t type; static constexpr int V = 4; };
+template <> struct KnnKey<float> { typedef uint32_t type; static constexpr int V = 8; };
+
+template <typename T>
+__global__ __launch_bounds__(KN_THREADS) void knn_select_any_kernel(
+    const T* __restrict__ coors, const uint8_t* __restrict__ mask, const uint8_t* __restrict__ adj, int64_t adj_bstride,
+    int N, int K, int C, int32_t* __restrict__ idx_out, T* __restrict__ rank_out)
+{
+    typedef typename KnnKey<T>::type key_t;
+    constexpr int BITS = 8 * (int)sizeof(key_t);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                  // [N]
-    uint64_t* selk = keys + N;                                           // [K] keys of the selected
+    key_t* keys = reinterpret_cast<key_t*>(smem);                        // [N]
+    key_t* selk = keys + N;                                              // [K] keys of the selected
     int* selj = reinterpret_cast<int*>(selk + K);                        // [K] their indices
     int* red = selj + K;                                                 // [2 * KN_WAVES]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y, i = blockIdx.x;
-    const double* cb = coors + (size_t)b * N * C;
+    const T* cb = coors + (size_t)b * N * C;
     const uint8_t* mb = mask ? mask + (size_t)b * N : nullptr;
     const bool mi = mb ? mb[i] != 0 : true;
     const uint8_t* adjrow = adj ? adj + (size_t)b * adj_bstride + (size_t)i * N : nullptr;
     const size_t obase = ((size_t)b * N + i) * K;
     if (!mi && !adjrow) {                                                // a masked row: all keys 1e5, the first K indices
-        for (int k = tid; k < K; k += KN_THREADS) { idx_out[obase + k] = k; rank_out[obase + k] = 1e5; }
+        for (int k = tid; k < K; k += KN_THREADS) { idx_out[obase + k] = k; rank_out[obase + k] = (T)1e5; }
         return;
     }
     for (int j = tid; j < N; j += KN_THREADS) {
-        double rel[8];
-        double rk = egnn_sqdist_f64(cb + (size_t)i * C, cb + (size_t)j * C, C, rel);
-        if (!(mi && (mb ? mb[j] != 0 : true))) rk = 1e5;                 // :240-242
+        T rk = egnn_sqdist_any<T, KnnKey<T>::V>(cb + (size_t)i * C, cb + (size_t)j * C, C);
+        if (!(mi && (mb ? mb[j] != 0 : true))) rk = (T)1e5;              // :240-242
         if (adjrow) {
-            if (j == i) rk = -1.0;                                       // :255
-            else if (adjrow[j]) rk = 0.0;                                // :256
+            if (j == i) rk = (T)-1;                                      // :255
+            else if (adjrow[j]) rk = (T)0;                               // :256
         }
-        keys[j] = d2key(rk);
+        keys[j] = to_key(rk);
     }
     __syncthreads();
     auto block_sum = [&](int v, int slot) {
@@ -202,23 +219,23 @@ __global__ __launch_bounds__(KN_THREADS) void knn_select_f64_kernel(
     // contiguous slice of candidate indices per thread (index order = thread order: the tie pick below relies on it)
     const int per = (N + KN_THREADS - 1) / KN_THREADS;
     const int j0 = tid * per < N ? tid * per : N, j1 = (j0 + per) < N ? (j0 + per) : N;
-    uint64_t T = 0;
+    key_t T_ = 0;
     int below = 0;
-    for (int bit = 63; bit >= 0; --bit) {
-        const uint64_t want = T >> bit;
+    for (int bit = BITS - 1; bit >= 0; --bit) {
+        const key_t want = T_ >> bit;
         int cnt = 0;
         for (int j = j0; j < j1; ++j) cnt += (keys[j] >> bit) == want ? 1 : 0;
         cnt = block_sum(cnt, bit & 1);                                   // (alternating slots: one barrier per step)
         if (below + cnt < K) {
             below += cnt;
-            T |= (1ull << bit);
+            T_ |= ((key_t)1 << bit);
         }
     }
     const int need = K - below;
     int nless = 0, neq = 0;
     for (int j = j0; j < j1; ++j) {
-        nless += keys[j] < T ? 1 : 0;
-        neq += keys[j] == T ? 1 : 0;
+        nless += keys[j] < T_ ? 1 : 0;
+        neq += keys[j] == T_ ? 1 : 0;
     }
     __syncthreads();
     const int il = egnn_wave_inclusive_scan(nless), ie = egnn_wave_inclusive_scan(neq);
@@ -228,22 +245,43 @@ __global__ __launch_bounds__(KN_THREADS) void knn_select_f64_kernel(
     for (int w = 0; w < wave; ++w) { offl += red[w]; offe += red[KN_WAVES + w]; }
     int pl = offl, pe = offe;
     for (int j = j0; j < j1; ++j) {
-        const uint64_t kj = keys[j];
-        if (kj < T) { selk[pl] = kj; selj[pl] = j; ++pl; }
-        else if (kj == T) {
+        const key_t kj = keys[j];
+        if (kj < T_) { selk[pl] = kj; selj[pl] = j; ++pl; }
+        else if (kj == T_) {
             if (pe < need) { selk[below + pe] = kj; selj[below + pe] = j; }
             ++pe;
         }
     }
     __syncthreads();
     for (int t = tid; t < K; t += KN_THREADS) {                          // sort by (value, index): rank by counting
-        const uint64_t mk = selk[t];
+        const key_t mk = selk[t];
         const int mj = selj[t];
         int rnk = 0;
         for (int u = 0; u < K; ++u) rnk += (selk[u] < mk || (selk[u] == mk && selj[u] < mj)) ? 1 : 0;
         idx_out[obase + rnk] = mj;
-        rank_out[obase + rnk] = key2d(mk);
+        rank_out[obase + rnk] = from_key(mk);
     }
+}
+
+template <typename T>
+int knn_select_any(const T* coors, const uint8_t* mask, const uint8_t* adj, int64_t adj_batch_stride, int B, int N, int K, int coor_dim,
+                   int32_t* idx_out, T* rank_out, void* stream)
+{
+    if (!coors || !idx_out || !rank_out) return EGNN_E_NULLPTR;
+    if (B <= 0 || N <= 0 || K <= 0) return EGNN_E_SHAPE;
+    if (coor_dim < 1 || coor_dim > 64) return EGNN_E_UNSUPPORTED;
+    if (K > N) return EGNN_E_K_GT_N;
+    if (K > 1024 || B > 65535) return EGNN_E_UNSUPPORTED;
+    typedef typename KnnKey<T>::type key_t;
+    const size_t lds = ((size_t)N * sizeof(key_t) + 7) / 8 * 8 + (size_t)K * (sizeof(key_t) + 4) + 2 * KN_WAVES * sizeof(int) + 8;
+    if (lds > 160 * 1024) return EGNN_E_UNSUPPORTED;                      // N <= ~ 20 000 (double) / 40 000 (float)
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_select_any_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(knn_select_any_kernel<T>, dim3(N, B), dim3(KN_THREADS), lds, static_cast<hipStream_t>(stream), coors, mask, adj,
+                       adj_batch_stride, N, K, coor_dim, idx_out, rank_out);
+    return egnn_launch_status();
 }
 
 }  // namespace
@@ -285,18 +323,12 @@ extern "C" int egnn_node_prep_f64(const double* feats, const double* m_i, const 
 extern "C" int egnn_knn_select_f64(const double* coors, const uint8_t* mask, const uint8_t* adj, int64_t adj_batch_stride, int B, int N,
                                    int K, int coor_dim, int32_t* idx_out, double* rank_out, void* stream)
 {
-    if (!coors || !idx_out || !rank_out) return EGNN_E_NULLPTR;
-    if (B <= 0 || N <= 0 || K <= 0) return EGNN_E_SHAPE;
-    if (coor_dim < 1 || coor_dim > 8) return EGNN_E_UNSUPPORTED;
-    if (K > N) return EGNN_E_K_GT_N;
-    if (K > 1024 || B > 65535) return EGNN_E_UNSUPPORTED;
-    const size_t lds = (size_t)N * 8 + (size_t)K * 12 + 2 * KN_WAVES * sizeof(int) + 8;
-    if (lds > 160 * 1024) return EGNN_E_UNSUPPORTED;                      // N <= ~ 20 000
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_select_f64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(knn_select_f64_kernel, dim3(N, B), dim3(KN_THREADS), lds, static_cast<hipStream_t>(stream), coors, mask, adj,
-                       adj_batch_stride, N, K, coor_dim, idx_out, rank_out);
-    return egnn_launch_status();
+    return knn_select_any<double>(coors, mask, adj, adj_batch_stride, B, N, K, coor_dim, idx_out, rank_out, stream);
+}
+
+// internal (knn_select.hip: egnn_knn_select_f32 with more than 8 coordinates)
+int egnn_knn_select_any_f32(const float* coors, const uint8_t* mask, const uint8_t* adj, int64_t adj_batch_stride, int B, int N, int K,
+                            int coor_dim, int32_t* idx_out, float* rank_out, void* stream)
+{
+    return knn_select_any<float>(coors, mask, adj, adj_batch_stride, B, N, K, coor_dim, idx_out, rank_out, stream);
 }

@@ -411,13 +411,19 @@ int launch_knn(const float* coors, const uint8_t* mask, const uint8_t* adj, int6
 
 }  // namespace
 
+// internal (fp64.hip: the one-workgroup-per-row kernel for any coordinate dimension)
+int egnn_knn_select_any_f32(const float* coors, const uint8_t* mask, const uint8_t* adj, int64_t adj_batch_stride, int B, int N, int K,
+                            int coor_dim, int32_t* idx_out, float* rank_out, void* stream);
+
 extern "C" int egnn_knn_select_f32(const float* coors, const uint8_t* mask, const uint8_t* adj,
                                    int64_t adj_batch_stride, int B, int N, int K, int coor_dim, int32_t* idx_out,
                                    float* rank_out, void* stream)
 {
     if (!coors || !idx_out || !rank_out) return EGNN_E_NULLPTR;
     if (B <= 0 || N <= 0 || K <= 0) return EGNN_E_SHAPE;
-    if (coor_dim < 1 || coor_dim > 8) return EGNN_E_UNSUPPORTED;
+    if (coor_dim < 1 || coor_dim > 64) return EGNN_E_UNSUPPORTED;
+    // more than 8 coordinates: one workgroup per row, coordinates read from memory, the reference's summation tree for any length
+    if (coor_dim > 8) return egnn_knn_select_any_f32(coors, mask, adj, adj_batch_stride, B, N, K, coor_dim, idx_out, rank_out, stream);
     const int C = coor_dim;
     if (K > N) return EGNN_E_K_GT_N;
     if (K > 1024 || B > 65535) return EGNN_E_UNSUPPORTED;

@@ -164,8 +164,8 @@ class EGNN(nn.Module):
             raise NotImplementedError(f"the gfx950 path takes floating-point feats / coors (got {feats.dtype}/{coors.dtype})")
         if feats.dim() != 3 or coors.dim() != 3 or feats.shape[:2] != coors.shape[:2]:
             raise ValueError(f"feats {tuple(feats.shape)} / coors {tuple(coors.shape)}: expected (B,N,dim) and (B,N,C)")
-        if not 1 <= coors.shape[-1] <= 8:
-            raise NotImplementedError("the gfx950 path supports coordinate dimensions 1..8")
+        if not 1 <= coors.shape[-1] <= 64:
+            raise NotImplementedError("the gfx950 path supports coordinate dimensions 1..64 (beyond 8 on the plain kernels)")
         if feats.shape[-1] != self.dim:
             raise ValueError(f"feats last dim {feats.shape[-1]} != dim {self.dim}")
         if self.training and self.dropout_p > 0 and (coors.shape[-1] != 3 or self.m_dim > 16):
@@ -260,7 +260,8 @@ class EGNN(nn.Module):
 
     def _forward_hip(self, feats, coors, edges, mask, adj_mat, order_hint=None, want_u=False, drop=None):
         # more per-edge scalars than the split-fp16 edge kernels carry (2 fourier + 1 + edge_dim > 16, up to 64): the plain-fp32 kernels
-        wide_shape = 16 < 2 * self.fourier_features + 1 + self.edge_dim <= 64
+        # ... and more than 8 coordinates (the fused kernels keep x_i - x_j in registers up to 8)
+        wide_shape = 16 < 2 * self.fourier_features + 1 + self.edge_dim <= 64 or coors.shape[-1] > 8
         if exact_active() or (wide_shape and not want_u and drop is None):
             if want_u or drop is not None:
                 raise NotImplementedError("the plain-fp32 (wide-range) kernels are inference-only: no backward, no training-mode dropout")

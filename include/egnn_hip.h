@@ -67,10 +67,11 @@ int egnn_padded_hidden(int H);
  * Neighbour selection: replaces egnn_pytorch.py:232-233 (pairwise rel_coors / rel_dist), :237-256
  * (ranking: masked pairs -> 1e5, with adj_mat: self -> -1, adjacent -> 0) and :258 (topk smallest K,
  * ascending).  Nothing of size N*N is materialised.
- *   coors  (B,N,coor_dim) fp32, 1 <= coor_dim <= 8.  For coor_dim == 3 rel_dist is computed as
+ *   coors  (B,N,coor_dim) fp32, 1 <= coor_dim <= 64.  For coor_dim == 3 rel_dist is computed as
  *          ((dx*dx + dy*dy) + dz*dz) with every multiply and add rounded separately (no FMA) -- bit-identical to the
- *          reference's CPU result; other dimensions follow the summation order measured on the reference
- *          (left to right for C in {1,2,4,8}; s0, s4 .. s_{C-1}, s1, s2, s3 for C in {5,6,7}).
+ *          reference's CPU result; other dimensions follow the summation tree of the reference's sum(dim=-1) (ATen's inner-dimension
+ *          sum: left to right for C in {1,2,4,8}; s0, s4 .. s_{C-1}, s1, s2, s3 for C in {5,6,7}; eight interleaved lanes with the
+ *          tail first beyond 8 -- csrc/egnn_common.h::egnn_sqdist_any).  More than 8 coordinates: one workgroup per row.
  *   mask   (B,N) bytes or NULL.
  *   adj    (N,N) bytes (adj_batch_stride = 0) or (B,N,N) bytes (adj_batch_stride = N*N), or NULL.
  *          The diagonal is ignored (the reference clears it, :254).
@@ -556,7 +557,7 @@ int egnn_node_prep_f32(const float* feats, const float* m_i, const float* gamma,
  *   Ws       = edge_mlp.0.weight + 2 dim: row h holds the S = 2 fourier + 1 + edge_dim scalar columns, ldws = Din;
  *   W2, b2   edge_mlp.3 (m_dim, H), (m_dim);  gate_w (m_dim), gate_b (1) or NULL;
  *   W3 (4 m_dim, m_dim), b3 (4 m_dim), W4 (4 m_dim), b4 (1): coors_mlp, or NULL (update_coors=False);  coors_scale (1) or NULL;
- *   coors (B,N,coor_dim), 1 <= coor_dim <= 8;  edges / edges_by_k / mask / idx / rank / valid_radius / clamp / pool_mean as in egnn_edge_args;
+ *   coors (B,N,coor_dim), 1 <= coor_dim <= 64;  edges / edges_by_k / mask / idx / rank / valid_radius / clamp / pool_mean as in egnn_edge_args;
  *   m_i (B*N, m_dim) and / or coors_out (B,N,coor_dim);  edge_ws: egnn_edge_exact_workspace_bytes() of scratch (per-edge rows,
  *   summed per node in k order: deterministic).
  * Limits: m_dim <= 64, at most 64 per-edge scalars. */
@@ -598,7 +599,7 @@ int egnn_edge_exact_f32(const egnn_edge_exact_args* args, void* stream);
  * significant bits per product.  A binding routes a module whose parameters are float64 through the entries below (the shipped one
  * does: egnn_pytorch_amd/layer.py) -- the same plain kernels as the wide-range path, instantiated for double:
  *   egnn_knn_select_f64   as egnn_knn_select_f32 (squared distances in the same operation order, ranking edits, exact top-K, ties
- *                         towards the lowest index); rank_out in float64.  One workgroup per row, keys in LDS: N <= 20 000, K <= 1024
+ *                         towards the lowest index), coor_dim <= 64; rank_out in float64.  One workgroup per row, keys in LDS: N <= 20 000, K <= 1024
  *   egnn_linear_f64       as egnn_linear_f32, on v_mfma_f64_16x16x4_f64
  *   egnn_node_prep_f64    as egnn_node_prep_f32
  *   egnn_edge_exact_f64   as egnn_edge_exact_f32 with every data pointer of egnn_edge_exact_args a double*; workspace twice

@@ -75,19 +75,55 @@ def pairwise(coors):
     rel_coors[b,i,j,:] = coors[b,i] - coors[b,j];  rel_dist = sum_c rel^2.
     For C == 3 the reference's CPU result is bit-identical to ((dx*dx + dy*dy) + dz*dz) with
     separately rounded multiplies and adds; that order is pinned here.
-    Other C (measured against torch 2.10 CPU, fp32, C <= 8): left to right for C in {1, 2, 4, 8}; for C in {5, 6, 7}
-    the order is s0, s4, ..., s_{C-1}, s1, s2, s3 (ATen's 4-wide inner reduction folds the tail into lane 0 first).
+    Other C: `inner_sum` below -- the summation tree of ATen's inner-dimension sum, which the ranking has to follow bit for bit.
     """
     rel = coors[:, :, None, :] - coors[:, None, :, :]
     sq = rel * rel
-    dist = None
-    for c in sum_order(coors.shape[-1]):
-        dist = sq[..., c] if dist is None else dist + sq[..., c]
-    return rel, dist
+    return rel, inner_sum(sq)
+
+
+def inner_sum(x):
+    """`x.sum(dim=-1)` of a contiguous tensor as the reference's CPU path computes it (ATen, aten/src/ATen/native/cpu/SumKernel.cpp:
+    vectorized_inner_sum / scalar_inner_sum over row_sum with four interleaved partial sums), restated and checked bit for bit against
+    torch 2.10 for C = 1 .. 513 in float32 and 1 .. 200 in float64 (tests/test_oracle_vs_reference.py).  V = lanes of the vector type:
+    8 for float32, 4 for float64.
+      C <  V: partial sums p[j] = x[j] + x[4 + j] + ..., the tail x[4 (C // 4):] added to p[0], then ((p0 + p1) + p2) + p3;
+      C >= V: whole vectors v_i = x[V i : V i + V] -- four interleaved partial vectors over groups of four, the remaining vectors added
+              to the first, the four folded into it; then a scalar that starts at 0, takes the tail x[V (C // V):] first and the V lanes
+              after.
+    (Rows longer than 512 / 256 elements cascade in blocks and are not covered.)  For C <= 8 in float32 this is: left to right for
+    C in {1, 2, 3, 4, 8}; s0, s4, ..., s_{C-1}, s1, s2, s3 for C in {5, 6, 7}."""
+    c = x.shape[-1]
+    v = 4 if x.dtype == np.float64 else 8
+    zero = np.zeros(x.shape[:-1], dtype=x.dtype)
+    if c < v:
+        p = [zero.copy() for _ in range(4)]
+        for i in range(c // 4):
+            for j in range(4):
+                p[j] = p[j] + x[..., 4 * i + j]
+        for k in range(4 * (c // 4), c):
+            p[0] = p[0] + x[..., k]
+        return ((p[0] + p[1]) + p[2]) + p[3]
+    nv = c // v
+    assert nv // 4 <= 16, "rows this long cascade in ATen: not restated"
+    p = [np.zeros(x.shape[:-1] + (v,), dtype=x.dtype) for _ in range(4)]
+    for i in range(nv // 4):
+        for j in range(4):
+            p[j] = p[j] + x[..., v * (4 * i + j):v * (4 * i + j) + v]
+    for i in range(4 * (nv // 4), nv):
+        p[0] = p[0] + x[..., v * i:v * i + v]
+    lanes = ((p[0] + p[1]) + p[2]) + p[3]
+    acc = zero.copy()
+    for k in range(v * nv, c):
+        acc = acc + x[..., k]
+    for k in range(v):
+        acc = acc + lanes[..., k]
+    return acc
 
 
 def sum_order(c):
-    """Order in which the reference's `(rel_coors ** 2).sum(-1)` adds its C terms (see pairwise)."""
+    """Order in which the reference's fp32 `(rel_coors ** 2).sum(-1)` adds its C <= 8 terms (`inner_sum` is the general statement)."""
+    assert c <= 8
     if c in (5, 6, 7):
         return [0] + list(range(4, c)) + [1, 2, 3]
     return list(range(c))

@@ -142,6 +142,10 @@ CASES = [
     ("knn8_coor_dim5_normcoors_mask", "layer", dict(dim=32, num_nearest_neighbors=8, norm_coors=True), 2, 40,
      dict(mask=True, coor_dim=5)),
     ("knn8_coor_dim2_mask", "layer", dict(dim=32, num_nearest_neighbors=8), 2, 40, dict(mask=True, coor_dim=2)),
+    # more than 8 coordinates (the fused kernels stop at 8: these run on the plain kernels; egnn_common.h::egnn_sqdist_any)
+    ("knn8_coor_dim11_mask", "layer", dict(dim=32, num_nearest_neighbors=8), 2, 40, dict(mask=True, coor_dim=11)),
+    ("knn8_coor_dim33_normcoors", "layer", dict(dim=24, num_nearest_neighbors=8, norm_coors=True, m_pool_method="mean"), 2, 36,
+     dict(mask=True, coor_dim=33)),
 ]
 
 

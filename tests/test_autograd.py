@@ -616,6 +616,32 @@ def test_backward_at_baseline_widths_matches_the_reference_autograd(ref, name, k
 
 
 @pytest.mark.gpu
+def test_more_than_eight_coordinates_train_through_the_recompute_backward(ref):
+    """C > 8 runs its forward on the plain kernels (inference-only); under autograd the backward is the chunked recompute over the
+    neighbour list they selected: gradients against the reference's float64 autograd."""
+    from egnn_pytorch_amd import EGNN
+    kw = dict(dim=24, num_nearest_neighbors=6)
+    torch.manual_seed(12)
+    rlayer = ref.EGNN(**kw)
+    for mod in rlayer.modules():
+        if isinstance(mod, torch.nn.Linear):
+            torch.nn.init.xavier_normal_(mod.weight)
+    layer = EGNN(**kw)
+    layer.load_state_dict(rlayer.state_dict(), strict=True)
+    layer, rlayer = layer.cuda(), rlayer.double().cuda()
+    g = torch.Generator().manual_seed(13)
+    feats, coors = torch.randn(2, 30, 24, generator=g).cuda(), torch.randn(2, 30, 12, generator=g).cuda()
+    f1, c1 = feats.clone().requires_grad_(True), coors.clone().requires_grad_(True)
+    f2, c2 = feats.double().requires_grad_(True), coors.double().requires_grad_(True)
+    got, _ = _grads(layer, lambda: layer(f1, c1), (f1, c1))
+    want, _ = _grads(rlayer, lambda: rlayer(f2, c2), (f2, c2))
+    for gg, ww in zip(got, want):
+        assert (gg is None) == (ww is None)
+        if gg is not None:
+            assert float((gg.double() - ww).abs().max()) <= 1e-4 * float(ww.abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,kw,b,n,cdim", [
     ("m32_knn8", dict(dim=64, m_dim=32, num_nearest_neighbors=8), 3, 96, 3),
     ("m32_knn32_normfeats", dict(dim=128, m_dim=32, num_nearest_neighbors=32, norm_feats=True), 2, 256, 3),

@@ -113,6 +113,7 @@ LAYER_CASES = [
     ("soft_edges_mean_radius", dict(dim=32, num_nearest_neighbors=8, soft_edges=True, m_pool_method="mean", valid_radius=1.5), 2, 50,
      dict(mask=True)),
     ("five_dims_m32", dict(dim=32, m_dim=32, num_nearest_neighbors=6), 2, 40, dict(cdim=5)),
+    ("eleven_dims_normcoors", dict(dim=32, num_nearest_neighbors=8, norm_coors=True), 2, 40, dict(cdim=11, mask=True)),
     ("sparse_adjacency", dict(dim=32, edge_dim=2, only_sparse_neighbors=True), 2, 48, dict(mask=True, edges=True, adj=True)),
     ("no_coors_update", dict(dim=32, update_coors=False, num_nearest_neighbors=5), 1, 30, dict()),
     ("ns_width", dict(dim=512, num_nearest_neighbors=32), 1, 128, dict(mask=True)),

@@ -100,6 +100,10 @@ CONFIGS = [
     ("coor_dim7_dense_edges", dict(dim=32, edge_dim=2), 1, 40, dict(edges=True, coor_dim=7)),
     ("coor_dim8_k20_mean", dict(dim=32, num_nearest_neighbors=20, m_pool_method="mean"), 2, 50, dict(mask=True, coor_dim=8)),
     ("coor_dim1_k8", dict(dim=32, num_nearest_neighbors=8), 1, 30, dict(coor_dim=1)),
+    # more than 8 coordinates: the plain kernels (the fused ones keep x_i - x_j in registers up to 8)
+    ("coor_dim11_k8_edges", dict(dim=32, num_nearest_neighbors=8, edge_dim=2), 2, 48, dict(mask=True, edges=True, coor_dim=11)),
+    ("coor_dim20_dense_normcoors", dict(dim=24, norm_coors=True, m_pool_method="mean"), 2, 30, dict(mask=True, coor_dim=20)),
+    ("coor_dim64_k16_gate", dict(dim=32, num_nearest_neighbors=16, soft_edges=True), 1, 64, dict(coor_dim=64)),
     # m_dim beyond one 16-channel MFMA tile: two / four accumulator tiles per edge tile (the reference has no limit, :153)
     ("m32_k32", dict(dim=64, m_dim=32, num_nearest_neighbors=32, soft_edges=True, norm_coors=True), 2, 96,
      dict(mask=True, scale={"edge_mlp.3.weight": 0.5})),

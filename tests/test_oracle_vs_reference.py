@@ -92,3 +92,36 @@ def test_sparse_chain_config4_layer():
     node, co = O.egnn_forward(cfg, params, feats.numpy(), coors.numpy(), edges.numpy(), mask.numpy(), adj.numpy())
     np.testing.assert_allclose(node, rn.numpy(), atol=3e-5, rtol=0)
     np.testing.assert_allclose(co, rc.numpy(), atol=3e-5, rtol=0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_squared_distance_summation_tree_matches_torch_bit_for_bit(dtype):
+    """`(rel_coors ** 2).sum(dim=-1)` (egnn_pytorch.py:233) for every coordinate dimension the kernels take: the oracle's restatement of
+    ATen's inner-dimension sum (egnn_oracle.inner_sum; the kernels' egnn_sqdist_any follows the same tree) against torch itself."""
+    rng = np.random.default_rng(0)
+    for c in list(range(1, 41)) + [48, 63, 64, 65, 100, 128, 200]:
+        a = rng.standard_normal((2, 24, c)).astype(dtype)
+        t = torch.from_numpy(a)
+        rel = t[:, :, None, :] - t[:, None, :, :]
+        want = (rel ** 2).sum(dim=-1).numpy()
+        got_rel, got = O.pairwise(a)
+        assert np.array_equal(got_rel, rel.numpy()), c
+        assert np.array_equal(got, want), (c, dtype)
+
+
+@pytest.mark.parametrize("kwargs,cdim", [(dict(dim=32, num_nearest_neighbors=8), 11), (dict(dim=24, num_nearest_neighbors=8, norm_coors=True), 33),
+                                         (dict(dim=16), 9)])
+def test_layer_with_more_than_eight_coordinates(kwargs, cdim):
+    ref = _ref()
+    torch.manual_seed(cdim)
+    layer = ref.EGNN(**kwargs).eval()
+    _xavier(layer, 3)
+    g = torch.Generator().manual_seed(cdim + 1)
+    feats, coors = torch.randn(2, 36, kwargs["dim"], generator=g), torch.randn(2, 36, cdim, generator=g)
+    mask = torch.arange(36)[None] < torch.tensor([[36], [29]])
+    with torch.no_grad():
+        want_n, want_c = layer(feats, coors, mask=mask)
+    params = {k: v.detach().numpy() for k, v in layer.state_dict().items()}
+    got_n, got_c = O.egnn_forward(O.EGNNConfig(**kwargs), params, feats.numpy(), coors.numpy(), mask=mask.numpy())
+    np.testing.assert_allclose(got_n, want_n.numpy(), atol=1e-5 * max(1.0, float(want_n.abs().max())), rtol=0)
+    np.testing.assert_allclose(got_c, want_c.numpy(), atol=1e-5 * max(1.0, float(want_c.abs().max())), rtol=0)
