@@ -574,7 +574,12 @@ def _backward_native(ctx, g_node, g_coors):
     lin0, lin3 = layer.edge_mlp[0], layer.edge_mlp[3]
     head = {id(lin0.weight), id(lin0.bias), id(lin3.weight), id(lin3.bias)}
     tail_params = [p for p in params if id(p) not in head]
-    grads_by_id = {id(p): torch.zeros_like(p) for p in params}
+    # (one zero fill for all parameter gradients: views of a flat buffer)
+    flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=feats.device)
+    grads_by_id, off = {}, 0
+    for p in params:
+        grads_by_id[id(p)] = flat[off:off + p.numel()].view(p.shape)
+        off += p.numel()
     g_feats = torch.zeros_like(feats)
     g_coors_in = torch.zeros_like(coors)
     want_ge = edges is not None and need[6]                 # (the (B,N,N,edge_dim) input: its gradient only if somebody asked for it)
@@ -606,9 +611,20 @@ def _backward_native(ctx, g_node, g_coors):
             step = min(step, _FUSED_MAX_GRAPHS)
     # the first Linear's blocks, zero padded to the kernel's hidden width Hp: everything below works on the contiguous
     # (E, Hp) buffers the kernel wrote (slicing [:, :H] first would copy 17 GB per use at the north-star shape)
-    w1p = torch.zeros(hp, lin0.weight.shape[1], dtype=torch.float32, device=feats.device)
-    w1p[:h] = lin0.weight.detach()
-    w_i, w_j, w_s = w1p[:, :dim].contiguous(), w1p[:, dim:2 * dim].contiguous(), w1p[:, 2 * dim:].contiguous()
+    # (padded copies of parameters are kept with the packed weights: `w` is rebuilt whenever a parameter changes, so once per
+    # optimizer step instead of a dozen small launches per backward)
+    pads = w.get("bwd_pads")
+    if pads is None or pads["device"] != feats.device:
+        pads = w["bwd_pads"] = {"device": feats.device}
+        w_s = torch.zeros(hp, lin0.weight.shape[1] - 2 * dim, dtype=torch.float32, device=feats.device)
+        w_s[:h] = lin0.weight.detach()[:, 2 * dim:]
+        pads["w_s"] = w_s
+    w_s = pads["w_s"]
+    w_i = w_j = None
+    if not (feats.is_cuda and _GRAD_GEMM):               # (host tensors -- the CPU tests: plain matmuls instead of the split-f16 GEMM)
+        w1p = torch.zeros(hp, lin0.weight.shape[1], dtype=torch.float32, device=feats.device)
+        w1p[:h] = lin0.weight.detach()
+        w_i, w_j = w1p[:, :dim].contiguous(), w1p[:, dim:2 * dim].contiguous()
     pi_split = k >= 6
     # the per-edge chain behind u in closed form on the device (egnn_edge_tail_bwd_f32) where it applies (m_dim <= 16, coors_mlp
     # hidden width <= 64); otherwise that part goes through autograd as well
@@ -642,9 +658,11 @@ def _backward_native(ctx, g_node, g_coors):
                 pm8 = None if pm is None else pm.contiguous().view(torch.uint8)
                 gate, mm_pre, mm = None, None, None
                 if layer.edge_gate is not None:                                              # soft_edges (:289-290)
-                    gw16 = torch.zeros(16, dtype=torch.float32, device=feats.device)
-                    gw16[:m] = layer.edge_gate[0].weight.detach()[0]
-                    gate = (gw16, layer.edge_gate[0].bias.detach().contiguous())
+                    if "gw16" not in pads:
+                        gw16 = torch.zeros(16, dtype=torch.float32, device=feats.device)
+                        gw16[:m] = layer.edge_gate[0].weight.detach()[0]
+                        pads["gw16"] = gw16
+                    gate = (pads["gw16"], layer.edge_gate[0].bias.detach().contiguous())
                 if reduce:
                     m_sum = _ops.edge_pool(u16, gate, pm8, bc, n, k)
                 else:
@@ -698,12 +716,15 @@ def _backward_native(ctx, g_node, g_coors):
                     g_msum[..., :m] = g_mi
                 lin_a, lin_b = layer.coors_mlp[0], layer.coors_mlp[3]
                 hid3 = lin_a.weight.shape[0]
-                w3p = torch.zeros(64, 16, dtype=torch.float32, device=feats.device)
-                w3p[:hid3, :m] = lin_a.weight.detach()
-                b3p = torch.zeros(64, dtype=torch.float32, device=feats.device)
-                b3p[:hid3] = lin_a.bias.detach()
-                w4p = torch.zeros(64, dtype=torch.float32, device=feats.device)
-                w4p[:hid3] = lin_b.weight.detach()[0]
+                if "w3p" not in pads:
+                    w3p = torch.zeros(64, 16, dtype=torch.float32, device=feats.device)
+                    w3p[:hid3, :m] = lin_a.weight.detach()
+                    b3p = torch.zeros(64, dtype=torch.float32, device=feats.device)
+                    b3p[:hid3] = lin_a.bias.detach()
+                    w4p = torch.zeros(64, dtype=torch.float32, device=feats.device)
+                    w4p[:hid3] = lin_b.weight.detach()[0]
+                    pads["w3p"], pads["b3p"], pads["w4p"] = w3p, b3p, w4p
+                w3p, b3p, w4p = pads["w3p"], pads["b3p"], pads["w4p"]
                 norm = layer.norm_coors
                 tail_args = (u16, c0, i32, pm8, g_coors[lo:hi_].contiguous(), g_msum, w3p, b3p, w4p, lin_b.bias.detach().contiguous(),
                              layer.coors_norm.scale.detach() if norm else None, layer.coors_norm.eps if norm else 0.0,
