@@ -53,6 +53,10 @@ constexpr int PW_WAVES = 4;
 #ifndef EGNN_PW_EARLY_W
 #define EGNN_PW_EARLY_W 1
 #endif
+// experiment: wave priorities -- 1: setup / epilogue high, hidden loop low; 2: the reverse; 0: none (measured: see the header comment)
+#ifndef EGNN_PW_PRIO
+#define EGNN_PW_PRIO 0
+#endif
 #ifndef EGNN_PW_HC
 #define EGNN_PW_HC 64
 #endif
@@ -399,6 +403,11 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, blo, acc[t], 0, 0, 0);
             }
         };
+#if EGNN_PW_PRIO == 1
+        asm volatile("s_setprio 0");
+#elif EGNN_PW_PRIO == 2
+        asm volatile("s_setprio 3");
+#endif
         for (int c = 0; c < nchunks; ++c, ++ring) {
             const int slot = ring & 1;
             const int c0 = c * PW_HC;
@@ -416,6 +425,11 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
             }
         }
 
+#if EGNN_PW_PRIO == 1
+        asm volatile("s_setprio 3");
+#elif EGNN_PW_PRIO == 2
+        asm volatile("s_setprio 0");
+#endif
         // ------------------------------------------------------------------ per-edge epilogue (registers; channel of (lane group g, register u) = 4 g + u)
         const pw_args_ptr pe = pw_args();                                   // epilogue arguments (scalar loads, this round only)
         const bool has_mask = pe->mask != nullptr;
