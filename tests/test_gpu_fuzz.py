@@ -1,0 +1,76 @@
+"""Seeded random walks over the constructor / input space of EGNN.forward (egnn_pytorch.py:149-168, 224-341): the HIP path against the
+numpy oracle, one small case per seed.  The hand-picked cases of tests/test_gpu_parity.py cover each option on its own and the
+combinations somebody thought of; this covers the ones nobody did (kernel variants are chosen by K, m_dim, the number of per-edge
+scalars, the coordinate dimension and the flags *together*).  1e-4 of the output's scale, as everywhere."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import egnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(x):
+    return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def _draw(seed):
+    rng = np.random.default_rng(1000 + seed)
+    pick = lambda xs: xs[int(rng.integers(len(xs)))]                                      # noqa: E731
+    kw = dict(dim=pick([8, 16, 24, 40, 64]), m_dim=pick([4, 16, 16, 16, 20, 32, 48]), edge_dim=pick([0, 0, 1, 3]),
+              fourier_features=pick([0, 0, 1, 2]), norm_feats=bool(rng.integers(2)), norm_coors=bool(rng.integers(2)),
+              m_pool_method=pick(["sum", "mean"]), soft_edges=bool(rng.integers(2)),
+              coor_weights_clamp_value=pick([None, None, 0.5, 2.0]), valid_radius=pick([float("inf"), float("inf"), 2.5]))
+    upd = pick(["both", "both", "feats", "coors"])
+    kw["update_feats"], kw["update_coors"] = upd != "coors", upd != "feats"
+    mode = pick(["dense", "knn", "knn", "knn", "sparse", "knn_adj"])
+    n = int(rng.integers(6, 90))
+    if mode in ("knn", "knn_adj"):
+        kw["num_nearest_neighbors"] = min(n, pick([3, 5, 8, 16, 32, 32, 64]))
+    if mode == "sparse":
+        kw["only_sparse_neighbors"] = True
+    cdim = pick([3, 3, 3, 1, 2, 5, 8, 11])
+    b = int(rng.integers(1, 4))
+    use_mask = bool(rng.integers(3))
+    return kw, mode, b, n, cdim, use_mask, rng
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EGNN_FUZZ_SEEDS", "64"))))      # (EGNN_FUZZ_SEEDS=1000: a longer walk)
+def test_random_configuration_against_the_oracle(seed):
+    from egnn_pytorch_amd import EGNN
+    kw, mode, b, n, cdim, use_mask, rng = _draw(seed)
+    cfg = O.EGNNConfig(**kw)
+    params = O.random_params(cfg, seed=seed)
+    # dense graphs and wide neighbourhoods sum many messages: keep the outputs of order one to ten (the 1e-4 bar is absolute up to 256)
+    k_eff = kw.get("num_nearest_neighbors", 0) or (3 if mode == "sparse" else n)
+    if "coors_mlp.3.weight" in params:
+        params["coors_mlp.3.weight"] = params["coors_mlp.3.weight"] * np.float32(min(1.0, 8.0 / k_eff))
+    params["edge_mlp.3.weight"] = params["edge_mlp.3.weight"] * np.float32(min(1.0, 4.0 / np.sqrt(k_eff)))
+    feats = rng.standard_normal((b, n, kw["dim"])).astype(np.float32)
+    coors = rng.standard_normal((b, n, cdim)).astype(np.float32)
+    edges = rng.standard_normal((b, n, n, kw["edge_dim"])).astype(np.float32) if kw["edge_dim"] else None
+    mask = None
+    if use_mask:
+        lo = max(1, kw.get("num_nearest_neighbors", 1))
+        lens = rng.integers(min(n, max(lo, n // 2)), n + 1, size=b)
+        mask = np.arange(n)[None, :] < lens[:, None]
+    adj = None
+    if mode in ("sparse", "knn_adj"):
+        i = np.arange(n)
+        adj = (np.abs(i[:, None] - i[None, :]) <= 1) | (rng.random((n, n)) < 0.02)
+        adj = adj | adj.T
+    want_n, want_c = O.egnn_forward(cfg, params, feats, coors, edges, mask, adj)
+    net = EGNN(**kw)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        node, co = net(_dev(feats), _dev(coors), _dev(edges), _dev(mask), _dev(adj))
+    what = (seed, kw, mode, b, n, cdim, use_mask)
+    for got, want in ((node, want_n), (co, want_c)):
+        assert np.isfinite(want).all(), what
+        tol = 1e-4 * max(1.0, float(np.abs(want).max()) / 256.0)
+        err = float(np.abs(got.cpu().numpy() - want).max())
+        assert err <= tol, (what, err, tol)
