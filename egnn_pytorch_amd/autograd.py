@@ -383,6 +383,18 @@ class EGNNFunction(torch.autograd.Function):
         return _backward_recompute(ctx, g_node, g_coors)
 
 
+def _unused_params(layer):
+    """ids of the parameters no output depends on -- node_norm without node_mlp (update_feats=False), CoorsNorm's scale without
+    coors_mlp (update_coors=False; egnn_pytorch.py:302-306 applies it inside that branch): autograd leaves their .grad None in the
+    reference, and so does this Function (an optimizer treats None and zeros differently: weight decay, state creation)."""
+    out = set()
+    if layer.node_mlp is None:
+        out |= {id(p) for p in layer.node_norm.parameters()}
+    if layer.coors_mlp is None:
+        out |= {id(p) for p in layer.coors_norm.parameters()}
+    return out
+
+
 def _unpack(ctx):
     feats, coors, edges, mask, idx, rank = ctx.saved_tensors[:6]
     has_mask, has_idx = ctx.flags
@@ -866,7 +878,9 @@ def _backward_native(ctx, g_node, g_coors):
                     g_coors_in[lo:hi_] -= g_rel.view(bc, n, n, 4).sum(dim=1)[..., :3]
                 else:
                     g_coors_in[lo:hi_] -= _ops.rows_gather_sum(g_rel, dest_lists.order, dest_lists.seg, bc * n).view(bc, n, 4)[..., :3]
-    out_params = [grads_by_id[id(p)].to(op.dtype) if need[7 + i] else None for i, (p, op) in enumerate(zip(params, orig_params))]
+    unused = _unused_params(layer)
+    out_params = [grads_by_id[id(p)].to(op.dtype) if (need[7 + i] and id(p) not in unused) else None
+                  for i, (p, op) in enumerate(zip(params, orig_params))]
     return (None, None, None, None, g_feats.to(in_dtypes[0]) if need[4] else None, g_coors_in.to(in_dtypes[1]) if need[5] else None,
             g_edges.to(in_dtypes[2]) if want_ge else None, *out_params)
 
@@ -934,6 +948,8 @@ def _backward_recompute(ctx, g_node, g_coors):
                 if g is not None:
                     gp.add_(g)
     cast = lambda g, dt: None if g is None else g.to(dt)                                        # noqa: E731
+    unused = _unused_params(layer)
+    g_params = [None if id(p) in unused else g for p, g in zip(params, g_params)]
     return (None, None, None, None, cast(g_feats, in_dtypes[0]), cast(g_coors_in, in_dtypes[1]), cast(g_edges, in_dtypes[2]), *g_params)
 
 
