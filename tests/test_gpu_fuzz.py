@@ -151,3 +151,82 @@ def test_random_configuration_gradients_against_the_reference_autograd(ref, seed
         # 2e-4 of the gradient's scale -- or, where the gradient is a heavily cancelling sum over all edges (a bias of 1e-3 made of
         # terms of 1e-1), no further from float64 than four times the reference's own fp32 autograd is
         assert err <= max(2e-4 * scale, 4.0 * float((rr.double() - ww).abs().max())), (what, i, err / scale)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EGNN_FUZZ_NET_SEEDS", "32"))))
+def test_random_network_against_the_oracle(seed):
+    """EGNN_Network (egnn_pytorch.py:343-454): token / position / edge-token / adjacency-degree front-end, induced-set attention blocks and
+    the layer loop, random combinations, against the oracle's restatement."""
+    from egnn_pytorch_amd import EGNN_Network
+    rng = np.random.default_rng(9000 + seed)
+    pick = lambda xs: xs[int(rng.integers(len(xs)))]                                      # noqa: E731
+    n, b, depth, dim = int(rng.integers(8, 48)), int(rng.integers(1, 3)), int(rng.integers(1, 4)), pick([16, 24, 32])
+    kw = dict(depth=depth, dim=dim)
+    num_tokens = pick([None, 11])
+    if num_tokens:
+        kw["num_tokens"] = num_tokens
+    if rng.integers(2):
+        kw["num_positions"] = n + int(rng.integers(0, 5))
+    edge_mode = pick(["none", "float", "tokens"])
+    edge_dim = 0
+    if edge_mode != "none":
+        edge_dim = pick([1, 3, 4])
+        kw["edge_dim"] = edge_dim
+        if edge_mode == "tokens":
+            kw["num_edge_tokens"] = 6
+    adj_degrees = pick([None, None, 1, 2, 3])
+    adj_dim = 0
+    if adj_degrees:
+        kw["num_adj_degrees"] = adj_degrees
+        adj_dim = pick([0, 2, 3])
+        kw["adj_dim"] = adj_dim
+    attn_every = pick([0, 0, 1, 2])
+    if attn_every:
+        kw.update(global_linear_attn_every=attn_every, global_linear_attn_heads=2, global_linear_attn_dim_head=8, num_global_tokens=int(rng.integers(1, 6)))
+    layer_kw = dict(m_dim=pick([8, 16, 16, 32]), fourier_features=pick([0, 0, 1]), norm_coors=bool(rng.integers(2)),
+                    m_pool_method=pick(["sum", "mean"]), soft_edges=bool(rng.integers(2)), coor_weights_clamp_value=pick([None, 1.0]))
+    mode = pick(["dense", "knn", "knn", "sparse"]) if adj_degrees else pick(["dense", "knn", "knn"])
+    if mode == "knn":
+        layer_kw["num_nearest_neighbors"] = min(n, pick([4, 8, 16, 32]))
+    elif mode == "sparse":
+        layer_kw["only_sparse_neighbors"] = True
+    kw.update(layer_kw)
+    torch.manual_seed(seed)
+    net = EGNN_Network(**kw)
+    k_eff = layer_kw.get("num_nearest_neighbors", 0) or (7 if mode == "sparse" else n)
+    with torch.no_grad():
+        for name, mod in net.named_modules():
+            if type(mod) is torch.nn.Linear:
+                torch.nn.init.xavier_normal_(mod.weight)
+                if name.endswith("coors_mlp.3"):                      # (stacked layers: keep the coordinate updates small)
+                    mod.weight.mul_(min(0.25, 1.0 / k_eff) * (1.0 if layer_kw["norm_coors"] else 0.05))
+                if name.endswith("edge_mlp.3"):
+                    mod.weight.mul_(min(1.0, 2.0 / k_eff ** 0.5))
+                if name.endswith("node_mlp.3"):
+                    mod.weight.mul_(0.5)
+    net = net.cuda().eval()
+    feats = rng.integers(0, 11, (b, n)) if num_tokens else rng.standard_normal((b, n, dim)).astype(np.float32)
+    coors = rng.standard_normal((b, n, 3)).astype(np.float32)
+    edges = None
+    if edge_mode == "float":
+        edges = rng.standard_normal((b, n, n, edge_dim)).astype(np.float32)
+    elif edge_mode == "tokens":
+        edges = rng.integers(0, 6, (b, n, n))
+    i = np.arange(n)
+    adj = ((np.abs(i[:, None] - i[None, :]) <= 1) | (rng.random((n, n)) < 0.03)) if (adj_degrees or rng.integers(2)) else None
+    if adj is not None:
+        adj = adj | adj.T
+    mask = (np.arange(n)[None, :] < rng.integers(max(layer_kw.get("num_nearest_neighbors", 1), n // 2), n + 1, size=(b, 1))) if rng.integers(3) else None
+    params = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    cfg = O.EGNNConfig(dim=dim, edge_dim=edge_dim + adj_dim, norm_feats=True, **layer_kw)
+    want_n, want_c = O.egnn_network_forward(depth, cfg, params, feats, coors, adj_mat=adj, edges=edges, mask=mask, num_adj_degrees=adj_degrees,
+                                            global_linear_attn_every=attn_every, global_linear_attn_heads=2)[:2]
+    with torch.no_grad():
+        node, co = net(_dev(feats), _dev(coors), adj_mat=_dev(adj), edges=_dev(edges), mask=_dev(mask))
+    what = (seed, kw, mode, b, n)
+    for got, want in ((node, want_n), (co, want_c)):
+        assert np.isfinite(want).all(), what
+        # (stacked layers amplify rounding differences: DESIGN.md section 6 -- 1e-4 of the output's scale, absolute up to 16)
+        tol = 1e-4 * max(1.0, float(np.abs(want).max()) / 16.0) * depth
+        err = float(np.abs(got.cpu().numpy() - want).max())
+        assert err <= tol, (what, err, tol)
