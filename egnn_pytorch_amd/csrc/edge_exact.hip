@@ -19,7 +19,6 @@
 namespace {
 
 constexpr int EX_THREADS = 256;
-constexpr int EX_SMAX = 64;                  // per-edge scalars 2 F + 1 + edge_dim (the fast path stops at 16)
 
 // (exp, not the fast exponential of the split-f16 kernels: this path trades speed for the reference's arithmetic class)
 __device__ __forceinline__ float ex_exp(float x) { return expf(x); }
@@ -180,6 +179,96 @@ __global__ __launch_bounds__(EX_THREADS) void edge_exact_kernel(const ExArgs<T> 
     row[m_dim + C] = keep ? (T)1 : (T)0;
 }
 
+// The same for heads wider than 64 channels (the reference has no m_dim limit, egnn_pytorch.py:153): the messages do not fit the
+// registers, so the second Linear runs in blocks of 64 channels -- the hidden loop is repeated per block -- and the edge's messages live
+// in its workspace row, which the gate, coors_mlp and the masks read back (same thread: program order).
+template <typename T>
+__global__ __launch_bounds__(EX_THREADS) void edge_exact_wide_kernel(const ExArgs<T> p)
+{
+    const int64_t E = (int64_t)p.B * p.N * p.K;
+    const int64_t q = (int64_t)blockIdx.x * EX_THREADS + threadIdx.x;
+    if (q >= E) return;
+    const int N = p.N, K = p.K, C = p.coor_dim, F = p.fourier, m_dim = p.m_dim, H = p.H;
+    const int S = 2 * F + 1 + p.edge_dim;
+    const int64_t node = q / K;
+    const int k = (int)(q - node * K);
+    const int64_t bN = node / N * N;
+    const int i = (int)(node - bN);
+    const int j = p.idx ? p.idx[q] : k;
+    const T* const ci = p.coors + (bN + i) * C;
+    const T* const cj = p.coors + (bN + j) * C;
+    const T d = ex_sqdist(ci, cj, C);
+    extern __shared__ __attribute__((aligned(16))) char scal_raw[];
+    T* const scal = reinterpret_cast<T*>(scal_raw) + threadIdx.x;
+    for (int f = 0; f < F; ++f) {
+        const T x = d / (T)(1u << f);
+        scal[f * EX_THREADS] = ex_sin(x);
+        scal[(F + f) * EX_THREADS] = ex_cos(x);
+    }
+    scal[2 * F * EX_THREADS] = d;
+    if (p.edge_dim > 0) {
+        const T* ep = p.edges + (p.edges_by_k ? (size_t)q : ((size_t)(bN + i) * N + j)) * p.edge_dim;
+        for (int s = 0; s < p.edge_dim; ++s) scal[(2 * F + 1 + s) * EX_THREADS] = ep[s];
+    }
+    const T* pi = p.Pi + (bN + i) * p.ldp;
+    const T* pj = p.Pj + (bN + j) * p.ldp;
+    T* row = p.edge_ws + (size_t)q * (m_dim + C + 1);
+    for (int cb = 0; cb < m_dim; cb += 64) {
+        T u[64];
+#pragma unroll
+        for (int c = 0; c < 64; ++c) u[c] = (T)0;
+        for (int h = 0; h < H; ++h) {
+            T x = pi[h] + pj[h];
+            const T* ws = p.Ws + (size_t)h * p.ldws;
+            for (int s = 0; s < S; ++s) x = ex_fma(scal[s * EX_THREADS], ws[s], x);
+            const T a = ex_silu(x);
+            const T* w2 = p.W2 + (size_t)cb * H + h;
+#pragma unroll
+            for (int c = 0; c < 64; ++c)
+                if (cb + c < m_dim) u[c] = ex_fma(w2[(size_t)c * H], a, u[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 64; ++c)
+            if (cb + c < m_dim) row[cb + c] = ex_silu(u[c] + p.b2[cb + c]);
+    }
+    T gt = (T)1;
+    if (p.gate_w) {                                                      // soft_edges (:289-290)
+        T gsum = p.gate_b[0];
+        for (int c = 0; c < m_dim; ++c) gsum = ex_fma(p.gate_w[c], row[c], gsum);
+        gt = (T)1 / ((T)1 + ex_exp(-gsum));
+    }
+    const bool has_mask = p.mask != nullptr;
+    bool keep = true;
+    if (has_mask) {
+        keep = p.mask[bN + i] && p.mask[bN + j];
+        if (p.rank && p.idx) keep = keep && (p.rank[q] <= p.valid_radius);
+    }
+    if (p.W3) {
+        const int hid = 4 * m_dim;
+        T cw = p.b4[0];
+        for (int r = 0; r < hid; ++r) {
+            T z = p.b3[r];
+            const T* w3 = p.W3 + (size_t)r * m_dim;
+            for (int c = 0; c < m_dim; ++c) z = ex_fma(w3[c], row[c] * gt, z);
+            cw = ex_fma(p.W4[r], ex_silu(z), cw);
+        }
+        T inv = (T)1;
+        if (p.coors_scale) {
+            T n2 = (T)0;
+            for (int c = 0; c < C; ++c) { const T r = ci[c] - cj[c]; n2 = ex_fma(r, r, n2); }
+            const T nrm = ex_sqrt(n2);
+            inv = p.coors_scale[0] / (nrm > (T)1e-8 ? nrm : (T)1e-8);
+        }
+        if (has_mask && !keep) cw = (T)0;
+        if (p.clamp >= (T)0) cw = cw < -p.clamp ? -p.clamp : (cw > p.clamp ? p.clamp : cw);
+        for (int c = 0; c < C; ++c) row[m_dim + c] = cw * ((ci[c] - cj[c]) * inv);
+    } else {
+        for (int c = 0; c < C; ++c) row[m_dim + c] = (T)0;
+    }
+    for (int c = 0; c < m_dim; ++c) row[c] = (has_mask && !keep) ? (T)0 : row[c] * gt;
+    row[m_dim + C] = keep ? (T)1 : (T)0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(EX_THREADS) void edge_exact_pool_kernel(const ExArgs<T> p)
 {
@@ -217,8 +306,10 @@ int edge_exact_launch(const egnn_edge_exact_args* args, void* stream)
     if (!a.Pi || !a.Pj || !a.Ws || !a.W2 || !a.b2 || !a.coors || !a.edge_ws) return EGNN_E_NULLPTR;
     if (!a.m_i && !a.coors_out) return EGNN_E_NULLPTR;
     if (a.B <= 0 || a.N <= 0 || a.K <= 0 || a.H <= 0 || a.ldp < a.H || a.ldws < 2 * a.fourier + 1 + a.edge_dim) return EGNN_E_SHAPE;
-    if (a.m_dim < 1 || a.m_dim > 64 || a.coor_dim < 1 || a.coor_dim > 64) return EGNN_E_UNSUPPORTED;
-    if (a.fourier < 0 || a.fourier > 31 || a.edge_dim < 0 || 2 * a.fourier + 1 + a.edge_dim > EX_SMAX) return EGNN_E_UNSUPPORTED;
+    if (a.m_dim < 1 || a.m_dim > 1024 || a.coor_dim < 1 || a.coor_dim > 64) return EGNN_E_UNSUPPORTED;
+    if (a.fourier < 0 || a.fourier > 31 || a.edge_dim < 0) return EGNN_E_UNSUPPORTED;
+    // (the scalars of a workgroup's 256 edges live in LDS: up to 160 per edge in fp32, 80 in float64)
+    if ((size_t)(2 * a.fourier + 1 + a.edge_dim) * EX_THREADS * sizeof(T) > 160 * 1024) return EGNN_E_UNSUPPORTED;
     if (a.edge_dim > 0 && !a.edges) return EGNN_E_NULLPTR;
     if (a.coors_out && (!a.W3 || !a.b3 || !a.W4 || !a.b4)) return EGNN_E_NULLPTR;
     if (a.gate_w && !a.gate_b) return EGNN_E_NULLPTR;
@@ -228,7 +319,7 @@ int edge_exact_launch(const egnn_edge_exact_args* args, void* stream)
     if (blocks > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const ExArgs<T> p = ex_args<T>(a);
-    const size_t lds = (size_t)(2 * a.fourier + 1 + a.edge_dim) * EX_THREADS * sizeof(T);      // <= 64 KB (fp32) / 128 KB (fp64)
+    const size_t lds = (size_t)(2 * a.fourier + 1 + a.edge_dim) * EX_THREADS * sizeof(T);
     auto run = [&](auto kern) -> int {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -240,7 +331,8 @@ int edge_exact_launch(const egnn_edge_exact_args* args, void* stream)
     int rc;
     if (a.m_dim <= 16) rc = run(edge_exact_kernel<T, 16>);
     else if (a.m_dim <= 32) rc = run(edge_exact_kernel<T, 32>);
-    else rc = run(edge_exact_kernel<T, 64>);
+    else if (a.m_dim <= 64) rc = run(edge_exact_kernel<T, 64>);
+    else rc = run(edge_exact_wide_kernel<T>);
     if (rc != EGNN_OK) return rc;
     const int64_t total = (int64_t)a.B * a.N * (a.m_dim + a.coor_dim);
     hipLaunchKernelGGL(edge_exact_pool_kernel<T>, dim3((unsigned)((total + EX_THREADS - 1) / EX_THREADS)), dim3(EX_THREADS), 0, s, p);

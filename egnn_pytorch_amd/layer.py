@@ -259,9 +259,10 @@ class EGNN(nn.Module):
         return self.compute_dtype() == torch.float64 and not self.dropout_active()
 
     def _forward_hip(self, feats, coors, edges, mask, adj_mat, order_hint=None, want_u=False, drop=None):
-        # more per-edge scalars than the split-fp16 edge kernels carry (2 fourier + 1 + edge_dim > 16, up to 64): the plain-fp32 kernels
+        # more per-edge scalars than the split-fp16 edge kernels carry (2 fourier + 1 + edge_dim > 16, up to 160): the plain-fp32 kernels
         # ... and more than 8 coordinates (the fused kernels keep x_i - x_j in registers up to 8)
-        wide_shape = 16 < 2 * self.fourier_features + 1 + self.edge_dim <= 64 or coors.shape[-1] > 8
+        # ... and heads wider than 64 message channels (the fused kernels hold up to four 16-channel accumulator tiles per edge tile)
+        wide_shape = 2 * self.fourier_features + 1 + self.edge_dim > 16 or coors.shape[-1] > 8 or self.m_dim > 64
         if exact_active() or (wide_shape and not want_u and drop is None):
             if want_u or drop is not None:
                 raise NotImplementedError("the plain-fp32 (wide-range) kernels are inference-only: no backward, no training-mode dropout")

@@ -560,7 +560,8 @@ int egnn_node_prep_f32(const float* feats, const float* m_i, const float* gamma,
  *   coors (B,N,coor_dim), 1 <= coor_dim <= 64;  edges / edges_by_k / mask / idx / rank / valid_radius / clamp / pool_mean as in egnn_edge_args;
  *   m_i (B*N, m_dim) and / or coors_out (B,N,coor_dim);  edge_ws: egnn_edge_exact_workspace_bytes() of scratch (per-edge rows,
  *   summed per node in k order: deterministic).
- * Limits: m_dim <= 64, at most 64 per-edge scalars. */
+ * Limits: m_dim <= 1024 (beyond 64 the second Linear runs in blocks of 64 channels and the messages live in the workspace row),
+ * per-edge scalars: 160 in fp32, 80 in float64 (a workgroup's 256 edges keep theirs in LDS), coor_dim <= 64. */
 typedef struct egnn_edge_exact_args {
     int32_t B, N, K, m_dim, H, fourier, edge_dim, coor_dim, pool_mean, edges_by_k;
     /* data pointers: float for egnn_edge_exact_f32, double for egnn_edge_exact_f64 */

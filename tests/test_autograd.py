@@ -616,11 +616,13 @@ def test_backward_at_baseline_widths_matches_the_reference_autograd(ref, name, k
 
 
 @pytest.mark.gpu
-def test_more_than_eight_coordinates_train_through_the_recompute_backward(ref):
-    """C > 8 runs its forward on the plain kernels (inference-only); under autograd the backward is the chunked recompute over the
-    neighbour list they selected: gradients against the reference's float64 autograd."""
+@pytest.mark.parametrize("kw,cdim", [(dict(dim=24, num_nearest_neighbors=6), 12), (dict(dim=24, m_dim=80, num_nearest_neighbors=6), 3),
+                                     (dict(dim=16, fourier_features=10, num_nearest_neighbors=5), 3)])
+def test_shapes_of_the_plain_kernels_train_through_the_recompute_backward(ref, kw, cdim):
+    """More than 8 coordinates, heads wider than 64 channels, more than 16 per-edge scalars: the forward runs on the plain kernels
+    (inference-only); under autograd the backward is the chunked recompute over the neighbour list they selected: gradients against
+    the reference's float64 autograd."""
     from egnn_pytorch_amd import EGNN
-    kw = dict(dim=24, num_nearest_neighbors=6)
     torch.manual_seed(12)
     rlayer = ref.EGNN(**kw)
     for mod in rlayer.modules():
@@ -630,7 +632,7 @@ def test_more_than_eight_coordinates_train_through_the_recompute_backward(ref):
     layer.load_state_dict(rlayer.state_dict(), strict=True)
     layer, rlayer = layer.cuda(), rlayer.double().cuda()
     g = torch.Generator().manual_seed(13)
-    feats, coors = torch.randn(2, 30, 24, generator=g).cuda(), torch.randn(2, 30, 12, generator=g).cuda()
+    feats, coors = torch.randn(2, 30, kw["dim"], generator=g).cuda(), torch.randn(2, 30, cdim, generator=g).cuda()
     f1, c1 = feats.clone().requires_grad_(True), coors.clone().requires_grad_(True)
     f2, c2 = feats.double().requires_grad_(True), coors.double().requires_grad_(True)
     got, _ = _grads(layer, lambda: layer(f1, c1), (f1, c1))

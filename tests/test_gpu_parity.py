@@ -104,6 +104,10 @@ CONFIGS = [
     ("coor_dim11_k8_edges", dict(dim=32, num_nearest_neighbors=8, edge_dim=2), 2, 48, dict(mask=True, edges=True, coor_dim=11)),
     ("coor_dim20_dense_normcoors", dict(dim=24, norm_coors=True, m_pool_method="mean"), 2, 30, dict(mask=True, coor_dim=20)),
     ("coor_dim64_k16_gate", dict(dim=32, num_nearest_neighbors=16, soft_edges=True), 1, 64, dict(coor_dim=64)),
+    # heads wider than 64 channels and more than 64 per-edge scalars: the plain kernels (the reference has no such limits, :149-168)
+    ("m96_k8_gate", dict(dim=32, m_dim=96, num_nearest_neighbors=8, soft_edges=True, norm_coors=True), 2, 40, dict(mask=True)),
+    ("m130_dense_mean", dict(dim=16, m_dim=130, m_pool_method="mean"), 1, 20, dict(mask=True, scale={"edge_mlp.3.weight": 0.5})),
+    ("scalars_101_k6", dict(dim=16, fourier_features=20, edge_dim=60, num_nearest_neighbors=6), 1, 24, dict(edges=True, scalar_cols=0.2)),
     # m_dim beyond one 16-channel MFMA tile: two / four accumulator tiles per edge tile (the reference has no limit, :153)
     ("m32_k32", dict(dim=64, m_dim=32, num_nearest_neighbors=32, soft_edges=True, norm_coors=True), 2, 96,
      dict(mask=True, scale={"edge_mlp.3.weight": 0.5})),
