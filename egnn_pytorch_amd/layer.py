@@ -25,6 +25,10 @@ from .attention import GlobalLinearAttention
 _SPATIAL_ORDER = os.environ.get("EGNN_SPATIAL_ORDER", "1") != "0"     # scheduling knob only; results do not depend on it
 _SLOT_PREP = os.environ.get("EGNN_SLOT_PREP", "1") != "0"             # per-slot records for the edge pass's setup (same results)
 _SIDE_STREAM = os.environ.get("EGNN_SIDE_STREAM", "1") != "0"         # neighbour selection beside the projection GEMM
+# EGNN_Network: the next layer's neighbour selection started right behind this layer's edge pass (it needs the new coordinates only).  Off:
+# measured at c3 / c5 full size it is worth -1.8 % / +0.5 % -- the selection already runs beside the next layer's projection, and two
+# kernels that share the CUs share their throughput (profiles/r04_experiments/network_selection_look_ahead.txt)
+_PREFETCH = os.environ.get("EGNN_PREFETCH", "0") != "0"
 # egnn_edge_args.algo: 0 = the library chooses (persistent wave-per-node kernel where it applies), 1 = the general edge kernel always
 # (A/B measurements; tests/test_gpu_kernels.py checks the two against each other)
 _EDGE_ALGO = int(os.environ.get("EGNN_EDGE_ALGO", "0"))
@@ -193,9 +197,10 @@ class EGNN(nn.Module):
                 out = self._call(feats, coors, edges, mask, adj_mat, None)[:2]
         return out
 
-    def _call(self, feats, coors, edges, mask, adj_mat, order_hint):
+    def _call(self, feats, coors, edges, mask, adj_mat, order_hint, presel=None, prefetch=None):
         """(node_out, coors_out, order): inference under no_grad, or -- when a graph has to be recorded -- through
-        autograd.EGNNFunction (HIP forward, recompute-in-backward)."""
+        autograd.EGNNFunction (HIP forward, recompute-in-backward).  presel / prefetch: EGNN_Network's look-ahead of the neighbour
+        selection (`_select_neighbors`), inference only."""
         if _ops.RANGE_CHECK == "deferred" and feats.is_cuda:
             _ops.check_range(feats.device, wait=False)              # an earlier call's status, if it has arrived
         if _autograd.wants_grad(self, feats, coors, edges):
@@ -204,7 +209,8 @@ class EGNN(nn.Module):
             order = None                                            # (scheduling hint only; recomputed by the next layer)
         else:
             with torch.no_grad():
-                node_out, coors_out, order = self._forward_with_hint(feats, coors, edges, mask, adj_mat, order_hint)[:3]
+                node_out, coors_out, order = self._forward_with_hint(feats, coors, edges, mask, adj_mat, order_hint, presel=presel,
+                                                                     prefetch=prefetch)[:3]
         return node_out, coors_out, order
 
     def _forward_hip_checked(self, feats, coors, edges, mask, adj_mat, order_hint, want_u=False, drop_seed=None):
@@ -217,7 +223,7 @@ class EGNN(nn.Module):
         """training mode with dropout > 0: every forward draws a fresh mask seed (egnn_pytorch_amd/_dropout.py)"""
         return self.training and self.dropout_p > 0
 
-    def _forward_with_hint(self, feats, coors, edges, mask, adj_mat, order_hint, want_u=False, drop_seed=None):
+    def _forward_with_hint(self, feats, coors, edges, mask, adj_mat, order_hint, want_u=False, drop_seed=None, presel=None, prefetch=None):
         """forward + the scheduling permutation it used (EGNN_Network hands layer 0's on to the next layers)."""
         self._check_inputs(feats, coors, edges, mask, adj_mat)
         _abi.load()
@@ -242,7 +248,8 @@ class EGNN(nn.Module):
                 drop_seed = _dropout.draw_seed()
             out = self._forward_hip(feats.float(), coors.float(),
                                     edges if (edges is None or isinstance(edges, EdgeLookup)) else edges.float(), mask, adj_mat, order_hint,
-                                    want_u=want_u, drop=(self.dropout_p, drop_seed) if self.dropout_active() else None)
+                                    want_u=want_u, drop=(self.dropout_p, drop_seed) if self.dropout_active() else None,
+                                    presel=presel, prefetch=prefetch)
         if f_dtype != torch.float32 or c_dtype != torch.float32:
             out = (out[0].to(f_dtype), out[1].to(c_dtype)) + tuple(out[2:])
         return out
@@ -258,7 +265,59 @@ class EGNN(nn.Module):
         kernels only: that combination keeps the boundary conversion (fp32-class arithmetic, with the one-time warning)."""
         return self.compute_dtype() == torch.float64 and not self.dropout_active()
 
-    def _forward_hip(self, feats, coors, edges, mask, adj_mat, order_hint=None, want_u=False, drop=None):
+    def _select_neighbors(self, coors, mask, adj_mat, order_hint):
+        """(idx, rank, order, slots, K, valid_radius) of egnn_pytorch.py:230-260 for fp32 coordinates on the device: the K nearest
+        neighbours (None, None, None, None, N on the dense path), the Morton order the edge pass schedules by, the per-slot records.
+        Launched on the side stream (EGNN_SIDE_STREAM=0: the current one); whoever consumes the result joins that stream first."""
+        b, n = coors.shape[:2]
+        num_nearest = self.num_nearest_neighbors
+        valid_radius = self.valid_radius
+        use_nearest = num_nearest > 0 or self.only_sparse_neighbors
+        idx = rank = order = slots = None
+        if not use_nearest:
+            return None, None, None, None, n, valid_radius
+        if adj_mat is not None and self.only_sparse_neighbors:
+            num_nearest = _ops.adj_max_degree(adj_mat)                # host sync, as upstream (:249)
+            valid_radius = 0.0
+        k = num_nearest
+        if k > n:
+            raise RuntimeError("selected index k out of range")      # torch.topk's error upstream
+        if k > 0:
+            # Neighbour selection (VALU / scalar bound, no MFMA) and the Morton order (one workgroup per graph) depend on
+            # the coordinates only; the projection GEMM that follows (MFMA bound) depends on the features only.  Forked onto
+            # a side stream they share the CUs instead of queueing (EGNN_SIDE_STREAM=0: one stream); joined before the
+            # edge pass.
+            # k-NN path: neighbours are spatial -> workgroups that own Morton-adjacent nodes share gathered rows in L1.
+            # Scheduling only (results do not depend on it), so a stack of layers reuses the first layer's order:
+            # coordinates move by small steps per layer and the locality survives.
+            mask8 = _ops._u8(mask)
+            want_order = adj_mat is None and 64 <= n <= 4096 and _SPATIAL_ORDER and coors.shape[-1] == 3
+            have_hint = order_hint is not None and tuple(order_hint.shape) == (b, n)
+
+            def select():
+                idx_, rank_ = _ops.knn_select(coors, mask, adj_mat, k)
+                order_ = (order_hint if have_hint else _ops.spatial_order(coors)) if want_order else None
+                # the edge pass's setup as one coalesced record per slot instead of a chain of dependent loads
+                slots_ = _ops.slot_prep(coors, mask8, idx_, rank_, order_, valid_radius) \
+                    if (_SLOT_PREP and coors.shape[-1] == 3) else None
+                return idx_, rank_, order_, slots_
+
+            # (not while per-kernel timing is on: events on two streams would charge one kernel's wait to another)
+            use_side = _SIDE_STREAM and _ops._timer is None
+            side = _ops.side_stream(coors.device) if use_side else None
+            if side is not None:
+                cur = torch.cuda.current_stream()
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    idx, rank, order, slots = select()
+                for t in (idx, rank, order, slots):
+                    if t is not None:
+                        t.record_stream(cur)
+            else:
+                idx, rank, order, slots = select()
+        return idx, rank, order, slots, k, valid_radius
+
+    def _forward_hip(self, feats, coors, edges, mask, adj_mat, order_hint=None, want_u=False, drop=None, presel=None, prefetch=None):
         # more per-edge scalars than the split-fp16 edge kernels carry (2 fourier + 1 + edge_dim > 16, up to 160): the plain-fp32 kernels
         # ... and more than 8 coordinates (the fused kernels keep x_i - x_j in registers up to 8)
         # ... and heads wider than 64 message channels (the fused kernels hold up to four 16-channel accumulator tiles per edge tile)
@@ -280,54 +339,12 @@ class EGNN(nn.Module):
         mask8 = _ops._u8(mask)
 
         # ---- neighbour selection (egnn_pytorch.py:230-260)
-        num_nearest = self.num_nearest_neighbors
-        valid_radius = self.valid_radius
-        use_nearest = num_nearest > 0 or self.only_sparse_neighbors
-        idx = rank = order = slots = None
+        use_nearest = self.num_nearest_neighbors > 0 or self.only_sparse_neighbors
         if b == 0 or (n == 0 and not use_nearest):
             # empty batch / empty dense graphs: the reference returns empty outputs (N = 0 on the k-NN path: topk's error)
-            return torch.empty_like(feats), torch.empty_like(coors), None, None, None, valid_radius, None, None
-        if use_nearest:
-            if adj_mat is not None and self.only_sparse_neighbors:
-                num_nearest = _ops.adj_max_degree(adj_mat)                # host sync, as upstream (:249)
-                valid_radius = 0.0
-            k = num_nearest
-            if k > n:
-                raise RuntimeError("selected index k out of range")      # torch.topk's error upstream
-            if k > 0:
-                # Neighbour selection (VALU / scalar bound, no MFMA) and the Morton order (one workgroup per graph) depend on
-                # the coordinates only; the projection GEMM that follows (MFMA bound) depends on the features only.  Forked onto
-                # a side stream they share the CUs instead of queueing (EGNN_SIDE_STREAM=0: one stream); joined before the
-                # edge pass.
-                # k-NN path: neighbours are spatial -> workgroups that own Morton-adjacent nodes share gathered rows in L1.
-                # Scheduling only (results do not depend on it), so a stack of layers reuses the first layer's order:
-                # coordinates move by small steps per layer and the locality survives.
-                want_order = adj_mat is None and 64 <= n <= 4096 and _SPATIAL_ORDER and coors.shape[-1] == 3
-                have_hint = order_hint is not None and tuple(order_hint.shape) == (b, n)
-
-                def select():
-                    idx_, rank_ = _ops.knn_select(coors, mask, adj_mat, k)
-                    order_ = (order_hint if have_hint else _ops.spatial_order(coors)) if want_order else None
-                    # the edge pass's setup as one coalesced record per slot instead of a chain of dependent loads
-                    slots_ = _ops.slot_prep(coors, mask8, idx_, rank_, order_, valid_radius) \
-                        if (_SLOT_PREP and coors.shape[-1] == 3) else None
-                    return idx_, rank_, order_, slots_
-
-                # (not while per-kernel timing is on: events on two streams would charge one kernel's wait to another)
-                use_side = _SIDE_STREAM and _ops._timer is None
-                side = _ops.side_stream(feats.device) if use_side else None
-                if side is not None:
-                    cur = torch.cuda.current_stream()
-                    side.wait_stream(cur)
-                    with torch.cuda.stream(side):
-                        idx, rank, order, slots = select()
-                    for t in (idx, rank, order, slots):
-                        if t is not None:
-                            t.record_stream(cur)
-                else:
-                    idx, rank, order, slots = select()
-        else:
-            k = n
+            return torch.empty_like(feats), torch.empty_like(coors), None, None, None, self.valid_radius, None, None
+        # (EGNN_Network hands over what the previous layer started on the side stream right behind its edge pass)
+        idx, rank, order, slots, k, valid_radius = presel if presel is not None else self._select_neighbors(coors, mask, adj_mat, order_hint)
         side_join = use_nearest and k > 0 and _SIDE_STREAM and _ops._timer is None
 
         node_out, coors_out = feats, coors
@@ -392,6 +409,10 @@ class EGNN(nn.Module):
                 a.U_out = u_pre.data_ptr()
             a.algo = _EDGE_ALGO
             _ops.edge_fused(a, feats.device)
+            if prefetch is not None:
+                # the next layer's neighbour selection needs this layer's coordinates and nothing else: started here, on the side
+                # stream, it runs beside this layer's node_mlp and the next layer's projection instead of in front of them
+                prefetch(coors_out, order)
             if u_pre is not None:
                 proj_kept = (proj, pi_split)
             del proj
@@ -605,10 +626,24 @@ class EGNN_Network(nn.Module):
             global_tokens = self.global_tokens[None].expand(b, -1, -1)
         coor_changes = [coors]
         order = None
-        for global_attn, egnn in self.layers:
+        # Inference look-ahead (EGNN_PREFETCH=1; off by default, see _PREFETCH): layer l + 1's neighbour selection depends on layer l's
+        # coordinates only, which its edge pass writes -- before node_mlp.  Started right behind that edge pass on the side stream, it
+        # runs beside node_mlp (and the next layer's attention block / projection) as well.
+        look_ahead = (_PREFETCH and not torch.is_grad_enabled() and coors.is_cuda and coors.dtype == torch.float32
+                      and _SIDE_STREAM and _ops._timer is None and not exact_active())
+        pending = [None]
+        layers = list(self.layers)
+        for li, (global_attn, egnn) in enumerate(layers):
             if global_attn is not None:
                 feats, global_tokens = global_attn(feats, global_tokens, mask=mask)           # :445-446
-            feats, coors, order = egnn._call(feats, coors, edges, mask, adj_mat, order)
+            presel, pending[0] = pending[0], None
+            prefetch = None
+            if look_ahead and li + 1 < len(layers):
+                nxt = layers[li + 1][1]
+                if (nxt.num_nearest_neighbors > 0 or nxt.only_sparse_neighbors) and not nxt.float64_kernels():
+                    def prefetch(coors_out, order_used, nxt=nxt):
+                        pending[0] = nxt._select_neighbors(coors_out, mask, adj_mat, order_used)
+            feats, coors, order = egnn._call(feats, coors, edges, mask, adj_mat, order, presel=presel, prefetch=prefetch)
             coor_changes.append(coors)
         if return_coor_changes:
             return feats, coors, coor_changes
