@@ -5,10 +5,11 @@ positional order of the two entry points), parameter names / shapes of the refer
 `state_dict`, error behaviour (asserts at construction, `topk` out-of-range when K > N).
 Reference: egnn_pytorch/egnn_pytorch.py:148-341 (EGNN), :343-454 (EGNN_Network).
 
-The forward pass runs ONLY on a CUDA(HIP) device in fp32.  There is no CPU or PyTorch-eager fallback for it:
-anything the kernels do not cover raises.  Under autograd (grad mode on and an input or a parameter
-requires grad) the same HIP forward is wrapped in an autograd.Function whose backward recomputes the layer
-a few graphs at a time (egnn_pytorch_amd/autograd.py).
+The forward pass runs ONLY on a CUDA(HIP) device, in fp32 (or, for a module converted with .double(), in float64 on the float64
+kernels).  There is no CPU or PyTorch-eager fallback for it: anything the kernels do not cover raises.  Under autograd (grad mode on
+and an input or a parameter requires grad) the same HIP forward is wrapped in an autograd.Function whose backward runs on the HIP
+kernels (the E x H work of every shape the fused forward covers) or recomputes the layer a few graphs at a time
+(egnn_pytorch_amd/autograd.py).
 """
 from __future__ import annotations
 
