@@ -123,6 +123,56 @@ def workload_label(kwargs, b, n, k):
     return f"{net}dim={kwargs['dim']}{opts}) {path} B={b}/GPU N={n} fp32"
 
 
+# rocprofv3 leaves kernels with _Float16 parameters mangled: the dominant kernels by the name fragments that identify them
+_TRAFFIC_KERNELS = {
+    "edge_fused": (r"edge_pw_kernel", r"edge_kernelI", r"edge_kernel<"),
+    "node_proj": (r"linear_hl_kernelILi\d+ELi0ELb0E", r"linear_hl_kernel<\d+, 0, false"),
+    "node_mlp0": (r"linear_hl_kernelILi\d+ELi1ELb0E", r"linear_hl_kernel<\d+, 1, false"),
+    "node_mlp1": (r"linear_hl_kernelILi\d+ELi0ELb1E", r"linear_hl_kernel<\d+, 0, true"),
+}
+
+
+def live_traffic(workload, kernel, timeout_s=150):
+    """HBM traffic of `kernel` per launch, measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE
+    cannot share a pass; PMC collection cannot run inside the timed process), collected and corrected as MI355X_MICROARCH.md's HBM
+    section prescribes -- both counters in KiB, FETCH_SIZE doubled on gfx950 (it reports half the bytes of 16-byte-per-lane coalesced
+    reads).  Returns (bytes per launch, note) or (None, why not)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3")
+    pats = _TRAFFIC_KERNELS.get(kernel)
+    if rp is None or pats is None:
+        return None, "rocprofv3 not on PATH" if rp is None else f"no kernel pattern for {kernel}"
+    vals = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp", EGNN_BENCH_TRAFFIC_CHILD="1")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [rp, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
+                   os.path.abspath(__file__), "--workload", workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-train-step",
+                   "--no-live-traffic"]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            except Exception as ex:                      # (never fatal: the line falls back to the committed profile)
+                return None, f"rocprofv3 --pmc {counter}: {type(ex).__name__}"
+            got = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] == counter and any(re.search(p, row["Kernel_Name"]) for p in pats):
+                            got.append(float(row["Counter_Value"]))
+            if not got:
+                return None, f"no {counter} rows for {kernel}"
+            vals[counter] = sum(got) / len(got)
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), \
+        "measured in this run: two child runs of this command under rocprofv3 --kernel-trace --pmc (FETCH_SIZE, WRITE_SIZE: separate " \
+        "passes), (2 FETCH_SIZE + WRITE_SIZE) * 1024 per launch (MI355X_MICROARCH.md: KiB units, gfx950 FETCH_SIZE correction)"
+
+
 def git_head():
     """Commit of the tree that printed the line: `git rev-parse`, or -- the GPU boxes get a snapshot without .git -- the file `.head`
     that tools/stamp_head.sh writes before a gpurun call."""
@@ -313,6 +363,9 @@ def main():
     ap.add_argument("--train-step", action="store_true", help="also time forward + backward of the same workload (not part of `value`); "
                                                                "on by default for the single-layer workloads at N = 1")
     ap.add_argument("--no-train-step", action="store_true", help="skip the forward + backward timing")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc passes that measure the dominant kernel's HBM traffic (roofline.traffic then "
+                         "comes from profiles/pmc_traffic.json, stamped with the commit of that profile run)")
     ap.add_argument("--reference-eager", action="store_true",
                     help="also time the reference module on the MI355X through PyTorch eager (secondary baseline)")
     args = ap.parse_args()
@@ -454,10 +507,20 @@ def main():
                 thead = per_wl.get("_head", tj.get("_head"))
             except Exception:
                 traffic = None
+        dominant["traffic_profile"] = traffic                # (the committed profile's figure, with the commit it was taken at)
+        dominant["traffic_head"] = thead
+        src = "profiles/pmc_traffic.json: (2 FETCH_SIZE + WRITE_SIZE) * 1024 per launch, separate rocprofv3 --pmc passes " \
+              "of this command (tools/profile.sh)" if traffic is not None else None
+        under_profiler = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+        if world == 1 and not args.no_live_traffic and os.environ.get("EGNN_BENCH_TRAFFIC_CHILD") != "1" and not under_profiler:
+            live, note = live_traffic(args.workload, dominant["kernel"])
+            if live is not None:
+                traffic, src = live, note
+                dominant["traffic_head"] = git_head()
+            else:
+                src = (src or "none") + f" [live measurement unavailable: {note}]"
         dominant["traffic"] = traffic
-        dominant["traffic_source"] = "profiles/pmc_traffic.json: (2 FETCH_SIZE + WRITE_SIZE) * 1024 per launch, separate rocprofv3 --pmc passes " \
-                                     "of this command (tools/profile.sh); PMC collection cannot run inside the timed process" if traffic is not None else None
-        dominant["traffic_head"] = thead                     # commit the profile run was taken at (a stale file is visible)
+        dominant["traffic_source"] = src
         graphs = world * b * args.steps
         value = graphs / elapsed
         out = {

@@ -16,11 +16,11 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 python bench.py --reference-eager --train-step > $OUT/bench_line.json 2> $OUT/bench_line.err; echo "bench rc=$?"
 python -c "
 import json; d=json.load(open('$OUT/bench_line.json')); print(d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'], d['cpu_baseline']['value'], d.get('reference_gpu_eager', {}).get('value'), d.get('train_step'))"
-python bench.py --ragged-mask --no-cpu-baseline > $OUT/bench_ragged_mask.json 2>> $OUT/bench_line.err
+python bench.py --ragged-mask --no-cpu-baseline --no-live-traffic > $OUT/bench_ragged_mask.json 2>> $OUT/bench_line.err
 for w in c2_dense c3_network c4_sparse c5_shard; do
   python bench.py --workload $w > $OUT/bench_$w.json 2>> $OUT/bench_line.err; head -c 160 $OUT/bench_$w.json; echo
 done
-python bench.py --workload c4_sparse --no-cpu-baseline --train-step > $OUT/bench_train_step_c4_sparse.json 2>> $OUT/bench_line.err
+python bench.py --workload c4_sparse --no-cpu-baseline --no-live-traffic --train-step > $OUT/bench_train_step_c4_sparse.json 2>> $OUT/bench_line.err
 python tools/train_step_probe.py 3 > $OUT/train_step_kernels.txt 2>&1; tail -2 $OUT/train_step_kernels.txt | cut -c1-400
 EGNN_PROBE_PHASES=1 python tools/net_train_probe.py > $OUT/net_train_step.txt 2>&1; grep "^c[35]" $OUT/net_train_step.txt
 bash tools/train_trace.sh $TAG > $OUT/train_trace.log 2>&1; cp gpurun_out/train_$TAG/kernels.txt $OUT/train_step_kernel_trace.txt; tail -1 $OUT/train_trace.log

@@ -15,13 +15,13 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 # (the counter passes leave the training step out: its gradient GEMMs share kernel instantiations with node_proj / node_mlp and
 # would be averaged into their counters)
-BENCH="python $REPO/bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-train-step"
+BENCH="python $REPO/bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-train-step --no-live-traffic"
 cd /tmp
 # the kernel trace runs the DEFAULT bench command (what the driver runs) minus the training step that the default appends AFTER the
 # timed region (--no-train-step: its gradient GEMMs share kernel instantiations with node_proj / node_mlp and would be averaged into
 # their rows; tools/train_trace.sh traces that part), so its per-kernel averages are the ones the bench line's live measurement has
 # to agree with; the counter passes use a shorter run
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python $REPO/bench.py --workload $WL --no-train-step $([ "$WL" = north_star ] || echo --no-cpu-baseline) > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python $REPO/bench.py --workload $WL --no-train-step --no-live-traffic $([ "$WL" = north_star ] || echo --no-cpu-baseline) > "$OUT/trace.log" 2>&1
 grep "^{\"metric\"" "$OUT/trace.log" | tail -1 > "$OUT/bench_line_under_rocprof.json"
 echo "trace rc=$?"
 i=0

@@ -8,7 +8,7 @@ OUT="$REPO/gpurun_out/train_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --train-step > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic --train-step > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
 grep "^{\"metric\"" "$OUT/trace.log" | tail -1 > "$OUT/bench_line.json"
 cd "$REPO"
