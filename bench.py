@@ -149,7 +149,11 @@ def live_traffic(workload, kernel, timeout_s=150):
         return None, "rocprofv3 not on PATH" if rp is None else f"no kernel pattern for {kernel}"
     vals = {}
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
-        env = dict(os.environ, TMPDIR="/tmp", EGNN_BENCH_TRAFFIC_CHILD="1")
+        # (a plain single-process child: nothing of a launcher's rendezvous may leak into it)
+        env = {k: v for k, v in os.environ.items()
+               if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
+               and not k.startswith("TORCHELASTIC")}
+        env.update(TMPDIR="/tmp", EGNN_BENCH_TRAFFIC_CHILD="1")
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = [rp, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "pmc", "--output-format", "csv", "--", sys.executable,

@@ -33,7 +33,7 @@ def test_bench_under_the_launcher_initialises_rccl_at_world_size_1():
     """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: the process group is real (backend nccl), the line
     says so, and the value agrees with the plain `python bench.py` run of the same steps within the box's run-to-run noise."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    common = ["--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-train-step"]
+    common = ["--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-train-step", "--no-live-traffic"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + common
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
