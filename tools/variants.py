@@ -80,6 +80,8 @@ def build(src, spec, full):
            "-Rpass-analysis=kernel-resource-usage"]
     if src == "edge_fused" and not full:
         cmd.append("-DEGNN_EDGE_TUNING_BUILD")
+    if src == "knn_select":
+        cmd.append("-ffp-contract=off")                  # (as csrc/build.sh: the ranking must reproduce the reference's un-fused sums)
     cmd += [f"-DEGNN_{k}={v}" for k, v in defs.items()] + ["-c", os.path.join(CSRC, src + ".hip"), "-o", o]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
