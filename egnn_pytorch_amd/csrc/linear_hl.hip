@@ -161,6 +161,9 @@ __device__ __forceinline__ void linear_hl_body(
     for (int t = 0; t < STAGES - 1; ++t) stage(kt0 + (t < nk ? t : nk - 1), t);
 
     int slot = 0;                                                      // ring slot of tile kt
+#if EGNN_HL_PRIO
+    asm volatile("s_setprio 3");             // the K loop issues ahead of the CU's other workgroup when that one is in its epilogue
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         if (STAGES == 4 && DPW == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else if (STAGES == 3 && DPW == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
@@ -237,6 +240,9 @@ __device__ __forceinline__ void linear_hl_body(
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the dummy DMAs before the LDS is released
+#if EGNN_HL_PRIO
+    asm volatile("s_setprio 0");
+#endif
 
 #if defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 16)
     {                                                                  // ablation: no epilogue at all (keeps the accumulators alive)
@@ -480,6 +486,9 @@ int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi,
 
 #ifndef EGNN_HL_ILV
 #define EGNN_HL_ILV 1
+#endif
+#ifndef EGNN_HL_PRIO
+#define EGNN_HL_PRIO 1
 #endif
 #ifndef EGNN_HL_CFG
 #define EGNN_HL_CFG 1
