@@ -6,6 +6,7 @@ enqueues one HIP kernel on torch's current stream.
 from __future__ import annotations
 
 import contextlib
+import contextvars
 import os
 from ctypes import byref
 
@@ -114,10 +115,30 @@ _status = {}
 
 
 class _Status:
+    """Two words per device: [0] is OR-ed by the kernels of a forward, [1] by the kernels of a backward (`backward_status()`), so that
+    bits a backward leaves behind are reported as what they are instead of being attributed to -- and re-run as -- the next forward."""
+
     def __init__(self, device):
-        self.dev = torch.zeros(1, dtype=torch.int32, device=device)
-        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.dev = torch.zeros(2, dtype=torch.int32, device=device)
+        self.host = torch.zeros(2, dtype=torch.int32).pin_memory()
         self.event = None
+
+
+_status_slot = contextvars.ContextVar("egnn_status_slot", default=0)
+
+
+@contextlib.contextmanager
+def backward_status():
+    """Kernels launched inside (the native backward) report range problems in the backward's status word."""
+    tok = _status_slot.set(1)
+    try:
+        yield
+    finally:
+        _status_slot.reset(tok)
+
+
+def _status_ptr(device):
+    return status_word(device).dev.data_ptr() + 4 * _status_slot.get()
 
 
 def status_word(device):
@@ -143,12 +164,17 @@ def range_check_after_forward(device, mode=None):
         return
     st = status_word(device)
     if mode == "sync":
-        bits = int(st.dev.item())                       # the one host synchronisation of the forward
-        if bits:
+        fwd, bwd = st.dev.tolist()                      # the one host synchronisation of the forward (8 bytes, one copy)
+        if fwd or bwd:
             st.dev.zero_()
-            _raise_range(bits, "this call")
+        if bwd and not fwd:                             # left by an earlier backward: not this call's, never a reason to re-run it
+            _raise_range(bwd, "an earlier backward")
+        if fwd:
+            _raise_range(fwd | bwd, "this call")
         return
-    # deferred: examined by the next call / check_range().  The 4-byte copy is a blit kernel: on the side stream, behind this forward's
+    # deferred: examined by the next call / check_range().  Attribution is relaxed in this mode: the copy runs on the side stream and may
+    # overlap the next forward's kernels OR-ing into the word (and check_range()'s zero_() on the launch stream), so a bit set by step
+    # n + 1 can be reported with step n, or be reported twice -- the OR is sticky, detection itself is never lost.  The copy is a blit kernel: on the side stream, behind this forward's
     # last kernel, it does not sit between this step and the next one on the launch stream (two launch gaps + 4 us per step)
     cur = torch.cuda.current_stream(st.dev.device)
     side = side_stream(st.dev.device)
@@ -172,7 +198,7 @@ def check_range(device=None, wait=True):
             st.event.synchronize()
         elif not st.event.query():
             continue
-        bits = int(st.host[0])
+        bits = int(st.host[0]) | int(st.host[1])
         st.event = None
         if bits:
             st.dev.zero_()
@@ -287,7 +313,7 @@ def split_f16(x2d):
     hi = _packed_empty(rows, kp, x2d.device)
     lo = _packed_empty(rows, kp, x2d.device)
     with _timed("split_f16"):
-        rc = _abi.load().egnn_split_f16(_ptr(x2d), cols, rows, cols, _ptr(hi), _ptr(lo), kp, _ptr(status_word(x2d.device).dev),
+        rc = _abi.load().egnn_split_f16(_ptr(x2d), cols, rows, cols, _ptr(hi), _ptr(lo), kp, _status_ptr(x2d.device),
                                         _stream())
     _abi.check(rc, "egnn_split_f16")
     return PackedHL(hi, lo, rows, kp)
@@ -318,7 +344,7 @@ def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32
             rc = _abi.load().egnn_linear_hl_f32(_ptr(a.hi), _ptr(a.lo), _ptr(whi), _ptr(wlo), float(inv), _ptr(bias),
                                                 _ptr(residual), ldr, _ptr(c), n, _ptr(out.hi) if out else None,
                                                 _ptr(out.lo) if out else None, kp_out, m, n, kp, w_rows, act, int(split_cols),
-                                                _ptr(status_word(dev).dev), _stream())
+                                                _status_ptr(dev), _stream())
         else:                                               # (p, seed): nn.Dropout between the Linear and its activation
             from . import _dropout
             p_drop, seed = drop
@@ -326,7 +352,7 @@ def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32
                                                      _ptr(residual), ldr, _ptr(c), n, _ptr(out.hi) if out else None,
                                                      _ptr(out.lo) if out else None, kp_out, m, n, kp, w_rows, act, int(split_cols),
                                                      _dropout.threshold(p_drop), int(seed), _dropout.inv_keep(p_drop),
-                                                     _ptr(status_word(dev).dev), _stream())
+                                                     _status_ptr(dev), _stream())
     _abi.check(rc, "egnn_linear_hl_f32")
     if out_f32 and out_hl:
         return c, out
@@ -393,7 +419,7 @@ def node_prep_hl(feats2d, m_i, gamma, beta, eps, m_dim, with_raw=False):
     with _timed("node_prep"):
         rc = _abi.load().egnn_node_prep_hl(_ptr(feats2d), _ptr(m_i), _ptr(gamma), _ptr(beta), float(eps), _ptr(hi), _ptr(lo),
                                            kp, _ptr(raw.hi) if raw else None, _ptr(raw.lo) if raw else None,
-                                           raw.kp if raw else 0, rows, dim, m_dim, _ptr(status_word(feats2d.device).dev),
+                                           raw.kp if raw else 0, rows, dim, m_dim, _status_ptr(feats2d.device),
                                            _stream())
     _abi.check(rc, "egnn_node_prep_hl")
     out = PackedHL(hi, lo, rows, kp)
@@ -401,7 +427,7 @@ def node_prep_hl(feats2d, m_i, gamma, beta, eps, m_dim, with_raw=False):
 
 
 def edge_fused(args: _abi.EdgeArgs, device):
-    args.status = _ptr(status_word(device).dev)
+    args.status = _status_ptr(device)
     with _timed("edge_fused"):
         rc = _abi.load().egnn_edge_fused_f32(byref(args), _stream())
     _abi.check(rc, "egnn_edge_fused_f32")
@@ -470,7 +496,7 @@ def split_scaled(x2d, scale, transposed=False, w_image=False):
     lo = _packed_empty(alloc_rows, kp, x2d.device, zero=w_image)
     with _timed("split_scaled"):
         rc = _abi.load().egnn_split_scaled_f16(_ptr(x2d), x2d.stride(0), rows, cols, float(scale), int(transposed), _ptr(hi), _ptr(lo), kp,
-                                               _ptr(status_word(x2d.device).dev), _stream())
+                                               _status_ptr(x2d.device), _stream())
     _abi.check(rc, "egnn_split_scaled_f16")
     return PackedHL(hi, lo, img_rows, kp), alloc_rows
 
@@ -483,7 +509,7 @@ def split_scaled_both(x2d, scale):
     hit, lot = _packed_empty(cols, kpt, x2d.device), _packed_empty(cols, kpt, x2d.device)
     with _timed("split_scaled"):
         rc = _abi.load().egnn_split_scaled_both_f16(_ptr(x2d), x2d.stride(0), rows, cols, float(scale), _ptr(hi), _ptr(lo), kp,
-                                                    _ptr(hit), _ptr(lot), kpt, _ptr(status_word(x2d.device).dev), _stream())
+                                                    _ptr(hit), _ptr(lot), kpt, _status_ptr(x2d.device), _stream())
     _abi.check(rc, "egnn_split_scaled_both_f16")
     return PackedHL(hi, lo, rows, kp), PackedHL(hit, lot, cols, kpt)
 
@@ -862,6 +888,6 @@ def forward_c(layer, feats, coors, edges=None, mask=None, adj_mat=None, packed=N
     node_out, coors_out = torch.empty_like(feats), torch.empty_like(coors)
     rc = lib.egnn_layer_forward_f32(byref(desc), byref(info), _ptr(blob_dev), _ptr(feats), _ptr(coors), _ptr(edges), _ptr(m8),
                                     _ptr(a8), stride, b, n, k, coors.shape[-1], _ptr(node_out), _ptr(coors_out), _ptr(ws),
-                                    nbytes, _ptr(status_word(feats.device).dev), _stream())
+                                    nbytes, _status_ptr(feats.device), _stream())
     _abi.check(rc, "egnn_layer_forward_f32")
     return node_out, coors_out

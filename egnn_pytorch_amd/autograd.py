@@ -379,7 +379,9 @@ class EGNNFunction(torch.autograd.Function):
                                    "operation: a parameter of egnn_pytorch_amd.EGNN changed between forward and backward "
                                    f"(version {p._version}, expected {v})")
         if ctx.has_u:
-            return _backward_native(ctx, g_node, g_coors)
+            from . import _ops
+            with _ops.backward_status():            # range bits of these kernels go to the backward's status word
+                return _backward_native(ctx, g_node, g_coors)
         return _backward_recompute(ctx, g_node, g_coors)
 
 
@@ -823,12 +825,20 @@ def _backward_native(ctx, g_node, g_coors):
                 if dest_lists is None and i32 is not None:
                     dest_lists = _ops.dest_lists(i32, bc, n, k, feats.device)
                 parts = []
-                for blk in range(mp // 16):
-                    wb = dict(w, W2Th=w["W2Th_blocks"][blk], w2_block=blk)
-                    parts.append(contract(layer, wb, f2d, c0, e0, sc2, i32, gu16[:, 16 * blk:16 * blk + 16].contiguous(), gu_scale, w_s, bc, n, k,
-                                          pi_split, dest_lists, proj))
+                # (only blocks that hold real channels: m_dim 33 .. 48 has mp = 64 -- the forward's NB = 4 -- but its fourth block of gU
+                # and W2 is all padding, a by-source + by-destination pass that would add exact zeros)
+                nblk = (m + 15) // 16
+                try:
+                    for blk in range(nblk):
+                        w["W2Th"], w["w2_block"] = w["W2Th_blocks"][blk], blk   # (in place: what the passes cache in `w` -- bwd_pads -- survives;
+                                                                                #  w2_block: read by the CPU tests' kernel emulation)
+                        parts.append(contract(layer, w, f2d, c0, e0, sc2, i32, gu16[:, 16 * blk:16 * blk + 16].contiguous(), gu_scale, w_s, bc, n,
+                                              k, pi_split, dest_lists, proj))
+                finally:
+                    w["W2Th"] = w["W2Th_blocks"][0]
+                    w.pop("w2_block", None)
                 gz_i, gz_j, g_ws, g_scal = (sum(p[q] for p in parts[1:]) + parts[0][q] for q in range(4))
-                g_w2 = torch.cat([p[4] for p in parts], dim=0)
+                g_w2 = torch.cat([p[4] for p in parts] + [torch.zeros_like(parts[0][4])] * (mp // 16 - nblk), dim=0)
                 del parts
             # ---- 3. node-level products: d/d feats = dP_i W_i + dP_j W_j, d/d W_i = dP_i^T feats, d/d W_j = dP_j^T feats.  On the
             # device: the forward's split-f16 matrix-core GEMM (operands pre-scaled by powers of two, the weight gradients split-K

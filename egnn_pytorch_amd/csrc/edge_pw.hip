@@ -60,6 +60,19 @@ constexpr int PW_WAVES = 4;
 #ifndef EGNN_PW_HC
 #define EGNN_PW_HC 64
 #endif
+// Timing-only ablations (results are wrong; profiles/r05_experiments/edge_pw_ablations.txt): 1 no gather DMA issue, 2 no pick-up of the
+// gathered lines (no vmcnt wait, no exchange-row reads), 4 no first-layer MFMAs, 8 no residual MFMAs, 16 no second-layer MFMAs,
+// 32 no transcendentals (a = y), 64 no per-edge epilogue (coors_mlp, second SiLU), 128 no staging ring (no chunk DMA, no barrier),
+// 256 no P_i loads, 512 no hi / lo conversions
+#ifndef EGNN_PW_ABL
+#define EGNN_PW_ABL 0
+#endif
+#ifndef EGNN_PW_SKEW
+#define EGNN_PW_SKEW 0                       // 1: skewed tile pick-up (see step)
+#endif
+#ifndef EGNN_PW_SILU_ILV
+#define EGNN_PW_SILU_ILV 0                   // 1: the four SiLU chains of an accumulator register quad written interleaved
+#endif
 constexpr int PW_HC = EGNN_PW_HC;            // hidden columns per slot of the staging ring (64: two steps of 32)
 constexpr int PW_XLD = 32;                   // floats per row of the gather exchange buffer (one 128-byte line, chunk-swizzled)
 // LDS (31 KB: five workgroups per CU):  W2 fragments, two ring slots | first-layer A fragments, two ring slots |
@@ -159,7 +172,8 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
         for (int pc = wave; pc < hcs / 16; pc += PW_WAVES) lds_dma16_s(src + pc * 1024, lane16, dst + pc * 1024);
         if (wave == 0) {
             const int tbytes = hcs * 16;                                   // one 16-byte row of four terms per hidden unit
-            if ((int)lane16 < tbytes) lds_dma16_s(wst_g + (size_t)c0s * 16, lane16, wst + slot * (PW_HC * 16));
+            for (int o = 0; o < tbytes; o += 1024)                         // (one instruction per 64 hidden units)
+                if ((int)lane16 + o < tbytes) lds_dma16_s(wst_g + (size_t)c0s * 16 + o, lane16, wst + slot * (PW_HC * 16) + o);
         }
     };
     // the 32 slot records of round r of node tau -> record buffer `buf` (lanes 0 .. 31: 512 bytes)
@@ -187,7 +201,11 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) xr[hb] = xch + e * PW_XLD + 4 * ((4 * hb + g) ^ ((e >> 1) & 7));
     // first-layer A fragments: row (hidden unit) e of the 16-block, split term g
+#if defined(EGNN_PW_WSTSWZ) && EGNN_PW_WSTSWZ
+    const char* const tl = wst + (e * 4 + (g ^ ((e >> 2) & 2))) * 4;     // timing experiment: units 8 .. 15 of a block read the other pair of banks
+#else
     const char* const tl = wst + (e * 4 + g) * 4;
+#endif
     constexpr int tstep = 16 * 4 * 4;                                      // bytes per 16 hidden units
 #if EGNN_PW_RESID4
     f16x4 neg_identity;                                                    // A operand of the 4x4x4 residual MFMA: row (lane & 3) of -I4
@@ -301,6 +319,9 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
         // upper 16-unit block is padding -- P, W_s and W2 are exactly zero there, so y = 0, a = 0 / (1 + 1) = 0, hi = lo = 0 -- and its
         // pick-up reads, first-layer MFMAs, 32 SiLU evaluations, conversions and residual MFMAs are skipped: the same bits, 40 VALU
         // instructions instead of 86 in that step (1 step of 17 at dim 128, of 33 at dim 256, of 65 at dim 512).
+#if EGNN_PW_SKEW
+        f32x4 x0n[2];                                                       // tile 0 of the coming step, as gathered (see step)
+#endif
         auto step = [&](auto half_tag, const int c, const int st, const int slot, const int hoff, const _Float16* w2c, const char* tlc) {
             constexpr bool HALF = decltype(half_tag)::value;
             constexpr int NHB = HALF ? 1 : 2;
@@ -308,6 +329,45 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
             const int hnext = more ? hoff + 32 : hoff;                       // last step: harmless re-read of the P_i words
             f32x4 x[2][2];
             uint32_t pivn[2];
+#if EGNN_PW_SKEW
+            // Skewed tiles (VERDICT r4 next #1a, without a second set of exchange rows or more registers): tile 0 of step s + 1 is picked
+            // up at the END of step s (its lines were requested early in step s), tile 1 of step s at its start -- the LDS round trip of
+            // tile 1 runs under tile 0's SiLU chain, that of tile 0 under the loop back-edge / chunk barrier, and the first v_exp_f32 of a
+            // step waits for one LDS read (the staged A fragments) + one MFMA instead of wait -> four reads -> wait -> four MFMAs.
+            u32x2 a0[2];
+#pragma unroll
+            for (int hb = 0; hb < NHB; ++hb)
+                a0[hb] = u32x2{0u, *reinterpret_cast<const uint32_t*>(tlc + st * 2 * tstep + hb * tstep)};
+            const f16x8 whi = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 0) * 64 + lane) * 8);
+            const f16x8 wlo = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 1) * 64 + lane) * 8);
+            if (hoff == 0) {                                                 // the round's first step: its lines landed before the chunk barrier
+#pragma unroll
+                for (int hb = 0; hb < NHB; ++hb) x0n[hb] = *reinterpret_cast<const f32x4*>(xr[hb]);
+            }
+#pragma unroll
+            for (int hb = 0; hb < NHB; ++hb) x[1][hb] = *reinterpret_cast<const f32x4*>(xr[hb] + 16 * PW_XLD);
+#pragma unroll
+            for (int hb = 0; hb < NHB; ++hb) a0[hb][0] = piv[hb];
+#pragma unroll
+            for (int hb = 0; hb < NHB; ++hb)
+                x[0][hb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a0[hb]), __builtin_bit_cast(f16x4, bq[0]), x0n[hb], 0, 0, 0);
+            // every row of this step is in registers before the next step's lines may land in them
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (!HALF) {
+                pivn[0] = buf_load1(pi_rsrc, piw, hnext * 4);
+                pivn[1] = buf_load1(pi_rsrc, piw, hnext * 4 + 64);
+            }
+            if (more) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) gather_dma16(pj_words, goff[qq], (uint32_t)(hnext * 4), xch_lds + qq * 1024);
+            }
+#pragma unroll
+            for (int hb = 0; hb < NHB; ++hb)
+                x[1][hb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a0[hb]), __builtin_bit_cast(f16x4, bq[1]), x[1][hb], 0, 0, 0);
+#else
 #if EGNN_PW_EARLY_W
             // this step's staged operands first (in LDS since the chunk's barrier): their LDS latency runs under the wait for the
             // gathered lines instead of after it
@@ -319,6 +379,12 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
             const f16x8 wlo = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 1) * 64 + lane) * 8);
 #endif
             // the lines of this step were requested a step ago and land in the wave's exchange rows by themselves
+#if EGNN_PW_ABL & 2
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int hb = 0; hb < NHB; ++hb) { x[t][hb] = acc[t] * 0.25f; asm volatile("" : "+v"(x[t][hb])); }
+#else
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
             asm volatile("" ::: "memory");
@@ -332,20 +398,29 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
             __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0)
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+#endif
             if (!HALF) {
+#if EGNN_PW_ABL & 256
+                pivn[0] = piv[0]; pivn[1] = piv[1];
+#else
                 pivn[0] = buf_load1(pi_rsrc, piw, hnext * 4);
                 pivn[1] = buf_load1(pi_rsrc, piw, hnext * 4 + 64);
+#endif
             }
+#if !(EGNN_PW_ABL & 128)
             if (st == 0) {
                 // the next chunk of the ring: the next one of this round, or -- the ring does not drain between the rounds of a
                 // workgroup -- the first one of the round that follows (its setup and this round's epilogue run with the chunk in flight)
                 if (c + 1 < nchunks) stage(c + 1, slot ^ 1);
                 else if (!last_round) stage(0, slot ^ 1);
             }
+#endif
+#if !(EGNN_PW_ABL & 1)
             if (more) {
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) gather_dma16(pj_words, goff[qq], (uint32_t)(hnext * 4), xch_lds + qq * 1024);
             }
+#endif
 
 #if EGNN_PW_EARLY_W
 #pragma unroll
@@ -366,8 +441,14 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int hb = 0; hb < NHB; ++hb)
+                for (int hb = 0; hb < NHB; ++hb) {
+#if EGNN_PW_ABL & 4
+                    asm volatile("" :: "v"(a0[hb]), "v"(bq[t]));
+#else
                     x[t][hb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a0[hb]), __builtin_bit_cast(f16x4, bq[t]), x[t][hb], 0, 0, 0);
+#endif
+                }
+#endif  // EGNN_PW_SKEW
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 // x holds y = -log2(e) * (pre-activation); a = y / (1 + 2^y) = SiLU(pre) / (-ln 2); hi = fp16(a) (IEEE: beyond 65504 ->
@@ -378,30 +459,89 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
 #pragma unroll
                 for (int hb = 0; hb < NHB; ++hb) {
                     f32x4 a4;
+#if EGNN_PW_SILU_ILV
+                    {
+                        float tt[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) tt[u] = __builtin_amdgcn_exp2f(x[t][hb][u]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) tt[u] = 1.0f + tt[u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) tt[u] = __builtin_amdgcn_rcpf(tt[u]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            float h = x[t][hb][u] * tt[u];
+                            asm("" : "+v"(h));
+                            a4[u] = h;
+                        }
+                    }
+#else
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const float y = x[t][hb][u];
+#if EGNN_PW_ABL & 32
+                        float h = y;
+#else
                         float h = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
+#endif
                         asm("" : "+v"(h));           // keeps the products scalar (v_pk_mul_f32 costs 9.3 cycles per pair against 2 x 2.8)
                         a4[u] = h;
                     }
+#endif
+#if EGNN_PW_ABL & 512
+                    const f16x2 h01 = __builtin_bit_cast(f16x2, a4[0]), h23 = __builtin_bit_cast(f16x2, a4[2]);
+#else
                     const f16x2 h01 = __builtin_convertvector((f32x2v){a4[0], a4[1]}, f16x2);
                     const f16x2 h23 = __builtin_convertvector((f32x2v){a4[2], a4[3]}, f16x2);
+#endif
                     const f16x4 hi4 = {h01[0], h01[1], h23[0], h23[1]};
-#if EGNN_PW_RESID4
+#if EGNN_PW_ABL & 8
+                    const f32x4 l4 = a4;
+                    asm volatile("" :: "v"(neg_identity));
+#elif EGNN_PW_RESID4
                     const f32x4 l4 = __builtin_amdgcn_mfma_f32_4x4x4f16(neg_identity, hi4, a4, 0, 0, 0);
 #else
                     const f32x4 l4 = __builtin_amdgcn_mfma_f32_16x16x16f16(neg_identity, hi4, a4, 0, 0, 0);
 #endif
+#if EGNN_PW_ABL & 512
+                    const f16x2 l01 = __builtin_bit_cast(f16x2, l4[1]), l23 = __builtin_bit_cast(f16x2, l4[3]);
+#else
                     const f16x2 l01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l4[0], l4[1]));
                     const f16x2 l23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(l4[2], l4[3]));
+#endif
                     bhi[4 * hb + 0] = h01[0]; bhi[4 * hb + 1] = h01[1]; bhi[4 * hb + 2] = h23[0]; bhi[4 * hb + 3] = h23[1];
                     blo[4 * hb + 0] = l01[0]; blo[4 * hb + 1] = l01[1]; blo[4 * hb + 2] = l23[0]; blo[4 * hb + 3] = l23[1];
                 }
+#if EGNN_PW_ABL & 16
+                f32x4 at = acc[t];
+                asm volatile("" : "+v"(at) : "v"(whi), "v"(wlo), "v"(bhi), "v"(blo));
+                acc[t] = at;
+#else
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, bhi, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, bhi, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, blo, acc[t], 0, 0, 0);
+#endif
             }
+#if EGNN_PW_SKEW
+            if (more) {
+                // tile 0 of the next step: its lines were requested early in this one
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0)
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                if (!HALF) {
+                    asm volatile("" : "+v"(pivn[0]), "+v"(pivn[1]));         // (landed: the compiler's own wait for them sits here, not behind the ring DMA below)
+                    piv[0] = pivn[0];
+                    piv[1] = pivn[1];
+                }
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) x0n[hb] = *reinterpret_cast<const f32x4*>(xr[hb]);
+            }
+            if (st == 0) {
+                if (c + 1 < nchunks) stage(c + 1, slot ^ 1);
+                else if (!last_round) stage(0, slot ^ 1);
+            }
+#endif
         };
 #if EGNN_PW_PRIO == 1
         asm volatile("s_setprio 0");
@@ -413,8 +553,18 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
             const int c0 = c * PW_HC;
             const int hc = (Hp - c0) < PW_HC ? (Hp - c0) : PW_HC;
             // chunk `ring` was requested one chunk ago; the only other loads in flight are the gathers of the coming step
+#if !(EGNN_PW_ABL & 128)
+#if EGNN_PW_SKEW
+            // (as a builtin: the compiler's own counter bookkeeping must know that nothing it issued -- the setup's P_i loads -- is still
+            // pending inside the steps, or it waits there with counts that stall on the ring DMA just issued)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
+            asm volatile("" ::: "memory");
+#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             __syncthreads();                 // every wave's pieces have landed, and every wave has left the other slot
+#endif
             const _Float16* w2c = w2s + slot * (PW_HC * 32);
             const char* tlc = tl + slot * (PW_HC * 16);
             const int nst = hc >> 5;
@@ -474,7 +624,11 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
             cw[t] = 0.f;
         }
 
+#if EGNN_PW_ABL & 64
+        const _Float16* const w3h = nullptr;
+#else
         const _Float16* const w3h = static_cast<const _Float16*>(pe->W3h);
+#endif
         if (w3h) {
             // coors_mlp (:203-208): first Linear (16 -> 64) on the matrix cores, split-f16: lane (e, g) holds channels 4g .. 4g+3 of its
             // edge = the B fragment of v_mfma_f32_16x16x16_f16; A = rows 16 blk + e of W3

@@ -14,6 +14,7 @@ kernels (the E x H work of every shape the fused forward covers) or recomputes t
 from __future__ import annotations
 
 import contextlib
+import contextvars
 import os
 import warnings
 
@@ -38,22 +39,31 @@ _EDGE_ALGO = int(os.environ.get("EGNN_EDGE_ALGO", "0"))
 # slower -- when the range status word is read synchronously (EGNN_RANGE_CHECK=sync, the default) and no graph is being recorded;
 # otherwise it raises EGNNRangeError.  "exact": always the plain-fp32 kernels (inference only).
 _PRECISION = os.environ.get("EGNN_PRECISION", "fast")
-_exact_now = False
+_exact_now = contextvars.ContextVar("egnn_exact_now", default=False)       # per thread / context: concurrent forwards do not see each other's
+_warned_rerun = False
 
 
 @contextlib.contextmanager
 def exact_arithmetic():
     """Run the enclosed forwards on the plain-fp32 (wide-range) kernels: include/egnn_hip.h, "The wide-range path"."""
-    global _exact_now
-    prev, _exact_now = _exact_now, True
+    tok = _exact_now.set(True)
     try:
         yield
     finally:
-        _exact_now = prev
+        _exact_now.reset(tok)
 
 
 def exact_active():
-    return _exact_now or _PRECISION == "exact"
+    return _exact_now.get() or _PRECISION == "exact"
+
+
+def _warn_rerun(err):
+    """Once per process: the automatic plain-fp32 re-run is several times slower than the fast path and costs a host synchronisation."""
+    global _warned_rerun
+    if not _warned_rerun:
+        _warned_rerun = True
+        warnings.warn("egnn_pytorch_amd: a forward left the range of the split-fp16 fast path and is being re-run on the plain-fp32 "
+                      f"kernels (several times slower; this warning is issued once). Cause: {err}", RuntimeWarning, stacklevel=3)
 
 
 def _rerun_exact_ok(module, *tensors):
@@ -191,9 +201,10 @@ class EGNN(nn.Module):
         try:
             out = self._call(feats, coors, edges, mask, adj_mat, None)[:2]
             _ops.range_check_after_forward(feats.device)            # EGNN_RANGE_CHECK: sync (default) | deferred | off
-        except _abi.EGNNRangeError:
-            if not _rerun_exact_ok(self, feats, coors, edges):
+        except _abi.EGNNRangeError as err:
+            if "an earlier backward" in str(err) or not _rerun_exact_ok(self, feats, coors, edges):
                 raise
+            _warn_rerun(err)
             with exact_arithmetic():                                # reference-legal inputs beyond the fp16 cast sites: plain fp32
                 out = self._call(feats, coors, edges, mask, adj_mat, None)[:2]
         return out
@@ -579,9 +590,10 @@ class EGNN_Network(nn.Module):
             with torch.enable_grad() if grad else torch.no_grad():
                 out = self._forward(feats, coors, adj_mat, edges, mask, return_coor_changes)
             _ops.range_check_after_forward(coors.device)            # once per network forward, not per layer
-        except _abi.EGNNRangeError:
-            if grad or not _rerun_exact_ok(self, feats, coors, edges):
+        except _abi.EGNNRangeError as err:
+            if grad or "an earlier backward" in str(err) or not _rerun_exact_ok(self, feats, coors, edges):
                 raise
+            _warn_rerun(err)
             with exact_arithmetic(), torch.no_grad():               # the whole stack again, in plain fp32
                 out = self._forward(feats, coors, adj_mat, edges, mask, return_coor_changes)
         return out
@@ -598,7 +610,7 @@ class EGNN_Network(nn.Module):
         # Edge features for the layers.  Inference: look-up tables (EdgeLookup) -- the (B,N,N,edge_dim+adj_dim) tensor of :410-432
         # is never materialised, the edge kernel reads the embedding rows of the K selected pairs of each node.  Under autograd:
         # the tensor, so that the embeddings receive gradients.
-        lazy = not torch.is_grad_enabled() and not self.layers[0][1].float64_kernels()
+        lazy = not torch.is_grad_enabled() and not any(l.float64_kernels() for _, l in self.layers)       # (depth = 0: an empty loop, as upstream)
         tok = tok_emb = None
         if edges is not None and self.edge_emb is not None:
             if lazy:

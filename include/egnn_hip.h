@@ -283,7 +283,8 @@ typedef struct egnn_edge_args {
     int32_t node_kp;            /*   [dim, dim + m_dim) (both or neither; node_kp % 32 == 0, >= dim + m_dim)          */
     int32_t* status;            /* optional range status word (EGNN_RANGE_SCALAR / _HIDDEN / _MESSAGE), see the enum above */
     /* autograd support (NULL for plain inference) */
-    float* U_out;               /* forward, optional: (B*N*K, 16 * ceil(m_dim / 16)) fp32 u = edge_mlp.3(SiLU(edge_mlp.0(.))) before the second
+    float* U_out;               /* forward, optional: (B*N*K, 16 * NB) fp32, NB = 1 / 2 / 4 accumulator blocks for m_dim <= 16 / <= 32 / <= 64
+                                   (so m_dim 33 .. 48 has rows of 64 floats, not 48): u = edge_mlp.3(SiLU(edge_mlp.0(.))) before the second
                                    SiLU (egnn_pytorch.py:181-183), one row per edge (b, i, k), pad channels 0: what the backward
                                    (egnn_edge_tail_bwd_f32 / egnn_edge_bwd_pass_f32) differentiates from */
     int32_t edges_by_k;         /* 0: `edges` is (B,N,N,edge_dim), read at [b,i,j];  1: `edges` is (B,N,K,edge_dim), the features of the
@@ -345,7 +346,7 @@ typedef struct egnn_edge_bwd_args {
     const void* Wst;            /* (Hp, wst_terms, 2) fp16: the forward's scalar-weight table */
     float ws_inv_scale;
     const int32_t* idx;         /* (B*N*K) neighbour of each edge, NULL = dense (K == N, j = k) */
-    const void* W2Th;           /* (Hp/32, 2, 2, 64, 4) fp16: W2^T fragments (egnn_edge_args.W2Th) */
+    const void* W2Th;           /* (Hp/32, 2, 2, 64, 4) fp16: W2^T fragments of ONE 16-channel block (hi | lo images; built by egnn_pytorch_amd/_weights.py::pack, key "W2Th_blocks") */
     const float* gU;            /* (E, 16) fp32 d loss / d u */
     float gu_scale;             /* power of two applied to gU before its fp16 split */
     float inv_scale;            /* 1 / (gu_scale * scale of W2Th) */
