@@ -19,6 +19,11 @@ done
 # the edge pass a second time for coordinate dimensions other than 3 (compile-time CDM = 8)
 ( "$HIPCC" $FLAGS -DEGNN_EDGE_GENERIC_C -c "$HERE/edge_fused.hip" -o "$HERE/obj/edge_fused_c.o" 2> "$HERE/obj/edge_fused_c.res" ) &
 pids+=($!)
+# ... and twice more for the training-mode dropout instantiations beyond the standard layer's (wide heads / other coordinate dimensions)
+( "$HIPCC" $FLAGS -DEGNN_EDGE_DROP_TU -c "$HERE/edge_fused.hip" -o "$HERE/obj/edge_fused_d.o" 2> "$HERE/obj/edge_fused_d.res" ) &
+pids+=($!)
+( "$HIPCC" $FLAGS -DEGNN_EDGE_DROP_TU -DEGNN_EDGE_GENERIC_C -c "$HERE/edge_fused.hip" -o "$HERE/obj/edge_fused_cd.o" 2> "$HERE/obj/edge_fused_cd.res" ) &
+pids+=($!)
 for p in "${pids[@]}"; do wait "$p" || true; done
 for res in "$HERE"/obj/*.res; do
   if [ ! -f "${res%.res}.o" ]; then
@@ -36,6 +41,8 @@ for res in "$HERE"/obj/*.res; do
     f="$(basename "$res" .res)"
     EXTRA=""; src="$f"
     [ "$f" = edge_fused_c ] && { EXTRA="-DEGNN_EDGE_GENERIC_C"; src=edge_fused; }
+    [ "$f" = edge_fused_d ] && { EXTRA="-DEGNN_EDGE_DROP_TU"; src=edge_fused; }
+    [ "$f" = edge_fused_cd ] && { EXTRA="-DEGNN_EDGE_DROP_TU -DEGNN_EDGE_GENERIC_C"; src=edge_fused; }
     [ "$f" = knn_select ] && EXTRA="-ffp-contract=off"
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed -Wno-inline-asm $EXTRA -S --cuda-device-only \
         -o "$HERE/obj/$f.s" "$HERE/$src.hip" 2> /dev/null

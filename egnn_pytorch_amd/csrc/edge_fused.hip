@@ -42,6 +42,10 @@
 #include "egnn_common.h"
 #include "egnn_lds_dma.h"
 
+// (internal: the dropout translation units of this file, -DEGNN_EDGE_DROP_TU)
+int egnn_edge_fused_c3_drop(const egnn_edge_args* args, void* stream);
+int egnn_edge_fused_generic_c_drop(const egnn_edge_args* args, void* stream);
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -88,12 +92,23 @@ constexpr int HC = EGNN_EDGE_HC;          // hidden columns per LDS chunk (steps
 constexpr int KSTEP = 32;                // hidden units per v_mfma_f32_16x16x32_f16
 // Coordinate dimension: this translation unit is compiled twice -- CDM = 3 (the fast path, every BASELINE config) and,
 // with -DEGNN_EDGE_GENERIC_C, CDM = 8 for 1 <= C <= 8 at run time (egnn_pytorch.py works for any C; its tests use C = 5).
+// -DEGNN_EDGE_DROP_TU: a translation unit of its own for the training-mode dropout instantiations (MODE 3) beyond the standard layer's --
+// 17 .. 64 message channels with 3-D coordinates, every head width with the other coordinate dimensions -- so that the two main
+// compilations keep their size (csrc/build.sh compiles all four in parallel).
 #ifdef EGNN_EDGE_GENERIC_C
 constexpr int CDM = 8;
+#ifdef EGNN_EDGE_DROP_TU
+#define EGNN_EDGE_ENTRY egnn_edge_fused_generic_c_drop
+#else
 #define EGNN_EDGE_ENTRY egnn_edge_fused_generic_c
+#endif
 #else
 constexpr int CDM = 3;
+#ifdef EGNN_EDGE_DROP_TU
+#define EGNN_EDGE_ENTRY egnn_edge_fused_c3_drop
+#else
 #define EGNN_EDGE_ENTRY egnn_edge_fused_c3
+#endif
 #endif
 // per-edge channels reduced per node: 16 NB message channels | CDM coords | 1 count (NB = 16-channel blocks of m_dim)
 constexpr int nch_of(int nb) { return 16 * nb + CDM + 1; }
@@ -1116,11 +1131,22 @@ int dispatch_tpi_nb(const egnn_edge_args& a, hipStream_t s)
 template <int NM, int HCT>
 int dispatch_tpi(const egnn_edge_args& a, hipStream_t s)
 {
+#ifdef EGNN_EDGE_DROP_TU
+    // training-mode dropout (egnn_pytorch.py:176-184, 203-208) for the shapes the main translation units do not instantiate it for
+    if (!a.drop_thr) return EGNN_E_UNSUPPORTED;
+#ifdef EGNN_EDGE_GENERIC_C
+    if (a.m_dim <= 16) return dispatch_tpi_nb<NM, HCT, 1, 3>(a, s);
+#else
+    if (a.m_dim <= 16) return EGNN_E_UNSUPPORTED;                                   // (the main translation unit's)
+#endif
+    if (a.m_dim <= 32) return dispatch_tpi_nb<NM, (HCT / 2 >= 64 ? HCT / 2 : 64), 2, 3>(a, s);
+    return dispatch_tpi_nb<NM, 64, 4, 3>(a, s);
+#else
 #ifndef EGNN_EDGE_GENERIC_C
-    if (a.drop_thr) return a.m_dim <= 16 ? dispatch_tpi_nb<NM, HCT, 1, 3>(a, s) : EGNN_E_UNSUPPORTED;   // training-mode dropout
+    if (a.drop_thr) return a.m_dim <= 16 ? dispatch_tpi_nb<NM, HCT, 1, 3>(a, s) : egnn_edge_fused_c3_drop(&a, s);   // training-mode dropout
     if (a.m_dim <= 16 && a.U_out) return dispatch_tpi_nb<NM, HCT, 1, 1>(a, s);      // forward under autograd: also writes u
 #else
-    if (a.drop_thr) return EGNN_E_UNSUPPORTED;
+    if (a.drop_thr) return egnn_edge_fused_generic_c_drop(&a, s);
 #endif
     if (a.m_dim <= 16) return dispatch_tpi_nb<NM, HCT, 1>(a, s);
 #ifndef EGNN_EDGE_TUNING_BUILD
@@ -1129,11 +1155,12 @@ int dispatch_tpi(const egnn_edge_args& a, hipStream_t s)
 #else
     return EGNN_E_UNSUPPORTED;
 #endif
+#endif  // EGNN_EDGE_DROP_TU
 }
 
 }  // namespace
 
-#ifndef EGNN_EDGE_GENERIC_C
+#if !defined(EGNN_EDGE_GENERIC_C) && !defined(EGNN_EDGE_DROP_TU)
 extern "C" int egnn_padded_hidden(int H) { return (H + 31) / 32 * 32; }
 
 extern "C" int egnn_edge_mfmas(int S) { return S <= 1 ? 1 : (S <= 4 ? 3 : (S <= 5 ? 4 : (S <= 8 ? 6 : 12))); }
@@ -1149,7 +1176,7 @@ int egnn_edge_pw_launch(const egnn_edge_args* args, void* stream);
 #define EGNN_EDGE_PW 1
 #endif
 
-#ifndef EGNN_EDGE_GENERIC_C
+#if !defined(EGNN_EDGE_GENERIC_C) && !defined(EGNN_EDGE_DROP_TU)
 extern "C" int egnn_edge_fused_f32(const egnn_edge_args* args, void* stream)
 {
     if (!args) return EGNN_E_NULLPTR;
@@ -1189,7 +1216,7 @@ int EGNN_EDGE_ENTRY(const egnn_edge_args* args, void* stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     // NM = ceil(3 S / 4) first-layer MFMAs, rounded up to an instantiated value; Wst must be laid out for that NM
     if (a.wst_terms != 4 * egnn_edge_mfmas(a.S)) return EGNN_E_SHAPE;
-#if !defined(EGNN_EDGE_GENERIC_C) && EGNN_EDGE_PW
+#if !defined(EGNN_EDGE_GENERIC_C) && !defined(EGNN_EDGE_DROP_TU) && EGNN_EDGE_PW
     if (a.algo == 0) {
         const int rc = egnn_edge_pw_launch(args, stream);
         if (rc != EGNN_E_UNSUPPORTED) return rc;
