@@ -24,6 +24,12 @@
 // 5 workgroups per CU, equal static shares: 10 % SLOWER (1.54 vs 1.39 ms at the north-star shape, same box): with equal shares
 // fixed at launch the five workgroups of a CU stay in step, their latency-bound setups and epilogues coincide instead of hiding under
 // each other's hidden loops, and it is the dispatcher's staggered refill that de-phases them (egnn_edge_pw_launch below).
+// Round 5 (profiles/r05_experiments/edge_pw_ablations_and_pipelining.txt; code in the history at commit aaff455): software pipelining
+// of the step head without extra registers (tile 0 of the next step picked up at the end of the current one), the four SiLU chains of
+// a register quad interleaved, conflict-free A-fragment reads, the P_i words through the staging ring instead of two loads per step,
+// four workgroups per CU with a barrier per three steps: all within the box's +-1.5 % or slower.  Timing-only ablations (EGNN_PW_ABL):
+// without any MFMA 1.10 ms of 1.33 -- the matrix-pipe work costs 0.23 ms of VALU time however it is scheduled; without the chunk
+// barrier a dim-128 layer is 2.8x SLOWER (the barrier keeps the four nodes' gathers on the same lines).
 // Also measured and not kept (profiles/r04_experiments/): W2 / W_s fragments straight from global memory instead of the LDS ring
 // (no barriers, but +2.5 KB of vector-memory traffic per wave-step: +22 %); a 32-column ring at six workgroups per CU (a barrier per
 // step: +3 %); the first Linear as one v_mfma_f32_32x32x16_f16 per (tile, 64 hidden units) (+8 %: a tile at a time leaves the wave
@@ -66,12 +72,6 @@ constexpr int PW_WAVES = 4;
 // 256 no P_i loads, 512 no hi / lo conversions
 #ifndef EGNN_PW_ABL
 #define EGNN_PW_ABL 0
-#endif
-#ifndef EGNN_PW_SKEW
-#define EGNN_PW_SKEW 0                       // 1: skewed tile pick-up (see step)
-#endif
-#ifndef EGNN_PW_SILU_ILV
-#define EGNN_PW_SILU_ILV 0                   // 1: the four SiLU chains of an accumulator register quad written interleaved
 #endif
 constexpr int PW_HC = EGNN_PW_HC;            // hidden columns per slot of the staging ring (64: two steps of 32)
 constexpr int PW_XLD = 32;                   // floats per row of the gather exchange buffer (one 128-byte line, chunk-swizzled)
@@ -201,11 +201,10 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) xr[hb] = xch + e * PW_XLD + 4 * ((4 * hb + g) ^ ((e >> 1) & 7));
     // first-layer A fragments: row (hidden unit) e of the 16-block, split term g
-#if defined(EGNN_PW_WSTSWZ) && EGNN_PW_WSTSWZ
-    const char* const tl = wst + (e * 4 + (g ^ ((e >> 2) & 2))) * 4;     // timing experiment: units 8 .. 15 of a block read the other pair of banks
-#else
+    // (units e and e + 8 of a 16-block share a bank in this read -- a 2-way conflict on one ds_read_b32 per step and 16-block, the
+    // 12 % of LDS cycles VERDICT r4 asked about; reading the other bank pair instead changed nothing measurable: the LDS pipe is
+    // busy a fifth of the time, profiles/r05_experiments/)
     const char* const tl = wst + (e * 4 + g) * 4;
-#endif
     constexpr int tstep = 16 * 4 * 4;                                      // bytes per 16 hidden units
 #if EGNN_PW_RESID4
     f16x4 neg_identity;                                                    // A operand of the 4x4x4 residual MFMA: row (lane & 3) of -I4
@@ -319,9 +318,6 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
         // upper 16-unit block is padding -- P, W_s and W2 are exactly zero there, so y = 0, a = 0 / (1 + 1) = 0, hi = lo = 0 -- and its
         // pick-up reads, first-layer MFMAs, 32 SiLU evaluations, conversions and residual MFMAs are skipped: the same bits, 40 VALU
         // instructions instead of 86 in that step (1 step of 17 at dim 128, of 33 at dim 256, of 65 at dim 512).
-#if EGNN_PW_SKEW
-        f32x4 x0n[2];                                                       // tile 0 of the coming step, as gathered (see step)
-#endif
         auto step = [&](auto half_tag, const int c, const int st, const int slot, const int hoff, const _Float16* w2c, const char* tlc) {
             constexpr bool HALF = decltype(half_tag)::value;
             constexpr int NHB = HALF ? 1 : 2;
@@ -329,45 +325,6 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
             const int hnext = more ? hoff + 32 : hoff;                       // last step: harmless re-read of the P_i words
             f32x4 x[2][2];
             uint32_t pivn[2];
-#if EGNN_PW_SKEW
-            // Skewed tiles (VERDICT r4 next #1a, without a second set of exchange rows or more registers): tile 0 of step s + 1 is picked
-            // up at the END of step s (its lines were requested early in step s), tile 1 of step s at its start -- the LDS round trip of
-            // tile 1 runs under tile 0's SiLU chain, that of tile 0 under the loop back-edge / chunk barrier, and the first v_exp_f32 of a
-            // step waits for one LDS read (the staged A fragments) + one MFMA instead of wait -> four reads -> wait -> four MFMAs.
-            u32x2 a0[2];
-#pragma unroll
-            for (int hb = 0; hb < NHB; ++hb)
-                a0[hb] = u32x2{0u, *reinterpret_cast<const uint32_t*>(tlc + st * 2 * tstep + hb * tstep)};
-            const f16x8 whi = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 0) * 64 + lane) * 8);
-            const f16x8 wlo = *reinterpret_cast<const f16x8*>(w2c + ((st * 2 + 1) * 64 + lane) * 8);
-            if (hoff == 0) {                                                 // the round's first step: its lines landed before the chunk barrier
-#pragma unroll
-                for (int hb = 0; hb < NHB; ++hb) x0n[hb] = *reinterpret_cast<const f32x4*>(xr[hb]);
-            }
-#pragma unroll
-            for (int hb = 0; hb < NHB; ++hb) x[1][hb] = *reinterpret_cast<const f32x4*>(xr[hb] + 16 * PW_XLD);
-#pragma unroll
-            for (int hb = 0; hb < NHB; ++hb) a0[hb][0] = piv[hb];
-#pragma unroll
-            for (int hb = 0; hb < NHB; ++hb)
-                x[0][hb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a0[hb]), __builtin_bit_cast(f16x4, bq[0]), x0n[hb], 0, 0, 0);
-            // every row of this step is in registers before the next step's lines may land in them
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0)
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            if (!HALF) {
-                pivn[0] = buf_load1(pi_rsrc, piw, hnext * 4);
-                pivn[1] = buf_load1(pi_rsrc, piw, hnext * 4 + 64);
-            }
-            if (more) {
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) gather_dma16(pj_words, goff[qq], (uint32_t)(hnext * 4), xch_lds + qq * 1024);
-            }
-#pragma unroll
-            for (int hb = 0; hb < NHB; ++hb)
-                x[1][hb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a0[hb]), __builtin_bit_cast(f16x4, bq[1]), x[1][hb], 0, 0, 0);
-#else
 #if EGNN_PW_EARLY_W
             // this step's staged operands first (in LDS since the chunk's barrier): their LDS latency runs under the wait for the
             // gathered lines instead of after it
@@ -448,7 +405,6 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
                     x[t][hb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a0[hb]), __builtin_bit_cast(f16x4, bq[t]), x[t][hb], 0, 0, 0);
 #endif
                 }
-#endif  // EGNN_PW_SKEW
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 // x holds y = -log2(e) * (pre-activation); a = y / (1 + 2^y) = SiLU(pre) / (-ln 2); hi = fp16(a) (IEEE: beyond 65504 ->
@@ -459,23 +415,6 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
 #pragma unroll
                 for (int hb = 0; hb < NHB; ++hb) {
                     f32x4 a4;
-#if EGNN_PW_SILU_ILV
-                    {
-                        float tt[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) tt[u] = __builtin_amdgcn_exp2f(x[t][hb][u]);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) tt[u] = 1.0f + tt[u];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) tt[u] = __builtin_amdgcn_rcpf(tt[u]);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            float h = x[t][hb][u] * tt[u];
-                            asm("" : "+v"(h));
-                            a4[u] = h;
-                        }
-                    }
-#else
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const float y = x[t][hb][u];
@@ -487,7 +426,6 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
                         asm("" : "+v"(h));           // keeps the products scalar (v_pk_mul_f32 costs 9.3 cycles per pair against 2 x 2.8)
                         a4[u] = h;
                     }
-#endif
 #if EGNN_PW_ABL & 512
                     const f16x2 h01 = __builtin_bit_cast(f16x2, a4[0]), h23 = __builtin_bit_cast(f16x2, a4[2]);
 #else
@@ -522,26 +460,6 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, blo, acc[t], 0, 0, 0);
 #endif
             }
-#if EGNN_PW_SKEW
-            if (more) {
-                // tile 0 of the next step: its lines were requested early in this one
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0)
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                if (!HALF) {
-                    asm volatile("" : "+v"(pivn[0]), "+v"(pivn[1]));         // (landed: the compiler's own wait for them sits here, not behind the ring DMA below)
-                    piv[0] = pivn[0];
-                    piv[1] = pivn[1];
-                }
-#pragma unroll
-                for (int hb = 0; hb < 2; ++hb) x0n[hb] = *reinterpret_cast<const f32x4*>(xr[hb]);
-            }
-            if (st == 0) {
-                if (c + 1 < nchunks) stage(c + 1, slot ^ 1);
-                else if (!last_round) stage(0, slot ^ 1);
-            }
-#endif
         };
 #if EGNN_PW_PRIO == 1
         asm volatile("s_setprio 0");
@@ -554,15 +472,7 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
             const int hc = (Hp - c0) < PW_HC ? (Hp - c0) : PW_HC;
             // chunk `ring` was requested one chunk ago; the only other loads in flight are the gathers of the coming step
 #if !(EGNN_PW_ABL & 128)
-#if EGNN_PW_SKEW
-            // (as a builtin: the compiler's own counter bookkeeping must know that nothing it issued -- the setup's P_i loads -- is still
-            // pending inside the steps, or it waits there with counts that stall on the ring DMA just issued)
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
-            asm volatile("" ::: "memory");
-#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             __syncthreads();                 // every wave's pieces have landed, and every wave has left the other slot
 #endif
             const _Float16* w2c = w2s + slot * (PW_HC * 32);
