@@ -302,6 +302,11 @@ def layer_given_neighbors(layer, feats, coors, edges, mask, idx, rank, valid_rad
     return layer_tail(layer, feats, coors, u, rel, mask, idx, rank, valid_radius, drop, graph_offset)
 
 
+def _exact_active():
+    from . import layer as _layer                         # (layer.py imports this module)
+    return _layer.exact_active()
+
+
 def _chunk_graphs(layer, n, k, batch):
     din = 2 * layer.dim + 2 * layer.fourier_features + 1 + layer.edge_dim
     per_graph = n * k * (2 * din) * 4.0 * _BYTES_PER_EDGE_FACTOR          # E x H pre-activation, activation, their gradients
@@ -335,7 +340,8 @@ class EGNNFunction(torch.autograd.Function):
         # chain behind u has its closed-form kernel for m_dim <= 16 and 3-D coordinates and goes through autograd on E x m tensors otherwise)
         native = (_NATIVE and layer.m_dim <= 64 and coors.shape[-1] <= 8 and (drop is None or (_dropout_native_ok(layer) and coors.shape[-1] == 3))
                   and 2 * layer.fourier_features + 1 + layer.edge_dim <= 16
-                  and not layer.float64_kernels())           # (a float64 module: float64 forward kernels, float64 recompute backward)
+                  and not layer.float64_kernels()            # (a float64 module: float64 forward kernels, float64 recompute backward)
+                  and not _exact_active())                   # (the wide-range re-run: plain-fp32 forward kernels, plain-fp32 recompute backward)
         with torch.no_grad():
             node_out, coors_out, order, idx, rank, valid_radius, u_pre, proj = layer._forward_hip_checked(
                 feats, coors, edges, mask, adj_mat, order_hint, want_u=native, drop_seed=None if drop is None else drop[1])

@@ -67,13 +67,17 @@ def _warn_rerun(err):
 
 
 def _rerun_exact_ok(module, *tensors):
-    """A forward that tripped the range status word may be re-run in plain fp32: the word was read for THIS call (sync mode),
-    nothing is being recorded for a backward (the native backward has the same fp16 cast sites), and no stream capture is going on."""
+    """A forward that tripped the range status word may be re-run in plain fp32: the word was read for THIS call (sync mode) and no
+    stream capture is going on.  Under autograd too (round 5): the re-run's forward is the plain-fp32 kernels and its backward the
+    recompute path -- plain fp32 ATen arithmetic over the neighbour list those kernels selected, no fp16 cast site anywhere -- so that
+    reference-legal inputs such as feats x 1e6 TRAIN instead of raising (slower: it is the wide-range path).  Not with training-mode
+    dropout, whose hash masks live in the fast kernels."""
     if _ops.RANGE_CHECK != "sync" or exact_active():
         return False
     if torch.is_grad_enabled() and (any(p.requires_grad for p in module.parameters()) or
                                     any(torch.is_tensor(t) and t.is_floating_point() and t.requires_grad for t in tensors)):
-        return False
+        if any(m.dropout_active() for m in module.modules() if isinstance(m, EGNN)):
+            return False
     return not torch.cuda.is_current_stream_capturing()
 # The kernels compute in fp32-class arithmetic (split-f16 products, fp32 accumulation: DESIGN.md §2).  Other floating dtypes
 # -- the reference is dtype-generic and its own tests run in float64 -- are accepted at the boundary: inputs are converted to
@@ -183,9 +187,10 @@ class EGNN(nn.Module):
             raise NotImplementedError("the gfx950 path supports coordinate dimensions 1..64 (beyond 8 on the plain kernels)")
         if feats.shape[-1] != self.dim:
             raise ValueError(f"feats last dim {feats.shape[-1]} != dim {self.dim}")
-        if self.training and self.dropout_p > 0 and (coors.shape[-1] != 3 or self.m_dim > 16):
-            raise NotImplementedError("training-mode dropout on the gfx950 path needs 3-D coordinates and m_dim <= 16 "
-                                      "(the dropout instantiation of the fused edge pass); use dropout=0 or call .eval()")
+        if self.training and self.dropout_p > 0 and (coors.shape[-1] > 8 or self.m_dim > 64 or 2 * self.fourier_features + 1 + self.edge_dim > 16):
+            raise NotImplementedError("training-mode dropout on the gfx950 path needs coordinate dimension <= 8, m_dim <= 64 and <= 16 per-edge scalars "
+                                      "(the hash masks live in the fused edge pass; wider shapes run on the plain kernels, which are "
+                                      "inference-only); use dropout=0 or call .eval()")
         if (edges is not None) != (self.edge_dim > 0):
             raise ValueError("`edges` must be passed if and only if edge_dim > 0")
         b, n = feats.shape[:2]
@@ -591,10 +596,10 @@ class EGNN_Network(nn.Module):
                 out = self._forward(feats, coors, adj_mat, edges, mask, return_coor_changes)
             _ops.range_check_after_forward(coors.device)            # once per network forward, not per layer
         except _abi.EGNNRangeError as err:
-            if grad or "an earlier backward" in str(err) or not _rerun_exact_ok(self, feats, coors, edges):
+            if "an earlier backward" in str(err) or not _rerun_exact_ok(self, feats, coors, edges):
                 raise
             _warn_rerun(err)
-            with exact_arithmetic(), torch.no_grad():               # the whole stack again, in plain fp32
+            with exact_arithmetic(), (torch.enable_grad() if grad else torch.no_grad()):    # the whole stack again, in plain fp32
                 out = self._forward(feats, coors, adj_mat, edges, mask, return_coor_changes)
         return out
 

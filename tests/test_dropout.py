@@ -74,7 +74,17 @@ CASES = [
     (dict(dim=32, dropout=0.5, m_pool_method="mean"), 20, False),                                 # dense all-pairs
     (dict(dim=24, num_nearest_neighbors=5, dropout=0.3, m_dim=8, coor_weights_clamp_value=1.0), 30, True),   # P_i on the VALU
     (dict(dim=32, num_nearest_neighbors=16, dropout=0.2, edge_dim=3, fourier_features=1), 48, True),
+    # round 5: the shapes beyond the standard layer's (their own translation units of csrc/edge_fused.hip, -DEGNN_EDGE_DROP_TU):
+    # two and four accumulator tiles per edge tile, the other coordinate dimensions (the reference's own test uses 5)
+    (dict(dim=64, num_nearest_neighbors=32, dropout=0.25, m_dim=32), 80, True),
+    (dict(dim=32, dropout=0.3, m_dim=48, soft_edges=True), 24, False),
+    (dict(dim=32, num_nearest_neighbors=8, dropout=0.2, norm_coors=True, cdim=5), 40, True),
+    (dict(dim=24, num_nearest_neighbors=12, dropout=0.15, m_dim=24, edge_dim=2, cdim=2), 36, False),
 ]
+
+
+def _layer_kw(kw):
+    return {k: v for k, v in kw.items() if k != "cdim"}
 
 
 @pytest.mark.gpu
@@ -84,14 +94,14 @@ def test_training_mode_forward_applies_exactly_the_hash_masks(kw, n, use_mask):
     dropout sites (1e-4, like every parity test): pins where the masks sit, their row / unit indexing and the rescaling."""
     from egnn_pytorch_amd import EGNN, autograd as A
     torch.manual_seed(11)
-    layer = EGNN(**kw)
+    layer = EGNN(**_layer_kw(kw))
     with torch.no_grad():
         for prm in layer.parameters():
             prm.mul_(40.0)
     layer = layer.cuda().train()
     g = torch.Generator().manual_seed(3)
     b = 3
-    feats, coors = torch.randn(b, n, kw["dim"], generator=g).cuda(), torch.randn(b, n, 3, generator=g).cuda()
+    feats, coors = torch.randn(b, n, kw["dim"], generator=g).cuda(), torch.randn(b, n, kw.get("cdim", 3), generator=g).cuda()
     mask = (torch.arange(n)[None] < torch.tensor([[n], [n - 3], [n // 2 + 2]])).cuda() if use_mask else None
     edges = torch.randn(b, n, n, kw["edge_dim"], generator=g).cuda() if kw.get("edge_dim") else None
     seed = 424242
@@ -129,6 +139,11 @@ BWD_CASES = [
     (dict(dim=32, num_nearest_neighbors=20, dropout=0.1, norm_coors=True, soft_edges=True, m_pool_method="mean", coor_weights_clamp_value=2.0), 50, True, True),
     (dict(dim=32, num_nearest_neighbors=16, dropout=0.2, edge_dim=2, fourier_features=1), 48, True, True),
     (dict(dim=24, num_nearest_neighbors=8, dropout=0.3, fourier_features=2, edge_dim=4, m_dim=8), 30, False, False),
+    # round 5: wide heads / other coordinate dimensions -- the forward's masks in the kernels, the backward on the recompute path
+    (dict(dim=32, num_nearest_neighbors=16, dropout=0.2, m_dim=32), 40, True, False),
+    # (no CoorsNorm here: on the fp32 recompute path -- as in the reference's own fp32 autograd -- the self pair's 1 / eps terms leave
+    # O(1) rounding noise in the coordinate gradient)
+    (dict(dim=32, num_nearest_neighbors=8, dropout=0.25, soft_edges=True, cdim=5), 30, False, False),
 ]
 
 
@@ -139,8 +154,9 @@ def test_training_mode_backward_differentiates_the_masked_layer(kw, n, use_mask,
     the masks of THAT forward call (the seed comes from torch's CPU generator: torch.manual_seed reproduces it)."""
     from egnn_pytorch_amd import EGNN, _dropout, autograd as A
     torch.manual_seed(21)
-    layer = EGNN(**kw)
-    assert A._dropout_native_ok(layer) == native
+    layer = EGNN(**_layer_kw(kw))
+    cdim = kw.get("cdim", 3)
+    assert (A._dropout_native_ok(layer) and cdim == 3) == native
     with torch.no_grad():
         for prm in layer.parameters():
             prm.mul_(40.0)
@@ -148,10 +164,10 @@ def test_training_mode_backward_differentiates_the_masked_layer(kw, n, use_mask,
     g = torch.Generator().manual_seed(4)
     b = 3
     dim, p = kw["dim"], kw["dropout"]
-    feats, coors = torch.randn(b, n, dim, generator=g).cuda(), torch.randn(b, n, 3, generator=g).cuda()
+    feats, coors = torch.randn(b, n, dim, generator=g).cuda(), torch.randn(b, n, cdim, generator=g).cuda()
     edges = torch.randn(b, n, n, kw["edge_dim"], generator=g).cuda() if kw.get("edge_dim") else None
     mask = (torch.arange(n)[None] < torch.tensor([[n], [n - 3], [n // 2 + 2]])).cuda() if use_mask else None
-    rn, rc = torch.randn(b, n, dim, generator=g).cuda(), torch.randn(b, n, 3, generator=g).cuda()
+    rn, rc = torch.randn(b, n, dim, generator=g).cuda(), torch.randn(b, n, cdim, generator=g).cuda()
     torch.manual_seed(77)
     seed = _dropout.draw_seed()
     torch.manual_seed(77)
@@ -182,11 +198,14 @@ def test_training_mode_backward_differentiates_the_masked_layer(kw, n, use_mask,
 
 
 @pytest.mark.gpu
-def test_dropout_configurations_outside_the_kernel_still_raise():
+def test_dropout_configurations_outside_the_fused_kernels_still_raise():
+    """Training-mode dropout covers every shape of the fused edge pass (m_dim <= 64, coordinate dimension <= 8); what runs on the plain
+    kernels -- wider heads, more coordinates -- is inference-only and says so."""
     from egnn_pytorch_amd import EGNN
-    f, c5 = torch.randn(1, 12, 16).cuda(), torch.randn(1, 12, 5).cuda()
+    f = torch.randn(1, 12, 16).cuda()
     with pytest.raises(NotImplementedError):
-        EGNN(dim=16, dropout=0.1).cuda().train()(f, c5)
+        EGNN(dim=16, dropout=0.1).cuda().train()(f, torch.randn(1, 12, 9).cuda())
     with pytest.raises(NotImplementedError):
-        EGNN(dim=16, dropout=0.1, m_dim=32).cuda().train()(f, torch.randn(1, 12, 3).cuda())
-    EGNN(dim=16, dropout=0.1, m_dim=32).cuda().eval()(f, torch.randn(1, 12, 3).cuda())      # eval: dropout is the identity
+        EGNN(dim=16, dropout=0.1, m_dim=80).cuda().train()(f, torch.randn(1, 12, 3).cuda())
+    EGNN(dim=16, dropout=0.1, m_dim=80).cuda().eval()(f, torch.randn(1, 12, 3).cuda())      # eval: dropout is the identity
+    EGNN(dim=16, dropout=0.1, m_dim=32).cuda().train()(f, torch.randn(1, 12, 5).cuda())     # (round 5: covered)

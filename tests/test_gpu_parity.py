@@ -495,7 +495,7 @@ def test_out_of_range_inputs_match_the_reference_through_the_wide_range_path(wha
     status bit -- never a silently clamped number -- and the module re-runs the call on the plain-fp32 kernels (csrc/edge_exact.hip,
     egnn_linear_f32): the result matches the oracle at 1e-4 of the output's scale.  Where the word cannot be read for the call itself
     (deferred mode) the old contract holds: non-finite outputs, EGNNRangeError naming the cause at the next check."""
-    from egnn_pytorch_amd import EGNNRangeError, _ops
+    from egnn_pytorch_amd import EGNNRangeError, _ops, exact_arithmetic
     kw = dict(dim=32, num_nearest_neighbors=8, edge_dim=2)
     cfg, params, net = _range_layer(kw)
     rng = np.random.default_rng(zlib.crc32(what.encode()))
@@ -538,11 +538,32 @@ def test_out_of_range_inputs_match_the_reference_through_the_wide_range_path(wha
         _ops.check_range()                                   # the word was cleared
     finally:
         _ops.RANGE_CHECK = old
-    # under autograd the native backward has the same cast sites: it raises instead of re-running
+    # under autograd (round 5): the call is re-run on the plain-fp32 kernels too and its backward is the recompute path in plain fp32 --
+    # the inputs TRAIN: every gradient against float64 autograd of the restated layer over the same neighbour list, 1e-4 of its scale
+    import copy
+    from egnn_pytorch_amd import autograd as A
+    net.train()                                              # (no dropout in this layer: train() only arms autograd-style use)
+    with torch.enable_grad(), _ops.phase_timer() as pt:
+        f, c, e = (t.clone().requires_grad_(True) for t in args)
+        node_g, co_g = net(f, c, e)
+        loss = (node_g / max(1.0, float(node_g.detach().abs().max()))).square().sum() + (co_g / max(1.0, float(co_g.detach().abs().max()))).square().sum()
+        got = torch.autograd.grad(loss, [f, c, e] + list(net.parameters()), allow_unused=True)
+    assert "edge_exact" in pt.summary()
+    np.testing.assert_allclose(node_g.detach().cpu().numpy(), ref_node, atol=ATOL * max(1.0, float(np.abs(ref_node).max())), rtol=0)
+    with torch.no_grad(), exact_arithmetic():
+        idx, rank, radius = net._forward_hip_checked(args[0], args[1], args[2], None, None, None)[3:6]
+    n64 = copy.deepcopy(net).double()
+    f2, c2, e2 = (t.double().clone().requires_grad_(True) for t in args)
     with torch.enable_grad():
-        f = args[0].clone().requires_grad_(True)
-        with pytest.raises(EGNNRangeError):
-            net(f, args[1], args[2])
+        n2, co2 = A.layer_given_neighbors(n64, f2, c2, e2, None, idx.long(), rank.double(), radius)
+        loss2 = (n2 / max(1.0, float(n2.detach().abs().max()))).square().sum() + (co2 / max(1.0, float(co2.detach().abs().max()))).square().sum()
+        want = torch.autograd.grad(loss2, [f2, c2, e2] + list(n64.parameters()), allow_unused=True)
+    for a, r in zip(got, want):
+        assert (a is None) == (r is None)
+        if a is not None:
+            assert torch.isfinite(a).all()
+            assert float((a.double() - r).abs().max()) <= 2e-4 * max(float(r.abs().max()), 1e-30), (float((a.double() - r).abs().max()), float(r.abs().max()))
+    net.eval()
     # and the module keeps working afterwards, on the fast path
     with _ops.phase_timer() as pt:
         small = net(_dev(feats * 0 + 1), _dev(rng.standard_normal((b, n, 3)).astype(np.float32)), _dev(edges * 0))
