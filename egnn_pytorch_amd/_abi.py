@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 31
+ABI_VERSION = 32
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -33,6 +33,7 @@ SYMBOLS = (
     "egnn_linear_hl_drop_f32",
     "egnn_linear_f32", "egnn_node_prep_f32", "egnn_edge_exact_f32", "egnn_edge_exact_workspace_bytes",
     "egnn_knn_select_f64", "egnn_linear_f64", "egnn_node_prep_f64", "egnn_edge_exact_f64",
+    "egnn_edge_exact_bwd_f32", "egnn_edge_exact_bwd_f64", "egnn_edge_exact_node_sums_f32", "egnn_edge_exact_node_sums_f64",
 )
 
 
@@ -71,7 +72,18 @@ class EdgeExactArgs(Structure):
         ("W3", c_void_p), ("b3", c_void_p), ("W4", c_void_p), ("b4", c_void_p), ("coors_scale", c_void_p),
         ("coors", c_void_p), ("edges", c_void_p), ("mask", c_void_p), ("idx", c_void_p), ("rank", c_void_p),
         ("valid_radius", c_double), ("clamp", c_double),
-        ("m_i", c_void_p), ("coors_out", c_void_p), ("edge_ws", c_void_p),
+        ("m_i", c_void_p), ("coors_out", c_void_p), ("edge_ws", c_void_p), ("U_out", c_void_p),
+    ]
+
+
+class EdgeExactBwdArgs(Structure):
+    """Mirror of `struct egnn_edge_exact_bwd_args` (include/egnn_hip.h): the E x H work of the plain-fp32 / float64 backward."""
+    _fields_ = [
+        ("B", c_int32), ("N", c_int32), ("K", c_int32), ("m_dim", c_int32), ("H", c_int32), ("fourier", c_int32),
+        ("edge_dim", c_int32), ("coor_dim", c_int32), ("edges_by_k", c_int32), ("reserved", c_int32),
+        ("Pi", c_void_p), ("Pj", c_void_p), ("ldp", c_int64), ("Ws", c_void_p), ("ldws", c_int64),
+        ("W2", c_void_p), ("coors", c_void_p), ("edges", c_void_p), ("idx", c_void_p), ("gU", c_void_p),
+        ("A_T", c_void_p), ("DZ_T", c_void_p), ("g_scal", c_void_p),
     ]
 
 
@@ -308,13 +320,19 @@ def load():
                                     c_int, c_void_p]
     lib.egnn_node_prep_f64.restype = c_int
     lib.egnn_node_prep_f64.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_int, c_int, c_void_p]
+    for fn in (lib.egnn_edge_exact_bwd_f32, lib.egnn_edge_exact_bwd_f64):
+        fn.restype = c_int
+        fn.argtypes = [POINTER(EdgeExactBwdArgs), c_void_p]
+    for fn in (lib.egnn_edge_exact_node_sums_f32, lib.egnn_edge_exact_node_sums_f64):
+        fn.restype = c_int
+        fn.argtypes = [c_void_p, c_int64, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.egnn_edge_exact_workspace_bytes.restype = c_size_t
     lib.egnn_edge_exact_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, c_int]
     if lib.egnn_abi_version() != ABI_VERSION:
         raise EGNNHipError(f"{path}: ABI version {lib.egnn_abi_version()} != {ABI_VERSION}; rebuild it")
     lib.egnn_struct_bytes.restype = c_int64
     lib.egnn_struct_bytes.argtypes = [c_int]
-    for which, mirror in enumerate((EdgeArgs, EdgeBwdArgs, EdgeTailArgs, LayerDesc, PackedInfo, EdgeExactArgs)):
+    for which, mirror in enumerate((EdgeArgs, EdgeBwdArgs, EdgeTailArgs, LayerDesc, PackedInfo, EdgeExactArgs, EdgeExactBwdArgs)):
         if lib.egnn_struct_bytes(which) != ctypes.sizeof(mirror):
             raise EGNNHipError(f"{path}: sizeof({mirror.__name__}) = {ctypes.sizeof(mirror)} here, {lib.egnn_struct_bytes(which)} in the "
                                f"library: the ctypes mirror in _abi.py and include/egnn_hip.h disagree")

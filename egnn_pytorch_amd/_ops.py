@@ -369,13 +369,14 @@ def linear_f32(a, w, n, k, bias=None, residual=None, act=0, out=None, name="line
     if out is None:
         out = empty(m, n, dtype=a.dtype, device=a.device)
     assert out.stride(1) == 1 and out.shape[0] == m
+    ld = lambda t, width: t.stride(0) if t.shape[0] > 1 else max(t.stride(0), width)      # noqa: E731  (a one-row matrix may carry any stride)
     ldr = 0
     if residual is not None:
         assert residual.stride(1) == 1 and residual.shape[0] == m
-        ldr = residual.stride(0)
+        ldr = ld(residual, n)
     with _timed(name):
         fn = _abi.load().egnn_linear_f64 if f64 else _abi.load().egnn_linear_f32
-        rc = fn(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(residual), ldr, _ptr(out), out.stride(0), m, n, k, act, _stream())
+        rc = fn(_ptr(a), ld(a, k), _ptr(w), ld(w, k), _ptr(bias), _ptr(residual), ldr, _ptr(out), ld(out, n), m, n, k, act, _stream())
     _abi.check(rc, "egnn_linear_f64" if f64 else "egnn_linear_f32")
     return out
 
@@ -402,6 +403,30 @@ def edge_exact(args: "_abi.EdgeExactArgs", device, dtype=torch.float32):
         rc = (lib.egnn_edge_exact_f64 if dtype == torch.float64 else lib.egnn_edge_exact_f32)(byref(args), _stream())
     _abi.check(rc, "egnn_edge_exact_f64" if dtype == torch.float64 else "egnn_edge_exact_f32")
     return ws
+
+
+def edge_exact_bwd(args: "_abi.EdgeExactBwdArgs", dtype):
+    """egnn_edge_exact_bwd_f32 / _f64: a^T, dz^T (H, E) and d/d scalars (E, S) of a chunk of graphs (include/egnn_hip.h)."""
+    lib = _abi.load()
+    f64 = dtype == torch.float64
+    with _timed("edge_exact_bwd"):
+        rc = (lib.egnn_edge_exact_bwd_f64 if f64 else lib.egnn_edge_exact_bwd_f32)(byref(args), _stream())
+    _abi.check(rc, "egnn_edge_exact_bwd_f64" if f64 else "egnn_edge_exact_bwd_f32")
+
+
+def edge_exact_node_sums(dz_t, nodes, k, order, seg):
+    """egnn_edge_exact_node_sums_*: (d/d P_i, its transpose, d/d P_j, its transpose) -- (nodes, H), (H, nodes) twice -- from dz^T (H, E):
+    the K edges leaving a node and the edges arriving at it (CSR lists of egnn_dest_lists_i32), summed in a fixed order."""
+    h, e = dz_t.shape
+    f64 = dz_t.dtype == torch.float64
+    gpi, gpj = (empty(nodes, h, dtype=dz_t.dtype, device=dz_t.device) for _ in range(2))
+    gpi_t, gpj_t = (empty(h, nodes, dtype=dz_t.dtype, device=dz_t.device) for _ in range(2))
+    lib = _abi.load()
+    with _timed("edge_exact_node_sums"):
+        rc = (lib.egnn_edge_exact_node_sums_f64 if f64 else lib.egnn_edge_exact_node_sums_f32)(
+            _ptr(dz_t), e, h, nodes, k, _ptr(order), _ptr(seg), _ptr(gpi), _ptr(gpi_t), _ptr(gpj), _ptr(gpj_t), _stream())
+    _abi.check(rc, "egnn_edge_exact_node_sums")
+    return gpi, gpi_t, gpj, gpj_t
 
 
 def node_prep_hl(feats2d, m_i, gamma, beta, eps, m_dim, with_raw=False):

@@ -42,6 +42,8 @@ _FUSED_SPLIT = os.environ.get("EGNN_BWD_SPLIT", "dest")
 _TAIL_KERNEL = os.environ.get("EGNN_BWD_TAIL_KERNEL", "1") != "0"      # 0: the per-edge chain behind u through autograd
 _GRAD_GEMM = os.environ.get("EGNN_BWD_GRAD_GEMM", "1") != "0"          # 0: the node-level gradient products as fp32 library GEMMs
 _TAIL_REDUCE = os.environ.get("EGNN_BWD_TAIL_REDUCE", "1") != "0"      # 0: the tail kernel writes its E x 64 factors out for library reductions
+_NATIVE_EXACT = os.environ.get("EGNN_NATIVE_BACKWARD_EXACT", "1") != "0"   # 0: float64 / wide-range / wide-shape layers on the recompute path
+_EXACT_BWD_BYTES = int(float(os.environ.get("EGNN_EXACT_BWD_GB", "2")) * (1 << 30))   # budget of the a^T / dz^T tables per chunk of graphs
 _KEEP_PROJ = os.environ.get("EGNN_BWD_KEEP_PROJ", "1") != "0"          # 0: the backward recomputes the P_i | P_j table (B N x 2 Hp fp32 less to keep)
 _FUSED_MAX_GRAPHS = 0                 # tests: force the chunking over graphs that very large batches need (0 = by size only)
 
@@ -342,10 +344,19 @@ class EGNNFunction(torch.autograd.Function):
                   and 2 * layer.fourier_features + 1 + layer.edge_dim <= 16
                   and not layer.float64_kernels()            # (a float64 module: float64 forward kernels, float64 recompute backward)
                   and not _exact_active())                   # (the wide-range re-run: plain-fp32 forward kernels, plain-fp32 recompute backward)
+        # the layers that run on the plain kernels (csrc/edge_exact.hip) -- float64 modules, the wide-range re-run, shapes beyond the fused
+        # kernels' limits -- have their own native backward (round 5: `_backward_exact`, csrc/edge_exact_bwd.hip)
+        s_in = 2 * layer.fourier_features + 1 + layer.edge_dim
+        f64 = layer.float64_kernels()
+        exact_path = f64 or _exact_active() or s_in > 16 or coors.shape[-1] > 8 or layer.m_dim > 64
+        exact_native = bool(_NATIVE_EXACT and exact_path and drop is None and s_in <= (40 if f64 else 80) and feats.is_cuda)
         with torch.no_grad():
             node_out, coors_out, order, idx, rank, valid_radius, u_pre, proj = layer._forward_hip_checked(
-                feats, coors, edges, mask, adj_mat, order_hint, want_u=native, drop_seed=None if drop is None else drop[1])
+                feats, coors, edges, mask, adj_mat, order_hint, want_u=native or exact_native, drop_seed=None if drop is None else drop[1])
         ctx.drop = drop
+        ctx.set_materialize_grads(False)
+        ctx.exact_native = exact_native and u_pre is not None
+        ctx.exact_dtype = torch.float64 if f64 else torch.float32
         use_nearest = layer.num_nearest_neighbors > 0 or layer.only_sparse_neighbors
         if use_nearest and idx is None:
             # neighbour path with K == 0 (only_sparse_neighbors and an empty adjacency): NO messages -- not the dense graph that
@@ -361,7 +372,7 @@ class EGNNFunction(torch.autograd.Function):
         ctx.save_for_backward(feats, coors, edges if edges is not None else none, mask if mask is not None else none,
                               idx if idx is not None else none, rank if rank is not None else none,
                               u_pre if u_pre is not None else none,
-                              proj[0] if (proj is not None and _KEEP_PROJ) else none)
+                              proj[0] if (proj is not None and (_KEEP_PROJ or exact_native)) else none)
         # the projection table as the forward's edge pass read it: P_i as (fp16 hi, fp16 lo) words when pi_split -- the backward turns
         # them into fp32 in place, once (a second backward over a retained graph finds them decoded)
         ctx.proj_words = bool(proj is not None and proj[1])
@@ -379,6 +390,10 @@ class EGNNFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_node, g_coors):
+        # (set_materialize_grads(False): an output the loss does not depend on arrives as None, not as zeros)
+        ctx.dead_outputs = (g_node is None, g_coors is None)
+        if g_node is None and g_coors is None:
+            return (None,) * (7 + len(ctx.param_versions))
         for p, v in zip(ctx.layer.parameters(), ctx.param_versions):
             if p._version != v:
                 raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace "
@@ -386,20 +401,153 @@ class EGNNFunction(torch.autograd.Function):
                                    f"(version {p._version}, expected {v})")
         if ctx.has_u:
             from . import _ops
+            if getattr(ctx, "exact_native", False):
+                return _backward_exact(ctx, g_node, g_coors)
             with _ops.backward_status():            # range bits of these kernels go to the backward's status word
                 return _backward_native(ctx, g_node, g_coors)
         return _backward_recompute(ctx, g_node, g_coors)
 
 
-def _unused_params(layer):
+def _backward_exact(ctx, g_node, g_coors):
+    """The backward of the layers that run on the plain kernels -- float64 modules (the reference's own training recipe,
+    denoise_sparse.py:11, 23-32), calls answered by the wide-range path, shapes beyond the fused kernels' limits -- in the arithmetic of
+    their forward (float64 / plain fp32), per chunk of graphs:
+      1. behind u (saved by the forward kernel): the small per-edge tail and the node-level modules through autograd on E x m / node-level
+         tensors (`layer_tail`)  ->  gU = d loss / d u, their parameters' gradients, the tail's share of d/d feats, d/d coors;
+      2. the E x H work on egnn_edge_exact_bwd_* (csrc/edge_exact_bwd.hip): z, a recomputed, dz = (W2^T gU) SiLU'(z); a^T, dz^T (H, E) and
+         d/d scalars; the per-node sums of dz over outgoing / incoming edges on egnn_edge_exact_node_sums_* (fixed order);
+      3. every contraction a C = X W^T product of egnn_linear_f32 / _f64 (exact v_mfma_f32 / v_mfma_f64): d/d W2 = gU^T a and
+         d/d W_s = dz^T s with the edges as the contraction, d/d feats = dP_i W_i + dP_j W_j, d/d W_i, W_j = dP^T feats;
+      4. d/d scalars -> coordinates / edge features through the scalars' own small graph (E x S).
+    Nothing of size E x H is touched by ATen; what stays there is E x m / E x S / node-level element-wise work, as in `_backward_native`."""
+    from . import _abi, _ops
+    dtype = ctx.exact_dtype
+    esz = 8 if dtype == torch.float64 else 4
+    orig_params = list(ctx.layer.parameters())
+    layer = ctx.layer if dtype == torch.float64 else _f32_shadow(ctx.layer)
+    feats, coors, edges, mask, idx32, rank = _unpack(ctx)
+    in_dtypes = (feats.dtype, coors.dtype, None if edges is None else edges.dtype)
+    feats, coors = feats.to(dtype), coors.to(dtype)
+    edges = None if edges is None else edges.to(dtype)
+    rank = None if rank is None else rank.to(dtype)
+    params = list(layer.parameters())
+    need = ctx.needs_input_grad
+    b, n, dim = feats.shape
+    dev = feats.device
+    k = idx32.shape[-1] if idx32 is not None else n
+    m, cdim = layer.m_dim, coors.shape[-1]
+    s_in = 2 * layer.fourier_features + 1 + layer.edge_dim
+    lin0, lin3 = layer.edge_mlp[0], layer.edge_mlp[3]
+    h = lin0.weight.shape[0]
+    head = {id(lin0.weight), id(lin0.bias), id(lin3.weight), id(lin3.bias)}
+    tail_params = [p for p in params if id(p) not in head]
+    grads = {id(p): torch.zeros_like(p, dtype=dtype) for p in params}
+    g_feats, g_coors_in = torch.zeros_like(feats), torch.zeros_like(coors)
+    want_ge = edges is not None and need[6]
+    g_edges = torch.zeros_like(edges) if want_ge else None
+    g_node = torch.zeros_like(feats) if g_node is None else g_node.to(dtype)
+    g_coors = torch.zeros_like(coors) if g_coors is None else g_coors.to(dtype)
+    u_all = ctx.saved_tensors[6].view(b, n, k, m)
+    proj = ctx.saved_tensors[7]                                           # (B N, 2 hq): [P_i incl. bias | P_j], what the forward's edge pass read
+    hq = proj.shape[1] // 2
+    w1 = lin0.weight.detach().to(dtype).contiguous()                      # (H, Din): [W_i | W_j | scalar columns]
+    w2 = lin3.weight.detach().to(dtype).contiguous()                      # (m, H)
+    w_it, w_jt = w1[:, :dim].t().contiguous(), w1[:, dim:2 * dim].t().contiguous()       # (dim, H): B operands of d/d feats
+    step = max(1, min(b, int(_EXACT_BWD_BYTES // max(1, 2 * n * k * h * esz))))
+    for lo in range(0, b, step):
+        hi_ = min(b, lo + step)
+        bc = hi_ - lo
+        ec, bn = bc * n * k, bc * n
+        f0, c0 = feats[lo:hi_].contiguous(), coors[lo:hi_].contiguous()
+        e0 = None if edges is None else edges[lo:hi_].contiguous()
+        m0 = None if mask is None else mask[lo:hi_]
+        i32 = None if idx32 is None else idx32[lo:hi_].contiguous()
+        i64 = None if i32 is None else i32.long()
+        r0 = None if rank is None else rank[lo:hi_]
+        # ---- 1. the small tail, through autograd (E x m, node-level)
+        with torch.enable_grad():
+            f = f0.detach().requires_grad_(True)
+            c = c0.detach().requires_grad_(True)
+            e = None if e0 is None else e0.detach().requires_grad_(want_ge)
+            u = u_all[lo:hi_].detach().requires_grad_(True)
+            rel, scal = edge_scalars(layer, c, e, i64)
+            out_n, out_c = layer_tail(layer, f, c, u, rel, m0, i64, r0, ctx.valid_radius)
+            outs, gouts = [], []
+            for o, g in ((out_n, g_node[lo:hi_]), (out_c, g_coors[lo:hi_])):
+                if o.requires_grad:
+                    outs.append(o)
+                    gouts.append(g)
+            live_tail = [p for p in tail_params if p.requires_grad]
+            tg = torch.autograd.grad(outs, [u, f, c] + live_tail, gouts, allow_unused=True, retain_graph=True)
+        g_u = (tg[0] if tg[0] is not None else torch.zeros_like(u)).reshape(ec, m).contiguous()
+        if tg[1] is not None:
+            g_feats[lo:hi_] += tg[1]
+        if tg[2] is not None:
+            g_coors_in[lo:hi_] += tg[2]
+        for p, g in zip(live_tail, tg[3:]):
+            if g is not None:
+                grads[id(p)] += g
+        with torch.no_grad():
+            # ---- 2. the E x H work
+            a_t = _ops.empty(h, ec, dtype=dtype, device=dev)
+            dz_t = _ops.empty(h, ec, dtype=dtype, device=dev)
+            g_scal = _ops.empty(ec, s_in, dtype=dtype, device=dev)
+            a = _abi.EdgeExactBwdArgs()
+            a.B, a.N, a.K, a.m_dim, a.H = bc, n, k, m, h
+            a.fourier, a.edge_dim, a.coor_dim, a.edges_by_k = layer.fourier_features, layer.edge_dim, cdim, 0
+            pc = proj[lo * n:hi_ * n]
+            a.Pi, a.Pj, a.ldp = pc.data_ptr(), pc.data_ptr() + esz * hq, 2 * hq
+            a.Ws, a.ldws = w1.data_ptr() + esz * 2 * dim, w1.shape[1]
+            a.W2, a.coors, a.edges, a.idx = w2.data_ptr(), c0.data_ptr(), _ops._ptr(e0), _ops._ptr(i32)
+            a.gU, a.A_T, a.DZ_T, a.g_scal = g_u.data_ptr(), a_t.data_ptr(), dz_t.data_ptr(), g_scal.data_ptr()
+            _ops.edge_exact_bwd(a, dtype)
+            dl = _ops.dest_lists(i32, bc, n, k, dev)
+            gpi, gpi_t, gpj, gpj_t = _ops.edge_exact_node_sums(dz_t, bn, k, dl.order, dl.seg)
+            # ---- 3. the contractions, on the exact GEMMs
+            grads[id(lin3.weight)] += _ops.linear_f32(g_u.t().contiguous(), a_t, h, ec, name="bwd_exact_dw2")        # (m, H) = gU^T a
+            grads[id(lin3.bias)] += g_u.sum(dim=0)
+            scal_t = scal.detach().reshape(ec, s_in).t().contiguous()                                               # (S, E)
+            gw1 = grads[id(lin0.weight)]
+            gw1[:, 2 * dim:] += _ops.linear_f32(dz_t, scal_t, s_in, ec, name="bwd_exact_dws")                        # (H, S) = dz^T s
+            del a_t, dz_t
+            f2d = f0.view(bn, dim)
+            t = _ops.linear_f32(gpi, w_it, dim, h, name="bwd_exact_dfeats")                                          # dP_i W_i
+            t = _ops.linear_f32(gpj, w_jt, dim, h, residual=t, name="bwd_exact_dfeats")                              # + dP_j W_j
+            g_feats[lo:hi_] += t.view(bc, n, dim)
+            f_t = f2d.t().contiguous()                                                                              # (dim, B N)
+            gw1[:, :dim] += _ops.linear_f32(gpi_t, f_t, dim, bn, name="bwd_exact_dw1")                               # dP_i^T feats
+            gw1[:, dim:2 * dim] += _ops.linear_f32(gpj_t, f_t, dim, bn, name="bwd_exact_dw1")
+            grads[id(lin0.bias)] += gpi.sum(dim=0)
+            del gpi, gpi_t, gpj, gpj_t, f_t
+        # ---- 4. d loss / d scalars -> coordinates (squared distance, fourier terms) and edge features
+        sg = torch.autograd.grad([scal], [c] + ([e] if want_ge else []), [g_scal.view_as(scal)], allow_unused=True)
+        if sg[0] is not None:
+            g_coors_in[lo:hi_] += sg[0]
+        if want_ge and sg[1] is not None:
+            g_edges[lo:hi_] += sg[1]
+    unused = _unused_params(layer, ctx)
+    out_params = [grads[id(p)].to(op.dtype) if (need[7 + i] and id(p) not in unused) else None
+                  for i, (p, op) in enumerate(zip(params, orig_params))]
+    return (None, None, None, None, g_feats.to(in_dtypes[0]) if need[4] else None, g_coors_in.to(in_dtypes[1]) if need[5] else None,
+            g_edges.to(in_dtypes[2]) if (want_ge and need[6]) else None) + tuple(out_params)
+
+
+def _unused_params(layer, ctx=None):
     """ids of the parameters no output depends on -- node_norm without node_mlp (update_feats=False), CoorsNorm's scale without
     coors_mlp (update_coors=False; egnn_pytorch.py:302-306 applies it inside that branch): autograd leaves their .grad None in the
-    reference, and so does this Function (an optimizer treats None and zeros differently: weight decay, state creation)."""
+    reference, and so does this Function (an optimizer treats None and zeros differently: weight decay, state creation).  Likewise
+    the parameters that reach the loss only through an output nobody used (ctx.dead_outputs: the last layer of a coordinate-denoising
+    network -- denoise_sparse.py:70-72 -- never has its node_mlp / node_norm differentiated upstream)."""
     out = set()
-    if layer.node_mlp is None:
+    dead_node, dead_coors = getattr(ctx, "dead_outputs", (False, False)) if ctx is not None else (False, False)
+    if layer.node_mlp is None or dead_node:
         out |= {id(p) for p in layer.node_norm.parameters()}
-    if layer.coors_mlp is None:
+    if layer.coors_mlp is None or dead_coors:
         out |= {id(p) for p in layer.coors_norm.parameters()}
+    if dead_node and layer.node_mlp is not None:
+        out |= {id(p) for p in layer.node_mlp.parameters()}
+    if dead_coors and layer.coors_mlp is not None:
+        out |= {id(p) for p in layer.coors_mlp.parameters()}
     return out
 
 
@@ -894,7 +1042,7 @@ def _backward_native(ctx, g_node, g_coors):
                     g_coors_in[lo:hi_] -= g_rel.view(bc, n, n, 4).sum(dim=1)[..., :3]
                 else:
                     g_coors_in[lo:hi_] -= _ops.rows_gather_sum(g_rel, dest_lists.order, dest_lists.seg, bc * n).view(bc, n, 4)[..., :3]
-    unused = _unused_params(layer)
+    unused = _unused_params(layer, ctx)
     out_params = [grads_by_id[id(p)].to(op.dtype) if (need[7 + i] and id(p) not in unused) else None
                   for i, (p, op) in enumerate(zip(params, orig_params))]
     return (None, None, None, None, g_feats.to(in_dtypes[0]) if need[4] else None, g_coors_in.to(in_dtypes[1]) if need[5] else None,
@@ -964,7 +1112,7 @@ def _backward_recompute(ctx, g_node, g_coors):
                 if g is not None:
                     gp.add_(g)
     cast = lambda g, dt: None if g is None else g.to(dt)                                        # noqa: E731
-    unused = _unused_params(layer)
+    unused = _unused_params(layer, ctx)
     g_params = [None if id(p) in unused else g for p, g in zip(params, g_params)]
     return (None, None, None, None, cast(g_feats, in_dtypes[0]), cast(g_coors_in, in_dtypes[1]), cast(g_edges, in_dtypes[2]), *g_params)
 

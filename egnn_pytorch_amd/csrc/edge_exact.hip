@@ -55,7 +55,7 @@ struct ExArgs {
     const uint8_t* mask;
     const int32_t* idx;
     T valid_radius, clamp;
-    T *m_i, *coors_out, *edge_ws;
+    T *m_i, *coors_out, *edge_ws, *U_out;
 };
 template <typename T>
 ExArgs<T> ex_args(const egnn_edge_exact_args& a)
@@ -72,6 +72,7 @@ ExArgs<T> ex_args(const egnn_edge_exact_args& a)
     p.ldp = a.ldp; p.ldws = a.ldws; p.mask = a.mask; p.idx = a.idx;
     p.valid_radius = (T)a.valid_radius; p.clamp = (T)a.clamp;
     p.m_i = static_cast<T*>(a.m_i); p.coors_out = static_cast<T*>(a.coors_out); p.edge_ws = static_cast<T*>(a.edge_ws);
+    p.U_out = static_cast<T*>(a.U_out);
     return p;
 }
 
@@ -125,6 +126,11 @@ __global__ __launch_bounds__(EX_THREADS) void edge_exact_kernel(const ExArgs<T> 
 #pragma unroll
         for (int c = 0; c < MB; ++c)
             if (c < m_dim) u[c] = ex_fma(w2[(size_t)c * H], a, u[c]);
+    }
+    if (p.U_out) {                                                       // forward under autograd: what the backward differentiates from
+#pragma unroll
+        for (int c = 0; c < MB; ++c)
+            if (c < m_dim) p.U_out[(size_t)q * m_dim + c] = u[c] + p.b2[c];
     }
     T m[MB];
 #pragma unroll
@@ -229,7 +235,10 @@ __global__ __launch_bounds__(EX_THREADS) void edge_exact_wide_kernel(const ExArg
         }
 #pragma unroll
         for (int c = 0; c < 64; ++c)
-            if (cb + c < m_dim) row[cb + c] = ex_silu(u[c] + p.b2[cb + c]);
+            if (cb + c < m_dim) {
+                if (p.U_out) p.U_out[(size_t)q * m_dim + cb + c] = u[c] + p.b2[cb + c];
+                row[cb + c] = ex_silu(u[c] + p.b2[cb + c]);
+            }
     }
     T gt = (T)1;
     if (p.gate_w) {                                                      // soft_edges (:289-290)

@@ -404,6 +404,7 @@ extern "C" int64_t egnn_struct_bytes(int which)
     case 3: return (int64_t)sizeof(egnn_layer_desc);
     case 4: return (int64_t)sizeof(egnn_packed_info);
     case 5: return (int64_t)sizeof(egnn_edge_exact_args);
+    case 6: return (int64_t)sizeof(egnn_edge_exact_bwd_args);
     default: return -1;
     }
 }

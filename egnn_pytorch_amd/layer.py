@@ -248,13 +248,11 @@ class EGNN(nn.Module):
         if self.float64_kernels():
             # a float64 module computes in float64, as the reference does (its own tests run in float64, tests/test_equivariance.py:6):
             # the plain kernels instantiated for double (include/egnn_hip.h, "The float64 path")
-            if want_u:
-                raise NotImplementedError("float64 modules run on the plain float64 kernels: no native backward")
             if isinstance(edges, EdgeLookup):
                 raise NotImplementedError("float64 modules take the materialised (B,N,N,edge_dim) edge features")
             with torch.cuda.device(feats.device):
                 out = self._forward_exact(feats.double(), coors.double(), None if edges is None else edges.double(), mask, adj_mat,
-                                          dtype=torch.float64)
+                                          dtype=torch.float64, want_u=want_u)
             if f_dtype != torch.float64 or c_dtype != torch.float64:
                 out = (out[0].to(f_dtype), out[1].to(c_dtype)) + tuple(out[2:])
             return out
@@ -339,10 +337,10 @@ class EGNN(nn.Module):
         # ... and more than 8 coordinates (the fused kernels keep x_i - x_j in registers up to 8)
         # ... and heads wider than 64 message channels (the fused kernels hold up to four 16-channel accumulator tiles per edge tile)
         wide_shape = 2 * self.fourier_features + 1 + self.edge_dim > 16 or coors.shape[-1] > 8 or self.m_dim > 64
-        if exact_active() or (wide_shape and not want_u and drop is None):
-            if want_u or drop is not None:
-                raise NotImplementedError("the plain-fp32 (wide-range) kernels are inference-only: no backward, no training-mode dropout")
-            return self._forward_exact(feats, coors, edges, mask, adj_mat)
+        if exact_active() or wide_shape:
+            if drop is not None:
+                raise NotImplementedError("the plain-fp32 (wide-range) kernels carry no training-mode dropout (its hash masks live in the fused edge pass)")
+            return self._forward_exact(feats, coors, edges, mask, adj_mat, want_u=want_u)
         b, n, dim = feats.shape
         w = self.packed_weights()
         feats = feats.contiguous()
@@ -444,7 +442,7 @@ class EGNN(nn.Module):
         return node_out, coors_out, order, idx, rank, valid_radius, u_pre, proj_kept
 
 
-    def _forward_exact(self, feats, coors, edges, mask, adj_mat, dtype=torch.float32):
+    def _forward_exact(self, feats, coors, edges, mask, adj_mat, dtype=torch.float32, want_u=False):
         """The layer on the plain-fp32 kernels (include/egnn_hip.h, "The wide-range path"): exact-fp32 GEMMs, fp32 node_norm, the edge
         pass as fp32 VALU arithmetic on the module's own weight tensors.  Same neighbour selection, same return tuple as _forward_hip.
         dtype = torch.float64: the same kernels instantiated for double ("The float64 path"; feats / coors / edges are float64)."""
@@ -477,6 +475,7 @@ class EGNN(nn.Module):
             k = n
         f32 = lambda t: t.detach().to(dtype).contiguous()                # noqa: E731  (the module's tensors in the compute dtype)
         node_out, coors_out, m_i = feats, coors, None
+        u_pre = proj_keep = None                                         # want_u (forward under autograd): u (E, m_dim) and the projection table
         if k > 0:
             lin0, lin3 = self.edge_mlp[0], self.edge_mlp[3]
             w1 = f32(lin0.weight)                                        # (H, Din): [W_i | W_j | scalar columns]
@@ -517,6 +516,10 @@ class EGNN(nn.Module):
             if self.node_mlp is not None:
                 m_i = _ops.empty(b * n, self.m_dim, dtype=dtype, device=feats.device)
                 a.m_i = m_i.data_ptr()
+            if want_u:
+                u_pre = _ops.empty(b * n * k, self.m_dim, dtype=dtype, device=feats.device)
+                a.U_out = u_pre.data_ptr()
+                proj_keep = (proj, False)
             _ops.edge_exact(a, feats.device, dtype)
             del proj, keep
         elif self.node_mlp is not None:
@@ -529,7 +532,7 @@ class EGNN(nn.Module):
             hid = _ops.linear_f32(node_in, f32(n0.weight), 2 * dim, dim + self.m_dim, bias=f32(n0.bias), act=1, name="node_mlp0_f32")
             node_out = _ops.linear_f32(hid, f32(n3.weight), dim, 2 * dim, bias=f32(n3.bias), residual=feats2d,
                                        name="node_mlp1_f32").view(b, n, dim)
-        return node_out, coors_out, None, idx, rank, valid_radius, None, None
+        return node_out, coors_out, None, idx, rank, valid_radius, u_pre, proj_keep
 
 
 _FP64_WARNED = False

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 31
+#define EGNN_ABI_VERSION 32
 
 enum {
     EGNN_OK = 0,
@@ -54,7 +54,7 @@ enum {
 
 int egnn_abi_version(void);
 /* sizeof of the argument structs as this library was compiled -- 0: egnn_edge_args, 1: egnn_edge_bwd_args, 2: egnn_edge_tail_args,
- * 3: egnn_layer_desc, 4: the packed-weights info struct, 5: egnn_edge_exact_args; -1 otherwise -- so that a binding that mirrors them (ctypes, cgo, JNI) can verify its
+ * 3: egnn_layer_desc, 4: the packed-weights info struct, 5: egnn_edge_exact_args, 6: egnn_edge_exact_bwd_args; -1 otherwise -- so that a binding that mirrors them (ctypes, cgo, JNI) can verify its
  * layout at load time instead of corrupting a call. */
 int64_t egnn_struct_bytes(int which);
 const char* egnn_error_string(int code);
@@ -589,10 +589,45 @@ typedef struct egnn_edge_exact_args {
     void* m_i;
     void* coors_out;
     void* edge_ws;
+    void* U_out;                /* optional (forward under autograd): (B*N*K, m_dim) u = edge_mlp.3(SiLU(edge_mlp.0(.))) incl. its bias, before the
+                                   second SiLU (egnn_pytorch.py:181-183) -- what egnn_edge_exact_bwd_* and the per-edge tail differentiate from */
 } egnn_edge_exact_args;
 
 size_t egnn_edge_exact_workspace_bytes(int B, int N, int K, int m_dim, int coor_dim);      /* fp32; twice that for egnn_edge_exact_f64 */
 int egnn_edge_exact_f32(const egnn_edge_exact_args* args, void* stream);
+
+/* The E x H work of the BACKWARD of that path (csrc/edge_exact_bwd.hip; autograd of egnn_pytorch.py:277-287): plain fp32 for calls that
+ * were answered by the wide-range path and for the shapes beyond the fused kernels' limits, float64 for float64 modules (the reference's
+ * own training recipe, denoise_sparse.py:11, 23-32).  With z = P_i[i] + P_j[j] + W_s s, a = SiLU(z) and gU = d loss / d u:
+ *     dz = (W2^T gU) SiLU'(z);  A_T (H, E) = a and DZ_T (H, E) = dz, TRANSPOSED so that d/d W2 = gU^T a and d/d W_s = dz^T s are plain
+ *     C = X W^T products of egnn_linear_f32 / _f64 with the edges as the contraction;  g_scal (E, S) = dz W_s.
+ * Same shape limits as the forward entry except the per-edge scalars: 80 in fp32, 40 in float64 (scalars and their gradients in LDS).
+ * egnn_edge_exact_node_sums_*: d/d P_i[n] = sum of dz over the K edges leaving n, d/d P_j[n] = sum over the edges arriving at n (the CSR
+ * lists of egnn_dest_lists_i32), in a fixed order, each in both layouts -- (nodes, H) and (H, nodes).  The caller bounds 2 H E elements
+ * by cutting the batch into chunks of graphs. */
+typedef struct egnn_edge_exact_bwd_args {
+    int32_t B, N, K, m_dim, H, fourier, edge_dim, coor_dim, edges_by_k, reserved;
+    /* data pointers: float for egnn_edge_exact_bwd_f32, double for egnn_edge_exact_bwd_f64 */
+    const void* Pi;             /* as egnn_edge_exact_args: the projection table the forward used */
+    const void* Pj;
+    int64_t ldp;
+    const void* Ws;
+    int64_t ldws;
+    const void* W2;             /* (m_dim, H) */
+    const void* coors;
+    const void* edges;
+    const int32_t* idx;
+    const void* gU;             /* (B*N*K, m_dim) d loss / d u */
+    void* A_T;                  /* out (H, B*N*K) */
+    void* DZ_T;                 /* out (H, B*N*K) */
+    void* g_scal;               /* out (B*N*K, S), S = 2 fourier + 1 + edge_dim: [sin.., cos.., dist, edge features..] */
+} egnn_edge_exact_bwd_args;
+int egnn_edge_exact_bwd_f32(const egnn_edge_exact_bwd_args* args, void* stream);
+int egnn_edge_exact_bwd_f64(const egnn_edge_exact_bwd_args* args, void* stream);
+int egnn_edge_exact_node_sums_f32(const void* DZ_T, int64_t E, int H, int64_t nodes, int K, const int64_t* csr_order, const int64_t* csr_seg,
+                                  void* gPi, void* gPi_T, void* gPj, void* gPj_T, void* stream);
+int egnn_edge_exact_node_sums_f64(const void* DZ_T, int64_t E, int H, int64_t nodes, int K, const int64_t* csr_order, const int64_t* csr_seg,
+                                  void* gPi, void* gPi_T, void* gPj, void* gPj_T, void* stream);
 
 /* =============================================================================================
  * The float64 path: a float64 module in float64 arithmetic.

@@ -618,11 +618,15 @@ def test_backward_at_baseline_widths_matches_the_reference_autograd(ref, name, k
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw,cdim", [(dict(dim=24, num_nearest_neighbors=6), 12), (dict(dim=24, m_dim=80, num_nearest_neighbors=6), 3),
                                      (dict(dim=16, fourier_features=10, num_nearest_neighbors=5), 3)])
-def test_shapes_of_the_plain_kernels_train_through_the_recompute_backward(ref, kw, cdim):
-    """More than 8 coordinates, heads wider than 64 channels, more than 16 per-edge scalars: the forward runs on the plain kernels
-    (inference-only); under autograd the backward is the chunked recompute over the neighbour list they selected: gradients against
-    the reference's float64 autograd."""
-    from egnn_pytorch_amd import EGNN
+def test_shapes_of_the_plain_kernels_train_on_their_own_backward_kernels(ref, kw, cdim, monkeypatch):
+    """More than 8 coordinates, heads wider than 64 channels, more than 16 per-edge scalars: the forward runs on the plain kernels and
+    -- round 5 -- the backward's E x H work on csrc/edge_exact_bwd.hip with the exact-fp32 GEMMs (`_backward_exact`), never on the ATen
+    recompute: gradients against the reference's float64 autograd."""
+    from egnn_pytorch_amd import EGNN, autograd as A, _ops
+
+    def no_recompute(*a, **k):
+        raise AssertionError("the ATen recompute backward ran")
+    monkeypatch.setattr(A, "_backward_recompute", no_recompute)
     torch.manual_seed(12)
     rlayer = ref.EGNN(**kw)
     for mod in rlayer.modules():
@@ -635,12 +639,70 @@ def test_shapes_of_the_plain_kernels_train_through_the_recompute_backward(ref, k
     feats, coors = torch.randn(2, 30, kw["dim"], generator=g).cuda(), torch.randn(2, 30, cdim, generator=g).cuda()
     f1, c1 = feats.clone().requires_grad_(True), coors.clone().requires_grad_(True)
     f2, c2 = feats.double().requires_grad_(True), coors.double().requires_grad_(True)
-    got, _ = _grads(layer, lambda: layer(f1, c1), (f1, c1))
+    with _ops.phase_timer() as pt:
+        got, _ = _grads(layer, lambda: layer(f1, c1), (f1, c1))
+    assert {"edge_exact", "edge_exact_bwd", "edge_exact_node_sums", "bwd_exact_dw2", "bwd_exact_dfeats"} <= set(pt.summary()), set(pt.summary())
     want, _ = _grads(rlayer, lambda: rlayer(f2, c2), (f2, c2))
     for gg, ww in zip(got, want):
         assert (gg is None) == (ww is None)
         if gg is not None:
             assert float((gg.double() - ww).abs().max()) <= 1e-4 * float(ww.abs().max())
+
+
+@pytest.mark.gpu
+def test_the_reference_training_recipe_trains_on_the_float64_kernels(ref, monkeypatch):
+    """denoise_sparse.py:11, 23-32, 45-78 -- what SURVEY.md section 8f-2 cites as the reason for a backward: a FLOAT64
+    EGNN_Network(num_tokens=21, num_positions=600, depth=5, dim=8, num_nearest_neighbors=16, fourier_features=2, norm_coors,
+    coor_weights_clamp_value=2) on a chain adjacency with a mask, MSE of the denoised coordinates, Adam.  Forward: the float64
+    kernels; backward: `_backward_exact` -- csrc/edge_exact_bwd.hip + egnn_linear_f64 -- with the ATen recompute disabled.  Gradients of
+    every parameter against the REFERENCE network's float64 autograd at 1e-7 of each gradient's scale, and three Adam steps side by
+    side with the reference (same losses)."""
+    from egnn_pytorch_amd import EGNN_Network, autograd as A, _ops
+
+    def no_recompute(*a, **k):
+        raise AssertionError("the ATen recompute backward ran")
+    monkeypatch.setattr(A, "_backward_recompute", no_recompute)
+    kw = dict(num_tokens=21, num_positions=600, depth=5, dim=8, num_nearest_neighbors=16, fourier_features=2, norm_coors=True,
+              coor_weights_clamp_value=2.0)
+    torch.manual_seed(5)
+    rnet = ref.EGNN_Network(**kw).double()
+    net = EGNN_Network(**kw).double()
+    net.load_state_dict(rnet.state_dict(), strict=True)
+    net, rnet = net.cuda(), rnet.cuda()
+    g = torch.Generator().manual_seed(6)
+    n = 3 * 40                                               # 40 residues x 3 backbone atoms (the script's repeat(... c = 3))
+    seq = torch.randint(0, 21, (1, n // 3), generator=g).repeat_interleave(3, dim=1).cuda()
+    coords = (torch.randn(1, n, 3, generator=g, dtype=torch.float64) * 3.0).cuda()
+    masks = (torch.arange(n)[None] < n - 6).cuda()
+    i = torch.arange(n)
+    adj = ((i[:, None] >= (i[None, :] - 1)) & (i[:, None] <= (i[None, :] + 1))).cuda()
+    noise = torch.randn(1, n, 3, generator=g, dtype=torch.float64).cuda()
+
+    def loss_of(model):
+        feats, den = model(seq, coords + noise, adj_mat=adj, mask=masks)
+        return torch.nn.functional.mse_loss(den[masks], coords[masks])
+
+    with _ops.phase_timer() as pt:
+        loss = loss_of(net)
+        got = torch.autograd.grad(loss, list(net.parameters()), allow_unused=True)
+    launched = set(pt.summary())
+    assert {"edge_exact", "edge_exact_bwd", "edge_exact_node_sums", "bwd_exact_dw2", "bwd_exact_dws", "bwd_exact_dw1"} <= launched, launched
+    rloss = loss_of(rnet)
+    want = torch.autograd.grad(rloss, list(rnet.parameters()), allow_unused=True)
+    assert abs(float(loss) - float(rloss)) <= 1e-9 * max(1.0, abs(float(rloss)))
+    for (nm, _), gg, ww in zip(net.named_parameters(), got, want):
+        assert (gg is None) == (ww is None), nm
+        if gg is not None and float(ww.abs().max()) > 0:
+            assert float((gg - ww).abs().max()) <= 1e-7 * float(ww.abs().max()), (nm, float((gg - ww).abs().max()), float(ww.abs().max()))
+    opt, ropt = torch.optim.Adam(net.parameters(), lr=1e-3), torch.optim.Adam(rnet.parameters(), lr=1e-3)
+    for _ in range(3):
+        for model, o in ((net, opt), (rnet, ropt)):
+            o.zero_grad()
+            l_ = loss_of(model)
+            l_.backward()
+            o.step()
+            model.last_loss = float(l_)
+        assert abs(net.last_loss - rnet.last_loss) <= 1e-7 * max(1.0, abs(rnet.last_loss))
 
 
 @pytest.mark.gpu
