@@ -103,10 +103,16 @@ def roofline_entry(name, counts, ms, launches=1):
         return dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 4), avg_ms=round(ms, 4), launches_per_step=launches, algorithmic_bytes=int(c["bytes"]))
     ach = SPLIT_TERMS * c["flops"] / sec / 1e12          # MFMA-issued flops (3 f16 MFMAs per fp32 product)
+    # a GEMM with a short contraction (dim 128 / 256: K = 128 ... 544) is bound by reading A and writing C, not by the matrix cores:
+    # both fractions are reported, `binding` says which roofline is the nearer one (c3's 0.14 - 0.22 of the MFMA peak
+    # is 0.3 - 0.4 of the HBM roofline on the compulsory bytes)
+    hbm = c["bytes"] / sec / 1e9
     return dict(kernel=name, bound="mfma", achieved=round(ach, 2), peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
                 frac=round(ach / MFMA_F16_PEAK_TFLOPS, 4), avg_ms=round(ms, 4), launches_per_step=launches,
                 mfma_issued_flops=SPLIT_TERMS * c["flops"],
-                algorithmic_tflops=round(c["flops"] / sec / 1e12, 2), mfma_dtype="f16 (split x3, fp32 accumulate)")
+                algorithmic_tflops=round(c["flops"] / sec / 1e12, 2), mfma_dtype="f16 (split x3, fp32 accumulate)",
+                compulsory_bytes=int(c["bytes"]), hbm_GBs=round(hbm, 1), hbm_frac=round(hbm / HBM_PEAK_GBS, 4),
+                binding="hbm" if hbm / HBM_PEAK_GBS > ach / MFMA_F16_PEAK_TFLOPS else "mfma")
 
 
 def workload_label(kwargs, b, n, k):
@@ -408,6 +414,9 @@ def main():
             dist.init_process_group(args.standin_backend, rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
+            if world > 1:
+                from egnn_pytorch_amd.sharding import pin_to_local_numa_node
+                pin_to_local_numa_node(local_rank)          # (best effort: the rank's host threads next to its GPU)
 
     def barrier():
         if dist is not None:
@@ -421,16 +430,36 @@ def main():
         return float(t.item())
 
     if standin:
-        # the rank logic only: a dummy step, the same timed region, the same rank-0 line (marked as a stand-in)
-        b = WORKLOADS[args.workload][1]
-        x = torch.randn(64, 64)
-        elapsed = timed_region(lambda: (x @ x).sum().item(), args.steps, args.warmup, lambda: None, barrier, reduce_max)
+        # the rank logic only (CPU, gloo): the module's REAL forward code above the kernels -- a small layer of the workload's kind on this
+        # rank's shard, rank-dependent input seeds, parameters broadcast from rank 0 -- with the kernel layer replaced by the torch
+        # restatement of tests/_cpu_stub.py; the same timed region, the same rank-0 line (marked as a stand-in)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _cpu_stub
+        _cpu_stub.install()
+        from egnn_pytorch_amd import EGNN, EGNN_Network
+        kwargs, b, _ = WORKLOADS[args.workload]
+        small = dict(kwargs, dim=16)
+        small["num_nearest_neighbors"] = min(kwargs.get("num_nearest_neighbors", 0), 4)
+        small.pop("edge_dim", None)
+        small.pop("only_sparse_neighbors", None)
+        torch.manual_seed(100 + rank)                       # ranks start with different weights; the broadcast makes them rank 0's
+        layer = (EGNN_Network(**small) if "depth" in small else EGNN(**small)).eval()
+        if dist is not None:
+            from egnn_pytorch_amd.sharding import broadcast_parameters
+            broadcast_parameters(layer)
+        feats, coors, mask = make_inputs(small, 2, 12, device, seed=1000 + rank)
+
+        @torch.no_grad()
+        def standin_step():
+            out = layer(feats, coors, mask=mask)
+            return float(out[0].sum())
+        elapsed = timed_region(standin_step, args.steps, args.warmup, lambda: None, barrier, reduce_max)
         if rank == 0:
             print(json.dumps({"metric": "EGNN.forward graphs/sec", "value": round(world * b * args.steps / elapsed, 2),
                               "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-                              "data": f"STAND-IN ({args.standin_backend}, CPU, dummy step): rank logic only, not a measurement",
+                              "data": f"STAND-IN ({args.standin_backend}, CPU, kernels stubbed by tests/_cpu_stub.py): rank logic only, not a measurement",
                               "config": {"workload": args.workload, "graphs_per_gpu": b, "global_batch": world * b}}), flush=True)
         if dist is not None:
             dist.barrier()
@@ -438,10 +467,11 @@ def main():
         return
 
     from egnn_pytorch_amd import EGNN, EGNN_Network, phase_timer, check_range, _ops
-    # Range status word (include/egnn_hip.h: EGNN_RANGE_*): the default mode reads it back after every forward (one host
-    # synchronisation per step, measured at ~2 % of the step); the timed loop uses the deferred mode -- the word is copied
-    # to pinned memory after each forward and examined at the next call and, for all steps, right after the timed region.
-    _ops.RANGE_CHECK = os.environ.get("EGNN_RANGE_CHECK", "deferred")
+    # Range status word (include/egnn_hip.h: EGNN_RANGE_*): the timed region runs the library's DEFAULT -- `sync`: every forward ends with
+    # one 8-byte device -> host read, which is also what arms the automatic plain-fp32 re-run of out-of-range calls -- so that `value` is
+    # the configuration a user gets (rounds 1 - 4 timed the deferred mode).  The deferred mode (no synchronisation:
+    # the word is copied to pinned memory after each forward and examined at the next call) is timed beside it: `value_range_check_deferred`.
+    _ops.RANGE_CHECK = os.environ.get("EGNN_RANGE_CHECK", "sync")
 
     kwargs, b, n = WORKLOADS[args.workload]
     torch.manual_seed(0)
@@ -472,15 +502,15 @@ def main():
     elapsed = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, reduce_max)
     check_range()                                        # raises if any timed step left the representable range
 
-    # the same K steps with the range status word read back synchronously (the library's default for user code: one 4-byte
-    # device -> host read per forward), so that the line shows what the deferred mode of the timed region saves
-    value_sync = None
-    if _ops.RANGE_CHECK != "sync" and world == 1:
+    # the same K steps in the other mode of the range check, so that the line shows what the per-forward synchronisation costs
+    value_other, other_mode = None, ("deferred" if _ops.RANGE_CHECK == "sync" else "sync")
+    if world == 1 and _ops.RANGE_CHECK in ("sync", "deferred"):
         mode = _ops.RANGE_CHECK
-        _ops.RANGE_CHECK = "sync"
+        _ops.RANGE_CHECK = other_mode
         try:
             el2 = timed_region(step, args.steps, 1, torch.cuda.synchronize, barrier, reduce_max)
-            value_sync = world * b * args.steps / el2
+            check_range()
+            value_other = world * b * args.steps / el2
         finally:
             _ops.RANGE_CHECK = mode
 
@@ -533,7 +563,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "edges_per_s": round(value * n * shp["K"] * depth, 1), "range_check": _ops.RANGE_CHECK,
-            "value_range_check_sync": None if value_sync is None else round(value_sync, 2),
+            f"value_range_check_{other_mode}": None if value_other is None else round(value_other, 2),
             "config": {"workload": workload_label(kwargs, b, n, shp["K"]), "name": args.workload,
                        "graphs_per_gpu": b, "nodes": n, "neighbors": shp["K"], "layers": depth, "global_batch": world * b,
                        "mask": "ragged" if args.ragged_mask else "all-true",

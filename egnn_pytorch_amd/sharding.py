@@ -65,3 +65,29 @@ def gather_batch(local: torch.Tensor, batch: int, group=None):
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad.contiguous(), group=group)
     return torch.cat([buf[: hi - lo] for buf, (lo, hi) in zip(bufs, sizes)], dim=0)
+
+
+def pin_to_local_numa_node(device_index: int | None = None):
+    """Best effort: restrict this process's threads to the CPU cores of the NUMA node its GPU hangs off (kernel launches and the
+    pinned-memory status read then stay on the socket next to the device: one process per GPU on a two-socket 8-GPU node).  Reads the
+    GPU's PCI address from the device properties and the node's core list from sysfs; returns the core set, or None when either is
+    unavailable (containers without sysfs topology, a single-node host) -- never raises."""
+    import os
+    try:
+        idx = torch.cuda.current_device() if device_index is None else device_index
+        pr = torch.cuda.get_device_properties(idx)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return cpus
+    except Exception:
+        return None

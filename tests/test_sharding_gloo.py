@@ -86,6 +86,50 @@ def test_two_rank_batch_shard(tmp_path, batch):
     assert t0 == t1                                             # both ranks report the max over ranks
 
 
+def _module_worker(rank, world, port, out_dir):
+    """The module's own forward code on this rank's shard: EGNN_Network (layer loop, embeddings) above the kernel layer, which
+    tests/_cpu_stub.py replaces by a torch restatement; parameters broadcast from rank 0; outputs gathered back in batch order."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import _cpu_stub
+    _cpu_stub.install()
+    from egnn_pytorch_amd import EGNN_Network, sharding
+    kw = dict(depth=2, dim=16, num_nearest_neighbors=5, num_tokens=11, norm_coors=True)
+    torch.manual_seed(7 + rank)                            # different weights per rank until the broadcast
+    net = EGNN_Network(**kw).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(20.0)
+    sharding.broadcast_parameters(net)
+    g = torch.Generator().manual_seed(0)                   # the same GLOBAL batch on every rank (5 graphs over 2 ranks: 3 + 2)
+    batch, n = 5, 14
+    tokens = torch.randint(0, 11, (batch, n), generator=g)
+    coors = torch.randn(batch, n, 3, generator=g)
+    mask = torch.rand(batch, n, generator=g) > 0.15
+    t, c, m = sharding.shard_batch(rank, world, tokens, coors, mask)
+    with torch.no_grad():
+        node, co = net(t, c, mask=m)
+        full_node, full_co = sharding.gather_batch(node, batch), sharding.gather_batch(co, batch)
+        want_node, want_co = net(tokens, coors, mask=mask)            # the whole batch in one process
+    assert torch.allclose(full_node, want_node, atol=1e-5) and torch.allclose(full_co, want_co, atol=1e-5)
+    lo, hi = sharding.shard_bounds(batch, rank, world)
+    assert torch.allclose(node, want_node[lo:hi], atol=1e-5)
+    np.save(os.path.join(out_dir, f"n{rank}.npy"), full_node.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_ranks_drive_the_module_itself_over_their_shards(tmp_path):
+    """the N > 1 path exercised with the module's real forward code (not a dummy step): rank-dependent initial
+    weights replaced by rank 0's, uneven shards, the layer loop of EGNN_Network on each shard, gather_batch restoring batch order --
+    every rank ends with the same (B, N, dim) tensor, equal to the single-process result."""
+    port = _free_port()
+    mp.spawn(_module_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    np.testing.assert_array_equal(np.load(tmp_path / "n0.npy"), np.load(tmp_path / "n1.npy"))
+
+
 def test_shard_batch_when_batch_equals_nodes():
     """B == N: a (B, N) mask and a shared (N, N) adjacency have the same shape; only `shared=` tells them apart."""
     from egnn_pytorch_amd import sharding
