@@ -6,7 +6,7 @@ import sys
 d = sys.argv[1] if len(sys.argv) > 1 else "profiles/r04_final"
 ld = lambda n: json.load(open(os.path.join(d, n)))          # noqa: E731
 b = ld("bench_line.json")
-print(f"head {b.get('head')}  value {b['value']:.0f} graphs/s  {b['ms_per_step']:.3f} ms  sync-mode value {b.get('value_range_check_sync')}")
+print(f"head {b.get('head')}  value {b['value']:.0f} graphs/s  {b['ms_per_step']:.3f} ms  deferred-mode value {b.get('value_range_check_deferred')}")
 print(f"cpu_baseline {b['cpu_baseline']['value']}  eager {b.get('reference_gpu_eager', {}).get('value')}  train {b.get('train_step')}")
 for k in b["kernels"]:
     print("  ", k.get("kernel"), f"{k['avg_ms']:.4f} ms", k.get("bound"), f"{k.get('achieved', 0):.1f} {k.get('unit')}", "frac", k.get("frac"))
