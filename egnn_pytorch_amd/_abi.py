@@ -34,6 +34,7 @@ SYMBOLS = (
     "egnn_linear_f32", "egnn_node_prep_f32", "egnn_edge_exact_f32", "egnn_edge_exact_workspace_bytes",
     "egnn_knn_select_f64", "egnn_linear_f64", "egnn_node_prep_f64", "egnn_edge_exact_f64",
     "egnn_edge_exact_bwd_f32", "egnn_edge_exact_bwd_f64", "egnn_edge_exact_node_sums_f32", "egnn_edge_exact_node_sums_f64",
+    "egnn_edge_tail_exact_bwd_f32", "egnn_edge_tail_exact_bwd_f64",
 )
 
 
@@ -84,6 +85,18 @@ class EdgeExactBwdArgs(Structure):
         ("Pi", c_void_p), ("Pj", c_void_p), ("ldp", c_int64), ("Ws", c_void_p), ("ldws", c_int64),
         ("W2", c_void_p), ("coors", c_void_p), ("edges", c_void_p), ("idx", c_void_p), ("gU", c_void_p),
         ("A_T", c_void_p), ("DZ_T", c_void_p), ("g_scal", c_void_p),
+    ]
+
+
+class EdgeTailExactArgs(Structure):
+    """Mirror of `struct egnn_edge_tail_exact_args` (include/egnn_hip.h): the per-edge chain behind u in closed form, any head / C."""
+    _fields_ = [
+        ("B", c_int32), ("N", c_int32), ("K", c_int32), ("m_dim", c_int32), ("coor_dim", c_int32), ("norm_coors", c_int32),
+        ("eps", c_double), ("clamp", c_double),
+        ("u", c_void_p), ("coors", c_void_p), ("idx", c_void_p), ("pair_mask", c_void_p), ("g_coors_out", c_void_p), ("g_msum", c_void_p),
+        ("W3", c_void_p), ("b3", c_void_p), ("W4", c_void_p), ("b4", c_void_p), ("scale", c_void_p), ("gate_w", c_void_p), ("gate_b", c_void_p),
+        ("gU", c_void_p), ("g_rel", c_void_p), ("ghid_t", c_void_p), ("a3_t", c_void_p), ("mm_t", c_void_p), ("m0_t", c_void_p),
+        ("g_w", c_void_p), ("g_scale", c_void_p), ("g_gate", c_void_p),
     ]
 
 
@@ -323,6 +336,9 @@ def load():
     for fn in (lib.egnn_edge_exact_bwd_f32, lib.egnn_edge_exact_bwd_f64):
         fn.restype = c_int
         fn.argtypes = [POINTER(EdgeExactBwdArgs), c_void_p]
+    for fn in (lib.egnn_edge_tail_exact_bwd_f32, lib.egnn_edge_tail_exact_bwd_f64):
+        fn.restype = c_int
+        fn.argtypes = [POINTER(EdgeTailExactArgs), c_void_p]
     for fn in (lib.egnn_edge_exact_node_sums_f32, lib.egnn_edge_exact_node_sums_f64):
         fn.restype = c_int
         fn.argtypes = [c_void_p, c_int64, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
@@ -332,7 +348,7 @@ def load():
         raise EGNNHipError(f"{path}: ABI version {lib.egnn_abi_version()} != {ABI_VERSION}; rebuild it")
     lib.egnn_struct_bytes.restype = c_int64
     lib.egnn_struct_bytes.argtypes = [c_int]
-    for which, mirror in enumerate((EdgeArgs, EdgeBwdArgs, EdgeTailArgs, LayerDesc, PackedInfo, EdgeExactArgs, EdgeExactBwdArgs)):
+    for which, mirror in enumerate((EdgeArgs, EdgeBwdArgs, EdgeTailArgs, LayerDesc, PackedInfo, EdgeExactArgs, EdgeExactBwdArgs, EdgeTailExactArgs)):
         if lib.egnn_struct_bytes(which) != ctypes.sizeof(mirror):
             raise EGNNHipError(f"{path}: sizeof({mirror.__name__}) = {ctypes.sizeof(mirror)} here, {lib.egnn_struct_bytes(which)} in the "
                                f"library: the ctypes mirror in _abi.py and include/egnn_hip.h disagree")

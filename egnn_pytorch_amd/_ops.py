@@ -75,7 +75,13 @@ def empty(*shape, dtype, device):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """The raw hipStream_t of torch's current stream on the current device.  Through the C binding when it exists: the public
+    torch.cuda.current_stream() builds a Stream object through three layers of device-index helpers (8 us a call, thirteen calls per
+    forward: a third of the host time of a forward, tools/host_overhead_probe.py)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except AttributeError:
+        return torch.cuda.current_stream().cuda_stream
 
 
 _side = {}
@@ -165,7 +171,8 @@ def range_check_after_forward(device, mode=None):
     st = status_word(device)
     if mode == "sync":
         # the one host synchronisation of the forward: 8 bytes into pinned memory + a stream synchronisation (a .tolist() / .item() goes
-        # through a staged pageable copy: measurably slower per forward)
+        # through a staged pageable copy: slower per forward; a one-thread kernel writing the words into pinned memory for the host to spin
+        # on was measured too: no faster -- what the synchronisation costs is the host time from forward() entry to its first launch)
         st.host.copy_(st.dev, non_blocking=True)
         torch.cuda.current_stream(st.dev.device).synchronize()
         fwd, bwd = int(st.host[0]), int(st.host[1])
@@ -432,6 +439,51 @@ def edge_exact_node_sums(dz_t, nodes, k, order, seg):
             _ptr(dz_t), e, h, nodes, k, _ptr(order), _ptr(seg), _ptr(gpi), _ptr(gpi_t), _ptr(gpj), _ptr(gpj_t), _stream())
     _abi.check(rc, "egnn_edge_exact_node_sums")
     return gpi, gpi_t, gpj, gpj_t
+
+
+def edge_tail_exact(u, coors, idx32, pair_mask, g_coors_out, g_msum, w3, b3, w4, b4, scale, eps, clamp, gate, b, n, k):
+    """egnn_edge_tail_exact_bwd_f32 / _f64: the per-edge chain behind u in closed form for any head width <= 64 / coordinate dimension,
+    in u's dtype.  u (E, m); coors (B, N, C); g_coors_out (B N, C); g_msum (B N, m) or None; w3 .. b4 = coors_mlp's tensors or None
+    (update_coors=False); scale = coors_norm.scale or None; gate = (weight (m), bias (1)) or None.  Returns a dict: gU (E, m), g_rel_t
+    (C, E) -- transposed: its per-node sums come from egnn_edge_exact_node_sums_* -- and the transposed operands of the parameter
+    gradients ghid_t, a3_t (4m, E), mm_t, m0_t (m, E), g_w, g_scale, g_gate (E)."""
+    e, m = u.shape
+    dt, dev = u.dtype, u.device
+    cdim = coors.shape[-1]
+    a = _abi.EdgeTailExactArgs()
+    a.B, a.N, a.K, a.m_dim, a.coor_dim, a.norm_coors = b, n, k, m, cdim, int(scale is not None)
+    a.eps, a.clamp = float(eps), -1.0 if clamp is None else float(clamp)
+    out = dict(gU=empty(e, m, dtype=dt, device=dev), g_rel_t=empty(cdim, e, dtype=dt, device=dev), mm_t=empty(m, e, dtype=dt, device=dev))
+    keep = [t.contiguous() for t in (u, coors, g_coors_out)]
+    a.u, a.coors, a.g_coors_out = (t.data_ptr() for t in keep)
+    a.idx, a.pair_mask = _ptr(idx32), _ptr(pair_mask)
+    if g_msum is not None:
+        keep.append(g_msum.contiguous())
+        a.g_msum = keep[-1].data_ptr()
+    if w3 is not None:
+        keep += [t.detach().to(dt).contiguous() for t in (w3, b3, w4.reshape(-1), b4.reshape(-1))]
+        a.W3, a.b3, a.W4, a.b4 = (t.data_ptr() for t in keep[-4:])
+        out.update(ghid_t=empty(4 * m, e, dtype=dt, device=dev), a3_t=empty(4 * m, e, dtype=dt, device=dev), g_w=empty(e, dtype=dt, device=dev))
+        a.ghid_t, a.a3_t, a.g_w = out["ghid_t"].data_ptr(), out["a3_t"].data_ptr(), out["g_w"].data_ptr()
+        if scale is not None:
+            keep.append(scale.detach().to(dt).contiguous())
+            a.scale = keep[-1].data_ptr()
+            out["g_scale"] = empty(e, dtype=dt, device=dev)
+            a.g_scale = out["g_scale"].data_ptr()
+    else:
+        a.norm_coors = 0
+    if gate is not None:
+        keep += [gate[0].detach().to(dt).reshape(-1).contiguous(), gate[1].detach().to(dt).reshape(-1).contiguous()]
+        a.gate_w, a.gate_b = keep[-2].data_ptr(), keep[-1].data_ptr()
+        out.update(m0_t=empty(m, e, dtype=dt, device=dev), g_gate=empty(e, dtype=dt, device=dev))
+        a.m0_t, a.g_gate = out["m0_t"].data_ptr(), out["g_gate"].data_ptr()
+    a.gU, a.g_rel, a.mm_t = out["gU"].data_ptr(), out["g_rel_t"].data_ptr(), out["mm_t"].data_ptr()
+    lib = _abi.load()
+    f64 = dt == torch.float64
+    with _timed("edge_tail_exact"):
+        rc = (lib.egnn_edge_tail_exact_bwd_f64 if f64 else lib.egnn_edge_tail_exact_bwd_f32)(byref(a), _stream())
+    _abi.check(rc, "egnn_edge_tail_exact_bwd")
+    return out
 
 
 def node_prep_hl(feats2d, m_i, gamma, beta, eps, m_dim, with_raw=False):

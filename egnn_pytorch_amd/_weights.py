@@ -306,5 +306,17 @@ def _pack(layer) -> dict:
 
 
 def version_key(layer):
-    """Cache key: identity + in-place version of every parameter (optimizer steps / load_state_dict bump it)."""
-    return tuple((p.data_ptr(), p._version, str(p.device)) for p in layer.parameters())
+    """Cache key: identity + in-place version of every parameter (optimizer steps / load_state_dict bump it).  The parameter list itself
+    is cached on the layer (walking nn.Module.parameters() costs 50 us per forward); it is rebuilt when the registered Parameter objects
+    change (re-assignment; `_apply` with overwrite_module_params_on_conversion)."""
+    cached = layer.__dict__.get("_param_cache")
+    mods = layer.__dict__.get("_param_cache_mods")
+    if cached is None or any(m._parameters.get(n) is not p for (m, n), p in zip(mods, cached)):
+        mods, cached = [], []
+        for m in layer.modules():
+            for n, p in m._parameters.items():
+                if p is not None:
+                    mods.append((m, n))
+                    cached.append(p)
+        layer.__dict__["_param_cache"], layer.__dict__["_param_cache_mods"] = cached, mods
+    return tuple((p.data_ptr(), p._version, p.device) for p in cached)

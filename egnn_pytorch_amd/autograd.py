@@ -1,23 +1,31 @@
 """Autograd support for the gfx950 EGNN layer (the reference is trained in practice,
 denoise_sparse.py:70-78, and every op of egnn_pytorch.py:224-341 is differentiable).
 
-Forward  = the HIP path (neighbour selection, fused edge pass, split-f16 GEMMs).  Nothing of size E x H is kept: the saved
-           tensors are the inputs, the neighbour list and u (E x 16), the output of edge_mlp's second Linear, which the
-           forward edge kernel writes on the side when a graph is being recorded.
-Backward = `_backward_native` (fp32, coordinate dimension 3, m_dim <= 16):
-             * behind u: the node-level modules (node_norm, node_mlp, residual) through autograd from the pooled messages, the
-               per-edge chain (second SiLU, masks, coors_mlp, CoorsNorm, clamp, coordinate update, pooling) in closed form on
-               egnn_edge_tail_bwd_f32 (csrc/edge_tail.hip; `tail_edge_backward` is its specification)  ->  gU, d/d (x_i - x_j) and
-               those parameters' gradients (weight gradients as split-K products, `_tn`).  With the edge gate (soft_edges) the
-               per-edge chain goes through autograd as well (`layer_tail`);
+Forward  = the HIP path (neighbour selection, fused edge pass, split-f16 GEMMs -- or the plain fp32 / float64 kernels for the layers
+           that run there).  Nothing of size E x H is kept: the saved tensors are the inputs, the neighbour list, the projection table
+           (node-level) and u (E x m), the output of edge_mlp's second Linear, which the forward edge kernel writes on the side when a
+           graph is being recorded.
+Backward, three paths:
+  `_backward_native` -- fp32 (half / bfloat16 modules through an fp32 shadow), every shape the fused forward kernels cover (m_dim <= 64,
+           coordinate dimension 1 .. 8, up to 16 per-edge scalars, training-mode dropout for the standard layer):
+             * behind u: node_norm / node_mlp on the split-f16 GEMMs (`_node_mlp_backward`), the per-edge chain (second SiLU, gate, masks,
+               coors_mlp, CoorsNorm, clamp, coordinate update, pooling) in closed form on egnn_edge_tail_bwd_f32 (csrc/edge_tail.hip;
+               `tail_edge_backward` is its specification) for m_dim <= 16 and 3-D coordinates, through autograd on E x m tensors
+               (`layer_tail`) otherwise  ->  gU, d/d (x_i - x_j) and those parameters' gradients;
              * the E x H work -- z = P_i + P_j + W_s s, a = SiLU(z), dz = (W2^T gU) SiLU'(z) and their contractions -- on
                egnn_edge_bwd_pass_f32 (csrc/edge_bwd.hip; `_edge_contract_fused`): one pass over the edges grouped by source node
-               (d/d P_i, d/d W_s, d/d scalars) and one over the edges sorted by destination (d/d P_j, d/d W_2), everything
-               recomputed and contracted in registers: nothing of size E x H reaches memory (8 GiB peak where the first native
-               backward needed 27); up to 16 per-edge scalars (beyond five: d/d scalars on the matrix cores);
+               (d/d P_i, d/d W_s, d/d scalars) and one over the edges sorted by destination (d/d P_j, d/d W_2), everything recomputed
+               and contracted in registers; heads wider than 16 channels: once per block of 16 channels (linear in gU);
              * the node-level products -- d/d feats, d/d edge_mlp.0, node_mlp -- on the forward's split-f16 GEMM (`_ops.grad_nn / grad_tn`).
-           `_backward_recompute` (everything else, and the native path's reference in the tests): the whole layer re-evaluated
-           a few graphs at a time as a differentiable chain of ATen ops over the neighbour list the HIP kernel selected,
+  `_backward_exact` (round 5) -- the layers whose forward runs on the plain kernels (csrc/edge_exact.hip): float64 modules (the reference's
+           own training recipe, denoise_sparse.py:11, 23-32), calls answered by the wide-range path (values beyond the split-fp16 range),
+           more than 16 per-edge scalars / 8 coordinates / 64 message channels.  The per-edge tail through autograd on E x m tensors,
+           the E x H work on egnn_edge_exact_bwd_f32 / _f64 + egnn_edge_exact_node_sums_* (csrc/edge_exact_bwd.hip), every contraction on
+           the exact GEMMs (egnn_linear_f32 / egnn_linear_f64), in the arithmetic of the forward.
+  `_backward_recompute` -- what is left: training-mode dropout outside the standard layer (masks re-evaluated by the torch twin of the
+           kernels' hash), more per-edge scalars than the exact backward keeps in LDS (80 in fp32, 40 in float64), EGNN_NATIVE_BACKWARD=0 /
+           EGNN_NATIVE_BACKWARD_EXACT=0, CPU tensors (the tests); also the native paths' reference in the tests.  The whole layer
+           re-evaluated a few graphs at a time as a differentiable chain of ATen ops over the neighbour list the HIP kernel selected,
            factorised like the forward, and differentiated by autograd.
 Gradients of feats / coors / edges / every parameter agree with the reference's autograd (tests/test_autograd.py).  Every sum
 over edges has a fixed order (partial rows + egnn_rows_gather_sum_f32, per-workgroup partials summed by index: no float
@@ -43,6 +51,7 @@ _TAIL_KERNEL = os.environ.get("EGNN_BWD_TAIL_KERNEL", "1") != "0"      # 0: the 
 _GRAD_GEMM = os.environ.get("EGNN_BWD_GRAD_GEMM", "1") != "0"          # 0: the node-level gradient products as fp32 library GEMMs
 _TAIL_REDUCE = os.environ.get("EGNN_BWD_TAIL_REDUCE", "1") != "0"      # 0: the tail kernel writes its E x 64 factors out for library reductions
 _NATIVE_EXACT = os.environ.get("EGNN_NATIVE_BACKWARD_EXACT", "1") != "0"   # 0: float64 / wide-range / wide-shape layers on the recompute path
+_TAIL_GENERIC = os.environ.get("EGNN_TAIL_GENERIC", "1") != "0"        # 0: the per-edge chain of wide heads / other coordinate dimensions / the plain path through autograd
 _EXACT_BWD_BYTES = int(float(os.environ.get("EGNN_EXACT_BWD_GB", "2")) * (1 << 30))   # budget of the a^T / dz^T tables per chunk of graphs
 _KEEP_PROJ = os.environ.get("EGNN_BWD_KEEP_PROJ", "1") != "0"          # 0: the backward recomputes the P_i | P_j table (B N x 2 Hp fp32 less to keep)
 _FUSED_MAX_GRAPHS = 0                 # tests: force the chunking over graphs that very large batches need (0 = by size only)
@@ -326,7 +335,7 @@ def _dropout_native_ok(layer):
 
 
 class EGNNFunction(torch.autograd.Function):
-    """forward: HIP kernels; backward: chunked recompute through autograd (module docstring)."""
+    """forward: HIP kernels; backward: `_backward_native` / `_backward_exact` / `_backward_recompute` (module docstring)."""
 
     @staticmethod
     def forward(ctx, layer, order_hint, mask, adj_mat, feats, coors, edges, *params):
@@ -408,6 +417,106 @@ class EGNNFunction(torch.autograd.Function):
         return _backward_recompute(ctx, g_node, g_coors)
 
 
+def _pooled_messages(layer, u, m0, i64, r0, valid_radius):
+    """(m_i, pair mask (B,N,K) bool or None, count or None) from u (B,N,K,m): egnn_pytorch.py:287-300, 319-333 on E x m tensors."""
+    b = u.shape[0]
+    k = u.shape[2]
+    pm = None
+    if m0 is not None:
+        if i64 is None:
+            pm = m0[:, :, None] & m0[:, None, :]
+        else:
+            bi = torch.arange(b, device=u.device)[:, None, None]
+            pm = m0[:, :, None] & m0[bi, i64] & (r0 <= valid_radius)
+    mm = torch.nn.functional.silu(u)
+    if layer.edge_gate is not None:
+        gl = layer.edge_gate[0]
+        mm = mm * torch.sigmoid(mm @ gl.weight.detach().to(u.dtype)[0] + gl.bias.detach().to(u.dtype))[..., None]
+    m_sum = (mm if pm is None else mm.masked_fill(~pm[..., None], 0.0)).sum(dim=2)
+    cnt = None
+    if layer.m_pool_method == "mean":
+        if pm is not None:
+            cnt = pm.sum(dim=-1, keepdim=True).to(m_sum.dtype)
+            m_i = (m_sum / cnt.clamp(min=1e-8)).masked_fill(cnt == 0, 0.0)
+        else:
+            m_i = m_sum / k
+    else:
+        m_i = m_sum
+    return m_i, pm, cnt
+
+
+def _node_mlp_backward_exact(layer, f2d, m_i, g_out, grads):
+    """node_norm + node_mlp + residual (egnn_pytorch.py:196-201, 335-337) differentiated on the exact GEMMs (egnn_linear_f32 / _f64) in
+    f2d's dtype: returns (d loss / d feats of this part (rows, dim), d loss / d m_i (rows, m)) and accumulates the parameter gradients.
+    node_norm itself (a LayerNorm on node-level rows) goes through autograd."""
+    from . import _ops
+    dt = f2d.dtype
+    dim = f2d.shape[1]
+    n0, n3 = layer.node_mlp[0], layer.node_mlp[3]
+    with torch.enable_grad():
+        fl = f2d.detach().requires_grad_(True)
+        ln = layer.node_norm(fl)
+    w5, w6 = n0.weight.detach().to(dt).contiguous(), n3.weight.detach().to(dt).contiguous()       # (2 dim, dim + m), (dim, 2 dim)
+    node_in = torch.cat((ln.detach(), m_i.to(dt)), dim=-1).contiguous()
+    kin, hid = node_in.shape[1], w5.shape[0]
+    rows = f2d.shape[0]
+    z1 = _ops.linear_f32(node_in, w5, hid, kin, bias=n0.bias.detach().to(dt).contiguous(), name="bwd_exact_node_mlp")
+    sg = torch.sigmoid(z1)
+    a1 = z1 * sg
+    g_out = g_out.contiguous()
+    g_a1 = _ops.linear_f32(g_out, w6.t().contiguous(), hid, dim, name="bwd_exact_node_mlp")                    # g_out W6
+    g_z1 = g_a1 * (sg * (1 + z1 * (1 - sg)))
+    got = g_out.t().contiguous()
+    grads[id(n3.weight)] += _ops.linear_f32(got, a1.t().contiguous(), hid, rows, name="bwd_exact_node_mlp")  # g_out^T a1
+    grads[id(n3.bias)] += g_out.sum(dim=0)
+    gzt = g_z1.t().contiguous()
+    grads[id(n0.weight)] += _ops.linear_f32(gzt, node_in.t().contiguous(), kin, rows, name="bwd_exact_node_mlp")
+    grads[id(n0.bias)] += g_z1.sum(dim=0)
+    g_in = _ops.linear_f32(g_z1, w5.t().contiguous(), kin, hid, name="bwd_exact_node_mlp")                      # g_z1 W5
+    g_f = g_out.clone()                                                        # the residual
+    if ln.requires_grad:
+        norm_params = [p for p in layer.node_norm.parameters() if p.requires_grad]
+        tg = torch.autograd.grad([ln], [fl] + norm_params, [g_in[:, :dim].contiguous()], allow_unused=True)
+        if tg[0] is not None:
+            g_f += tg[0]
+        for p, g in zip(norm_params, tg[1:]):
+            if g is not None:
+                grads[id(p)] += g
+    return g_f, g_in[:, dim:].contiguous()
+
+
+def _tail_closed_form(layer, u2d, c0, i32, pm, g_coors_chunk, g_msum, grads, dl, b, n, k):
+    """The per-edge chain behind u on egnn_edge_tail_exact_bwd_* (csrc/edge_exact_bwd.hip; `tail_edge_backward` is the specification)
+    in u2d's dtype, its parameter gradients contracted on the exact GEMMs (the kernel leaves their operands transposed: the edges are the
+    K dimension).  Returns gU (E, m) and d loss / d coors of this part (B, N, C): x_i - x_j reaches the coordinates at the source (sum
+    over a node's K edges) and, negated, at the neighbour (fixed-order sum over the CSR lists)."""
+    from . import _ops
+    dt = u2d.dtype
+    e, m = u2d.shape
+    cm = layer.coors_mlp
+    gate = None if layer.edge_gate is None else (layer.edge_gate[0].weight, layer.edge_gate[0].bias)
+    norm = layer.norm_coors and cm is not None
+    pm8 = None if pm is None else pm.contiguous().view(torch.uint8)
+    out = _ops.edge_tail_exact(u2d, c0, i32, pm8, g_coors_chunk.reshape(b * n, -1), g_msum,
+                               None if cm is None else cm[0].weight, None if cm is None else cm[0].bias,
+                               None if cm is None else cm[3].weight, None if cm is None else cm[3].bias,
+                               layer.coors_norm.scale if norm else None, layer.coors_norm.eps if norm else 0.0,
+                               layer.coor_weights_clamp_value, gate, b, n, k)
+    one = lambda v: v.view(1, e)                                                # noqa: E731
+    if cm is not None:
+        grads[id(cm[0].weight)] += _ops.linear_f32(out["ghid_t"], out["mm_t"], m, e, name="bwd_exact_tail")           # g_hid^T m
+        grads[id(cm[0].bias)] += out["ghid_t"].sum(dim=1)
+        grads[id(cm[3].weight)] += _ops.linear_f32(one(out["g_w"]), out["a3_t"], 4 * m, e, name="bwd_exact_tail")    # g_w^T a3
+        grads[id(cm[3].bias)] += out["g_w"].sum().reshape(1)
+        if norm:
+            grads[id(layer.coors_norm.scale)] += out["g_scale"].sum().reshape(1)
+    if gate is not None:
+        grads[id(gate[0])] += _ops.linear_f32(one(out["g_gate"]), out["m0_t"], m, e, name="bwd_exact_tail")           # g_gate^T m0
+        grads[id(gate[1])] += out["g_gate"].sum().reshape(1)
+    src, _, dst, _ = _ops.edge_exact_node_sums(out["g_rel_t"], b * n, k, dl.order, dl.seg)
+    return out["gU"], (src - dst).view(b, n, -1)
+
+
 def _backward_exact(ctx, g_node, g_coors):
     """The backward of the layers that run on the plain kernels -- float64 modules (the reference's own training recipe,
     denoise_sparse.py:11, 23-32), calls answered by the wide-range path, shapes beyond the fused kernels' limits -- in the arithmetic of
@@ -464,29 +573,51 @@ def _backward_exact(ctx, g_node, g_coors):
         i32 = None if idx32 is None else idx32[lo:hi_].contiguous()
         i64 = None if i32 is None else i32.long()
         r0 = None if rank is None else rank[lo:hi_]
-        # ---- 1. the small tail, through autograd (E x m, node-level)
+        dl = _ops.dest_lists(i32, bc, n, k, dev)
         with torch.enable_grad():
-            f = f0.detach().requires_grad_(True)
             c = c0.detach().requires_grad_(True)
             e = None if e0 is None else e0.detach().requires_grad_(want_ge)
-            u = u_all[lo:hi_].detach().requires_grad_(True)
-            rel, scal = edge_scalars(layer, c, e, i64)
-            out_n, out_c = layer_tail(layer, f, c, u, rel, m0, i64, r0, ctx.valid_radius)
-            outs, gouts = [], []
-            for o, g in ((out_n, g_node[lo:hi_]), (out_c, g_coors[lo:hi_])):
-                if o.requires_grad:
-                    outs.append(o)
-                    gouts.append(g)
-            live_tail = [p for p in tail_params if p.requires_grad]
-            tg = torch.autograd.grad(outs, [u, f, c] + live_tail, gouts, allow_unused=True, retain_graph=True)
-        g_u = (tg[0] if tg[0] is not None else torch.zeros_like(u)).reshape(ec, m).contiguous()
-        if tg[1] is not None:
-            g_feats[lo:hi_] += tg[1]
-        if tg[2] is not None:
-            g_coors_in[lo:hi_] += tg[2]
-        for p, g in zip(live_tail, tg[3:]):
-            if g is not None:
-                grads[id(p)] += g
+            rel, scal = edge_scalars(layer, c, e, i64)                            # (the scalars' own graph: step 4)
+        if m <= 64 and _TAIL_GENERIC:
+            # ---- 1. behind u, in closed form: the pooled messages (E x m element-wise), node_norm / node_mlp on the exact GEMMs, the
+            # per-edge chain on egnn_edge_tail_exact_bwd_* with its parameter gradients contracted on the exact GEMMs
+            with torch.no_grad():
+                u4 = u_all[lo:hi_]
+                m_i, pm, cnt = _pooled_messages(layer, u4, m0, i64, r0, ctx.valid_radius)
+                g_msum = None
+                if layer.node_mlp is not None:
+                    g_f, g_mi = _node_mlp_backward_exact(layer, f0.view(bn, dim), m_i.reshape(bn, m), g_node[lo:hi_].reshape(bn, dim), grads)
+                    g_feats[lo:hi_] += g_f.view(bc, n, dim)
+                    g_mi = g_mi.view(bc, n, m)
+                    if layer.m_pool_method == "mean":
+                        g_mi = (g_mi / cnt.clamp(min=1e-8)).masked_fill(cnt == 0, 0.0) if cnt is not None else g_mi / k
+                    g_msum = g_mi.reshape(bn, m).contiguous()
+                else:
+                    g_feats[lo:hi_] += g_node[lo:hi_]                                # (update_feats=False: node_out is feats)
+                g_coors_in[lo:hi_] += g_coors[lo:hi_]                                # the residual of the coordinate update
+                g_u, g_c = _tail_closed_form(layer, u4.reshape(ec, m).contiguous(), c0, i32, pm, g_coors[lo:hi_], g_msum, grads, dl, bc, n, k)
+                g_coors_in[lo:hi_] += g_c
+        else:
+            # ---- 1. the small tail, through autograd (E x m, node-level): heads wider than 64 channels
+            with torch.enable_grad():
+                f = f0.detach().requires_grad_(True)
+                u = u_all[lo:hi_].detach().requires_grad_(True)
+                out_n, out_c = layer_tail(layer, f, c, u, rel, m0, i64, r0, ctx.valid_radius)
+                outs, gouts = [], []
+                for o, g in ((out_n, g_node[lo:hi_]), (out_c, g_coors[lo:hi_])):
+                    if o.requires_grad:
+                        outs.append(o)
+                        gouts.append(g)
+                live_tail = [p for p in tail_params if p.requires_grad]
+                tg = torch.autograd.grad(outs, [u, f, c] + live_tail, gouts, allow_unused=True, retain_graph=True)
+            g_u = (tg[0] if tg[0] is not None else torch.zeros_like(u)).reshape(ec, m).contiguous()
+            if tg[1] is not None:
+                g_feats[lo:hi_] += tg[1]
+            if tg[2] is not None:
+                g_coors_in[lo:hi_] += tg[2]
+            for p, g in zip(live_tail, tg[3:]):
+                if g is not None:
+                    grads[id(p)] += g
         with torch.no_grad():
             # ---- 2. the E x H work
             a_t = _ops.empty(h, ec, dtype=dtype, device=dev)
@@ -501,7 +632,6 @@ def _backward_exact(ctx, g_node, g_coors):
             a.W2, a.coors, a.edges, a.idx = w2.data_ptr(), c0.data_ptr(), _ops._ptr(e0), _ops._ptr(i32)
             a.gU, a.A_T, a.DZ_T, a.g_scal = g_u.data_ptr(), a_t.data_ptr(), dz_t.data_ptr(), g_scal.data_ptr()
             _ops.edge_exact_bwd(a, dtype)
-            dl = _ops.dest_lists(i32, bc, n, k, dev)
             gpi, gpi_t, gpj, gpj_t = _ops.edge_exact_node_sums(dz_t, bn, k, dl.order, dl.seg)
             # ---- 3. the contractions, on the exact GEMMs
             grads[id(lin3.weight)] += _ops.linear_f32(g_u.t().contiguous(), a_t, h, ec, name="bwd_exact_dw2")        # (m, H) = gU^T a
@@ -931,6 +1061,35 @@ def _backward_native(ctx, g_node, g_coors):
                 g_coors_in[lo:hi_] += g_coors[lo:hi_]                              # (the residual; g_rel reaches the coordinates below)
                 if i64 is not None:
                     dest_lists = _ops.dest_lists(i32, bc, n, k, feats.device)                  # (shared with the E x H passes below)
+        elif f0.is_cuda and _TAIL_GENERIC and _GRAD_GEMM and drop is None and m <= 64:
+            # ---- 1. behind u for the heads of 17 .. 64 channels and the other coordinate dimensions (round 5): the pooled messages on
+            # E x m tensors, node_mlp on the split-f16 GEMMs, the per-edge chain in closed form on egnn_edge_tail_exact_bwd_f32 (one
+            # thread per edge; csrc/edge_exact_bwd.hip) with its parameter gradients on the exact-fp32 GEMM
+            closed_dist, g_rel, bias2, gu_bits = False, None, None, None
+            with torch.enable_grad():
+                c = c0.detach().requires_grad_(True)
+                e = None if e0 is None else e0.detach().requires_grad_(want_ge)
+                rel, scal = edge_scalars(layer, c, e, i64)                        # (only the scalars' graph is used below)
+            with torch.no_grad():
+                u4 = u_all[lo:hi_, :, :, :m]
+                m_i, pm, cnt = _pooled_messages(layer, u4, m0, i64, r0, ctx.valid_radius)
+                g_msum = None
+                if layer.node_mlp is not None:
+                    f = f0.detach().requires_grad_(True)
+                    g_f, g_mi = _node_mlp_backward(layer, w, f, m_i, g_node[lo:hi_], grads_by_id, None, lo * n)
+                    g_feats[lo:hi_] += g_f
+                    if layer.m_pool_method == "mean":
+                        g_mi = (g_mi / cnt.clamp(min=1e-8)).masked_fill(cnt == 0, 0.0) if cnt is not None else g_mi / k
+                    g_msum = g_mi.reshape(bc * n, m).contiguous()
+                else:
+                    g_feats[lo:hi_] += g_node[lo:hi_]
+                g_coors_in[lo:hi_] += g_coors[lo:hi_]
+                dest_lists = _ops.dest_lists(i32, bc, n, k, feats.device)
+                g_u, g_c = _tail_closed_form(layer, u4.reshape(ec, m).contiguous(), c0, i32, pm, g_coors[lo:hi_], g_msum, grads_by_id,
+                                             dest_lists, bc, n, k)
+                g_coors_in[lo:hi_] += g_c
+                gu16 = torch.zeros(ec, mp, dtype=torch.float32, device=feats.device)
+                gu16[:, :m] = g_u
         else:
             closed_dist, g_rel, bias2, gu_bits = False, None, None, None
             # ---- 1. the small tail, through autograd
@@ -1050,8 +1209,9 @@ def _backward_native(ctx, g_node, g_coors):
 
 
 def _backward_recompute(ctx, g_node, g_coors):
-    """The pure-ATen backward: chunked recompute of the whole layer through autograd (module docstring).  Used for the shapes
-    the native kernel does not cover (m_dim > 16, coordinate dimension != 3, non-fp32) and as its reference in the tests."""
+    """The pure-ATen backward: chunked recompute of the whole layer through autograd (module docstring).  Used where neither native
+    path applies -- training-mode dropout outside the standard layer, more per-edge scalars than `_backward_exact` carries, CPU tensors,
+    the EGNN_NATIVE_BACKWARD* switches -- and as the native paths' reference in the tests."""
     layer = ctx.layer
     feats, coors, edges, mask, idx, rank = _unpack(ctx)
     idx = None if idx is None else idx.long()

@@ -209,3 +209,180 @@ extern "C" int egnn_edge_exact_node_sums_f64(const void* DZ_T, int64_t E, int H,
 {
     return node_sums_launch<double>(DZ_T, E, H, nodes, K, csr_order, csr_seg, gPi, gPi_T, gPj, gPj_T, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The per-edge chain BEHIND u in closed form, any head width up to 64 channels, any coordinate dimension, fp32 or float64 (autograd of
+// egnn_pytorch.py:287 second SiLU, :289-290 gate, :292-317 pair mask / coors_mlp / CoorsNorm / clamp / coordinate update, :319-333
+// pooling).  csrc/edge_tail.hip is the matrix-core version of this for the standard layer (16 channels, 3-D, fp32); this one serves
+// the shapes it does not: heads of 17 .. 64 channels and the other coordinate dimensions on the fast path, and everything on the plain
+// fp32 / float64 path.  egnn_pytorch_amd/autograd.py::tail_edge_backward is the specification.  One thread per edge, coors_mlp's hidden
+// units walked twice (its output first, then their gradients); the operands of the parameter gradients -- sums over all edges -- are
+// written TRANSPOSED, (rows, E), so that the host contracts them with egnn_linear_f32 / _f64 (the edges as the K dimension).
+template <typename T>
+struct XtArgs {
+    int B, N, K, m_dim, coor_dim, norm_coors;
+    const T *u, *coors, *g_coors_out, *g_msum, *W3, *b3, *W4, *b4, *scale, *gate_w, *gate_b;
+    const int32_t* idx;
+    const uint8_t* pair_mask;
+    T eps, clamp;
+    T *gU, *g_rel, *ghid_t, *a3_t, *mm_t, *m0_t, *g_w, *g_scale, *g_gate;
+};
+
+template <typename T, int MB>
+__global__ __launch_bounds__(XB_THREADS) void edge_tail_exact_bwd_kernel(const XtArgs<T> p)
+{
+    const int64_t E = (int64_t)p.B * p.N * p.K;
+    const int64_t q = (int64_t)blockIdx.x * XB_THREADS + threadIdx.x;
+    if (q >= E) return;
+    const int N = p.N, K = p.K, C = p.coor_dim, m_dim = p.m_dim, hid = 4 * p.m_dim;
+    const int64_t node = q / K;
+    const int k = (int)(q - node * K);
+    const int64_t bN = node / N * N;
+    const int j = p.idx ? p.idx[q] : k;
+    const bool keep = p.pair_mask ? p.pair_mask[q] != 0 : true;
+    const bool has_mask = p.pair_mask != nullptr;
+
+    // m0 = SiLU(u), the gate, m = m0 * gate (:287-290)
+    // (two arrays of MB values live through the kernel -- the messages and their gradients; u and SiLU(u) are re-read / recomputed where
+    // they are needed: with 64 channels in float64 even these two are the whole register file)
+    const T* const urow = p.u + (size_t)q * m_dim;
+    T mm[MB];
+    T gsum = p.gate_w ? p.gate_b[0] : (T)0;
+#pragma unroll
+    for (int c = 0; c < MB; ++c) {
+        const T uc = c < m_dim ? urow[c] : (T)0;
+        mm[c] = uc / ((T)1 + xb_exp(-uc));                              // m0 = SiLU(u)
+        if (p.gate_w && c < m_dim) gsum = xb_fma(p.gate_w[c], mm[c], gsum);
+    }
+    const T gt = p.gate_w ? (T)1 / ((T)1 + xb_exp(-gsum)) : (T)1;
+#pragma unroll
+    for (int c = 0; c < MB; ++c) {
+        if (c < m_dim && p.m0_t) p.m0_t[(size_t)c * E + q] = mm[c];
+        mm[c] *= gt;
+        if (c < m_dim) p.mm_t[(size_t)c * E + q] = mm[c];
+    }
+    // g_m: d loss / d m, starting with the pooled messages' share (masked_fill of :320-322)
+    T gm[MB];
+#pragma unroll
+    for (int c = 0; c < MB; ++c) gm[c] = (c < m_dim && p.g_msum && keep) ? p.g_msum[(size_t)node * m_dim + c] : (T)0;
+
+    T g_w = (T)0;
+    if (p.W3) {
+        // coors_mlp forward (:203-208): w = W4 SiLU(W3 m + b3) + b4
+        T w = p.b4[0];
+        for (int r = 0; r < hid; ++r) {
+            T z = p.b3[r];
+            const T* w3 = p.W3 + (size_t)r * m_dim;
+#pragma unroll
+            for (int c = 0; c < MB; ++c)
+                if (c < m_dim) z = xb_fma(w3[c], mm[c], z);
+            const T sg = (T)1 / ((T)1 + xb_exp(-z));
+            w = xb_fma(p.W4[r], z * sg, w);
+        }
+        // rel, CoorsNorm (:67-77), mask, clamp (:308-313); g = d loss / d coors_out[i]
+        const T* ci = p.coors + (size_t)node * C;
+        const T* cj = p.coors + (size_t)(bN + j) * C;
+        const T* g = p.g_coors_out + (size_t)node * C;
+        T n2 = (T)0;
+        for (int c = 0; c < C; ++c) { const T r = ci[c] - cj[c]; n2 = xb_fma(r, r, n2); }
+        const T rn = p.norm_coors ? (T)sqrt((double)n2) : (T)1;
+        const T den = p.norm_coors ? (rn > p.eps ? rn : p.eps) : (T)1;
+        const T sc = p.norm_coors ? p.scale[0] : (T)1;
+        const T wm = (has_mask && !keep) ? (T)0 : w;
+        const bool clamped = p.clamp >= (T)0 && (wm < -p.clamp || wm > p.clamp);
+        const T wc = p.clamp >= (T)0 ? (wm < -p.clamp ? -p.clamp : (wm > p.clamp ? p.clamp : wm)) : wm;
+        T g_wc = (T)0, dot = (T)0;                                      // g . relp  and  g_relp . rel
+        for (int c = 0; c < C; ++c) {
+            const T r = ci[c] - cj[c];
+            g_wc = xb_fma(g[c], r / den * sc, g_wc);
+            dot = xb_fma(wc * g[c], r, dot);
+        }
+        g_w = clamped ? (T)0 : g_wc;
+        if (has_mask && !keep) g_w = (T)0;
+        const bool self_pair = (bN + j) == node;                        // x_i - x_i is identically 0: its gradient reaches x_i once with each
+        for (int c = 0; c < C; ++c) {                                   // sign -- under CoorsNorm two 1 / eps-sized terms whose fp32 sum is noise,
+            const T r = ci[c] - cj[c];                                  // written as the exact zero they add up to (as csrc/edge_tail.hip does)
+            T gr = wc * g[c];                                            // g_relp
+            if (p.norm_coors) {
+                gr = gr * (sc / den);
+                if (rn >= p.eps) gr -= dot * sc / (den * den) * (r / (rn > (T)1e-30 ? rn : (T)1e-30));
+            }
+            p.g_rel[(size_t)c * E + q] = self_pair ? (T)0 : gr;
+        }
+        if (p.g_scale) p.g_scale[q] = p.norm_coors ? dot / den : (T)0;
+        // coors_mlp backward: g_hid = g_w W4 SiLU'(hid);  g_m += g_hid W3
+        for (int r = 0; r < hid; ++r) {
+            T z = p.b3[r];
+            const T* w3 = p.W3 + (size_t)r * m_dim;
+#pragma unroll
+            for (int c = 0; c < MB; ++c)
+                if (c < m_dim) z = xb_fma(w3[c], mm[c], z);
+            const T sg = (T)1 / ((T)1 + xb_exp(-z));
+            const T gh = g_w * p.W4[r] * (sg * ((T)1 + z * ((T)1 - sg)));
+            p.a3_t[(size_t)r * E + q] = z * sg;
+            p.ghid_t[(size_t)r * E + q] = gh;
+#pragma unroll
+            for (int c = 0; c < MB; ++c)
+                if (c < m_dim) gm[c] = xb_fma(gh, w3[c], gm[c]);
+        }
+    } else {
+        for (int c = 0; c < C; ++c) p.g_rel[(size_t)c * E + q] = (T)0;
+        if (p.g_scale) p.g_scale[q] = (T)0;
+    }
+    if (p.g_w) p.g_w[q] = g_w;
+    // the gate (:289-290): m = m0 sigmoid(gate_w . m0 + gate_b)
+    if (p.gate_w) {
+        T s = (T)0;
+#pragma unroll
+        for (int c = 0; c < MB; ++c)
+            if (c < m_dim) s = xb_fma(gm[c], mm[c] / (gt > (T)0 ? gt : (T)1), s);   // m0 = m / gate (a sigmoid that underflowed to 0: the
+        const T gs = s * gt * ((T)1 - gt);                                          //  factor gate (1 - gate) below is 0 as well)
+#pragma unroll
+        for (int c = 0; c < MB; ++c)
+            if (c < m_dim) gm[c] = gm[c] * gt + gs * p.gate_w[c];
+        if (p.g_gate) p.g_gate[q] = gs;
+    }
+    // the second SiLU of edge_mlp (:183)
+#pragma unroll
+    for (int c = 0; c < MB; ++c)
+        if (c < m_dim) {
+            const T uc = urow[c];
+            const T sg = (T)1 / ((T)1 + xb_exp(-uc));
+            p.gU[(size_t)q * m_dim + c] = gm[c] * (sg * ((T)1 + uc * ((T)1 - sg)));
+        }
+}
+
+template <typename T>
+int edge_tail_exact_launch(const egnn_edge_tail_exact_args* args, void* stream)
+{
+    if (!args) return EGNN_E_NULLPTR;
+    const egnn_edge_tail_exact_args& a = *args;
+    if (!a.u || !a.coors || !a.gU || !a.g_rel || !a.mm_t) return EGNN_E_NULLPTR;
+    if (a.B <= 0 || a.N <= 0 || a.K <= 0) return EGNN_E_SHAPE;
+    if (a.m_dim < 1 || a.m_dim > 64 || a.coor_dim < 1 || a.coor_dim > 64) return EGNN_E_UNSUPPORTED;
+    if (!a.idx && a.K != a.N) return EGNN_E_SHAPE;
+    if (a.W3 && (!a.b3 || !a.W4 || !a.b4 || !a.g_coors_out || !a.ghid_t || !a.a3_t)) return EGNN_E_NULLPTR;
+    if (a.norm_coors && !a.scale) return EGNN_E_NULLPTR;
+    if (a.gate_w && !a.gate_b) return EGNN_E_NULLPTR;
+    const int64_t E = (int64_t)a.B * a.N * a.K;
+    const int64_t blocks = (E + XB_THREADS - 1) / XB_THREADS;
+    if (blocks > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
+    XtArgs<T> p;
+    p.B = a.B; p.N = a.N; p.K = a.K; p.m_dim = a.m_dim; p.coor_dim = a.coor_dim; p.norm_coors = a.norm_coors;
+    p.u = static_cast<const T*>(a.u); p.coors = static_cast<const T*>(a.coors); p.g_coors_out = static_cast<const T*>(a.g_coors_out);
+    p.g_msum = static_cast<const T*>(a.g_msum); p.W3 = static_cast<const T*>(a.W3); p.b3 = static_cast<const T*>(a.b3);
+    p.W4 = static_cast<const T*>(a.W4); p.b4 = static_cast<const T*>(a.b4); p.scale = static_cast<const T*>(a.scale);
+    p.gate_w = static_cast<const T*>(a.gate_w); p.gate_b = static_cast<const T*>(a.gate_b);
+    p.idx = a.idx; p.pair_mask = a.pair_mask; p.eps = (T)a.eps; p.clamp = (T)a.clamp;
+    p.gU = static_cast<T*>(a.gU); p.g_rel = static_cast<T*>(a.g_rel); p.ghid_t = static_cast<T*>(a.ghid_t); p.a3_t = static_cast<T*>(a.a3_t);
+    p.mm_t = static_cast<T*>(a.mm_t); p.m0_t = static_cast<T*>(a.m0_t); p.g_w = static_cast<T*>(a.g_w); p.g_scale = static_cast<T*>(a.g_scale);
+    p.g_gate = static_cast<T*>(a.g_gate);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a.m_dim <= 16) hipLaunchKernelGGL((edge_tail_exact_bwd_kernel<T, 16>), dim3((unsigned)blocks), dim3(XB_THREADS), 0, s, p);
+    else if (a.m_dim <= 32) hipLaunchKernelGGL((edge_tail_exact_bwd_kernel<T, 32>), dim3((unsigned)blocks), dim3(XB_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((edge_tail_exact_bwd_kernel<T, 64>), dim3((unsigned)blocks), dim3(XB_THREADS), 0, s, p);
+    return egnn_launch_status();
+}
+
+extern "C" int egnn_edge_tail_exact_bwd_f32(const egnn_edge_tail_exact_args* args, void* stream) { return edge_tail_exact_launch<float>(args, stream); }
+extern "C" int egnn_edge_tail_exact_bwd_f64(const egnn_edge_tail_exact_args* args, void* stream) { return edge_tail_exact_launch<double>(args, stream); }

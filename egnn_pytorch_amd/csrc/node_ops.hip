@@ -405,6 +405,7 @@ extern "C" int64_t egnn_struct_bytes(int which)
     case 4: return (int64_t)sizeof(egnn_packed_info);
     case 5: return (int64_t)sizeof(egnn_edge_exact_args);
     case 6: return (int64_t)sizeof(egnn_edge_exact_bwd_args);
+    case 7: return (int64_t)sizeof(egnn_edge_tail_exact_args);
     default: return -1;
     }
 }

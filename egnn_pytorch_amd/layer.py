@@ -359,8 +359,18 @@ class EGNN(nn.Module):
             # empty batch / empty dense graphs: the reference returns empty outputs (N = 0 on the k-NN path: topk's error)
             return torch.empty_like(feats), torch.empty_like(coors), None, None, None, self.valid_radius, None, None
         # (EGNN_Network hands over what the previous layer started on the side stream right behind its edge pass)
-        idx, rank, order, slots, k, valid_radius = presel if presel is not None else self._select_neighbors(coors, mask, adj_mat, order_hint)
-        side_join = use_nearest and k > 0 and _SIDE_STREAM and _ops._timer is None
+        # When K is known without looking at the data (the k-NN path; not only_sparse_neighbors, whose K is the adjacency's maximum degree),
+        # the node-level launches go FIRST and the selection -- on the side stream, needed by the edge pass only -- is enqueued behind
+        # them: the first kernel of the forward starts ~30 us earlier, which is what a synchronous range check exposes per call.
+        sel = presel
+        late_select = (sel is None and use_nearest and 0 < self.num_nearest_neighbors <= n
+                       and not (adj_mat is not None and self.only_sparse_neighbors))
+        if sel is None and not late_select:
+            sel = self._select_neighbors(coors, mask, adj_mat, order_hint)
+        idx = rank = order = slots = None
+        k, valid_radius = self.num_nearest_neighbors, self.valid_radius
+        if sel is not None:
+            idx, rank, order, slots, k, valid_radius = sel
 
         node_out, coors_out = feats, coors
         node_in = u_pre = proj_kept = None
@@ -379,6 +389,11 @@ class EGNN(nn.Module):
             proj = _ops.linear_hl(feats_hl, w["Wcat_split"], 2 * hp, w["bcat"], name="node_proj",
                                   split_cols=hp if pi_split else 0)
             del feats_hl
+            if sel is None:
+                sel = self._select_neighbors(coors, mask, adj_mat, order_hint)
+            idx, rank, order, slots, k_sel, valid_radius = sel
+            assert k_sel == k
+            side_join = use_nearest and k > 0 and _SIDE_STREAM and _ops._timer is None
             a = _abi.EdgeArgs()
             a.B, a.N, a.K, a.dim, a.m_dim = b, n, k, dim, self.m_dim
             a.H, a.Hp = w["H"], hp

@@ -54,7 +54,7 @@ enum {
 
 int egnn_abi_version(void);
 /* sizeof of the argument structs as this library was compiled -- 0: egnn_edge_args, 1: egnn_edge_bwd_args, 2: egnn_edge_tail_args,
- * 3: egnn_layer_desc, 4: the packed-weights info struct, 5: egnn_edge_exact_args, 6: egnn_edge_exact_bwd_args; -1 otherwise -- so that a binding that mirrors them (ctypes, cgo, JNI) can verify its
+ * 3: egnn_layer_desc, 4: the packed-weights info struct, 5: egnn_edge_exact_args, 6: egnn_edge_exact_bwd_args, 7: egnn_edge_tail_exact_args; -1 otherwise -- so that a binding that mirrors them (ctypes, cgo, JNI) can verify its
  * layout at load time instead of corrupting a call. */
 int64_t egnn_struct_bytes(int which);
 const char* egnn_error_string(int code);
@@ -628,6 +628,48 @@ int egnn_edge_exact_node_sums_f32(const void* DZ_T, int64_t E, int H, int64_t no
                                   void* gPi, void* gPi_T, void* gPj, void* gPj_T, void* stream);
 int egnn_edge_exact_node_sums_f64(const void* DZ_T, int64_t E, int H, int64_t nodes, int K, const int64_t* csr_order, const int64_t* csr_seg,
                                   void* gPi, void* gPi_T, void* gPj, void* gPj_T, void* stream);
+
+/* The per-edge chain BEHIND u in closed form for any head width up to 64 channels and any coordinate dimension, fp32 or float64
+ * (autograd of egnn_pytorch.py:287 second SiLU, :289-290 gate, :292-317 pair mask / coors_mlp / CoorsNorm / clamp / coordinate update,
+ * :319-333 pooling): what egnn_edge_tail_bwd_f32 is for the standard layer (16 channels, 3-D coordinates, matrix cores).  One thread per
+ * edge; egnn_pytorch_amd/autograd.py::tail_edge_backward is the specification.  Per edge e = (b, i, k), neighbour j:
+ *     gU (E, m_dim) = d loss / d u;   g_rel (coor_dim, E) = d loss / d (x_i - x_j) without the distance path (a self pair: exact 0),
+ *     transposed like the other per-edge outputs so that egnn_edge_exact_node_sums_* turns it into the per-node sums;
+ *     the operands of the parameter gradients, TRANSPOSED (rows, E) so that the sums over all edges are C = X W^T products of
+ *     egnn_linear_f32 / _f64:  ghid_t, a3_t (4 m_dim, E) = d/d (pre-activation of coors_mlp's SiLU) and its activation,
+ *     mm_t (m_dim, E) = the (gated) messages, m0_t (m_dim, E) = SiLU(u) (gate only);  g_w, g_scale, g_gate (E) = d/d coors_mlp's output,
+ *     the terms of d/d coors_norm.scale, d/d the gate's pre-activation.
+ * Inputs: u (E, m_dim); g_coors_out (B N, coor_dim) = d loss / d coors_out; g_msum (B N, m_dim) = d loss / d (sum over k of the
+ * pair-masked messages) or NULL; pair_mask (E) bytes or NULL (the reference applies masks only when a mask is passed, :292); W3 NULL =
+ * no coors_mlp (update_coors = False); clamp < 0 = none. */
+typedef struct egnn_edge_tail_exact_args {
+    int32_t B, N, K, m_dim, coor_dim, norm_coors;
+    double eps, clamp;
+    const void* u;
+    const void* coors;
+    const int32_t* idx;         /* (E) or NULL = dense (K == N, j = k) */
+    const uint8_t* pair_mask;
+    const void* g_coors_out;
+    const void* g_msum;
+    const void* W3;             /* coors_mlp.0.weight (4 m_dim, m_dim), .bias; coors_mlp.3.weight (4 m_dim), .bias (1) */
+    const void* b3;
+    const void* W4;
+    const void* b4;
+    const void* scale;          /* coors_norm.scale (1) when norm_coors */
+    const void* gate_w;         /* edge_gate.0.weight (m_dim), .bias (1), or NULL */
+    const void* gate_b;
+    void* gU;
+    void* g_rel;
+    void* ghid_t;
+    void* a3_t;
+    void* mm_t;
+    void* m0_t;                 /* optional (gate) */
+    void* g_w;                  /* optional */
+    void* g_scale;              /* optional */
+    void* g_gate;               /* optional */
+} egnn_edge_tail_exact_args;
+int egnn_edge_tail_exact_bwd_f32(const egnn_edge_tail_exact_args* args, void* stream);
+int egnn_edge_tail_exact_bwd_f64(const egnn_edge_tail_exact_args* args, void* stream);
 
 /* =============================================================================================
  * The float64 path: a float64 module in float64 arithmetic.
