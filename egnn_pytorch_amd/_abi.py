@@ -34,7 +34,7 @@ SYMBOLS = (
     "egnn_linear_f32", "egnn_node_prep_f32", "egnn_edge_exact_f32", "egnn_edge_exact_workspace_bytes",
     "egnn_knn_select_f64", "egnn_linear_f64", "egnn_node_prep_f64", "egnn_edge_exact_f64",
     "egnn_edge_exact_bwd_f32", "egnn_edge_exact_bwd_f64", "egnn_edge_exact_node_sums_f32", "egnn_edge_exact_node_sums_f64",
-    "egnn_edge_tail_exact_bwd_f32", "egnn_edge_tail_exact_bwd_f64",
+    "egnn_edge_tail_exact_bwd_f32", "egnn_edge_tail_exact_bwd_f64", "egnn_status_publish",
 )
 
 
@@ -342,6 +342,8 @@ def load():
     for fn in (lib.egnn_edge_exact_node_sums_f32, lib.egnn_edge_exact_node_sums_f64):
         fn.restype = c_int
         fn.argtypes = [c_void_p, c_int64, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.egnn_status_publish.restype = c_int
+    lib.egnn_status_publish.argtypes = [c_void_p, c_void_p, c_int, c_int32, c_void_p]
     lib.egnn_edge_exact_workspace_bytes.restype = c_size_t
     lib.egnn_edge_exact_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, c_int]
     if lib.egnn_abi_version() != ABI_VERSION:

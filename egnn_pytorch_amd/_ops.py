@@ -74,14 +74,19 @@ def empty(*shape, dtype, device):
     return t
 
 
+_RAW_STREAM = os.environ.get("EGNN_RAW_STREAM", "1") != "0"
+
+
 def _stream():
     """The raw hipStream_t of torch's current stream on the current device.  Through the C binding when it exists: the public
     torch.cuda.current_stream() builds a Stream object through three layers of device-index helpers (8 us a call, thirteen calls per
     forward: a third of the host time of a forward, tools/host_overhead_probe.py)."""
-    try:
-        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
-    except AttributeError:
-        return torch.cuda.current_stream().cuda_stream
+    if _RAW_STREAM:
+        try:
+            return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+        except AttributeError:
+            pass
+    return torch.cuda.current_stream().cuda_stream
 
 
 _side = {}
@@ -117,6 +122,8 @@ def _u8(t):
 #                              the start of the next one (or by egnn_pytorch_amd.check_range()); bench.py uses this
 #   EGNN_RANGE_CHECK=off       never read (outputs are still non-finite when it happens)
 RANGE_CHECK = os.environ.get("EGNN_RANGE_CHECK", "sync")
+_SPIN = os.environ.get("EGNN_RANGE_SPIN", "1") != "0"
+_SPIN_LIMIT = 50_000_000                                # ~ seconds of spinning before the copy + synchronise fallback
 _status = {}
 
 
@@ -128,6 +135,10 @@ class _Status:
         self.dev = torch.zeros(2, dtype=torch.int32, device=device)
         self.host = torch.zeros(2, dtype=torch.int32).pin_memory()
         self.event = None
+        # sync mode: the words + a sequence number written by a one-thread kernel into pinned memory the host spins on (egnn_status_publish)
+        self.pub = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self.pub_np = self.pub.numpy()
+        self.seq = 0
 
 
 _status_slot = contextvars.ContextVar("egnn_status_slot", default=0)
@@ -173,9 +184,21 @@ def range_check_after_forward(device, mode=None):
         # the one host synchronisation of the forward: 8 bytes into pinned memory + a stream synchronisation (a .tolist() / .item() goes
         # through a staged pageable copy: slower per forward; a one-thread kernel writing the words into pinned memory for the host to spin
         # on was measured too: no faster -- what the synchronisation costs is the host time from forward() entry to its first launch)
-        st.host.copy_(st.dev, non_blocking=True)
-        torch.cuda.current_stream(st.dev.device).synchronize()
-        fwd, bwd = int(st.host[0]), int(st.host[1])
+        fwd = bwd = None
+        if _SPIN:
+            st.seq = (st.seq % 0x7ffffff0) + 1
+            with torch.cuda.device(st.dev.device):
+                rc = _abi.load().egnn_status_publish(st.dev.data_ptr(), st.pub.data_ptr(), 2, st.seq, _stream())
+            _abi.check(rc, "egnn_status_publish")
+            view, seq, spins = st.pub_np, st.seq, 0
+            while view[2] != seq and spins < _SPIN_LIMIT:
+                spins += 1
+            if view[2] == seq:
+                fwd, bwd = int(view[0]), int(view[1])
+        if fwd is None:                                 # (EGNN_RANGE_SPIN=0, or the pinned word never changed: copy + synchronise)
+            st.host.copy_(st.dev, non_blocking=True)
+            torch.cuda.current_stream(st.dev.device).synchronize()
+            fwd, bwd = int(st.host[0]), int(st.host[1])
         if fwd or bwd:
             st.dev.zero_()
             st.host.zero_()

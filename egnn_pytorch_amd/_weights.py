@@ -23,6 +23,7 @@ Zero padding is exact: padded hidden units see y = 0 -> 0 / (1 + 1) = 0 and meet
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 

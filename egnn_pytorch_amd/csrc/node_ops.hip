@@ -393,6 +393,23 @@ extern "C" int egnn_node_prep_hl(const float* feats, const float* m_i, const flo
                                  rows, dim, m_dim, status, stream);
 }
 
+// The range status words handed to the host without a copy engine and without a stream synchronisation: one thread copies them into
+// pinned (host-coherent) memory and then writes a sequence number behind them; the host spins on the sequence number.
+__global__ void status_publish_kernel(const int32_t* __restrict__ st, volatile int32_t* host, int32_t nwords, int32_t seq)
+{
+    for (int i = 0; i < nwords; ++i) host[i] = st[i];
+    __threadfence_system();
+    host[nwords] = seq;
+}
+
+extern "C" int egnn_status_publish(const int32_t* status_dev, int32_t* host_pinned, int nwords, int32_t seq, void* stream)
+{
+    if (!status_dev || !host_pinned) return EGNN_E_NULLPTR;
+    if (nwords < 1 || nwords > 8) return EGNN_E_SHAPE;
+    hipLaunchKernelGGL(status_publish_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), status_dev, host_pinned, nwords, seq);
+    return egnn_launch_status();
+}
+
 extern "C" int egnn_abi_version(void) { return EGNN_ABI_VERSION; }
 
 extern "C" int64_t egnn_struct_bytes(int which)

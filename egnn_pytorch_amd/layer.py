@@ -39,6 +39,7 @@ _EDGE_ALGO = int(os.environ.get("EGNN_EDGE_ALGO", "0"))
 # slower -- when the range status word is read synchronously (EGNN_RANGE_CHECK=sync, the default) and no graph is being recorded;
 # otherwise it raises EGNNRangeError.  "exact": always the plain-fp32 kernels (inference only).
 _PRECISION = os.environ.get("EGNN_PRECISION", "fast")
+_LATE_SELECT = os.environ.get("EGNN_LATE_SELECT", "1") != "0"      # node-level launches before the neighbour selection (see _forward_hip)
 _exact_now = contextvars.ContextVar("egnn_exact_now", default=False)       # per thread / context: concurrent forwards do not see each other's
 _warned_rerun = False
 
@@ -363,7 +364,7 @@ class EGNN(nn.Module):
         # the node-level launches go FIRST and the selection -- on the side stream, needed by the edge pass only -- is enqueued behind
         # them: the first kernel of the forward starts ~30 us earlier, which is what a synchronous range check exposes per call.
         sel = presel
-        late_select = (sel is None and use_nearest and 0 < self.num_nearest_neighbors <= n
+        late_select = (_LATE_SELECT and sel is None and use_nearest and 0 < self.num_nearest_neighbors <= n
                        and not (adj_mat is not None and self.only_sparse_neighbors))
         if sel is None and not late_select:
             sel = self._select_neighbors(coors, mask, adj_mat, order_hint)

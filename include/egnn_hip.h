@@ -57,6 +57,11 @@ int egnn_abi_version(void);
  * 3: egnn_layer_desc, 4: the packed-weights info struct, 5: egnn_edge_exact_args, 6: egnn_edge_exact_bwd_args, 7: egnn_edge_tail_exact_args; -1 otherwise -- so that a binding that mirrors them (ctypes, cgo, JNI) can verify its
  * layout at load time instead of corrupting a call. */
 int64_t egnn_struct_bytes(int which);
+/* Hands `nwords` (<= 8) int32 status words to the host without a copy engine and without a stream synchronisation: a one-thread kernel on
+ * `stream` copies them into host_pinned[0 .. nwords) -- pinned, host-coherent memory the device can address (hipHostMalloc; torch's
+ * pin_memory()) -- and then writes `seq` to host_pinned[nwords]; the caller spins until it reads `seq` there.  What the Python layer's
+ * default range check does after every forward. */
+int egnn_status_publish(const int32_t* status_dev, int32_t* host_pinned, int nwords, int32_t seq, void* stream);
 const char* egnn_error_string(int code);
 
 /* Padded hidden width the projection / edge kernels use for H = 2*edge_input_dim:
