@@ -277,8 +277,11 @@ def spatial_order(coors):
 
 def slot_prep(coors, mask8, idx, rank, order, valid_radius):
     """(B*N*K, 4) int32 per-slot records {j | pair_ok << 31, x_i - x_j} in the edge pass's consumption order --
-    egnn_slot_prep_f32 (flattens the setup's index chain: include/egnn_hip.h)."""
-    b, n, k = idx.shape
+    egnn_slot_prep_f32 (flattens the setup's index chain: include/egnn_hip.h).  idx None: the dense all-pairs layer (K = N, j = k)."""
+    if idx is None:
+        b, n, k = coors.shape[0], coors.shape[1], coors.shape[1]
+    else:
+        b, n, k = idx.shape
     slots = empty(b * n * k, 4, dtype=torch.int32, device=coors.device)
     with _timed("slot_prep"):
         rc = _abi.load().egnn_slot_prep_f32(_ptr(coors), _ptr(mask8), _ptr(idx), _ptr(rank), _ptr(order),

@@ -1204,7 +1204,7 @@ int EGNN_EDGE_ENTRY(const egnn_edge_args* args, void* stream)
     if ((a.pi_split != 0) != (a.K >= 6)) return EGNN_E_SHAPE;          // P_i format must match the kernel variant
     if (a.edge_dim > 0 && !a.edges) return EGNN_E_NULLPTR;
     if (a.idx == nullptr && a.K != a.N) return EGNN_E_SHAPE;          // dense path: K == N
-    if (a.slots && (!a.idx || a.coor_dim != 3)) return EGNN_E_SHAPE;  // records exist for the neighbour path with 3-D coordinates
+    if (a.slots && ((!a.idx && a.K != a.N) || a.coor_dim != 3)) return EGNN_E_SHAPE;  // records: 3-D coordinates; dense (idx NULL) means K == N
     if (a.drop_thr && !(a.drop_inv_keep >= 1.f)) return EGNN_E_SHAPE;
     if (a.slots && (reinterpret_cast<uintptr_t>(a.slots) & 15)) return EGNN_E_ALIGN;
     if ((reinterpret_cast<uintptr_t>(a.Pi) & 15) || (reinterpret_cast<uintptr_t>(a.Pj) & 15) ||

@@ -1,4 +1,4 @@
-// The edge pass of the k-NN layers with ONE WAVE PER NODE (reference: egnn_pytorch/egnn_pytorch.py:262-333).
+// The edge pass of the k-NN layers -- and of dense all-pairs layers with N % 32 == 0 -- with ONE WAVE PER NODE (reference: egnn_pytorch/egnn_pytorch.py:262-333).
 //
 // Same arithmetic, same operand layouts and -- for K <= 128 -- the same bits as edge_fused.hip's general kernel, for the shape every
 // k-NN configuration of BASELINE.json has: K % 32 == 0 neighbours, squared distance as the only per-edge scalar (no fourier
@@ -732,7 +732,7 @@ int egnn_edge_pw_launch(const egnn_edge_args* args, void* stream)
     const egnn_edge_args& a = *args;
     if (a.coor_dim != 3 || a.K < 32 || (a.K % 32) != 0 || a.K > 4096) return EGNN_E_UNSUPPORTED;
     if (a.S != 1 || a.fourier != 0 || a.edge_dim != 0 || a.m_dim > 16 || a.wst_terms != 4) return EGNN_E_UNSUPPORTED;
-    if (!a.slots || !a.idx || !a.pi_split) return EGNN_E_UNSUPPORTED;
+    if (!a.slots || !a.pi_split || (!a.idx && a.K != a.N)) return EGNN_E_UNSUPPORTED;       // (idx NULL: the dense all-pairs layer, records with j = k)
     if (a.drop_thr) return EGNN_E_UNSUPPORTED;                            // training-mode dropout keeps the general kernel (its MODE 3)
     if ((int64_t)a.B * a.N * a.K * 16 > 0xffffffffLL) return EGNN_E_UNSUPPORTED;       // slot records behind one 32-bit buffer resource
     if ((int64_t)a.N * a.ldp * 4 > 0xffffffffLL) return EGNN_E_UNSUPPORTED;

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void slot_prep_kernel(const float* __restrict_
     const int64_t bN = node / N * N;
     const int i = order ? order[node] : (int)(node - bN);
     const int64_t e = (bN + i) * K + k;
-    const int j = idx[e];
+    const int j = idx ? idx[e] : k;                          // idx NULL: dense all-pairs (K == N), neighbour k is node k
     const float* ci = coors + (bN + i) * 3;
     const float* cj = coors + (bN + j) * 3;
     bool ok = true;
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256) void slot_prep_kernel(const float* __restrict_
 extern "C" int egnn_slot_prep_f32(const float* coors, const uint8_t* mask, const int32_t* idx, const float* rank, const int32_t* order,
                                   float valid_radius, int B, int N, int K, void* slots, void* stream)
 {
-    if (!coors || !idx || !slots) return EGNN_E_NULLPTR;
-    if (B <= 0 || N <= 0 || K <= 0) return EGNN_E_SHAPE;
+    if (!coors || !slots) return EGNN_E_NULLPTR;
+    if (B <= 0 || N <= 0 || K <= 0 || (!idx && K != N)) return EGNN_E_SHAPE;
     if (reinterpret_cast<uintptr_t>(slots) & 15) return EGNN_E_ALIGN;
     const int64_t total = (int64_t)B * N * K;
     const int64_t blocks = (total + 255) / 256;

@@ -39,6 +39,7 @@ _EDGE_ALGO = int(os.environ.get("EGNN_EDGE_ALGO", "0"))
 # slower -- when the range status word is read synchronously (EGNN_RANGE_CHECK=sync, the default) and no graph is being recorded;
 # otherwise it raises EGNNRangeError.  "exact": always the plain-fp32 kernels (inference only).
 _PRECISION = os.environ.get("EGNN_PRECISION", "fast")
+_DENSE_PW = os.environ.get("EGNN_DENSE_PW", "1") != "0"            # dense layers with N % 32 == 0 on the wave-per-node edge kernel
 _LATE_SELECT = os.environ.get("EGNN_LATE_SELECT", "1") != "0"      # node-level launches before the neighbour selection (see _forward_hip)
 _exact_now = contextvars.ContextVar("egnn_exact_now", default=False)       # per thread / context: concurrent forwards do not see each other's
 _warned_rerun = False
@@ -291,7 +292,14 @@ class EGNN(nn.Module):
         use_nearest = num_nearest > 0 or self.only_sparse_neighbors
         idx = rank = order = slots = None
         if not use_nearest:
-            return None, None, None, None, n, valid_radius
+            # dense all-pairs.  With N % 32 == 0 and the standard layer's shape the wave-per-node edge kernel applies (csrc/edge_pw.hip):
+            # it reads per-slot records, here with j = k.  Only when the batch fills the chip with one wave per node (measured, round 5:
+            # B N = 16 384 ... 32 768 nodes -2 ... -6.5 %; BASELINE.json's c2 -- 2048 nodes, each wave walking 8 rounds -- +25 %, so c2
+            # stays on the general kernel, which splits a node's slots over workgroups).  The records are 16 B N^2 bytes: bounded.
+            if (_SLOT_PREP and _DENSE_PW and b * n >= 8192 and n % 32 == 0 and 32 <= n <= 4096 and coors.shape[-1] == 3 and self.m_dim <= 16
+                    and self.edge_dim == 0 and self.fourier_features == 0 and not self.dropout_active() and b * n * n * 16 <= (1 << 28)):
+                slots = _ops.slot_prep(coors, _ops._u8(mask), None, None, None, valid_radius)
+            return None, None, None, slots, n, valid_radius
         if adj_mat is not None and self.only_sparse_neighbors:
             num_nearest = _ops.adj_max_degree(adj_mat)                # host sync, as upstream (:249)
             valid_radius = 0.0

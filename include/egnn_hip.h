@@ -119,7 +119,8 @@ int egnn_dest_lists_i32(const int32_t* idx, int B, int N, int K, int32_t* ent, s
  * 16-byte record per slot:
  *     slots[(b*N + pos)*K + k] = { j | (pair_ok << 31),  x_i - x_j  (3 floats, the reference's :232 subtraction bit for bit) }
  * with i = order ? order[b,pos] : pos, j = idx[b,i,k], pair_ok = mask ? mask[b,i] && mask[b,j] && (rank ? rank[b,i,k] <= valid_radius : 1) : 1
- * (:292-300).  The edge pass then needs one coalesced load per slot (egnn_edge_args.slots).  slots: B*N*K records of 4 dwords. */
+ * (:292-300).  The edge pass then needs one coalesced load per slot (egnn_edge_args.slots).  slots: B*N*K records of 4 dwords.
+ * idx NULL = the dense all-pairs layer (K == N, j = k): with the records a dense layer with N % 32 == 0 runs the wave-per-node edge kernel. */
 int egnn_slot_prep_f32(const float* coors, const uint8_t* mask, const int32_t* idx, const float* rank, const int32_t* order,
                        float valid_radius, int B, int N, int K, void* slots, void* stream);
 
