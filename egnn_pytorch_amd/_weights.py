@@ -65,7 +65,7 @@ def edge_mfmas(s: int) -> int:
 
 
 def scalar_table(ws: torch.Tensor, amax=None):
-    """(S, Hp) fp32 scalar weights -> (Wst, ws_inv_scale).  Wst is (Hp, 4 * edge_mfmas(S), 2) fp16: per hidden unit h
+    """(S, Hp) fp32 scalar weights -> (Wst, ws_inv_scale).  Wst is (Hp, 4 * edge_mfmas(S), 2) fp16 (stored through `swizzle_terms`): per hidden unit h
     the (fp16, fp16) words that sit in K-slots 4g+2, 4g+3 of lane group g of first-layer MFMA m
     (v_mfma_f32_16x16x16_f16; K-slots 4g, 4g+1 belong to the (hi, lo) pair of P_i), term index 4 m + g = 3 s + kind:
         kind 0: (hi, lo) of c * W * 2^10      x  B = (s1, s1),      s1 = fp16(s' / 2^10)
@@ -83,7 +83,17 @@ def scalar_table(ws: torch.Tensor, amax=None):
     terms = torch.stack([torch.stack([ahi, alo], -1), torch.stack([hi, lo], -1), torch.stack([hi, zero], -1)], dim=2)
     tab = torch.zeros(hp, 4 * edge_mfmas(s_), 2, dtype=torch.float16, device=ws.device)
     tab[:, :3 * s_] = terms.reshape(hp, 3 * s_, 2)                   # (Hp, S, 3, 2) -> term index 3 s + kind
-    return tab.contiguous(), 1.0 / c
+    return swizzle_terms(tab).contiguous(), 1.0 / c
+
+
+def swizzle_terms(tab: torch.Tensor) -> torch.Tensor:
+    """The table as the kernels read it: units 8 .. 15 of every 16-block keep the term pairs (0, 1) and (2, 3) of each four-term group
+    swapped -- lane (unit e, group g) reads position g ^ 2 there, so that units e and e + 8 (32 dwords apart) do not meet in one LDS bank
+    (round 5: SQ_LDS_BANK_CONFLICT of the edge pass 16.9 M -> 0).  An involution: applying it twice gives the plain table back."""
+    hp, nt, _ = tab.shape
+    t = tab.reshape(hp, nt // 4, 2, 2, 2)
+    upper = ((torch.arange(hp, device=tab.device) & 8) != 0).view(hp, 1, 1, 1, 1)
+    return torch.where(upper, t.flip(2), t).reshape(hp, nt, 2)
 
 
 def pack_tiles(x: torch.Tensor) -> torch.Tensor:

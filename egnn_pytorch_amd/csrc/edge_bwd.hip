@@ -450,7 +450,7 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
                 // first Linear's scalar term, operands swapped against the forward: D[edge][hidden] += [scalars] x [W_s]
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
-                    const u32x2 bv = u32x2{0u, wstl[(st * 32 + 16 * hb + hq) * (4 * NM) + 4 * m + g]};
+                    const u32x2 bv = u32x2{0u, wstl[(st * 32 + 16 * hb + hq) * (4 * NM) + 4 * m + (g ^ ((hq >> 2) & 2))]};   // (the table's pair swap for units 8 .. 15)
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
                         x[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, bq[t][m]), __builtin_bit_cast(f16x4, bv), x[t], 0, 0, 0);

@@ -395,7 +395,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) neg_identity[u] = (e == 4 * g + u) ? (_Float16)-1.f : (_Float16)0.f;
         // first-layer A fragments: row (hidden unit) e of the 16-block, split term 4 m + g
-        const char* tl = wst + (e * (4 * NM) + g) * 4;
+        const char* tl = wst + (e * (4 * NM) + (g ^ ((e >> 2) & 2))) * 4;      // (units 8 .. 15 of a block: term pairs swapped in the table, no bank conflict)
         constexpr int tstep = 16 * 4 * NM * 4;                          // bytes per 16 hidden units
 
         f32x4 acc[TILES][NB];

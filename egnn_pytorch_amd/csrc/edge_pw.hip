@@ -201,10 +201,11 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) xr[hb] = xch + e * PW_XLD + 4 * ((4 * hb + g) ^ ((e >> 1) & 7));
     // first-layer A fragments: row (hidden unit) e of the 16-block, split term g
-    // (units e and e + 8 of a 16-block share a bank in this read -- a 2-way conflict on one ds_read_b32 per step and 16-block, the
-    // 12 % of LDS cycles VERDICT r4 asked about; reading the other bank pair instead changed nothing measurable: the LDS pipe is
-    // busy a fifth of the time, profiles/r05_experiments/)
-    const char* const tl = wst + (e * 4 + g) * 4;
+    // (units e and e + 8 of a 16-block are 32 dwords apart: read at position g they would share a bank -- a 2-way conflict on this
+    // ds_read_b32, the 12 % of LDS cycles VERDICT r4 asked about (16.9 M of 138 M).  The table therefore stores the terms of units
+    // 8 .. 15 of a block with the pairs (0, 1) and (2, 3) swapped (_weights.scalar_table / egnn_pack_weights_host) and the lane reads
+    // position g ^ 2 there: SQ_LDS_BANK_CONFLICT 0, same time -- the LDS pipe is busy a fifth of it -- profiles/r05_experiments/)
+    const char* const tl = wst + (e * 4 + (g ^ ((e >> 2) & 2))) * 4;
     constexpr int tstep = 16 * 4 * 4;                                      // bytes per 16 hidden units
 #if EGNN_PW_RESID4
     f16x4 neg_identity;                                                    // A operand of the 4x4x4 residual MFMA: row (lane & 3) of -I4

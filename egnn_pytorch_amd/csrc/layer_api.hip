@@ -174,10 +174,14 @@ extern "C" int egnn_pack_weights_host(const egnn_layer_desc* desc, const egnn_la
                 const float wa = w * 1024.0f;
                 const _Float16 hi = (_Float16)w, ahi = (_Float16)wa;
                 const _Float16 lo = (_Float16)(w - (float)hi), alo = (_Float16)(wa - (float)ahi);
-                _Float16* t = tab + ((size_t)h * terms + 3 * s) * 2;
-                t[0] = ahi; t[1] = alo;                                       // kind 0: (hi, lo) of 2^10 c W
-                t[2] = hi; t[3] = lo;                                         // kind 1: (hi, lo) of c W
-                t[4] = hi; t[5] = (_Float16)0.f;                              // kind 2: (hi, 0)  of c W
+                // term index ti = 3 s + kind sits at position (ti & ~3) | ((ti & 3) ^ sw): units 8 .. 15 of a 16-block keep the pairs
+                // (0, 1) and (2, 3) of every four-term group swapped (the kernels' conflict-free LDS read, _weights.scalar_table)
+                const int sw = (h & 8) ? 2 : 0;
+                auto at = [&](int ti) { return tab + ((size_t)h * terms + ((ti & ~3) | ((ti & 3) ^ sw))) * 2; };
+                _Float16* t0 = at(3 * s), *t1 = at(3 * s + 1), *t2 = at(3 * s + 2);
+                t0[0] = ahi; t0[1] = alo;                                     // kind 0: (hi, lo) of 2^10 c W
+                t1[0] = hi; t1[1] = lo;                                       // kind 1: (hi, lo) of c W
+                t2[0] = hi; t2[1] = (_Float16)0.f;                            // kind 2: (hi, 0)  of c W
             }
     }
     // ---- second Linear of edge_mlp in v_mfma_f32_16x16x32_f16 fragment order

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 32
+#define EGNN_ABI_VERSION 33
 
 enum {
     EGNN_OK = 0,
@@ -252,7 +252,9 @@ typedef struct egnn_edge_args {
     const void* Wst;            /* (Hp, wst_terms, 2) fp16: columns [2dim .. 2dim+S) of edge_mlp.0.weight x -log2(e) x ws_scale as
                                    A fragments of the first-layer MFMA (v_mfma_f32_16x16x16_f16, K-slots 4g+2, 4g+3 of lane
                                    group g of MFMA m hold term 4m+g); per hidden unit and scalar s three (fp16, fp16) words,
-                                   terms 3s .. 3s+2:  (hi, lo) of 2^10 w | (hi, lo) of w | (hi, 0) of w;  rest zero */
+                                   terms 3s .. 3s+2:  (hi, lo) of 2^10 w | (hi, lo) of w | (hi, 0) of w;  rest zero.  Position of term
+                                   4m + g inside unit h's row: 4m + (g ^ (h & 8 ? 2 : 0)) -- units 8 .. 15 of a 16-block keep the pairs
+                                   (0, 1) and (2, 3) swapped so that the kernels' LDS read of units e and e + 8 is conflict-free */
     int32_t wst_terms;          /* = 4 * egnn_edge_mfmas(S) */
     float ws_inv_scale;         /* 1 / ws_scale (a power of two): the kernel multiplies the per-edge scalars by it */
     const void* W2h;            /* (Hp/32, NB, 2, 64, 8) fp16: -ln2 * w2_scale * edge_mlp.3.weight split into hi | lo halves,

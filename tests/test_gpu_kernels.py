@@ -704,6 +704,51 @@ def test_persistent_edge_kernel_equals_the_general_one(b, n, k, dim, kw, ragged)
     assert torch.equal(new[1], ref[1]), float((new[1] - ref[1]).abs().max())
 
 
+@pytest.mark.parametrize("b,n,dim,kw,ragged", [
+    (64, 128, 32, {}, True),                                                     # four rounds per node (K = N = 128): the same bits
+    (32, 256, 24, dict(norm_coors=True, soft_edges=True, m_pool_method="mean"), True),   # eight rounds: another summation order across rounds
+])
+def test_dense_layers_on_the_wave_per_node_kernel(b, n, dim, kw, ragged):
+    """Round 5: a dense all-pairs layer with N % 32 == 0 runs csrc/edge_pw.hip when the batch fills the chip (B N >= 8192): per-slot
+    records with j = k (egnn_slot_prep_f32 with idx = NULL).  Against the general kernel on the same inputs (bit-identical up to four
+    rounds per node; beyond, the rounds of a node are summed in another order: 1e-5 of the output's scale) and, for two graphs, against
+    the oracle at the parity tolerance."""
+    from egnn_pytorch_amd import EGNN, layer as L, _ops
+    g = torch.Generator().manual_seed(b + n + dim)
+    layer = EGNN(dim=dim, **kw)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.xavier_normal_(m.weight, generator=g)
+            m.weight.data.mul_(0.3)                                               # (hundreds of neighbours per node: damped, as the dense goldens)
+    layer = layer.cuda().eval()
+    feats = torch.randn(b, n, dim, generator=g).cuda()
+    coors = torch.randn(b, n, 3, generator=g).cuda()
+    mask = (torch.arange(n)[None] < torch.randint(n // 2, n + 1, (b, 1), generator=g)).cuda() if ragged else None
+    old = L._DENSE_PW
+    try:
+        with torch.no_grad():
+            L._DENSE_PW = False
+            ref = layer(feats, coors, mask=mask)
+            L._DENSE_PW = True
+            with _ops.phase_timer() as pt:
+                new = layer(feats, coors, mask=mask)
+    finally:
+        L._DENSE_PW = old
+    assert "slot_prep" in pt.summary()                                           # (the records were built: the wave-per-node path ran)
+    for a, r in zip(new, ref):
+        scale = max(1.0, float(r.abs().max()))
+        if n <= 128:
+            assert torch.equal(a, r), float((a - r).abs().max())
+        else:
+            assert float((a - r).abs().max()) <= 1e-5 * scale
+    from oracle import egnn_oracle as O
+    cfg = O.EGNNConfig(dim=dim, **kw)
+    params = {k_: v.detach().cpu().numpy() for k_, v in layer.state_dict().items()}
+    want = O.egnn_forward(cfg, params, feats[:2].cpu().numpy(), coors[:2].cpu().numpy(), None, None if mask is None else mask[:2].cpu().numpy(), None)
+    for a, w in zip(new, want):
+        np.testing.assert_allclose(a[:2].cpu().numpy(), w, atol=1e-4 * max(1.0, float(np.abs(w).max())), rtol=0)
+
+
 @pytest.mark.parametrize("b,n,k,dim,ragged", [(2, 150, 32, 64, True), (1, 80, 64, 32, False)])
 def test_wave_per_node_kernel_writes_the_same_u_for_the_backward(b, n, k, dim, ragged):
     """The forward under autograd keeps u = edge_mlp.3(SiLU(edge_mlp.0(.))) (E x 16), written by the edge kernel on the side

@@ -191,8 +191,9 @@ def test_weight_relayout_is_exact(kw):
     # the scalar columns as first-layer MFMA fragments: five fp16 products per (scalar, hidden unit) rebuild W * s
     nt = 4 * _weights.edge_mfmas(s)
     assert w["Wst"].dtype == np.float16 and w["Wst"].shape == (hp, nt, 2) and 3 * s <= nt
-    assert np.all(w["Wst"][:, 3 * s:] == 0)
-    tab = w["Wst"][:, :3 * s].astype(np.float64).reshape(hp, s, 3, 2)  # (hidden unit, scalar, kind, hi|lo)
+    plain = _weights.swizzle_terms(torch.from_numpy(np.ascontiguousarray(w["Wst"]))).numpy()    # (an involution: undoes the pair swap of units 8 .. 15)
+    assert np.all(plain[:, 3 * s:] == 0)
+    tab = plain[:, :3 * s].astype(np.float64).reshape(hp, s, 3, 2)     # (hidden unit, scalar, kind, hi|lo)
     sp = sc.astype(np.float64) * w["ws_inv_scale"]                    # what the kernel splits: s' = s / ws_scale
     s1 = (sp / 1024).astype(np.float16).astype(np.float64)
     r = sp - 1024 * s1
