@@ -35,6 +35,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 #ifndef EGNN_KNN_BITS
 #define EGNN_KNN_BITS 16
 #endif
+#ifndef EGNN_KNN_PAIR
+#define EGNN_KNN_PAIR 1                      // two query rows per wave on the standard shape (see process_pair; 0: one row per wave everywhere)
+#endif
 constexpr int KNN_PREFIX_BITS = EGNN_KNN_BITS;   // key bits resolved by the pruning threshold of the fast path
 constexpr int KNN_SURVIVORS = 128;               // ... and survivors the fast path ranks directly (two per lane)
 constexpr int KNN_THREADS = 256;
@@ -70,9 +73,103 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
 
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
+#if EGNN_KNN_PAIR
+    // Two query rows per wave (round 5): the candidates' coordinates and mask bytes are read from LDS once for both rows, and the two
+    // serial ballot / popcount chains of the threshold search interleave.  The standard shape only -- 3-D coordinates, K <= 32, no
+    // adjacency, both rows unmasked, at most one survivor per lane in each row -- anything else returns false and the rows take the
+    // single-row code below.  Same keys, same (value, index) ranking: the same bits.
+    auto process_pair = [&](const int i0, const int i1) -> bool {
+        const float ax = xs[i0], ay = xs[Npad + i0], az = xs[2 * Npad + i0];
+        const float bx = xs[i1], by = xs[Npad + i1], bz = xs[2 * Npad + i1];
+        uint32_t k0[CPL], k1[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = c * 64 + lane;
+            uint32_t q0 = 0xFFFFFFFFu, q1 = 0xFFFFFFFFu;
+            if (j < N) {
+                const float xj = xs[j], yj = xs[Npad + j], zj = xs[2 * Npad + j];
+                float dx, dy, dz;
+                float r0 = egnn_sqdist(ax, ay, az, xj, yj, zj, dx, dy, dz);
+                float r1 = egnn_sqdist(bx, by, bz, xj, yj, zj, dx, dy, dz);
+                if (ms[j] == 0) { r0 = 1e5f; r1 = 1e5f; }            // :240-242 (both query rows are unmasked)
+                q0 = f2key(r0);
+                q1 = f2key(r1);
+            }
+            k0[c] = q0;
+            k1[c] = q1;
+        }
+        uint32_t m0 = k0[0], m1 = k1[0];
+#pragma unroll
+        for (int c = 1; c < CPL; ++c) {
+            m0 = k0[c] < m0 ? k0[c] : m0;
+            m1 = k1[c] < m1 ? k1[c] : m1;
+        }
+        uint32_t M0 = 0, M1 = 0;
+        int below0 = 0, below1 = 0;
+        for (int bit = 31; bit >= 32 - KNN_PREFIX_BITS; --bit) {
+            const int c0 = __popcll(__ballot((m0 >> bit) == (M0 >> bit)));
+            const int c1 = __popcll(__ballot((m1 >> bit) == (M1 >> bit)));
+            if (below0 + c0 < K) { below0 += c0; M0 |= (1u << bit); }
+            if (below1 + c1 < K) { below1 += c1; M1 |= (1u << bit); }
+        }
+        M0 |= (1u << (32 - KNN_PREFIX_BITS)) - 1u;
+        M1 |= (1u << (32 - KNN_PREFIX_BITS)) - 1u;
+        int cl0 = 0, cl1 = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            cl0 += k0[c] <= M0 ? 1 : 0;
+            cl1 += k1[c] <= M1 ? 1 : 0;
+        }
+        const int incl = egnn_wave_inclusive_scan(cl0 | (cl1 << 16));   // (both prefix sums in one scan: counts stay below 2^16)
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
+        const int S0 = tot & 0xffff, S1 = tot >> 16;
+        if (S0 > 64 || S1 > 64) return false;                           // wave-uniform
+        uint64_t* const sel0 = selbuf;
+        uint64_t* const sel1 = selbuf + 64;
+        int p0 = (incl & 0xffff) - cl0, p1 = (incl >> 16) - cl1;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            if (k0[c] <= M0) sel0[p0++] = ((uint64_t)k0[c] << 32) | (uint32_t)(c * 64 + lane);
+            if (k1[c] <= M1) sel1[p1++] = ((uint64_t)k1[c] << 32) | (uint32_t)(c * 64 + lane);
+        }
+        wave_lds_sync();
+        const uint64_t mine0 = lane < S0 ? sel0[lane] : ~0ull;
+        const uint64_t mine1 = lane < S1 ? sel1[lane] : ~0ull;
+        int rnk0 = 0, rnk1 = 0;
+        const int Smin = S0 < S1 ? S0 : S1;
+        for (int u = 0; u < Smin; ++u) {
+            rnk0 += (sel0[u] < mine0) ? 1 : 0;
+            rnk1 += (sel1[u] < mine1) ? 1 : 0;
+        }
+        for (int u = Smin; u < S0; ++u) rnk0 += (sel0[u] < mine0) ? 1 : 0;
+        for (int u = Smin; u < S1; ++u) rnk1 += (sel1[u] < mine1) ? 1 : 0;
+        const size_t ob0 = ((size_t)b * N + i0) * K, ob1 = ((size_t)b * N + i1) * K;
+        if (lane < S0 && rnk0 < K) {
+            idx_out[ob0 + rnk0] = (int32_t)(uint32_t)(mine0 & 0xFFFFFFFFull);
+            rank_out[ob0 + rnk0] = key2f((uint32_t)(mine0 >> 32));
+        }
+        if (lane < S1 && rnk1 < K) {
+            idx_out[ob1 + rnk1] = (int32_t)(uint32_t)(mine1 & 0xFFFFFFFFull);
+            rank_out[ob1 + rnk1] = key2f((uint32_t)(mine1 >> 32));
+        }
+        wave_lds_sync();
+        return true;
+    };
+#endif
+
     for (int r = wave; r < rows_per_wg; r += KNN_WAVES) {
         const int i = row0 + r;
         if (i >= N) break;                       // wave-uniform
+#if EGNN_KNN_PAIR
+        if constexpr (CDM == 3 && CPL <= 16) {                           // (N <= 1024: two rows' keys are 32 registers)
+            if (K <= 32 && !adj && r + KNN_WAVES < rows_per_wg && i + KNN_WAVES < N && ms[i] != 0 && ms[i + KNN_WAVES] != 0) {
+                if (process_pair(i, i + KNN_WAVES)) {
+                    r += KNN_WAVES;
+                    continue;
+                }
+            }
+        }
+#endif
         float ci[CDM];
 #pragma unroll
         for (int c = 0; c < CDM; ++c) ci[c] = c < C ? xs[c * Npad + i] : 0.f;
