@@ -499,13 +499,12 @@ def main():
         else:
             layer(feats, coors, edges, mask, adj)
 
-    # Priming, before the W warm-up steps of the contract (untimed, reported as `priming_steps`): a process's first ~20 forwards of a
-    # network workload run at half speed while the host runs ahead of the device (the caching allocator grows its pool with synchronous
-    # hipMalloc calls until the buffers of the steps in flight fit), and with 20 short steps that landed in whichever timed region came
-    # first -- c3: 15 - 18 k instead of 27 - 30 k graphs/s, at random (profiles/r05_experiments/bench_first_region.txt).  The north-star
-    # line is not affected (22.4 - 22.6 k with and without).
+    # Priming, before the W warm-up steps of the contract (untimed, reported as `priming_steps`): on most boxes a one-off stall of ~35 ms
+    # lands somewhere in a process's first few dozen forwards of the network workloads, and with 20 short steps it dominated whichever
+    # timed region came first -- c3: 15 - 18 k instead of 27 - 30 k graphs/s (profiles/r05_experiments/bench_first_region.txt).  The
+    # north-star line is not affected (22.4 - 22.6 k with and without).
     mode0 = _ops.RANGE_CHECK
-    PRIME_STEPS = 24                                     # (the first ~20 forwards of a process run at half speed when the host runs ahead)
+    PRIME_STEPS = int(os.environ.get("EGNN_BENCH_PRIME", "24"))   # (0: no priming)
     for m_, cnt in (("deferred", PRIME_STEPS), ("sync", 3)):
         if mode0 == "off":
             break

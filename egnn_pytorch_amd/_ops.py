@@ -241,13 +241,16 @@ def check_range(device=None, wait=True):
             _raise_range(bits, "an earlier call")
 
 
-def knn_select(coors, mask, adj_mat, k):
+def knn_select(coors, mask, adj_mat, k, out=None):
     """(idx int32 (B,N,K), rank (B,N,K) in the coordinates' dtype) -- egnn_knn_select_f32; float64 coordinates (a float64 module):
-    egnn_knn_select_f64."""
+    egnn_knn_select_f64.  out = (idx, rank): caller-allocated outputs (the side-stream fork allocates them on the launch stream)."""
     b, n, cdim = coors.shape
     f64 = coors.dtype == torch.float64
-    idx = empty(b, n, k, dtype=torch.int32, device=coors.device)
-    rank = empty(b, n, k, dtype=coors.dtype, device=coors.device)
+    if out is not None:
+        idx, rank = out
+    else:
+        idx = empty(b, n, k, dtype=torch.int32, device=coors.device)
+        rank = empty(b, n, k, dtype=coors.dtype, device=coors.device)
     m8 = _u8(mask)
     a8 = _u8(adj_mat)
     stride = 0
@@ -265,24 +268,24 @@ def knn_select(coors, mask, adj_mat, k):
     return idx, rank
 
 
-def spatial_order(coors):
+def spatial_order(coors, out=None):
     """(B,N) int32 Morton permutation -- egnn_spatial_order_f32 (scheduling aid for the edge pass)."""
     b, n, _ = coors.shape
-    order = empty(b, n, dtype=torch.int32, device=coors.device)
+    order = out if out is not None else empty(b, n, dtype=torch.int32, device=coors.device)
     with _timed("spatial_order"):
         rc = _abi.load().egnn_spatial_order_f32(_ptr(coors), b, n, _ptr(order), _stream())
     _abi.check(rc, "egnn_spatial_order_f32")
     return order
 
 
-def slot_prep(coors, mask8, idx, rank, order, valid_radius):
+def slot_prep(coors, mask8, idx, rank, order, valid_radius, out=None):
     """(B*N*K, 4) int32 per-slot records {j | pair_ok << 31, x_i - x_j} in the edge pass's consumption order --
     egnn_slot_prep_f32 (flattens the setup's index chain: include/egnn_hip.h).  idx None: the dense all-pairs layer (K = N, j = k)."""
     if idx is None:
         b, n, k = coors.shape[0], coors.shape[1], coors.shape[1]
     else:
         b, n, k = idx.shape
-    slots = empty(b * n * k, 4, dtype=torch.int32, device=coors.device)
+    slots = out if out is not None else empty(b * n * k, 4, dtype=torch.int32, device=coors.device)
     with _timed("slot_prep"):
         rc = _abi.load().egnn_slot_prep_f32(_ptr(coors), _ptr(mask8), _ptr(idx), _ptr(rank), _ptr(order),
                                             float(min(valid_radius, 3.0e38)), b, n, k, _ptr(slots), _stream())

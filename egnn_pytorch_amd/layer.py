@@ -318,12 +318,21 @@ class EGNN(nn.Module):
             want_order = adj_mat is None and 64 <= n <= 4096 and _SPATIAL_ORDER and coors.shape[-1] == 3
             have_hint = order_hint is not None and tuple(order_hint.shape) == (b, n)
 
+            # The four outputs are allocated HERE, on the launch stream, and written by the side stream: the launch stream waits for the
+            # side stream before it reads them, so when they are freed every use is ordered before the launch stream's later work and the
+            # allocator may reuse the blocks at once.  (Allocated inside the fork they belonged to the side stream's pool and needed
+            # record_stream(): four calls per forward and frees deferred to events.)
+            dev = coors.device
+            idx_o = _ops.empty(b, n, k, dtype=torch.int32, device=dev)
+            rank_o = _ops.empty(b, n, k, dtype=torch.float32, device=dev)
+            order_o = _ops.empty(b, n, dtype=torch.int32, device=dev) if (want_order and not have_hint) else None
+            slots_o = _ops.empty(b * n * k, 4, dtype=torch.int32, device=dev) if (_SLOT_PREP and coors.shape[-1] == 3) else None
+
             def select():
-                idx_, rank_ = _ops.knn_select(coors, mask, adj_mat, k)
-                order_ = (order_hint if have_hint else _ops.spatial_order(coors)) if want_order else None
+                idx_, rank_ = _ops.knn_select(coors, mask, adj_mat, k, out=(idx_o, rank_o))
+                order_ = (order_hint if have_hint else _ops.spatial_order(coors, out=order_o)) if want_order else None
                 # the edge pass's setup as one coalesced record per slot instead of a chain of dependent loads
-                slots_ = _ops.slot_prep(coors, mask8, idx_, rank_, order_, valid_radius) \
-                    if (_SLOT_PREP and coors.shape[-1] == 3) else None
+                slots_ = _ops.slot_prep(coors, mask8, idx_, rank_, order_, valid_radius, out=slots_o) if slots_o is not None else None
                 return idx_, rank_, order_, slots_
 
             # (not while per-kernel timing is on: events on two streams would charge one kernel's wait to another)
@@ -334,14 +343,21 @@ class EGNN(nn.Module):
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     idx, rank, order, slots = select()
-                for t in (idx, rank, order, slots):
-                    if t is not None:
-                        t.record_stream(cur)
             else:
                 idx, rank, order, slots = select()
         return idx, rank, order, slots, k, valid_radius
 
     def _forward_hip(self, feats, coors, edges, mask, adj_mat, order_hint=None, want_u=False, drop=None, presel=None, prefetch=None):
+        try:
+            return self._forward_hip_impl(feats, coors, edges, mask, adj_mat, order_hint, want_u, drop, presel, prefetch)
+        except BaseException:
+            # the neighbour selection may still be writing its outputs on the side stream: join it before they are freed (they belong
+            # to the launch stream's pool: `_select_neighbors`)
+            if _SIDE_STREAM and feats.is_cuda:
+                torch.cuda.current_stream().wait_stream(_ops.side_stream(feats.device))
+            raise
+
+    def _forward_hip_impl(self, feats, coors, edges, mask, adj_mat, order_hint, want_u, drop, presel, prefetch):
         # more per-edge scalars than the split-fp16 edge kernels carry (2 fourier + 1 + edge_dim > 16, up to 160): the plain-fp32 kernels
         # ... and more than 8 coordinates (the fused kernels keep x_i - x_j in registers up to 8)
         # ... and heads wider than 64 message channels (the fused kernels hold up to four 16-channel accumulator tiles per edge tile)
