@@ -290,3 +290,123 @@ def test_node_prep_f64_kernel():
     assert float((out - want).abs().max()) <= 1e-13 * float(want.abs().max())
     out = _ops.node_prep_f32(x, None, None, None, 1e-5, 16)
     assert torch.equal(out[:, :130], x) and not out[:, 130:].any()
+
+
+# ------------------------------------------------------------------------------------------------ the backward kernels on their own
+@pytest.mark.parametrize("kw,n,k,cdim,use_mask", [
+    (dict(dim=8, m_dim=16, num_nearest_neighbors=6), 20, 6, 3, False),
+    (dict(dim=8, m_dim=24, num_nearest_neighbors=5, soft_edges=True, norm_coors=True, coor_weights_clamp_value=0.7), 18, 5, 5, True),
+    (dict(dim=8, m_dim=40), 12, 12, 2, True),                                     # dense (idx = NULL)
+    (dict(dim=8, m_dim=7, num_nearest_neighbors=4, update_coors=False), 15, 4, 3, False),
+])
+def test_closed_form_tail_kernel_equals_its_specification(kw, n, k, cdim, use_mask):
+    """egnn_edge_tail_exact_bwd_f64 against egnn_pytorch_amd.autograd.tail_edge_backward (the torch specification, itself equal to
+    autograd of the restated layer): d/d u, the operands of the parameter gradients and -- through the per-node sums -- d/d coors, at
+    1e-12 of each tensor's scale.  (d/d rel is compared through its per-node sums: the kernel writes a self pair's as the exact zero it
+    sums to.)"""
+    from egnn_pytorch_amd import EGNN, _ops, autograd as A
+    g = torch.Generator().manual_seed(n * 31 + k)
+    layer = EGNN(**kw).double()
+    _xavier_(layer, g)
+    layer = layer.cuda()
+    b, m = 2, kw["m_dim"]
+    dense = "num_nearest_neighbors" not in kw
+    u = torch.randn(b, n, k, m, generator=g, dtype=torch.float64).cuda()
+    coors = torch.randn(b, n, cdim, generator=g, dtype=torch.float64).cuda()
+    idx = None if dense else torch.stack([torch.stack([torch.randperm(n, generator=g)[:k] for _ in range(n)]) for _ in range(b)]).cuda()
+    if idx is not None:
+        idx[:, :, 0] = torch.arange(n, device="cuda")[None]                        # every node has its self pair, as the k-NN lists do
+    pm = (torch.rand(b, n, k, generator=g) > 0.2).cuda() if use_mask else None
+    g_co = torch.randn(b, n, cdim, generator=g, dtype=torch.float64).cuda()
+    g_ms = torch.randn(b, n, m, generator=g, dtype=torch.float64).cuda()
+    with torch.no_grad():
+        want = A.tail_edge_backward(layer, u, coors, idx, pm, g_co, g_ms) if layer.coors_mlp is not None else None
+    i32 = None if idx is None else idx.int().contiguous()
+    dl = _ops.dest_lists(i32, b, n, k, u.device)
+    grads = {id(p): torch.zeros_like(p) for p in layer.parameters()}
+    with torch.no_grad():
+        g_u, g_c = A._tail_closed_form(layer, u.reshape(b * n * k, m).contiguous(), coors, i32, pm, g_co, g_ms.reshape(b * n, m).contiguous(),
+                                       grads, dl, b, n, k)
+    close = lambda a, w: float((a - w).abs().max()) <= 1e-12 * max(1.0, float(w.abs().max()))     # noqa: E731
+    if want is None:                                                                # update_coors=False: only the pooling / SiLU chain
+        sg = torch.sigmoid(u)
+        gm = g_ms[:, :, None, :].expand(b, n, k, m)
+        assert close(g_u.view(b, n, k, m), gm * (sg * (1 + u * (1 - sg))))
+        assert float(g_c.abs().max()) == 0.0
+        return
+    assert close(g_u.view(b, n, k, m), want["g_u"])
+    # d/d coors of this part = sum over k of g_rel at the source, minus the sum over the edges arriving at the node
+    g_rel = want["g_rel"].clone()
+    ar = torch.arange(n, device="cuda")
+    self_pair = (ar[None, :, None] == (ar[None, None, :] if idx is None else idx)).expand(b, n, k)
+    g_rel[self_pair] = 0.0                        # x_i - x_i: contributes +g and -g to the same coordinate (1 / eps-sized under CoorsNorm)
+    src = g_rel.sum(dim=2)
+    dst = torch.zeros_like(src)
+    if idx is None:
+        dst = g_rel.sum(dim=1)
+    else:
+        bi = torch.arange(b, device="cuda")[:, None, None].expand(b, n, k)
+        dst.index_put_((bi.reshape(-1), idx.reshape(-1)), g_rel.reshape(-1, cdim), accumulate=True)
+    assert close(g_c, src - dst)
+    cm = layer.coors_mlp
+    e = b * n * k
+    assert close(grads[id(cm[0].weight)], want["g_hid"].t() @ want["m"])
+    assert close(grads[id(cm[0].bias)], want["g_hid"].sum(0))
+    assert close(grads[id(cm[3].weight)], (want["g_w"][None] @ want["a3"]))
+    assert close(grads[id(cm[3].bias)], want["g_w"].sum().reshape(1))
+    if layer.norm_coors:
+        assert close(grads[id(layer.coors_norm.scale)], want["g_scale"].sum().reshape(1))
+    if layer.edge_gate is not None:
+        assert close(grads[id(layer.edge_gate[0].weight)], want["g_gate"][None] @ want["m0"])
+        assert close(grads[id(layer.edge_gate[0].bias)], want["g_gate"].sum().reshape(1))
+
+
+@pytest.mark.parametrize("dim,m,n,k,four,edim,cdim", [(8, 16, 20, 6, 0, 0, 3), (6, 24, 16, 16, 2, 3, 5), (4, 80, 10, 4, 1, 0, 2)])
+def test_exact_backward_kernels_equal_autograd_of_the_first_linear(dim, m, n, k, four, edim, cdim):
+    """egnn_edge_exact_bwd_f64 + egnn_edge_exact_node_sums_f64 against torch autograd of u = W2 SiLU(P_i[i] + P_j[j] + W_s s) + b2 in
+    float64: a^T, dz^T, d/d scalars and the per-node sums of dz (d/d P_i, d/d P_j), 1e-12."""
+    from egnn_pytorch_amd import _abi, _ops, autograd as A
+    g = torch.Generator().manual_seed(dim + m + n)
+    b, dense = 2, k == n
+    h = 2 * (2 * dim + 2 * four + 1 + edim)
+    s_in = 2 * four + 1 + edim
+    dev = torch.device("cuda")
+    r = lambda *sh: torch.randn(*sh, generator=g, dtype=torch.float64).to(dev)          # noqa: E731
+    proj = r(b * n, 2 * h)                                                             # [P_i | P_j]
+    ws, w2, coors, gu = r(h, s_in) * 0.3, r(m, h) * 0.3, r(b, n, cdim), r(b * n * k, m)
+    edges = r(b, n, n, edim) if edim else None
+    idx = None if dense else torch.stack([torch.stack([torch.randperm(n, generator=g)[:k] for _ in range(n)]) for _ in range(b)]).to(dev)
+    i32 = None if idx is None else idx.int().contiguous()
+
+    class L:                                                                           # what edge_scalars reads of a layer
+        fourier_features = four
+    pr = proj.clone().requires_grad_(True)
+    rel, scal = A.edge_scalars(L, coors, edges, idx)
+    sc = scal.detach().clone().requires_grad_(True)
+    pi, pj = pr[:, :h].view(b, n, h), pr[:, h:].view(b, n, h)
+    bi = torch.arange(b, device=dev)[:, None, None]
+    z = pi[:, :, None, :] + (pj[:, None, :, :] if dense else pj[bi, idx]) + sc @ ws.t()
+    a_ref = torch.nn.functional.silu(z)
+    u = a_ref @ w2.t()
+    z.retain_grad()
+    (u.reshape(-1, m) * gu).sum().backward()
+    e = b * n * k
+    a_t = torch.empty(h, e, dtype=torch.float64, device=dev)
+    dz_t = torch.empty(h, e, dtype=torch.float64, device=dev)
+    g_scal = torch.empty(e, s_in, dtype=torch.float64, device=dev)
+    args = _abi.EdgeExactBwdArgs()
+    args.B, args.N, args.K, args.m_dim, args.H = b, n, k, m, h
+    args.fourier, args.edge_dim, args.coor_dim, args.edges_by_k = four, edim, cdim, 0
+    args.Pi, args.Pj, args.ldp = proj.data_ptr(), proj.data_ptr() + 8 * h, 2 * h
+    args.Ws, args.ldws, args.W2 = ws.data_ptr(), s_in, w2.data_ptr()
+    args.coors, args.edges, args.idx = coors.data_ptr(), _ops._ptr(edges), _ops._ptr(i32)
+    args.gU, args.A_T, args.DZ_T, args.g_scal = gu.data_ptr(), a_t.data_ptr(), dz_t.data_ptr(), g_scal.data_ptr()
+    _ops.edge_exact_bwd(args, torch.float64)
+    dl = _ops.dest_lists(i32, b, n, k, dev)
+    gpi, gpi_t, gpj, gpj_t = _ops.edge_exact_node_sums(dz_t, b * n, k, dl.order, dl.seg)
+    close = lambda x, w: float((x - w).abs().max()) <= 1e-12 * max(1.0, float(w.abs().max()))     # noqa: E731
+    assert close(a_t.t().reshape(b, n, k, h), a_ref.detach())
+    assert close(dz_t.t().reshape(b, n, k, h), z.grad)
+    assert close(g_scal.view_as(sc), sc.grad)
+    assert close(gpi, pr.grad[:, :h]) and close(gpj, pr.grad[:, h:])
+    assert torch.equal(gpi_t, gpi.t()) and torch.equal(gpj_t, gpj.t())

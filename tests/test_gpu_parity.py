@@ -806,3 +806,17 @@ def test_global_attention_block_on_the_hip_kernels(dim, heads, dim_head, tokens)
     with torch.enable_grad():
         at_x, at_q = blk(x, q, mask=mask)
     np.testing.assert_allclose(got_x.cpu().numpy(), at_x.detach().cpu().numpy(), atol=ATOL, rtol=0)
+
+
+def test_network_without_layers_returns_its_embeddings():
+    """depth = 0: the reference runs an empty layer loop and returns the embedded features and the coordinates unchanged
+    (egnn_pytorch.py:442-454); nothing of the first layer may be looked at."""
+    from egnn_pytorch_amd import EGNN_Network
+    torch.manual_seed(3)
+    net = EGNN_Network(num_tokens=7, num_positions=12, dim=8, depth=0).cuda().eval()
+    tokens = torch.randint(0, 7, (2, 9)).cuda()
+    coors = torch.randn(2, 9, 3).cuda()
+    with torch.no_grad():
+        feats, out_coors = net(tokens, coors)
+        want = net.token_emb(tokens) + net.pos_emb(torch.arange(9, device="cuda"))[None]
+    assert torch.equal(feats, want) and torch.equal(out_coors, coors)
