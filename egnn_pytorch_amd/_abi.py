@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 33
+ABI_VERSION = 34
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -29,7 +29,7 @@ SYMBOLS = (
     "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32",
     "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_bwd_work_bytes", "egnn_edge_tail_bwd_f32", "egnn_edge_tail_part_floats", "egnn_edge_pool_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
     "egnn_induced_attn_f32", "egnn_token_attn_f32", "egnn_slot_prep_f32", "egnn_struct_bytes",
-    "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32", "egnn_split_scaled_both_f16", "egnn_silu_bwd_f32", "egnn_silu_bwd_drop_f32",
+    "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32", "egnn_split_scaled_both_f16", "egnn_split_scaled_colsum_rows", "egnn_silu_bwd_f32", "egnn_silu_bwd_drop_f32",
     "egnn_linear_hl_drop_f32",
     "egnn_linear_f32", "egnn_node_prep_f32", "egnn_edge_exact_f32", "egnn_edge_exact_workspace_bytes",
     "egnn_knn_select_f64", "egnn_linear_f64", "egnn_node_prep_f64", "egnn_edge_exact_f64",
@@ -271,7 +271,9 @@ def load():
     lib.egnn_absmax_f32.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
     lib.egnn_split_scaled_both_f16.restype = c_int
     lib.egnn_split_scaled_both_f16.argtypes = [c_void_p, c_int64, c_int64, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
-                                               c_void_p, c_void_p]
+                                               c_void_p, c_void_p, c_int64, c_void_p]
+    lib.egnn_split_scaled_colsum_rows.restype = c_int64
+    lib.egnn_split_scaled_colsum_rows.argtypes = [c_int64, c_int]
     lib.egnn_silu_bwd_f32.restype = c_int
     lib.egnn_silu_bwd_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
     lib.egnn_silu_bwd_drop_f32.restype = c_int

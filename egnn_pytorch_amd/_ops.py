@@ -612,16 +612,23 @@ def split_scaled(x2d, scale, transposed=False, w_image=False):
     return PackedHL(hi, lo, img_rows, kp), alloc_rows
 
 
-def split_scaled_both(x2d, scale):
-    """(plain image, transposed image) of scale * x2d from one read -- egnn_split_scaled_both_f16."""
+def split_scaled_both(x2d, scale, colsum=False):
+    """(plain image, transposed image) of scale * x2d from one read -- egnn_split_scaled_both_f16.  colsum: also the column sums of
+    x2d (cols,), a by-product of the same read: per 64-row block inside the kernel, the blocks added up in fixed order (`sum_rows`)."""
     rows, cols = x2d.shape
     kp, kpt = _kpad(cols), _kpad(rows)
     hi, lo = _packed_empty(rows, kp, x2d.device), _packed_empty(rows, kp, x2d.device)
     hit, lot = _packed_empty(cols, kpt, x2d.device), _packed_empty(cols, kpt, x2d.device)
+    lib = _abi.load()
+    parts, ld = None, (cols + 3) // 4 * 4
+    if colsum:
+        parts = empty(int(lib.egnn_split_scaled_colsum_rows(rows, kpt)), ld, dtype=torch.float32, device=x2d.device)
     with _timed("split_scaled"):
-        rc = _abi.load().egnn_split_scaled_both_f16(_ptr(x2d), x2d.stride(0), rows, cols, float(scale), _ptr(hi), _ptr(lo), kp,
-                                                    _ptr(hit), _ptr(lot), kpt, _status_ptr(x2d.device), _stream())
+        rc = lib.egnn_split_scaled_both_f16(_ptr(x2d), x2d.stride(0), rows, cols, float(scale), _ptr(hi), _ptr(lo), kp,
+                                            _ptr(hit), _ptr(lot), kpt, _status_ptr(x2d.device), _ptr(parts), ld, _stream())
     _abi.check(rc, "egnn_split_scaled_both_f16")
+    if colsum:
+        return PackedHL(hi, lo, rows, kp), PackedHL(hit, lot, cols, kpt), sum_rows(parts, 1.0 / float(scale))[:cols]
     return PackedHL(hi, lo, rows, kp), PackedHL(hit, lot, cols, kpt)
 
 
@@ -645,13 +652,18 @@ class GradOperand:
     """A gradient matrix g (R, M) prepared once for its two products: .plain = image of s g (the A operand of g @ W), .t = image of
     (s g)^T (the A operand of g^T @ x), .scale = s (a power of two, grad_scale); .zero: g is all zero / not finite."""
 
-    def __init__(self, g2d, amax=None):
+    def __init__(self, g2d, amax=None, colsum=False):
         self.shape = g2d.shape
         self.scale = grad_scale(absmax(g2d) if amax is None else amax)
         self.zero = self.scale is None
-        self.plain = self.t = None
+        self.plain = self.t = self.colsum = None
         if not self.zero and self.scale is not NONFINITE:
-            self.plain, self.t = split_scaled_both(g2d, self.scale)
+            if colsum:                       # (the column sums -- a bias gradient -- ride along with the split's read of g)
+                self.plain, self.t, self.colsum = split_scaled_both(g2d, self.scale, colsum=True)
+            else:
+                self.plain, self.t = split_scaled_both(g2d, self.scale)
+        elif colsum:
+            self.colsum = g2d.sum(dim=0)     # (all zero, or not finite: the sum says so)
 
 
 def absmax(x):
@@ -783,9 +795,9 @@ def dest_lists(idx32, b, n, k, device):
     return DestLists(ent[:length], tile_seg, order, seg)
 
 
-def sum_rows(part):
-    """Column sums of a (rows, count) fp32 array with many rows, in a fixed order, on egnn_sum_parts_f32 (which walks its parts one
-    after the other per output element: made for a handful of split-K parts): first the rows p G + g over p for each of G groups
+def sum_rows(part, scale=1.0):
+    """scale * column sums of a (rows, count) fp32 array with many rows, in a fixed order, on egnn_sum_parts_f32 (which walks its parts
+    one after the other per output element: made for a handful of split-K parts): first the rows p G + g over p for each of G groups
     (the array read as (rows / G) parts of G * count elements), then the G group sums."""
     rows, count = part.shape
     lib = _abi.load()
@@ -798,7 +810,7 @@ def sum_rows(part):
             mid = empty(g, count, dtype=torch.float32, device=part.device)
             _abi.check(lib.egnn_sum_parts_f32(_ptr(part), rows // g, g * count, 1.0, _ptr(mid), _stream()), "egnn_sum_parts_f32")
             part, rows = mid, g
-        _abi.check(lib.egnn_sum_parts_f32(_ptr(part), rows, count, 1.0, _ptr(out), _stream()), "egnn_sum_parts_f32")
+        _abi.check(lib.egnn_sum_parts_f32(_ptr(part), rows, count, float(scale), _ptr(out), _stream()), "egnn_sum_parts_f32")
     return out
 
 
@@ -943,7 +955,7 @@ def edge_bwd_pass(w, proj, idx32, gu16, gu_scale, scal, ent, b, n, k, by_dest, w
     _abi.check(rc, "egnn_edge_bwd_pass_f32")
     out = {"rows": rows[:n_rows], "amax_bits": amax_bits}
     if want_w2:
-        out["w2"] = dw2.sum(dim=0)
+        out["w2"] = dw2.sum(dim=0)          # (340 MB of per-slab partials at the north-star shape: 0.19 ms; `sum_rows` measured 0.21)
     if ws_nat is not None:
         if s_in > 1:                                          # one partial per wave (every 4th row of the array), times col_scale
             out["ws"] = (dws.view(n_slabs * 4, 4, s_in, hp)[:, 0].sum(dim=0) / col_scale[:, None]).t().contiguous()

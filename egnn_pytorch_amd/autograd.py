@@ -809,7 +809,7 @@ def _node_mlp_backward(layer, w, f, m_i, g_out, grads_by_id, drop=None, row0=0):
         in32 = torch.cat((ln.detach(), m_i), dim=-1).view(rows, dim + m)
         g2d = g_out.reshape(rows, dim).contiguous()
         z1 = _ops.linear_hl(_ops.split_f16(in32), w["W5_split"], 2 * dim, w["b5"], name="bwd_node_mlp")        # (rows, 2 dim) pre-activation
-        go = _ops.GradOperand(g2d)
+        go = _ops.GradOperand(g2d, colsum=lin6.bias.requires_grad)        # (column sums = d/d bias: by-products of the operand split)
         g_a1 = _ops.grad_nn(go, w["W6T_split"], 2 * dim, name="bwd_node_mlp")
         if z1.numel() % 4 == 0:
             a1, g_z1, bits = _ops.silu_bwd_(z1, g_a1, drop, row0)
@@ -821,14 +821,14 @@ def _node_mlp_backward(layer, w, f, m_i, g_out, grads_by_id, drop=None, row0=0):
         if lin6.weight.requires_grad:
             grads_by_id[id(lin6.weight)] += _ops.grad_tn(go, a1, name="bwd_node_mlp_w", x_operand=_ops.grad_tn_operand(a1, amax_a1))
         if lin6.bias.requires_grad:
-            grads_by_id[id(lin6.bias)] += g2d.sum(dim=0)
+            grads_by_id[id(lin6.bias)] += go.colsum
         del go, a1
-        gz = _ops.GradOperand(g_z1, amax=amax_gz)
+        gz = _ops.GradOperand(g_z1, amax=amax_gz, colsum=lin5.bias.requires_grad)
         g_in = _ops.grad_nn(gz, w["W5T_split"], dim + m, name="bwd_node_mlp")
         if lin5.weight.requires_grad:
             grads_by_id[id(lin5.weight)] += _ops.grad_tn(gz, in32, name="bwd_node_mlp_w")
         if lin5.bias.requires_grad:
-            grads_by_id[id(lin5.bias)] += g_z1.sum(dim=0)
+            grads_by_id[id(lin5.bias)] += gz.colsum
         del gz, g_z1
         g_ln = g_in[:, :dim].reshape(bc, n, dim)
         g_mi = g_in[:, dim:].reshape(bc, n, m)
@@ -1160,7 +1160,8 @@ def _backward_native(ctx, g_node, g_coors):
             if f2d.is_cuda and _GRAD_GEMM:
                 # (each matrix: one absmax, one read for its plain and transposed images; feats^T split once for both weight gradients)
                 ib, jb = getattr(gz_i, "amax_bits", None), getattr(gz_j, "amax_bits", None)
-                op_i = _ops.GradOperand(gz_i, amax=None if ib is None else _ops.bits_to_floats(ib)[0])
+                op_i = _ops.GradOperand(gz_i, amax=None if ib is None else _ops.bits_to_floats(ib)[0], colsum=True)
+                gb1 = op_i.colsum
                 op_j = _ops.GradOperand(gz_j, amax=None if jb is None else _ops.bits_to_floats(jb)[0])
                 t = _ops.grad_nn(op_i, w["WiT_split"], dim, name="bwd_dfeats")
                 t = _ops.grad_nn(op_j, w["WjT_split"], dim, residual=t, name="bwd_dfeats")
@@ -1173,8 +1174,9 @@ def _backward_native(ctx, g_node, g_coors):
                 g_feats[lo:hi_] += (gz_i @ w_i + gz_j @ w_j).view(bc, n, dim)
                 gw1[:, :dim] += _tn(gz_i, f2d)[:h]
                 gw1[:, dim:2 * dim] += _tn(gz_j, f2d)[:h]
+                gb1 = gz_i.sum(dim=0)
             gw1[:, 2 * dim:] += g_ws[:h]
-            grads_by_id[id(lin0.bias)] += gz_i.sum(dim=0)[:h]
+            grads_by_id[id(lin0.bias)] += gb1[:h]
             g_scal = g_scal.view_as(scal)
             grads_by_id[id(lin3.weight)] += g_w2[:m, :h]
             grads_by_id[id(lin3.bias)] += bias2 if bias2 is not None else gu16[:, :m].sum(dim=0)

@@ -123,13 +123,18 @@ __global__ __launch_bounds__(256) void node_prep_hl_kernel(const float* __restri
 // One workgroup = 64 X-rows x 32 X-columns through LDS; every thread emits one 16-byte chunk (8 consecutive K values of one
 // image row) per image, so that the workgroup's stores fill whole 1 KB (row block, K-tile) pieces.
 // transposed = 2: both images from one read of X (hi / lo = the plain image, hiT / loT = the transposed one).
+// colsum_parts (or NULL): row blockIdx.y of a (gridDim.y, ld_cs) array receives the tile's column sums of scale * X -- a gradient matrix's
+// column sums are the gradient of the Linear's bias, and this pass reads every element anyway (summed over the row blocks in fixed
+// order by egnn_sum_parts_f32; the scale is a power of two: exact).
 __global__ __launch_bounds__(256) void split_scaled_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int cols, float scale,
                                                            int transposed, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int nkt,
                                                            int64_t img_rows_p, _Float16* __restrict__ hiT, _Float16* __restrict__ loT, int nktT,
-                                                           int64_t img_rows_pT, int32_t* __restrict__ status)
+                                                           int64_t img_rows_pT, int32_t* __restrict__ status,
+                                                           float* __restrict__ colsum_parts = nullptr, int64_t ld_cs = 0)
 {
     typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
     __shared__ float tile[64][33];
+    __shared__ float csum[8][32];
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.y * 64;
     const int c0 = blockIdx.x * 32;
@@ -140,6 +145,20 @@ __global__ __launch_bounds__(256) void split_scaled_kernel(const float* __restri
         tile[r][c] = v;
     }
     __syncthreads();
+    if (colsum_parts) {                       // (uniform branch) rows 8 q .. 8 q + 7 of column c, then the eight partial sums in order
+        const int c = tid & 31, q = tid >> 5;
+        float sacc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sacc += tile[8 * q + u][c];
+        csum[q][c] = sacc;
+        __syncthreads();
+        if (tid < 32 && c0 + tid < ld_cs) {
+            float t = csum[0][tid];
+#pragma unroll
+            for (int u = 1; u < 8; ++u) t += csum[u][tid];
+            colsum_parts[(int64_t)blockIdx.y * ld_cs + c0 + tid] = t;
+        }
+    }
     for (int pass = 0; pass < (transposed == 2 ? 2 : 1); ++pass) {
     const bool tr = transposed == 2 ? pass == 1 : transposed != 0;
     _Float16* ohi = (transposed == 2 && pass == 1) ? hiT : hi;
@@ -325,9 +344,16 @@ extern "C" int egnn_split_scaled_f16(const float* X, int64_t ldx, int64_t rows, 
     return egnn_launch_status();
 }
 
-extern "C" int egnn_split_scaled_both_f16(const float* X, int64_t ldx, int64_t rows, int cols, float scale, void* hi, void* lo, int Kp,
-                                          void* hiT, void* loT, int KpT, int32_t* status, void* stream)
+extern "C" int64_t egnn_split_scaled_colsum_rows(int64_t rows, int KpT)
 {
+    const int64_t rows32 = (rows + 31) / 32 * 32;
+    return ((rows32 > KpT ? rows32 : KpT) + 63) / 64;
+}
+
+extern "C" int egnn_split_scaled_both_f16(const float* X, int64_t ldx, int64_t rows, int cols, float scale, void* hi, void* lo, int Kp,
+                                          void* hiT, void* loT, int KpT, int32_t* status, float* colsum_parts, int64_t ld_colsum, void* stream)
+{
+    if (colsum_parts && ld_colsum < cols) return EGNN_E_SHAPE;
     if (!X || !hi || !lo || !hiT || !loT) return EGNN_E_NULLPTR;
     if (rows <= 0 || cols <= 0 || ldx < cols || Kp < cols || (Kp % 32) != 0 || KpT < rows || (KpT % 32) != 0 || !(scale > 0.f) || !(scale < __builtin_inff())) return EGNN_E_SHAPE;
     // the grid covers both padded images: X rows up to max(rows | 32, KpT), X columns up to max(Kp, cols | 32)
@@ -337,7 +363,7 @@ extern "C" int egnn_split_scaled_both_f16(const float* X, int64_t ldx, int64_t r
     if (gy > 65535 || gx > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
     hipLaunchKernelGGL(split_scaled_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, static_cast<hipStream_t>(stream), X, ldx, rows, cols,
                        scale, 2, static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), Kp / 16, rows32,
-                       static_cast<_Float16*>(hiT), static_cast<_Float16*>(loT), KpT / 16, cols32, status);
+                       static_cast<_Float16*>(hiT), static_cast<_Float16*>(loT), KpT / 16, cols32, status, colsum_parts, ld_colsum);
     return egnn_launch_status();
 }
 

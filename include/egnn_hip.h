@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 33
+#define EGNN_ABI_VERSION 34
 
 enum {
     EGNN_OK = 0,
@@ -194,9 +194,14 @@ int egnn_linear_hl_drop_f32(const void* A_hi, const void* A_lo, const void* W_hi
 int egnn_split_scaled_f16(const float* X, int64_t ldx, int64_t rows, int cols, float scale, int transposed, void* hi, void* lo, int Kp,
                           int32_t* status, void* stream);
 /* both images of egnn_split_scaled_f16 from one read of X: hi / lo (`rows` image rows, K = cols padded to Kp) and hiT / loT (`cols` image
- * rows, K = rows padded to KpT) -- a gradient matrix enters one NN product (d/d input) and one TN product (d/d weight). */
+ * rows, K = rows padded to KpT) -- a gradient matrix enters one NN product (d/d input) and one TN product (d/d weight).
+ * colsum_parts (or NULL; ABI 34): a (egnn_split_scaled_colsum_rows(rows, KpT), ld_colsum >= cols) fp32 array; row r receives the sums of
+ * scale * X over X rows 64 r .. 64 r + 63 per column (columns >= cols up to min(ld_colsum, the grid's cover): 0) -- the column sums of
+ * a gradient matrix are the gradient of the Linear's bias and this pass reads every element anyway; egnn_sum_parts_f32 adds the rows
+ * up in fixed order (scale: a power of two, so 1 / scale there is exact). */
 int egnn_split_scaled_both_f16(const float* X, int64_t ldx, int64_t rows, int cols, float scale, void* hi, void* lo, int Kp,
-                               void* hiT, void* loT, int KpT, int32_t* status, void* stream);
+                               void* hiT, void* loT, int KpT, int32_t* status, float* colsum_parts, int64_t ld_colsum, void* stream);
+int64_t egnn_split_scaled_colsum_rows(int64_t rows, int KpT);
 /* backward of an MLP's SiLU (node_mlp, egnn_pytorch.py:196-201) in one pass: a_out = SiLU(z), gz_out = g * SiLU'(z); count % 4 == 0,
  * 16-byte aligned; a_out may be z and gz_out may be g (element-wise); amax_bits (2 words) or NULL: the bit patterns of max |a_out| and
  * max |gz_out| (egnn_absmax_f32's contract) -- both are operands of the next gradient GEMMs. */

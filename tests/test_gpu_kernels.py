@@ -617,6 +617,18 @@ def test_split_scaled_both_equals_the_two_single_splits(rows, cols):
     for a, b in ((plain, p1), (tr, t1)):
         assert a.kp == b.kp and a.rows == b.rows
         assert torch.equal(a.hi, b.hi) and torch.equal(a.lo, b.lo)
+    # ... and, on request, the column sums of X as a by-product of the same read (a bias gradient): same images, sums against float64,
+    # bit-reproducible (per 64-row block in the kernel, blocks added in fixed order)
+    plain2, tr2, cs = _ops.split_scaled_both(x, scale, colsum=True)
+    for a, b in ((plain2, p1), (tr2, t1)):
+        assert torch.equal(a.hi, b.hi) and torch.equal(a.lo, b.lo)
+    want = x.double().sum(dim=0)
+    assert cs.shape == (cols,)
+    assert float((cs.double() - want).abs().max()) <= 2e-6 * float(x.double().abs().sum(dim=0).max())
+    assert torch.equal(cs, _ops.split_scaled_both(x, scale, colsum=True)[2])
+    op = _ops.GradOperand(x, colsum=True)
+    assert torch.equal(op.colsum, cs)
+    assert float(_ops.GradOperand(torch.zeros_like(x), colsum=True).colsum.abs().max()) == 0.0
 
 
 def test_silu_bwd_matches_autograd():
