@@ -367,6 +367,12 @@ def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32
     split_cols: columns [0, split_cols) of C hold (fp16 hi, fp16 lo) words instead of fp32 values."""
     whi, wlo, inv, w_rows = wsplit
     m, kp = a.rows, a.kp
+    kp_a = 0
+    if whi.numel() != w_rows * kp:
+        # the A image is wider than the contraction: the product runs over its first kp columns (egnn_linear_hl_lda_f32 -- the
+        # projection reads feats out of the [feats | m_i] image of node_mlp's input)
+        kp_a, kp = kp, whi.numel() // w_rows
+        assert kp < kp_a and kp % 32 == 0 and drop is None
     assert whi.numel() == w_rows * kp and w_rows >= n
     dev = a.hi.device
     c = empty(m, n, dtype=torch.float32, device=dev) if out_f32 else None
@@ -381,7 +387,12 @@ def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32
         assert residual.shape == (m, n) and residual.is_contiguous()
         ldr = n
     with _timed(name):
-        if drop is None:
+        if kp_a:
+            rc = _abi.load().egnn_linear_hl_lda_f32(_ptr(a.hi), _ptr(a.lo), kp_a, _ptr(whi), _ptr(wlo), float(inv), _ptr(bias),
+                                                    _ptr(residual), ldr, _ptr(c), n, _ptr(out.hi) if out else None,
+                                                    _ptr(out.lo) if out else None, kp_out, m, n, kp, w_rows, act, int(split_cols),
+                                                    _status_ptr(dev), _stream())
+        elif drop is None:
             rc = _abi.load().egnn_linear_hl_f32(_ptr(a.hi), _ptr(a.lo), _ptr(whi), _ptr(wlo), float(inv), _ptr(bias),
                                                 _ptr(residual), ldr, _ptr(c), n, _ptr(out.hi) if out else None,
                                                 _ptr(out.lo) if out else None, kp_out, m, n, kp, w_rows, act, int(split_cols),

@@ -63,7 +63,7 @@ __device__ __forceinline__ void linear_hl_body(
     const float* __restrict__ bias, const float* __restrict__ R, int64_t ldr,
     float* __restrict__ C, int64_t ldc, _Float16* __restrict__ Chi, _Float16* __restrict__ Clo, int nkt_out,
     int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, int32_t* __restrict__ status, char* smem, const int bid,
-    const int kt0 = 0, const int kt_count = -1, const DropArgs drop = DropArgs{0u, 0u, 1.f})
+    const int kt0 = 0, const int kt_count = -1, const DropArgs drop = DropArgs{0u, 0u, 1.f}, const int a_nkt = 0)
 {
     using C_ = Cfg<CFG>;
     constexpr int BM = C_::BM, BN = C_::BN, TI = C_::TI, TJ = C_::TJ, STAGES = C_::STAGES;
@@ -121,7 +121,8 @@ __device__ __forceinline__ void linear_hl_body(
                 base = e < WRB ? Whi : Wlo;
                 off = 2 * AARR + (e < WRB ? 0 : WARR) + blk * 32 * ROWB;
             }
-            src[j] = base + rb * nkt * 512 + lane * 8;
+            // (a_nkt: K-tiles per row block of the A image when it is wider than the contraction -- egnn_linear_hl_lda_f32)
+            src[j] = base + rb * ((d < 2 * ARB && a_nkt) ? a_nkt : nkt) * 512 + lane * 8;
             dst[j] = off;
         }
     }
@@ -418,11 +419,11 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
     const float* __restrict__ bias, const float* __restrict__ R, int64_t ldr,
     float* __restrict__ C, int64_t ldc, _Float16* __restrict__ Chi, _Float16* __restrict__ Clo, int nkt_out,
-    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, int32_t* __restrict__ status, const DropArgs drop)
+    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, int32_t* __restrict__ status, const DropArgs drop, const int a_nkt)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // STAGES x BUF
     linear_hl_body<CFG, ACT, HAS_RES, DROP>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, ntm, ntn,
-                                            out_scale, split_cols, status, smem, blockIdx.x, 0, -1, drop);
+                                            out_scale, split_cols, status, smem, blockIdx.x, 0, -1, drop, a_nkt);
 }
 
 // Split-K: blockIdx.y = part; the part's partial product goes to its own (M, ldc) slab (summed afterwards in fixed order)
@@ -455,7 +456,7 @@ template <int CFG, int ACT, bool HAS_RES>
 int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, const _Float16* Wlo,
                   const float* bias, const float* R, int64_t ldr, float* C, int64_t ldc, _Float16* Chi, _Float16* Clo,
                   int nkt_out, int64_t M, int N, int Kp, float out_scale, int split_cols, int32_t* status, hipStream_t s,
-                  const DropArgs drop = DropArgs{0u, 0u, 1.f})
+                  const DropArgs drop = DropArgs{0u, 0u, 1.f}, const int a_nkt = 0)
 {
     using C_ = Cfg<CFG>;
     const int64_t ntm = (M + C_::BM - 1) / C_::BM;
@@ -470,7 +471,7 @@ int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
             hipLaunchKernelGGL((linear_hl_kernel<CFG, ACT, HAS_RES, true>), dim3((unsigned)(ntm * ntn)), dim3(C_::WM * C_::WN * 64), lds, s,
-                               Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale, split_cols, status, drop);
+                               Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale, split_cols, status, drop, a_nkt);
             return egnn_launch_status();
         }
     } else if (drop.thr) {
@@ -480,7 +481,7 @@ int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((linear_hl_kernel<CFG, ACT, HAS_RES>), dim3((unsigned)(ntm * ntn)), dim3(C_::WM * C_::WN * 64), lds, s,
-                       Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale, split_cols, status, drop);
+                       Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale, split_cols, status, drop, a_nkt);
     return egnn_launch_status();
 }
 
@@ -498,14 +499,14 @@ template <int ACT, bool HAS_RES>
 int launch_hl(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, const _Float16* Wlo,
               const float* bias, const float* R, int64_t ldr, float* C, int64_t ldc, _Float16* Chi, _Float16* Clo,
               int nkt_out, int64_t M, int N, int Kp, float out_scale, int w_rows, int split_cols, int32_t* status, hipStream_t s,
-              const DropArgs drop = DropArgs{0u, 0u, 1.f})
+              const DropArgs drop = DropArgs{0u, 0u, 1.f}, const int a_nkt = 0)
 {
     // Large problems (enough 256 x 128 tiles to fill the chip twice) use the larger tile; small ones the 128 x 128 tile.
     constexpr int BIG = EGNN_HL_CFG;
     const int64_t tbig = ((M + Cfg<BIG>::BM - 1) / Cfg<BIG>::BM) * ((N + Cfg<BIG>::BN - 1) / Cfg<BIG>::BN);
     if (BIG != 0 && tbig >= 512 && w_rows >= (N + Cfg<BIG>::BN - 1) / Cfg<BIG>::BN * Cfg<BIG>::BN)
-        return launch_hl_cfg<BIG, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, split_cols, status, s, drop);
-    return launch_hl_cfg<0, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, split_cols, status, s, drop);
+        return launch_hl_cfg<BIG, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, split_cols, status, s, drop, a_nkt);
+    return launch_hl_cfg<0, ACT, HAS_RES>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, out_scale, split_cols, status, s, drop, a_nkt);
 }
 
 }  // namespace
@@ -513,8 +514,10 @@ int launch_hl(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, con
 static int linear_hl_entry(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo,
                            float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
                            float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
-                           int w_rows, int act, int split_cols, int32_t* status, void* stream, const DropArgs drop)
+                           int w_rows, int act, int split_cols, int32_t* status, void* stream, const DropArgs drop, const int Kp_a = 0)
 {
+    if (Kp_a && (Kp_a < Kp || (Kp_a % 32) != 0)) return EGNN_E_SHAPE;
+    const int a_nkt = Kp_a / 16;
     if (!A_hi || !A_lo || !W_hi || !W_lo) return EGNN_E_NULLPTR;
     if (!C && !C_hi) return EGNN_E_NULLPTR;
     if ((C_hi == nullptr) != (C_lo == nullptr)) return EGNN_E_NULLPTR;
@@ -536,12 +539,12 @@ static int linear_hl_entry(const void* A_hi, const void* A_lo, const void* W_hi,
     _Float16 *ch = static_cast<_Float16*>(C_hi), *cl = static_cast<_Float16*>(C_lo);
     const int nkt_out = Kp_out / 16;
     if (act == 0) {
-        if (residual) return launch_hl<0, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s, drop);
-        return launch_hl<0, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s, drop);
+        if (residual) return launch_hl<0, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s, drop, a_nkt);
+        return launch_hl<0, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s, drop, a_nkt);
     }
-    if (act == 2) return launch_hl<2, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s, drop);
-    if (residual) return launch_hl<1, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s, drop);
-    return launch_hl<1, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s, drop);
+    if (act == 2) return launch_hl<2, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s, drop, a_nkt);
+    if (residual) return launch_hl<1, true>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s, drop, a_nkt);
+    return launch_hl<1, false>(ah, al, wh, wl, bias, residual, ldr, C, ldc, ch, cl, nkt_out, M, N, Kp, w_inv_scale, w_rows, split_cols, status, s, drop, a_nkt);
 }
 
 extern "C" int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo,
@@ -551,6 +554,17 @@ extern "C" int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void
 {
     return linear_hl_entry(A_hi, A_lo, W_hi, W_lo, w_inv_scale, bias, residual, ldr, C, ldc, C_hi, C_lo, Kp_out, M, N, Kp, w_rows, act,
                            split_cols, status, stream, DropArgs{0u, 0u, 1.f});
+}
+
+// ... with the A image wider than the contraction: Kp_a (>= Kp, % 32 == 0) is the K padding the image was written with, the product
+// runs over its first Kp columns (the projection reads feats out of the [feats | m_i] image of node_mlp's input: no second image)
+extern "C" int egnn_linear_hl_lda_f32(const void* A_hi, const void* A_lo, int Kp_a, const void* W_hi, const void* W_lo,
+                                      float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
+                                      float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
+                                      int w_rows, int act, int split_cols, int32_t* status, void* stream)
+{
+    return linear_hl_entry(A_hi, A_lo, W_hi, W_lo, w_inv_scale, bias, residual, ldr, C, ldc, C_hi, C_lo, Kp_out, M, N, Kp, w_rows, act,
+                           split_cols, status, stream, DropArgs{0u, 0u, 1.f}, Kp_a);
 }
 
 extern "C" int egnn_linear_hl_drop_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo,

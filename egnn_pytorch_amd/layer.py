@@ -40,6 +40,7 @@ _EDGE_ALGO = int(os.environ.get("EGNN_EDGE_ALGO", "0"))
 # otherwise it raises EGNNRangeError.  "exact": always the plain-fp32 kernels (inference only).
 _PRECISION = os.environ.get("EGNN_PRECISION", "fast")
 _DENSE_PW = os.environ.get("EGNN_DENSE_PW", "1") != "0"            # dense layers with N % 32 == 0 on the wave-per-node edge kernel
+_SHARED_FEATS_IMAGE = os.environ.get("EGNN_SHARED_FEATS_IMAGE", "1") != "0"   # 0: a second packed image of feats for the projection
 _LATE_SELECT = os.environ.get("EGNN_LATE_SELECT", "1") != "0"      # node-level launches before the neighbour selection (see _forward_hip)
 _exact_now = contextvars.ContextVar("egnn_exact_now", default=False)       # per thread / context: concurrent forwards do not see each other's
 _warned_rerun = False
@@ -407,8 +408,14 @@ class EGNN(nn.Module):
             if self.node_mlp is not None:
                 # one pass over feats: its (hi, lo) split for the projection AND [LayerNorm(feats) | 0] for node_mlp
                 # (egnn_pytorch.py:335-336); the edge pass drops m_i into the zero columns
-                node_in, feats_hl = _ops.node_prep_hl(feats2d, None, w.get("gamma"), w.get("beta"), w.get("ln_eps", 1e-5),
-                                                      self.m_dim, with_raw=True)
+                # (node_norm = Identity, the reference's default: the two are the same values -- the projection reads the first
+                # `dim` columns of the [feats | 0] image, egnn_linear_hl_lda_f32; 134 MB less to write at the north-star shape)
+                shared = _SHARED_FEATS_IMAGE and w.get("gamma") is None
+                if shared:
+                    node_in = feats_hl = _ops.node_prep_hl(feats2d, None, None, None, 1e-5, self.m_dim)
+                else:
+                    node_in, feats_hl = _ops.node_prep_hl(feats2d, None, w.get("gamma"), w.get("beta"), w.get("ln_eps", 1e-5),
+                                                          self.m_dim, with_raw=True)
             else:
                 feats_hl = _ops.split_f16(feats2d)
             proj = _ops.linear_hl(feats_hl, w["Wcat_split"], 2 * hp, w["bcat"], name="node_proj",

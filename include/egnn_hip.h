@@ -171,6 +171,13 @@ int egnn_linear_hl_f32(const void* A_hi, const void* A_lo, const void* W_hi, con
                        float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
                        float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
                        int w_rows, int act, int split_cols, int32_t* status, void* stream);
+/* The same with an A image that is wider than the contraction (ABI 34): A_hi / A_lo were written with K padding Kp_a (>= Kp, % 32 == 0),
+ * the product runs over their first Kp columns.  The projection (egnn_pytorch.py:279: feats enters edge_mlp) reads feats out of the
+ * [feats | m_i] image that egnn_node_prep_hl writes for node_mlp's first Linear when node_norm is the identity: one image, not two. */
+int egnn_linear_hl_lda_f32(const void* A_hi, const void* A_lo, int Kp_a, const void* W_hi, const void* W_lo,
+                           float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
+                           float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
+                           int w_rows, int act, int split_cols, int32_t* status, void* stream);
 /* The same with training-mode dropout between the Linear and the activation (node_mlp, egnn_pytorch.py:196-201): element (row, col) of
  * A W^T + bias is kept iff the hash of [seed, site = node, row, col] (csrc/egnn_common.h) is >= drop_thr and multiplied by drop_inv_keep,
  * else zeroed. */
