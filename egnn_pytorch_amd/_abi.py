@@ -97,6 +97,7 @@ class EdgeTailExactArgs(Structure):
         ("W3", c_void_p), ("b3", c_void_p), ("W4", c_void_p), ("b4", c_void_p), ("scale", c_void_p), ("gate_w", c_void_p), ("gate_b", c_void_p),
         ("gU", c_void_p), ("g_rel", c_void_p), ("ghid_t", c_void_p), ("a3_t", c_void_p), ("mm_t", c_void_p), ("m0_t", c_void_p),
         ("g_w", c_void_p), ("g_scale", c_void_p), ("g_gate", c_void_p),
+        ("drop_thr", c_uint32), ("drop_seed", c_uint32), ("drop_inv_keep", c_float), ("drop_eid0", c_int64),
     ]
 
 

@@ -481,12 +481,13 @@ def edge_exact_node_sums(dz_t, nodes, k, order, seg):
     return gpi, gpi_t, gpj, gpj_t
 
 
-def edge_tail_exact(u, coors, idx32, pair_mask, g_coors_out, g_msum, w3, b3, w4, b4, scale, eps, clamp, gate, b, n, k):
+def edge_tail_exact(u, coors, idx32, pair_mask, g_coors_out, g_msum, w3, b3, w4, b4, scale, eps, clamp, gate, b, n, k, drop=None, eid0=0):
     """egnn_edge_tail_exact_bwd_f32 / _f64: the per-edge chain behind u in closed form for any head width <= 64 / coordinate dimension,
     in u's dtype.  u (E, m); coors (B, N, C); g_coors_out (B N, C); g_msum (B N, m) or None; w3 .. b4 = coors_mlp's tensors or None
     (update_coors=False); scale = coors_norm.scale or None; gate = (weight (m), bias (1)) or None.  Returns a dict: gU (E, m), g_rel_t
     (C, E) -- transposed: its per-node sums come from egnn_edge_exact_node_sums_* -- and the transposed operands of the parameter
-    gradients ghid_t, a3_t (4m, E), mm_t, m0_t (m, E), g_w, g_scale, g_gate (E)."""
+    gradients ghid_t, a3_t (4m, E), mm_t, m0_t (m, E), g_w, g_scale, g_gate (E).  drop = (p, seed), eid0: training-mode dropout in
+    coors_mlp -- the forward's hash mask of edge rows eid0 .. re-evaluated."""
     e, m = u.shape
     dt, dev = u.dtype, u.device
     cdim = coors.shape[-1]
@@ -518,6 +519,9 @@ def edge_tail_exact(u, coors, idx32, pair_mask, g_coors_out, g_msum, w3, b3, w4,
         out.update(m0_t=empty(m, e, dtype=dt, device=dev), g_gate=empty(e, dtype=dt, device=dev))
         a.m0_t, a.g_gate = out["m0_t"].data_ptr(), out["g_gate"].data_ptr()
     a.gU, a.g_rel, a.mm_t = out["gU"].data_ptr(), out["g_rel_t"].data_ptr(), out["mm_t"].data_ptr()
+    if drop is not None:
+        from . import _dropout
+        a.drop_thr, a.drop_seed, a.drop_inv_keep, a.drop_eid0 = _dropout.threshold(drop[0]), int(drop[1]), _dropout.inv_keep(drop[0]), int(eid0)
     lib = _abi.load()
     f64 = dt == torch.float64
     with _timed("edge_tail_exact"):

@@ -7,7 +7,7 @@ Forward  = the HIP path (neighbour selection, fused edge pass, split-f16 GEMMs -
            graph is being recorded.
 Backward, three paths:
   `_backward_native` -- fp32 (half / bfloat16 modules through an fp32 shadow), every shape the fused forward kernels cover (m_dim <= 64,
-           coordinate dimension 1 .. 8, up to 16 per-edge scalars, training-mode dropout for the standard layer):
+           coordinate dimension 1 .. 8, up to 16 per-edge scalars; training-mode dropout with up to five per-edge scalars):
              * behind u: node_norm / node_mlp on the split-f16 GEMMs (`_node_mlp_backward`), the per-edge chain (second SiLU, gate, masks,
                coors_mlp, CoorsNorm, clamp, coordinate update, pooling) in closed form on egnn_edge_tail_bwd_f32 (csrc/edge_tail.hip;
                `tail_edge_backward` is its specification) for m_dim <= 16 and 3-D coordinates, through autograd on E x m tensors
@@ -22,8 +22,8 @@ Backward, three paths:
            more than 16 per-edge scalars / 8 coordinates / 64 message channels.  The per-edge tail through autograd on E x m tensors,
            the E x H work on egnn_edge_exact_bwd_f32 / _f64 + egnn_edge_exact_node_sums_* (csrc/edge_exact_bwd.hip), every contraction on
            the exact GEMMs (egnn_linear_f32 / egnn_linear_f64), in the arithmetic of the forward.
-  `_backward_recompute` -- what is left: training-mode dropout outside the standard layer (masks re-evaluated by the torch twin of the
-           kernels' hash), more per-edge scalars than the exact backward keeps in LDS (80 in fp32, 40 in float64), EGNN_NATIVE_BACKWARD=0 /
+  `_backward_recompute` -- what is left: training-mode dropout with more than five per-edge scalars (masks re-evaluated by the torch
+           twin of the kernels' hash), more per-edge scalars than the exact backward keeps in LDS (80 in fp32, 40 in float64), EGNN_NATIVE_BACKWARD=0 /
            EGNN_NATIVE_BACKWARD_EXACT=0, CPU tensors (the tests); also the native paths' reference in the tests.  The whole layer
            re-evaluated a few graphs at a time as a differentiable chain of ATen ops over the neighbour list the HIP kernel selected,
            factorised like the forward, and differentiated by autograd.
@@ -325,11 +325,12 @@ def _chunk_graphs(layer, n, k, batch):
 
 
 def _dropout_native_ok(layer):
-    """Training-mode dropout on the native backward: the kernels that re-evaluate the forward's hash masks are built for the standard
-    layer with up to five per-edge scalars (egnn_edge_bwd_pass_f32 with drop_thr, the matrix-core tail kernel,
-    egnn_silu_bwd_drop_f32); everything else differentiates the masked layer on the recompute path."""
-    return (_TAIL_KERNEL and _TAIL_REDUCE and _GRAD_GEMM and _FUSED_SPLIT == "dest"
-            and 2 * layer.fourier_features + 1 + layer.edge_dim <= 5 and layer.m_dim <= 16
+    """Training-mode dropout on the native backward: the kernels that re-evaluate the forward's hash masks (egnn_edge_bwd_pass_f32 with
+    drop_thr, the two tail kernels, egnn_silu_bwd_drop_f32) carry up to five per-edge scalars; heads up to 64 channels and coordinate
+    dimensions up to 8 since round 5 (the generic tail kernel re-evaluates coors_mlp's mask); everything else differentiates the masked
+    layer on the recompute path."""
+    return (_TAIL_KERNEL and _TAIL_REDUCE and _GRAD_GEMM and _FUSED_SPLIT == "dest" and _TAIL_GENERIC
+            and 2 * layer.fourier_features + 1 + layer.edge_dim <= 5 and layer.m_dim <= 64
             and layer.coors_mlp is not None and layer.node_mlp is not None and layer.dim % 2 == 0
             and os.environ.get("EGNN_TAIL_SCALAR", "0") != "1" and os.environ.get("EGNN_BWD_DROP_NATIVE", "1") != "0")
 
@@ -342,14 +343,14 @@ class EGNNFunction(torch.autograd.Function):
         # the native backward computes in fp32 like the forward: float64 / bfloat16 / float16 modules and inputs pass through
         # the same boundary conversion (gradients are returned in the callers' dtypes)
         # training-mode dropout: the forward kernels draw their masks from a hash of (seed, site, row, unit); the backward re-evaluates
-        # the layer with the same masks (egnn_pytorch_amd/_dropout.py) on the recompute path
+        # the same masks -- inside its kernels (`_dropout_native_ok`) or on the recompute path (egnn_pytorch_amd/_dropout.py)
         drop = None
         if layer.dropout_active():
             from . import _dropout
             drop = (layer.dropout_p, _dropout.draw_seed())
         # (the E x H work of every shape the forward kernels cover -- m_dim <= 64, coordinate dimension 1 .. 8 -- is native; the per-edge
         # chain behind u has its closed-form kernel for m_dim <= 16 and 3-D coordinates and goes through autograd on E x m tensors otherwise)
-        native = (_NATIVE and layer.m_dim <= 64 and coors.shape[-1] <= 8 and (drop is None or (_dropout_native_ok(layer) and coors.shape[-1] == 3))
+        native = (_NATIVE and layer.m_dim <= 64 and coors.shape[-1] <= 8 and (drop is None or _dropout_native_ok(layer))
                   and 2 * layer.fourier_features + 1 + layer.edge_dim <= 16
                   and not layer.float64_kernels()            # (a float64 module: float64 forward kernels, float64 recompute backward)
                   and not _exact_active())                   # (the wide-range re-run: plain-fp32 forward kernels, plain-fp32 recompute backward)
@@ -485,7 +486,7 @@ def _node_mlp_backward_exact(layer, f2d, m_i, g_out, grads):
     return g_f, g_in[:, dim:].contiguous()
 
 
-def _tail_closed_form(layer, u2d, c0, i32, pm, g_coors_chunk, g_msum, grads, dl, b, n, k):
+def _tail_closed_form(layer, u2d, c0, i32, pm, g_coors_chunk, g_msum, grads, dl, b, n, k, drop=None, eid0=0):
     """The per-edge chain behind u on egnn_edge_tail_exact_bwd_* (csrc/edge_exact_bwd.hip; `tail_edge_backward` is the specification)
     in u2d's dtype, its parameter gradients contracted on the exact GEMMs (the kernel leaves their operands transposed: the edges are the
     K dimension).  Returns gU (E, m) and d loss / d coors of this part (B, N, C): x_i - x_j reaches the coordinates at the source (sum
@@ -501,7 +502,7 @@ def _tail_closed_form(layer, u2d, c0, i32, pm, g_coors_chunk, g_msum, grads, dl,
                                None if cm is None else cm[0].weight, None if cm is None else cm[0].bias,
                                None if cm is None else cm[3].weight, None if cm is None else cm[3].bias,
                                layer.coors_norm.scale if norm else None, layer.coors_norm.eps if norm else 0.0,
-                               layer.coor_weights_clamp_value, gate, b, n, k)
+                               layer.coor_weights_clamp_value, gate, b, n, k, drop, eid0)
     one = lambda v: v.view(1, e)                                                # noqa: E731
     if cm is not None:
         grads[id(cm[0].weight)] += _ops.linear_f32(out["ghid_t"], out["mm_t"], m, e, name="bwd_exact_tail")           # g_hid^T m
@@ -1061,7 +1062,7 @@ def _backward_native(ctx, g_node, g_coors):
                 g_coors_in[lo:hi_] += g_coors[lo:hi_]                              # (the residual; g_rel reaches the coordinates below)
                 if i64 is not None:
                     dest_lists = _ops.dest_lists(i32, bc, n, k, feats.device)                  # (shared with the E x H passes below)
-        elif f0.is_cuda and _TAIL_GENERIC and _GRAD_GEMM and drop is None and m <= 64:
+        elif f0.is_cuda and _TAIL_GENERIC and _GRAD_GEMM and m <= 64:
             # ---- 1. behind u for the heads of 17 .. 64 channels and the other coordinate dimensions (round 5): the pooled messages on
             # E x m tensors, node_mlp on the split-f16 GEMMs, the per-edge chain in closed form on egnn_edge_tail_exact_bwd_f32 (one
             # thread per edge; csrc/edge_exact_bwd.hip) with its parameter gradients on the exact-fp32 GEMM
@@ -1076,7 +1077,7 @@ def _backward_native(ctx, g_node, g_coors):
                 g_msum = None
                 if layer.node_mlp is not None:
                     f = f0.detach().requires_grad_(True)
-                    g_f, g_mi = _node_mlp_backward(layer, w, f, m_i, g_node[lo:hi_], grads_by_id, None, lo * n)
+                    g_f, g_mi = _node_mlp_backward(layer, w, f, m_i, g_node[lo:hi_], grads_by_id, drop, lo * n)
                     g_feats[lo:hi_] += g_f
                     if layer.m_pool_method == "mean":
                         g_mi = (g_mi / cnt.clamp(min=1e-8)).masked_fill(cnt == 0, 0.0) if cnt is not None else g_mi / k
@@ -1086,7 +1087,7 @@ def _backward_native(ctx, g_node, g_coors):
                 g_coors_in[lo:hi_] += g_coors[lo:hi_]
                 dest_lists = _ops.dest_lists(i32, bc, n, k, feats.device)
                 g_u, g_c = _tail_closed_form(layer, u4.reshape(ec, m).contiguous(), c0, i32, pm, g_coors[lo:hi_], g_msum, grads_by_id,
-                                             dest_lists, bc, n, k)
+                                             dest_lists, bc, n, k, drop, lo * n * k)
                 g_coors_in[lo:hi_] += g_c
                 gu16 = torch.zeros(ec, mp, dtype=torch.float32, device=feats.device)
                 gu16[:, :m] = g_u
@@ -1126,8 +1127,8 @@ def _backward_native(ctx, g_node, g_coors):
             sc2 = scal.detach().reshape(ec, s_in).contiguous()
             contract = _edge_contract_fused
             proj = None if proj_all is None else proj_all[lo * n:hi_ * n]
-            if drop is not None:
-                assert fused and tail_kernel and reduce                                # (_dropout_native_ok: nothing else keeps u)
+            if drop is not None and mp == 16:
+                assert fused                                                           # (_dropout_native_ok)
                 gz_i, gz_j, g_ws, g_scal, g_w2 = contract(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, bc, n, k, pi_split, dest_lists, proj,
                                                           drop, lo * n * k)
             elif mp == 16:
@@ -1146,7 +1147,7 @@ def _backward_native(ctx, g_node, g_coors):
                         w["W2Th"], w["w2_block"] = w["W2Th_blocks"][blk], blk   # (in place: what the passes cache in `w` -- bwd_pads -- survives;
                                                                                 #  w2_block: read by the CPU tests' kernel emulation)
                         parts.append(contract(layer, w, f2d, c0, e0, sc2, i32, gu16[:, 16 * blk:16 * blk + 16].contiguous(), gu_scale, w_s, bc, n,
-                                              k, pi_split, dest_lists, proj))
+                                              k, pi_split, dest_lists, proj, drop, lo * n * k))       # (the mask of z: the same for every block)
                 finally:
                     w["W2Th"] = w["W2Th_blocks"][0]
                     w.pop("w2_block", None)
@@ -1212,7 +1213,7 @@ def _backward_native(ctx, g_node, g_coors):
 
 def _backward_recompute(ctx, g_node, g_coors):
     """The pure-ATen backward: chunked recompute of the whole layer through autograd (module docstring).  Used where neither native
-    path applies -- training-mode dropout outside the standard layer, more per-edge scalars than `_backward_exact` carries, CPU tensors,
+    path applies -- training-mode dropout with more than five per-edge scalars, more per-edge scalars than `_backward_exact` carries, CPU tensors,
     the EGNN_NATIVE_BACKWARD* switches -- and as the native paths' reference in the tests."""
     layer = ctx.layer
     feats, coors, edges, mask, idx, rank = _unpack(ctx)

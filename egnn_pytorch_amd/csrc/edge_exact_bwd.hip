@@ -226,6 +226,9 @@ struct XtArgs {
     const uint8_t* pair_mask;
     T eps, clamp;
     T *gU, *g_rel, *ghid_t, *a3_t, *mm_t, *m0_t, *g_w, *g_scale, *g_gate;
+    uint32_t drop_thr, drop_seed;
+    float drop_inv_keep;
+    int64_t drop_eid0;
 };
 
 template <typename T, int MB>
@@ -267,8 +270,10 @@ __global__ __launch_bounds__(XB_THREADS) void edge_tail_exact_bwd_kernel(const X
     for (int c = 0; c < MB; ++c) gm[c] = (c < m_dim && p.g_msum && keep) ? p.g_msum[(size_t)node * m_dim + c] : (T)0;
 
     T g_w = (T)0;
+    // (training-mode dropout between coors_mlp's Linear and its SiLU: the forward's hash mask of this edge's row, per hidden unit)
+    const uint32_t ckey = p.drop_thr ? egnn_drop_base(p.drop_seed, EGNN_DROP_SITE_COORS, (uint32_t)(q + p.drop_eid0)) : 0u;
     if (p.W3) {
-        // coors_mlp forward (:203-208): w = W4 SiLU(W3 m + b3) + b4
+        // coors_mlp forward (:203-208): w = W4 SiLU(drop(W3 m + b3)) + b4
         T w = p.b4[0];
         for (int r = 0; r < hid; ++r) {
             T z = p.b3[r];
@@ -276,6 +281,7 @@ __global__ __launch_bounds__(XB_THREADS) void edge_tail_exact_bwd_kernel(const X
 #pragma unroll
             for (int c = 0; c < MB; ++c)
                 if (c < m_dim) z = xb_fma(w3[c], mm[c], z);
+            if (p.drop_thr) z = egnn_drop_hash(ckey, (uint32_t)r) >= p.drop_thr ? z * (T)p.drop_inv_keep : (T)0;
             const T sg = (T)1 / ((T)1 + xb_exp(-z));
             w = xb_fma(p.W4[r], z * sg, w);
         }
@@ -317,8 +323,13 @@ __global__ __launch_bounds__(XB_THREADS) void edge_tail_exact_bwd_kernel(const X
 #pragma unroll
             for (int c = 0; c < MB; ++c)
                 if (c < m_dim) z = xb_fma(w3[c], mm[c], z);
+            T dk = (T)1;                                               // d (dropped pre-activation) / d (pre-activation)
+            if (p.drop_thr) {
+                dk = egnn_drop_hash(ckey, (uint32_t)r) >= p.drop_thr ? (T)p.drop_inv_keep : (T)0;
+                z *= dk;
+            }
             const T sg = (T)1 / ((T)1 + xb_exp(-z));
-            const T gh = g_w * p.W4[r] * (sg * ((T)1 + z * ((T)1 - sg)));
+            const T gh = g_w * p.W4[r] * (sg * ((T)1 + z * ((T)1 - sg))) * dk;
             p.a3_t[(size_t)r * E + q] = z * sg;
             p.ghid_t[(size_t)r * E + q] = gh;
 #pragma unroll
@@ -377,6 +388,8 @@ int edge_tail_exact_launch(const egnn_edge_tail_exact_args* args, void* stream)
     p.gU = static_cast<T*>(a.gU); p.g_rel = static_cast<T*>(a.g_rel); p.ghid_t = static_cast<T*>(a.ghid_t); p.a3_t = static_cast<T*>(a.a3_t);
     p.mm_t = static_cast<T*>(a.mm_t); p.m0_t = static_cast<T*>(a.m0_t); p.g_w = static_cast<T*>(a.g_w); p.g_scale = static_cast<T*>(a.g_scale);
     p.g_gate = static_cast<T*>(a.g_gate);
+    if (a.drop_thr && (!(a.drop_inv_keep >= 1.f) || a.drop_eid0 < 0 || a.drop_eid0 + E > 0xffffffffLL)) return EGNN_E_SHAPE;    // (32-bit row counter)
+    p.drop_thr = a.drop_thr; p.drop_seed = a.drop_seed; p.drop_inv_keep = a.drop_inv_keep; p.drop_eid0 = a.drop_eid0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.m_dim <= 16) hipLaunchKernelGGL((edge_tail_exact_bwd_kernel<T, 16>), dim3((unsigned)blocks), dim3(XB_THREADS), 0, s, p);
     else if (a.m_dim <= 32) hipLaunchKernelGGL((edge_tail_exact_bwd_kernel<T, 32>), dim3((unsigned)blocks), dim3(XB_THREADS), 0, s, p);

@@ -661,7 +661,8 @@ int egnn_edge_exact_node_sums_f64(const void* DZ_T, int64_t E, int H, int64_t no
  *     the terms of d/d coors_norm.scale, d/d the gate's pre-activation.
  * Inputs: u (E, m_dim); g_coors_out (B N, coor_dim) = d loss / d coors_out; g_msum (B N, m_dim) = d loss / d (sum over k of the
  * pair-masked messages) or NULL; pair_mask (E) bytes or NULL (the reference applies masks only when a mask is passed, :292); W3 NULL =
- * no coors_mlp (update_coors = False); clamp < 0 = none. */
+ * no coors_mlp (update_coors = False); clamp < 0 = none.  With drop_thr != 0, a3_t holds SiLU of the DROPPED pre-activation and ghid_t
+ * the gradient with respect to the Linear's output (mask and 1 / keep applied). */
 typedef struct egnn_edge_tail_exact_args {
     int32_t B, N, K, m_dim, coor_dim, norm_coors;
     double eps, clamp;
@@ -687,6 +688,11 @@ typedef struct egnn_edge_tail_exact_args {
     void* g_w;                  /* optional */
     void* g_scale;              /* optional */
     void* g_gate;               /* optional */
+    /* training-mode dropout behind coors_mlp's first Linear (egnn_pytorch.py:203-208; ABI 34): the forward's hash mask (csrc/egnn_common.h:
+     * site coors, row = drop_eid0 + edge, column = hidden unit) re-evaluated; drop_thr = 0: none */
+    uint32_t drop_thr, drop_seed;
+    float drop_inv_keep;
+    int64_t drop_eid0;
 } egnn_edge_tail_exact_args;
 int egnn_edge_tail_exact_bwd_f32(const egnn_edge_tail_exact_args* args, void* stream);
 int egnn_edge_tail_exact_bwd_f64(const egnn_edge_tail_exact_args* args, void* stream);
