@@ -752,8 +752,16 @@ int launch_v(const egnn_edge_bwd_args& a, hipStream_t s)
 template <int NM>
 int launch_many(const egnn_edge_bwd_args& a, hipStream_t s)
 {
-    if (a.drop_thr) return EGNN_E_UNSUPPORTED;
     if (a.dW2_part && a.dWs_part) return EGNN_E_UNSUPPORTED;
+    if (a.drop_thr) {
+        // training-mode dropout: the same variants with the forward's mask of z re-evaluated
+        if (a.dW2_part) return launch_v<NM, 2, true, false, CH_W2, false, true>(a, s);
+        if (a.dWs_part) {
+            if (!a.WsTh || !(a.wst_inv_scale > 0.f)) return EGNN_E_NULLPTR;
+            return a.row_pairs ? launch_v<NM, 2, false, true, CH_S, true, true, true>(a, s) : launch_v<NM, 2, false, true, CH_S, false, true, true>(a, s);
+        }
+        return launch_v<NM, 2, false, false, CH_S, false, true>(a, s);
+    }
     if (a.dW2_part) return launch_v<NM, 2, true, false, CH_W2>(a, s);
     if (a.dWs_part) {
         if (!a.WsTh || !(a.wst_inv_scale > 0.f)) return EGNN_E_NULLPTR;

@@ -133,12 +133,12 @@ def test_training_mode_forward_applies_exactly_the_hash_masks(kw, n, use_mask):
 BWD_CASES = [
     # (the first three take the NATIVE backward -- the hash masks re-evaluated inside egnn_edge_bwd_pass_f32, the matrix-core tail kernel
     # and egnn_silu_bwd_drop_f32: one tile per node, two tiles per node summed in the kernel, the gate + CoorsNorm + mean pooling + masks;
-    # per-edge features + a fourier pair = five scalars; the last -- nine scalars -- takes the recompute path)
+    # per-edge features + a fourier pair = five scalars; nine scalars)
     (dict(dim=32, num_nearest_neighbors=8, dropout=0.2, norm_feats=True), 40, False, True),
     (dict(dim=64, num_nearest_neighbors=32, dropout=0.25), 96, True, True),
     (dict(dim=32, num_nearest_neighbors=20, dropout=0.1, norm_coors=True, soft_edges=True, m_pool_method="mean", coor_weights_clamp_value=2.0), 50, True, True),
     (dict(dim=32, num_nearest_neighbors=16, dropout=0.2, edge_dim=2, fourier_features=1), 48, True, True),
-    (dict(dim=24, num_nearest_neighbors=8, dropout=0.3, fourier_features=2, edge_dim=4, m_dim=8), 30, False, False),
+    (dict(dim=24, num_nearest_neighbors=8, dropout=0.3, fourier_features=2, edge_dim=4, m_dim=8), 30, False, True),
     # round 5: wide heads / other coordinate dimensions -- the forward's masks in the kernels; the backward native as well: the E x H
     # passes once per block of 16 channels with the same mask of z, coors_mlp's mask re-evaluated by the generic tail kernel
     # (egnn_edge_tail_exact_bwd_f32 with drop_thr)
@@ -146,8 +146,12 @@ BWD_CASES = [
     (dict(dim=32, num_nearest_neighbors=8, dropout=0.25, soft_edges=True, cdim=5), 30, False, True),
     (dict(dim=32, num_nearest_neighbors=12, dropout=0.2, norm_coors=True, m_dim=40, m_pool_method="mean", cdim=2, coor_weights_clamp_value=1.5), 36, True, True),
     (dict(dim=24, dropout=0.3, m_dim=24, edge_dim=2), 20, True, True),                                   # dense, three scalars
-    # ... more than five per-edge scalars with a wide head: the recompute path
-    (dict(dim=24, num_nearest_neighbors=8, dropout=0.2, m_dim=32, fourier_features=3), 30, False, False),
+    # ... more than five per-edge scalars (d/d W_s and d/d s on the matrix cores, their DROP instantiations): 7 with a wide head, 9, 13
+    (dict(dim=24, num_nearest_neighbors=8, dropout=0.2, m_dim=32, fourier_features=3), 30, False, True),
+    (dict(dim=32, num_nearest_neighbors=20, dropout=0.25, fourier_features=4, norm_coors=True), 40, True, True),
+    (dict(dim=24, num_nearest_neighbors=6, dropout=0.15, fourier_features=4, edge_dim=4, cdim=4), 24, True, True),
+    # no coors_mlp: the recompute path
+    (dict(dim=24, num_nearest_neighbors=8, dropout=0.2, update_coors=False), 30, False, False),
 ]
 
 
