@@ -593,8 +593,46 @@ def token_attn(q, kv_tok, b, n, heads, dim_head, scale):
     return out
 
 
+_HOST_READ_EVENTS = os.environ.get("EGNN_HOST_READ_EVENTS", "1") != "0"     # 0: every small read-back drains the stream (`.tolist()`)
+
+
+class HostRead:
+    """A few words of device memory on their way to the host WITHOUT draining the stream: created right behind the kernel that writes
+    them -- a copy to pinned memory and an event behind that copy -- and waited for (`tensor()` / `floats()` / `ints()`) only where the
+    values are needed.  The backward chooses its power-of-two scales from max |x| words that its kernels leave behind; read with
+    `.tolist()` each of them waited for EVERYTHING queued so far and left the device idle until the host had caught up (eight times per
+    training step: profiles/r05_experiments/train_step_timeline.txt).  With the wait pinned to the producing kernel the host goes on
+    queueing independent work in between and wakes up while the device is still busy."""
+
+    def __init__(self, t):
+        self.dtype = t.dtype
+        if t.is_cuda and _HOST_READ_EVENTS:
+            self.buf = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+            self.buf.copy_(t.reshape(-1), non_blocking=True)
+            self.ev = torch.cuda.Event()
+            self.ev.record()
+        else:
+            self.buf, self.ev = t.reshape(-1), None
+
+    def tensor(self):
+        if self.ev is not None:
+            self.ev.synchronize()
+            self.ev = None
+        return self.buf
+
+    def floats(self):
+        """max-|x| bit patterns (egnn_absmax_f32's contract) as Python floats"""
+        t = self.tensor()
+        return (t.view(torch.float32) if t.dtype == torch.int32 else t).tolist()
+
+    def ints(self):
+        return self.tensor().tolist()
+
+
 def bits_to_floats(bits):
-    """The floats behind a tensor of max-|x| bit patterns (egnn_absmax_f32's contract), in ONE host read."""
+    """The floats behind a tensor of max-|x| bit patterns (egnn_absmax_f32's contract), in ONE host read (or behind a HostRead)."""
+    if isinstance(bits, HostRead):
+        return bits.floats()
     return bits.view(torch.float32).tolist()
 
 
@@ -687,12 +725,19 @@ def absmax(x):
     the backward's host logic -- go through torch.)"""
     if not x.is_cuda:
         return float(x.abs().max())
+    return absmax_async(x).floats()[0]
+
+
+def absmax_async(x):
+    """`absmax` whose host read can wait: the launch now, a HostRead of the bit pattern (`.floats()[0]` = max |x|)."""
+    if not x.is_cuda:
+        return HostRead(x.abs().max().reshape(1).float())
     x = x if x.is_contiguous() else x.contiguous()
     out = torch.empty(1, dtype=torch.int32, device=x.device)
     with _timed("absmax"):
         rc = _abi.load().egnn_absmax_f32(_ptr(x), x.numel(), _ptr(out), _stream())
     _abi.check(rc, "egnn_absmax_f32")
-    return float(out.view(torch.float32).item())
+    return HostRead(out)
 
 
 def unsplit_words_(table, cols):
@@ -789,8 +834,16 @@ class DestLists:
     """The edges sorted stably by destination (egnn_dest_lists_i32): `ent` / `tile_seg` = the padded entry list of
     egnn_edge_bwd_pass_f32 (by_dest = 1), `order` / `seg` = the CSR form egnn_rows_gather_sum_f32 reads."""
 
-    def __init__(self, ent, tile_seg, order, seg):
-        self.ent, self.tile_seg, self.order, self.seg = ent, tile_seg, order, seg
+    def __init__(self, ent, tile_seg, order, seg, tiles=None):
+        self._ent, self.tile_seg, self.order, self.seg, self._tiles = ent, tile_seg, order, seg, tiles
+
+    @property
+    def ent(self):
+        """the entry list cut to its length -- the one host read (the number of tiles), taken when the list is first used"""
+        if self._tiles is not None:
+            tiles = int(self._tiles.ints()[0])
+            self._ent, self._tiles = self._ent[:max(128, (tiles * 16 + 127) // 128 * 128)], None
+        return self._ent
 
 
 def dest_lists(idx32, b, n, k, device):
@@ -805,9 +858,7 @@ def dest_lists(idx32, b, n, k, device):
     with _timed("dest_lists"):
         rc = lib.egnn_dest_lists_i32(_ptr(idx32), b, n, k, _ptr(ent), cap, _ptr(tile_seg), _ptr(order), _ptr(seg), _ptr(scratch), _stream())
     _abi.check(rc, "egnn_dest_lists_i32")
-    tiles = int(tile_seg[-1])
-    length = max(128, (tiles * 16 + 127) // 128 * 128)
-    return DestLists(ent[:length], tile_seg, order, seg)
+    return DestLists(ent, tile_seg, order, seg, HostRead(tile_seg[-1:]))
 
 
 def sum_rows(part, scale=1.0):

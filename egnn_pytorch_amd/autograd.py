@@ -768,7 +768,7 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
     if pairs or k <= 16:
         gz_i = o["rows"][:bc * n]
         if o.get("amax_bits") is not None:
-            gz_i.amax_bits = o["amax_bits"]                  # (max |d/d P_i| as a by-product of the pass)
+            gz_i.amax_bits = _ops.HostRead(o["amax_bits"])   # (max |d/d P_i| as a by-product of the pass; read behind THIS pass)
     else:
         ident = torch.arange(o["rows"].shape[0], device=dev)
         gz_i = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n)
@@ -785,20 +785,21 @@ def _edge_contract_fused(layer, w, f2d, c0, e0, sc2, i32, gu16, gu_scale, w_s, b
     ident = torch.arange(o["rows"].shape[0], device=dev)
     if dev.type == "cuda":
         gz_j, bits = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n, want_amax=True)
-        gz_j.amax_bits = bits                                 # (max |d/d P_j| as a by-product: the scale of its gradient GEMM operands)
+        gz_j.amax_bits = _ops.HostRead(bits)                  # (max |d/d P_j| as a by-product: the scale of its gradient GEMM operands)
     else:
         gz_j = _ops.rows_gather_sum(o["rows"], ident, seg, bc * n)
     return gz_i, gz_j, g_ws, g_scal, g_w2
 
 
-def _node_mlp_backward(layer, w, f, m_i, g_out, grads_by_id, drop=None, row0=0):
+def _node_mlp_backward(layer, w, f, m_i, g_out, grads_by_id, drop=None, row0=0, overlap=None):
     """Backward of the node update out = node_mlp(cat(node_norm(f), m_i)) + f (egnn_pytorch.py:335-337) on the split-f16 GEMMs:
     the hidden pre-activation recomputed by the forward's GEMM, then per Linear one NN product (d/d input) and one split-K TN product
     (d/d weight) that share one (plain, transposed) split of the incoming gradient; SiLU and its derivative in one pass
     (egnn_silu_bwd_f32).  node_norm (LayerNorm or Identity, element-wise per node) stays with autograd.  f: (bc, n, dim) leaf that
     requires grad; m_i (bc, n, m); g_out (bc, n, dim).  Adds the parameter gradients into grads_by_id; returns (d/d f, d/d m_i).
     drop = (p, seed), row0: training-mode dropout behind the first Linear -- the forward's hash mask of node rows row0 .. is
-    re-evaluated inside the SiLU-backward pass."""
+    re-evaluated inside the SiLU-backward pass.  overlap: a callable that queues launches which do not depend on this function's results;
+    called while the SiLU pass -- whose max |.| words the next operand scales are chosen from -- is still running (_ops.HostRead)."""
     from . import _ops
     bc, n, dim = f.shape
     m = m_i.shape[-1]
@@ -809,12 +810,17 @@ def _node_mlp_backward(layer, w, f, m_i, g_out, grads_by_id, drop=None, row0=0):
     with torch.no_grad():
         in32 = torch.cat((ln.detach(), m_i), dim=-1).view(rows, dim + m)
         g2d = g_out.reshape(rows, dim).contiguous()
+        # (max |.| of the two operands that exist already: launched first, read behind the GEMM that is queued next)
+        hr_g, hr_in = _ops.absmax_async(g2d), _ops.absmax_async(in32)
         z1 = _ops.linear_hl(_ops.split_f16(in32), w["W5_split"], 2 * dim, w["b5"], name="bwd_node_mlp")        # (rows, 2 dim) pre-activation
-        go = _ops.GradOperand(g2d, colsum=lin6.bias.requires_grad)        # (column sums = d/d bias: by-products of the operand split)
+        go = _ops.GradOperand(g2d, amax=hr_g.floats()[0], colsum=lin6.bias.requires_grad)   # (column sums = d/d bias: by-products of the split)
         g_a1 = _ops.grad_nn(go, w["W6T_split"], 2 * dim, name="bwd_node_mlp")
         if z1.numel() % 4 == 0:
             a1, g_z1, bits = _ops.silu_bwd_(z1, g_a1, drop, row0)
-            amax_a1, amax_gz = _ops.bits_to_floats(bits)               # (by-products of the pass: no absmax launches for these two)
+            bits = _ops.HostRead(bits)
+            if overlap is not None:
+                overlap()
+            amax_a1, amax_gz = bits.floats()                            # (by-products of the pass: no absmax launches for these two)
         else:
             sg = torch.sigmoid(z1)
             a1, g_z1 = z1 * sg, g_a1 * (sg * (1 + z1 * (1 - sg)))
@@ -827,7 +833,7 @@ def _node_mlp_backward(layer, w, f, m_i, g_out, grads_by_id, drop=None, row0=0):
         gz = _ops.GradOperand(g_z1, amax=amax_gz, colsum=lin5.bias.requires_grad)
         g_in = _ops.grad_nn(gz, w["W5T_split"], dim + m, name="bwd_node_mlp")
         if lin5.weight.requires_grad:
-            grads_by_id[id(lin5.weight)] += _ops.grad_tn(gz, in32, name="bwd_node_mlp_w")
+            grads_by_id[id(lin5.weight)] += _ops.grad_tn(gz, in32, name="bwd_node_mlp_w", x_operand=_ops.grad_tn_operand(in32, hr_in.floats()[0]))
         if lin5.bias.requires_grad:
             grads_by_id[id(lin5.bias)] += gz.colsum
         del gz, g_z1
@@ -897,10 +903,8 @@ def _backward_native(ctx, g_node, g_coors):
         raise NotImplementedError("the native backward carries more than five per-edge scalars only with EGNN_BWD_SPLIT=dest (the default)")
     proj_all = None
     if len(ctx.saved_tensors) > 7 and ctx.saved_tensors[7].numel() and fused:
-        proj_all = ctx.saved_tensors[7]                                   # (B N, 2 Hp): what the forward's edge pass read
-        if ctx.proj_words:
-            _ops.unsplit_words_(proj_all, hp)
-            ctx.proj_words = False
+        proj_all = ctx.saved_tensors[7]                                   # (B N, 2 Hp): what the forward's edge pass read (P_i still as
+                                                                          # (hi, lo) words when ctx.proj_words: decoded in `early` below)
     if True:
         # nothing of size E x H: graphs are only chunked to keep the P table below 4 GB (32-bit buffer offsets) and E below 2^31
         # (the kernel addresses both with signed 32-bit scalar offsets)
@@ -940,6 +944,17 @@ def _backward_native(ctx, g_node, g_coors):
         r0 = None if rank is None else rank[lo:hi_]
         ec = bc * n * k
         dest_lists = None
+        hr_f = _ops.absmax_async(f0.view(bc * n, dim)) if (f0.is_cuda and _GRAD_GEMM) else None      # (read in step 3)
+
+        def early():
+            """Launches that depend on the saved inputs only -- P_i decoded in place (once), the edges sorted by destination: queued where
+            the node-level part waits for a scale, so that the device has work while the host is woken up (_ops.HostRead)."""
+            nonlocal dest_lists
+            if proj_all is not None and ctx.proj_words:
+                _ops.unsplit_words_(proj_all, hp)
+                ctx.proj_words = False
+            if dest_lists is None and (i32 is not None or not tail_kernel):
+                dest_lists = _ops.dest_lists(i32, bc, n, k, feats.device)                     # (shared by the tail and the E x H passes)
         if tail_kernel:
             # ---- 1. behind u: the node-level modules through autograd (node_norm, node_mlp, residual: from the pooled messages),
             # the per-edge chain (second SiLU, masks, coors_mlp, CoorsNorm, clamp, coordinate update, pooling) in closed form on
@@ -992,7 +1007,7 @@ def _backward_native(ctx, g_node, g_coors):
                 else:
                     rel, scal = edge_scalars(layer, c, e, i64)                               # (only the scalars' graph is used below)
             if f0.is_cuda and _GRAD_GEMM:
-                g_f, g_mi = _node_mlp_backward(layer, w, f, m_i[..., :m], g_node[lo:hi_], grads_by_id, drop, lo * n)
+                g_f, g_mi = _node_mlp_backward(layer, w, f, m_i[..., :m], g_node[lo:hi_], grads_by_id, drop, lo * n, overlap=early)
                 g_feats[lo:hi_] += g_f
             else:
                 with torch.enable_grad():
@@ -1032,6 +1047,7 @@ def _backward_native(ctx, g_node, g_coors):
                 if reduce:
                     gu16, g_rel, sums, rel4, dist, gu_bits = _ops.edge_tail_bwd(*tail_args, gate=gate, reduce=True, want_rel=closed_dist,
                                                                                drop=drop, eid0=lo * n * k)
+                    gu_bits = _ops.HostRead(gu_bits)                              # (read in step 2, behind the small launches below)
                     grads_by_id[id(lin_a.weight)] += sums[:1024].view(64, 16)[:hid3, :m]
                     grads_by_id[id(lin_a.bias)] += sums[1024:1024 + hid3]
                     grads_by_id[id(lin_b.weight)] += sums[1088:1088 + hid3][None, :]
@@ -1060,8 +1076,7 @@ def _backward_native(ctx, g_node, g_coors):
                         grads_by_id[id(layer.coors_norm.scale)] += g_sc.sum()[None]
                     del g_hid, a3, mm
                 g_coors_in[lo:hi_] += g_coors[lo:hi_]                              # (the residual; g_rel reaches the coordinates below)
-                if i64 is not None:
-                    dest_lists = _ops.dest_lists(i32, bc, n, k, feats.device)                  # (shared with the E x H passes below)
+                early()
         elif f0.is_cuda and _TAIL_GENERIC and _GRAD_GEMM and m <= 64:
             # ---- 1. behind u for the heads of 17 .. 64 channels and the other coordinate dimensions (round 5): the pooled messages on
             # E x m tensors, node_mlp on the split-f16 GEMMs, the per-edge chain in closed form on egnn_edge_tail_exact_bwd_f32 (one
@@ -1077,7 +1092,7 @@ def _backward_native(ctx, g_node, g_coors):
                 g_msum = None
                 if layer.node_mlp is not None:
                     f = f0.detach().requires_grad_(True)
-                    g_f, g_mi = _node_mlp_backward(layer, w, f, m_i, g_node[lo:hi_], grads_by_id, drop, lo * n)
+                    g_f, g_mi = _node_mlp_backward(layer, w, f, m_i, g_node[lo:hi_], grads_by_id, drop, lo * n, overlap=early)
                     g_feats[lo:hi_] += g_f
                     if layer.m_pool_method == "mean":
                         g_mi = (g_mi / cnt.clamp(min=1e-8)).masked_fill(cnt == 0, 0.0) if cnt is not None else g_mi / k
@@ -1085,7 +1100,7 @@ def _backward_native(ctx, g_node, g_coors):
                 else:
                     g_feats[lo:hi_] += g_node[lo:hi_]
                 g_coors_in[lo:hi_] += g_coors[lo:hi_]
-                dest_lists = _ops.dest_lists(i32, bc, n, k, feats.device)
+                early()
                 g_u, g_c = _tail_closed_form(layer, u4.reshape(ec, m).contiguous(), c0, i32, pm, g_coors[lo:hi_], g_msum, grads_by_id,
                                              dest_lists, bc, n, k, drop, lo * n * k)
                 g_coors_in[lo:hi_] += g_c
@@ -1120,6 +1135,7 @@ def _backward_native(ctx, g_node, g_coors):
             gu16 = torch.zeros(ec, mp, dtype=torch.float32, device=feats.device)
             gu16[:, :m] = g_u.reshape(ec, m)
         # ---- 2. the E x H work: d/d P_i, d/d P_j (per node), d/d W_s, d/d scalars, d/d W_2
+        early()
         amax = _ops.bits_to_floats(gu_bits)[0] if gu_bits is not None else _ops.absmax(gu16)
         gu_scale = _weights.pow2_scale(amax) if amax > 0 else 1.0
         with torch.no_grad():
@@ -1160,17 +1176,20 @@ def _backward_native(ctx, g_node, g_coors):
             gw1 = grads_by_id[id(lin0.weight)]
             if f2d.is_cuda and _GRAD_GEMM:
                 # (each matrix: one absmax, one read for its plain and transposed images; feats^T split once for both weight gradients)
+                # (launch order: everything of d/d P_i first -- its max |.| word was written by the by-source pass, long finished -- so that
+                # the device is busy with it while the host waits for the word of d/d P_j, which the last kernel queued above writes)
                 ib, jb = getattr(gz_i, "amax_bits", None), getattr(gz_j, "amax_bits", None)
                 op_i = _ops.GradOperand(gz_i, amax=None if ib is None else _ops.bits_to_floats(ib)[0], colsum=True)
                 gb1 = op_i.colsum
-                op_j = _ops.GradOperand(gz_j, amax=None if jb is None else _ops.bits_to_floats(jb)[0])
                 t = _ops.grad_nn(op_i, w["WiT_split"], dim, name="bwd_dfeats")
+                f_op = _ops.grad_tn_operand(f2d, None if hr_f is None else hr_f.floats()[0])
+                gw1[:, :dim] += _ops.grad_tn(op_i, f2d, name="bwd_dw1", x_operand=f_op)[:h]
+                del op_i
+                op_j = _ops.GradOperand(gz_j, amax=None if jb is None else _ops.bits_to_floats(jb)[0])
                 t = _ops.grad_nn(op_j, w["WjT_split"], dim, residual=t, name="bwd_dfeats")
                 g_feats[lo:hi_] += t.view(bc, n, dim)
-                f_op = _ops.grad_tn_operand(f2d)
-                gw1[:, :dim] += _ops.grad_tn(op_i, f2d, name="bwd_dw1", x_operand=f_op)[:h]
                 gw1[:, dim:2 * dim] += _ops.grad_tn(op_j, f2d, name="bwd_dw1", x_operand=f_op)[:h]
-                del f_op, op_i, op_j
+                del f_op, op_j
             else:
                 g_feats[lo:hi_] += (gz_i @ w_i + gz_j @ w_j).view(bc, n, dim)
                 gw1[:, :dim] += _tn(gz_i, f2d)[:h]
