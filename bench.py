@@ -376,6 +376,8 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc passes that measure the dominant kernel's HBM traffic (roofline.traffic then "
                          "comes from profiles/pmc_traffic.json, stamped with the commit of that profile run)")
+    ap.add_argument("--hipgraph", action="store_true",
+                    help="also time the step as a captured HIP graph (egnn_pytorch_amd.graphed), after everything else (secondary figure)")
     ap.add_argument("--reference-eager", action="store_true",
                     help="also time the reference module on the MI355X through PyTorch eager (secondary baseline)")
     args = ap.parse_args()
@@ -602,6 +604,23 @@ def main():
                 out["train_step"] = train_step(layer, feats, coors, mask, edges, adj)
             except Exception as exc:                           # noqa: BLE001
                 out["train_step"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        if args.hipgraph and world == 1 and not kwargs.get("only_sparse_neighbors"):
+            # the same K steps as ONE captured HIP graph per step (egnn_pytorch_amd.graphed: the launch sequence replayed, the range word
+            # read after every replay): what the host-side launch path costs at this size.  Secondary figure, never `value`.
+            try:
+                from egnn_pytorch_amd import graphed
+                with torch.no_grad():
+                    if is_net:
+                        run = graphed(layer, feats, coors, adj_mat=adj, edges=edges, mask=mask, range_check="sync")
+                        gstep = lambda: run(feats, coors, adj_mat=adj, edges=edges, mask=mask)     # noqa: E731
+                    else:
+                        run = graphed(layer, feats, coors, edges, mask, adj, range_check="sync")
+                        gstep = lambda: run(feats, coors, edges, mask, adj)                        # noqa: E731
+                    elg = timed_region(gstep, args.steps, args.warmup, torch.cuda.synchronize, barrier, reduce_max)
+                out["hipgraph_replay"] = {"value": round(b * args.steps / elg, 2), "ms_per_step": round(elg / args.steps * 1e3, 4),
+                                          "range_check": "sync", "includes": "copy of the inputs into the graph's buffers"}
+            except Exception as exc:                           # noqa: BLE001
+                out["hipgraph_replay"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         print(json.dumps(out), flush=True)
 
     if dist is not None:
