@@ -18,7 +18,8 @@ python -c "
 import json; d=json.load(open('$OUT/bench_line.json')); print(d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'], d['cpu_baseline']['value'], d.get('reference_gpu_eager', {}).get('value'), d.get('train_step'))"
 python bench.py --ragged-mask --no-cpu-baseline --no-live-traffic > $OUT/bench_ragged_mask.json 2>> $OUT/bench_line.err
 for w in c2_dense c3_network c4_sparse c5_shard; do
-  python bench.py --workload $w > $OUT/bench_$w.json 2>> $OUT/bench_line.err; head -c 160 $OUT/bench_$w.json; echo
+  HG="--hipgraph"; [ $w = c4_sparse ] && HG=""
+  python bench.py --workload $w $HG > $OUT/bench_$w.json 2>> $OUT/bench_line.err; head -c 160 $OUT/bench_$w.json; echo
 done
 python bench.py --workload c4_sparse --no-cpu-baseline --no-live-traffic --train-step > $OUT/bench_train_step_c4_sparse.json 2>> $OUT/bench_line.err
 python tools/train_step_probe.py 3 > $OUT/train_step_kernels.txt 2>&1; tail -2 $OUT/train_step_kernels.txt | cut -c1-400
