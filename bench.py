@@ -75,8 +75,10 @@ def model_counts(kwargs, b, n):
         "node_mlp0": dict(bound="mfma", flops=2.0 * bn * (dim + m) * 2 * dim,
                           bytes=4 * (bn * (dim + m) + 2 * dim * (dim + m) + bn * 2 * dim)),
         "node_mlp1": dict(bound="mfma", flops=2.0 * bn * 2 * dim * dim, bytes=4 * (bn * 2 * dim + 2 * dim * dim + 2 * bn * dim)),
-        # one pass over feats: read fp32 rows once, write the (hi, lo) split and [LayerNorm | 0] as a second (hi, lo) pair
-        "node_prep": dict(bound="hbm", bytes=4 * bn * dim + 4 * bn * dim + 4 * bn * (dim + m), flops=10.0 * bn * dim),
+        # one pass over feats: read fp32 rows once, write [node_norm(feats) | 0] as a (hi, lo) pair -- and the raw rows as a second pair
+        # only when node_norm is a LayerNorm (the projection reads the one image otherwise: egnn_linear_hl_lda_f32)
+        "node_prep": dict(bound="hbm", bytes=4 * bn * dim + (4 * bn * dim if kwargs.get("norm_feats") else 0) + 4 * bn * (dim + m),
+                          flops=10.0 * bn * dim),
         "split_f16": dict(bound="hbm", bytes=4 * 2 * bn * dim, flops=2.0 * bn * dim),
         "spatial_order": dict(bound="hbm", bytes=16 * bn, flops=0.0),
         # per-slot records for the edge pass's setup: reads the neighbour list, rank and two coordinate rows, writes 16 bytes per slot
