@@ -608,9 +608,10 @@ class HostRead:
         self.dtype = t.dtype
         if t.is_cuda and _HOST_READ_EVENTS:
             self.buf = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
-            self.buf.copy_(t.reshape(-1), non_blocking=True)
-            self.ev = torch.cuda.Event()
-            self.ev.record()
+            with torch.cuda.device(t.device):                # (the copy and the event on the tensor's device's current stream)
+                self.buf.copy_(t.reshape(-1), non_blocking=True)
+                self.ev = torch.cuda.Event()
+                self.ev.record(torch.cuda.current_stream(t.device))
         else:
             self.buf, self.ev = t.reshape(-1), None
 
