@@ -333,16 +333,27 @@ extern "C" int egnn_layer_forward_f32(const egnn_layer_desc* desc, const egnn_pa
 
     if (K > 0) {
         // ---- operand prep + node-level projections P = feats [W_i ; W_j]^T + [b1 ; 0]
-        if (desc->update_feats)
+        // (node_norm = Identity, the reference's default: [feats | 0] for node_mlp and feats for the projection hold the same values --
+        // one packed image, the projection contracts over its first kp_dim columns: egnn_linear_hl_lda_f32)
+        const bool shared = desc->update_feats && !gamma;
+        if (shared)
+            EGNN_TRY(egnn_node_prep_hl(feats, nullptr, nullptr, nullptr, desc->ln_eps, node_hi, node_lo, x.kp_node, nullptr, nullptr, 0,
+                                       rows, dim, x.m, status, stream));
+        else if (desc->update_feats)
             EGNN_TRY(egnn_node_prep_hl(feats, nullptr, gamma, beta, desc->ln_eps, node_hi, node_lo, x.kp_node, ws + w.raw_hi, ws + w.raw_lo,
                                        x.kp_dim, rows, dim, x.m, status, stream));
         else
             EGNN_TRY(egnn_split_f16(feats, dim, rows, dim, ws + w.raw_hi, ws + w.raw_lo, x.kp_dim, status, stream));
         const int pi_split = K >= 6;
         float* proj = reinterpret_cast<float*>(ws + w.proj);
-        EGNN_TRY(egnn_linear_hl_f32(ws + w.raw_hi, ws + w.raw_lo, blob + info->wcat_hi, blob + info->wcat_lo, info->wcat_inv_scale,
-                                    F(info->bcat), nullptr, 0, proj, 2 * x.Hp, nullptr, nullptr, 0, rows, 2 * x.Hp, x.kp_dim,
-                                    info->wcat_rows, 0, pi_split ? x.Hp : 0, status, stream));
+        if (shared)
+            EGNN_TRY(egnn_linear_hl_lda_f32(node_hi, node_lo, x.kp_node, blob + info->wcat_hi, blob + info->wcat_lo, info->wcat_inv_scale,
+                                            F(info->bcat), nullptr, 0, proj, 2 * x.Hp, nullptr, nullptr, 0, rows, 2 * x.Hp, x.kp_dim,
+                                            info->wcat_rows, 0, pi_split ? x.Hp : 0, status, stream));
+        else
+            EGNN_TRY(egnn_linear_hl_f32(ws + w.raw_hi, ws + w.raw_lo, blob + info->wcat_hi, blob + info->wcat_lo, info->wcat_inv_scale,
+                                        F(info->bcat), nullptr, 0, proj, 2 * x.Hp, nullptr, nullptr, 0, rows, 2 * x.Hp, x.kp_dim,
+                                        info->wcat_rows, 0, pi_split ? x.Hp : 0, status, stream));
         egnn_edge_args a;
         std::memset(&a, 0, sizeof(a));
         a.B = B; a.N = N; a.K = K; a.dim = dim; a.m_dim = x.m; a.H = x.H; a.Hp = x.Hp;
