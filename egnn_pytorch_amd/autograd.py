@@ -9,9 +9,10 @@ Backward, three paths:
   `_backward_native` -- fp32 (half / bfloat16 modules through an fp32 shadow), every shape the fused forward kernels cover (m_dim <= 64,
            coordinate dimension 1 .. 8, up to 16 per-edge scalars, with or without training-mode dropout):
              * behind u: node_norm / node_mlp on the split-f16 GEMMs (`_node_mlp_backward`), the per-edge chain (second SiLU, gate, masks,
-               coors_mlp, CoorsNorm, clamp, coordinate update, pooling) in closed form on egnn_edge_tail_bwd_f32 (csrc/edge_tail.hip;
-               `tail_edge_backward` is its specification) for m_dim <= 16 and 3-D coordinates, through autograd on E x m tensors
-               (`layer_tail`) otherwise  ->  gU, d/d (x_i - x_j) and those parameters' gradients;
+               coors_mlp, CoorsNorm, clamp, coordinate update, pooling) in closed form -- egnn_edge_tail_bwd_f32 (csrc/edge_tail.hip, matrix
+               cores) for m_dim <= 16 and 3-D coordinates, egnn_edge_tail_exact_bwd_f32 (csrc/edge_exact_bwd.hip, one thread per edge) for
+               wider heads / other coordinate dimensions; `tail_edge_backward` is their specification (autograd on E x m tensors,
+               `layer_tail`, only on the CPU and behind EGNN_TAIL_GENERIC=0)  ->  gU, d/d (x_i - x_j) and those parameters' gradients;
              * the E x H work -- z = P_i + P_j + W_s s, a = SiLU(z), dz = (W2^T gU) SiLU'(z) and their contractions -- on
                egnn_edge_bwd_pass_f32 (csrc/edge_bwd.hip; `_edge_contract_fused`): one pass over the edges grouped by source node
                (d/d P_i, d/d W_s, d/d scalars) and one over the edges sorted by destination (d/d P_j, d/d W_2), everything recomputed
@@ -348,12 +349,12 @@ class EGNNFunction(torch.autograd.Function):
         if layer.dropout_active():
             from . import _dropout
             drop = (layer.dropout_p, _dropout.draw_seed())
-        # (the E x H work of every shape the forward kernels cover -- m_dim <= 64, coordinate dimension 1 .. 8 -- is native; the per-edge
-        # chain behind u has its closed-form kernel for m_dim <= 16 and 3-D coordinates and goes through autograd on E x m tensors otherwise)
+        # (every shape the fused forward kernels cover -- m_dim <= 64, coordinate dimension 1 .. 8, up to 16 scalars -- is native: the E x H
+        # work and the per-edge chain behind u, which has its closed-form kernels for all of them)
         native = (_NATIVE and layer.m_dim <= 64 and coors.shape[-1] <= 8 and (drop is None or _dropout_native_ok(layer))
                   and 2 * layer.fourier_features + 1 + layer.edge_dim <= 16
-                  and not layer.float64_kernels()            # (a float64 module: float64 forward kernels, float64 recompute backward)
-                  and not _exact_active())                   # (the wide-range re-run: plain-fp32 forward kernels, plain-fp32 recompute backward)
+                  and not layer.float64_kernels()            # (a float64 module: float64 forward kernels, `_backward_exact` in float64)
+                  and not _exact_active())                   # (the wide-range re-run: plain-fp32 forward kernels, `_backward_exact`)
         # the layers that run on the plain kernels (csrc/edge_exact.hip) -- float64 modules, the wide-range re-run, shapes beyond the fused
         # kernels' limits -- have their own native backward (round 5: `_backward_exact`, csrc/edge_exact_bwd.hip)
         s_in = 2 * layer.fourier_features + 1 + layer.edge_dim
