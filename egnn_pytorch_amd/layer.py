@@ -192,8 +192,8 @@ class EGNN(nn.Module):
             raise ValueError(f"feats last dim {feats.shape[-1]} != dim {self.dim}")
         if self.training and self.dropout_p > 0 and (coors.shape[-1] > 8 or self.m_dim > 64 or 2 * self.fourier_features + 1 + self.edge_dim > 16):
             raise NotImplementedError("training-mode dropout on the gfx950 path needs coordinate dimension <= 8, m_dim <= 64 and <= 16 per-edge scalars "
-                                      "(the hash masks live in the fused edge pass; wider shapes run on the plain kernels, which are "
-                                      "inference-only); use dropout=0 or call .eval()")
+                                      "(the hash masks live in the fused edge pass; wider shapes run -- and train -- on the plain kernels, "
+                                      "which carry no dropout); use dropout=0 or call .eval()")
         if (edges is not None) != (self.edge_dim > 0):
             raise ValueError("`edges` must be passed if and only if edge_dim > 0")
         b, n = feats.shape[:2]

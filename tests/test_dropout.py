@@ -208,7 +208,7 @@ def test_training_mode_backward_differentiates_the_masked_layer(kw, n, use_mask,
 @pytest.mark.gpu
 def test_dropout_configurations_outside_the_fused_kernels_still_raise():
     """Training-mode dropout covers every shape of the fused edge pass (m_dim <= 64, coordinate dimension <= 8); what runs on the plain
-    kernels -- wider heads, more coordinates -- is inference-only and says so."""
+    kernels -- wider heads, more coordinates -- carries no dropout and says so."""
     from egnn_pytorch_amd import EGNN
     f = torch.randn(1, 12, 16).cuda()
     with pytest.raises(NotImplementedError):
