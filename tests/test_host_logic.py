@@ -317,3 +317,20 @@ def test_workspace_bytes_and_descriptor_checks():
     bad = _abi.layer_desc(EGNN(dim=8, m_dim=16))
     bad.m_dim = 65                                                             # beyond the four accumulator tiles
     assert lib.egnn_packed_weights_bytes(byref(bad)) == 0 and lib.egnn_workspace_bytes(byref(bad), 1, 4, 4) == 0
+
+
+def test_host_read_and_lazy_destination_lists_on_the_cpu():
+    """_ops.HostRead on host tensors (the CPU tests of the backward run through it): the values themselves, no event; max-|x| bit
+    patterns decode to floats; DestLists cuts its entry list to length on first use, from the tile count it was given as a HostRead."""
+    from egnn_pytorch_amd import _ops
+    bits = torch.tensor([1.5, 0.0, float("inf")], dtype=torch.float32).view(torch.int32)
+    hr = _ops.HostRead(bits)
+    assert hr.ev is None and hr.floats() == [1.5, 0.0, float("inf")]
+    assert _ops.bits_to_floats(hr) == [1.5, 0.0, float("inf")] and _ops.bits_to_floats(bits) == [1.5, 0.0, float("inf")]
+    assert _ops.HostRead(torch.tensor([7, 9], dtype=torch.int64)).ints() == [7, 9]
+    assert _ops.absmax_async(torch.tensor([[-3.0, 2.0]])).floats()[0] == 3.0
+    ent = torch.arange(1024, dtype=torch.int32)
+    dl = _ops.DestLists(ent, torch.zeros(3, dtype=torch.int64), torch.zeros(4, dtype=torch.int64), torch.zeros(3, dtype=torch.int64),
+                        _ops.HostRead(torch.tensor([20], dtype=torch.int64)))
+    assert dl.ent.numel() == 384 and dl.ent.numel() == 384            # 20 tiles x 16 entries, whole 128-entry rounds; resolved once
+    assert _ops.DestLists(ent[:256], None, None, None).ent.numel() == 256
