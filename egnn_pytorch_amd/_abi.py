@@ -29,7 +29,7 @@ SYMBOLS = (
     "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32",
     "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_bwd_work_bytes", "egnn_edge_tail_bwd_f32", "egnn_edge_tail_part_floats", "egnn_edge_pool_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
     "egnn_induced_attn_f32", "egnn_token_attn_f32", "egnn_slot_prep_f32", "egnn_struct_bytes",
-    "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32", "egnn_split_scaled_both_f16", "egnn_split_scaled_colsum_rows", "egnn_silu_bwd_f32", "egnn_silu_bwd_drop_f32",
+    "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32", "egnn_split_scaled_both_f16", "egnn_split_scaled_colsum_rows", "egnn_drop_silu_f32", "egnn_drop_silu_f64", "egnn_silu_bwd_f32", "egnn_silu_bwd_drop_f32",
     "egnn_linear_hl_drop_f32", "egnn_linear_hl_lda_f32",
     "egnn_linear_f32", "egnn_node_prep_f32", "egnn_edge_exact_f32", "egnn_edge_exact_workspace_bytes",
     "egnn_knn_select_f64", "egnn_linear_f64", "egnn_node_prep_f64", "egnn_edge_exact_f64",
@@ -74,6 +74,7 @@ class EdgeExactArgs(Structure):
         ("coors", c_void_p), ("edges", c_void_p), ("mask", c_void_p), ("idx", c_void_p), ("rank", c_void_p),
         ("valid_radius", c_double), ("clamp", c_double),
         ("m_i", c_void_p), ("coors_out", c_void_p), ("edge_ws", c_void_p), ("U_out", c_void_p),
+        ("drop_thr", c_uint32), ("drop_seed", c_uint32), ("drop_inv_keep", c_float), ("drop_eid0", c_int64),
     ]
 
 
@@ -85,6 +86,7 @@ class EdgeExactBwdArgs(Structure):
         ("Pi", c_void_p), ("Pj", c_void_p), ("ldp", c_int64), ("Ws", c_void_p), ("ldws", c_int64),
         ("W2", c_void_p), ("coors", c_void_p), ("edges", c_void_p), ("idx", c_void_p), ("gU", c_void_p),
         ("A_T", c_void_p), ("DZ_T", c_void_p), ("g_scal", c_void_p),
+        ("drop_thr", c_uint32), ("drop_seed", c_uint32), ("drop_inv_keep", c_float), ("drop_eid0", c_int64),
     ]
 
 
@@ -276,6 +278,9 @@ def load():
     lib.egnn_split_scaled_both_f16.restype = c_int
     lib.egnn_split_scaled_both_f16.argtypes = [c_void_p, c_int64, c_int64, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                                c_void_p, c_void_p, c_int64, c_void_p]
+    for fn in (lib.egnn_drop_silu_f32, lib.egnn_drop_silu_f64):
+        fn.restype = c_int
+        fn.argtypes = [c_void_p, c_int64, c_int64, c_int, c_uint32, c_uint32, c_float, c_int64, c_void_p]
     lib.egnn_split_scaled_colsum_rows.restype = c_int64
     lib.egnn_split_scaled_colsum_rows.argtypes = [c_int64, c_int]
     lib.egnn_silu_bwd_f32.restype = c_int

@@ -457,6 +457,28 @@ def edge_exact(args: "_abi.EdgeExactArgs", device, dtype=torch.float32):
     return ws
 
 
+def set_drop(args, drop, eid0=0):
+    """drop = (p, seed) -> the drop_* fields of an argument block of the plain kernels (None: no dropout)"""
+    if drop is not None:
+        from . import _dropout
+        args.drop_thr, args.drop_seed, args.drop_inv_keep, args.drop_eid0 = (_dropout.threshold(drop[0]), int(drop[1]),
+                                                                             _dropout.inv_keep(drop[0]), int(eid0))
+
+
+def drop_silu_(z, drop, row0=0):
+    """z (rows, cols) <- SiLU(dropout(z)) in place (egnn_drop_silu_f32 / _f64): nn.Dropout between node_mlp's first Linear and its SiLU on
+    the plain kernels, the mask = the kernels' hash of node rows row0 .. (drop = (p, seed); None: plain SiLU)."""
+    from . import _dropout
+    assert z.dim() == 2 and z.stride(1) == 1 and z.dtype in (torch.float32, torch.float64)
+    lib = _abi.load()
+    thr, seed, inv = (0, 0, 1.0) if drop is None else (_dropout.threshold(drop[0]), int(drop[1]), _dropout.inv_keep(drop[0]))
+    with _timed("drop_silu"):
+        rc = (lib.egnn_drop_silu_f64 if z.dtype == torch.float64 else lib.egnn_drop_silu_f32)(_ptr(z), z.stride(0) if z.shape[0] > 1 else z.shape[1],
+                                                                                            z.shape[0], z.shape[1], thr, seed, inv, int(row0), _stream())
+    _abi.check(rc, "egnn_drop_silu")
+    return z
+
+
 def edge_exact_bwd(args: "_abi.EdgeExactBwdArgs", dtype):
     """egnn_edge_exact_bwd_f32 / _f64: a^T, dz^T (H, E) and d/d scalars (E, S) of a chunk of graphs (include/egnn_hip.h)."""
     lib = _abi.load()

@@ -360,7 +360,7 @@ class EGNNFunction(torch.autograd.Function):
         s_in = 2 * layer.fourier_features + 1 + layer.edge_dim
         f64 = layer.float64_kernels()
         exact_path = f64 or _exact_active() or s_in > 16 or coors.shape[-1] > 8 or layer.m_dim > 64
-        exact_native = bool(_NATIVE_EXACT and exact_path and drop is None and s_in <= (40 if f64 else 80) and feats.is_cuda)
+        exact_native = bool(_NATIVE_EXACT and exact_path and s_in <= (40 if f64 else 80) and feats.is_cuda)
         with torch.no_grad():
             node_out, coors_out, order, idx, rank, valid_radius, u_pre, proj = layer._forward_hip_checked(
                 feats, coors, edges, mask, adj_mat, order_hint, want_u=native or exact_native, drop_seed=None if drop is None else drop[1])
@@ -447,10 +447,11 @@ def _pooled_messages(layer, u, m0, i64, r0, valid_radius):
     return m_i, pm, cnt
 
 
-def _node_mlp_backward_exact(layer, f2d, m_i, g_out, grads):
+def _node_mlp_backward_exact(layer, f2d, m_i, g_out, grads, drop=None, row0=0):
     """node_norm + node_mlp + residual (egnn_pytorch.py:196-201, 335-337) differentiated on the exact GEMMs (egnn_linear_f32 / _f64) in
     f2d's dtype: returns (d loss / d feats of this part (rows, dim), d loss / d m_i (rows, m)) and accumulates the parameter gradients.
-    node_norm itself (a LayerNorm on node-level rows) goes through autograd."""
+    node_norm itself (a LayerNorm on node-level rows) goes through autograd.  drop = (p, seed), row0: training-mode dropout between the
+    first Linear and its SiLU -- the forward's hash mask of node rows row0 .. (the torch twin of the kernels' hash, node-level)."""
     from . import _ops
     dt = f2d.dtype
     dim = f2d.shape[1]
@@ -463,11 +464,18 @@ def _node_mlp_backward_exact(layer, f2d, m_i, g_out, grads):
     kin, hid = node_in.shape[1], w5.shape[0]
     rows = f2d.shape[0]
     z1 = _ops.linear_f32(node_in, w5, hid, kin, bias=n0.bias.detach().to(dt).contiguous(), name="bwd_exact_node_mlp")
+    dk = None
+    if drop is not None:                                                       # z_d = z keep / (1 - p); d z_d / d z = keep / (1 - p)
+        from . import _dropout
+        dk = _dropout.apply(torch.ones_like(z1), drop[1], _dropout.SITE_NODE, torch.arange(row0, row0 + rows, device=z1.device), drop[0])
+        z1 = z1 * dk
     sg = torch.sigmoid(z1)
     a1 = z1 * sg
     g_out = g_out.contiguous()
     g_a1 = _ops.linear_f32(g_out, w6.t().contiguous(), hid, dim, name="bwd_exact_node_mlp")                    # g_out W6
     g_z1 = g_a1 * (sg * (1 + z1 * (1 - sg)))
+    if dk is not None:
+        g_z1 = g_z1 * dk
     got = g_out.t().contiguous()
     grads[id(n3.weight)] += _ops.linear_f32(got, a1.t().contiguous(), hid, rows, name="bwd_exact_node_mlp")  # g_out^T a1
     grads[id(n3.bias)] += g_out.sum(dim=0)
@@ -559,6 +567,7 @@ def _backward_exact(ctx, g_node, g_coors):
     g_node = torch.zeros_like(feats) if g_node is None else g_node.to(dtype)
     g_coors = torch.zeros_like(coors) if g_coors is None else g_coors.to(dtype)
     u_all = ctx.saved_tensors[6].view(b, n, k, m)
+    drop = getattr(ctx, "drop", None)                                     # (p, seed) of a training-mode forward: the same hash masks re-evaluated
     proj = ctx.saved_tensors[7]                                           # (B N, 2 hq): [P_i incl. bias | P_j], what the forward's edge pass read
     hq = proj.shape[1] // 2
     w1 = lin0.weight.detach().to(dtype).contiguous()                      # (H, Din): [W_i | W_j | scalar columns]
@@ -588,7 +597,8 @@ def _backward_exact(ctx, g_node, g_coors):
                 m_i, pm, cnt = _pooled_messages(layer, u4, m0, i64, r0, ctx.valid_radius)
                 g_msum = None
                 if layer.node_mlp is not None:
-                    g_f, g_mi = _node_mlp_backward_exact(layer, f0.view(bn, dim), m_i.reshape(bn, m), g_node[lo:hi_].reshape(bn, dim), grads)
+                    g_f, g_mi = _node_mlp_backward_exact(layer, f0.view(bn, dim), m_i.reshape(bn, m), g_node[lo:hi_].reshape(bn, dim), grads,
+                                                         drop, lo * n)
                     g_feats[lo:hi_] += g_f.view(bc, n, dim)
                     g_mi = g_mi.view(bc, n, m)
                     if layer.m_pool_method == "mean":
@@ -597,14 +607,15 @@ def _backward_exact(ctx, g_node, g_coors):
                 else:
                     g_feats[lo:hi_] += g_node[lo:hi_]                                # (update_feats=False: node_out is feats)
                 g_coors_in[lo:hi_] += g_coors[lo:hi_]                                # the residual of the coordinate update
-                g_u, g_c = _tail_closed_form(layer, u4.reshape(ec, m).contiguous(), c0, i32, pm, g_coors[lo:hi_], g_msum, grads, dl, bc, n, k)
+                g_u, g_c = _tail_closed_form(layer, u4.reshape(ec, m).contiguous(), c0, i32, pm, g_coors[lo:hi_], g_msum, grads, dl, bc, n, k,
+                                             drop, lo * n * k)
                 g_coors_in[lo:hi_] += g_c
         else:
             # ---- 1. the small tail, through autograd (E x m, node-level): heads wider than 64 channels
             with torch.enable_grad():
                 f = f0.detach().requires_grad_(True)
                 u = u_all[lo:hi_].detach().requires_grad_(True)
-                out_n, out_c = layer_tail(layer, f, c, u, rel, m0, i64, r0, ctx.valid_radius)
+                out_n, out_c = layer_tail(layer, f, c, u, rel, m0, i64, r0, ctx.valid_radius, drop=drop, graph_offset=lo)
                 outs, gouts = [], []
                 for o, g in ((out_n, g_node[lo:hi_]), (out_c, g_coors[lo:hi_])):
                     if o.requires_grad:
@@ -633,6 +644,7 @@ def _backward_exact(ctx, g_node, g_coors):
             a.Ws, a.ldws = w1.data_ptr() + esz * 2 * dim, w1.shape[1]
             a.W2, a.coors, a.edges, a.idx = w2.data_ptr(), c0.data_ptr(), _ops._ptr(e0), _ops._ptr(i32)
             a.gU, a.A_T, a.DZ_T, a.g_scal = g_u.data_ptr(), a_t.data_ptr(), dz_t.data_ptr(), g_scal.data_ptr()
+            _ops.set_drop(a, drop, lo * n * k)
             _ops.edge_exact_bwd(a, dtype)
             gpi, gpi_t, gpj, gpj_t = _ops.edge_exact_node_sums(dz_t, bn, k, dl.order, dl.seg)
             # ---- 3. the contractions, on the exact GEMMs

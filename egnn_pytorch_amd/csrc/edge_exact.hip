@@ -56,6 +56,9 @@ struct ExArgs {
     const int32_t* idx;
     T valid_radius, clamp;
     T *m_i, *coors_out, *edge_ws, *U_out;
+    uint32_t drop_thr, drop_seed;
+    float drop_inv_keep;
+    int64_t drop_eid0;
 };
 template <typename T>
 ExArgs<T> ex_args(const egnn_edge_exact_args& a)
@@ -73,6 +76,7 @@ ExArgs<T> ex_args(const egnn_edge_exact_args& a)
     p.valid_radius = (T)a.valid_radius; p.clamp = (T)a.clamp;
     p.m_i = static_cast<T*>(a.m_i); p.coors_out = static_cast<T*>(a.coors_out); p.edge_ws = static_cast<T*>(a.edge_ws);
     p.U_out = static_cast<T*>(a.U_out);
+    p.drop_thr = a.drop_thr; p.drop_seed = a.drop_seed; p.drop_inv_keep = a.drop_inv_keep; p.drop_eid0 = a.drop_eid0;
     return p;
 }
 
@@ -89,6 +93,9 @@ __global__ __launch_bounds__(EX_THREADS) void edge_exact_kernel(const ExArgs<T> 
     const int64_t bN = node / N * N;
     const int i = (int)(node - bN);
     const int j = p.idx ? p.idx[q] : k;
+    // (training-mode dropout: the fused kernels' hash masks -- row = global edge id -- of the edge_mlp and coors_mlp sites)
+    const uint32_t ekey = p.drop_thr ? egnn_drop_base(p.drop_seed, EGNN_DROP_SITE_EDGE, (uint32_t)(q + p.drop_eid0)) : 0u;
+    const uint32_t ckey = p.drop_thr ? egnn_drop_base(p.drop_seed, EGNN_DROP_SITE_COORS, (uint32_t)(q + p.drop_eid0)) : 0u;
 
     // x_i - x_j and the squared distance, in the reference's operation order (egnn_common.h): what the neighbour selection ranked by
     const T* const ci = p.coors + (bN + i) * C;
@@ -121,6 +128,7 @@ __global__ __launch_bounds__(EX_THREADS) void edge_exact_kernel(const ExArgs<T> 
         const T* ws = p.Ws + (size_t)h * p.ldws;
         if (S == 1) x = ex_fma(d, ws[0], x);                             // (the common case stays in a register)
         else for (int s = 0; s < S; ++s) x = ex_fma(scal[s * EX_THREADS], ws[s], x);
+        if (p.drop_thr) x = egnn_drop_hash(ekey, (uint32_t)h) >= p.drop_thr ? x * (T)p.drop_inv_keep : (T)0;      // :178-184 (training mode)
         const T a = ex_silu(x);
         const T* w2 = p.W2 + h;
 #pragma unroll
@@ -164,6 +172,7 @@ __global__ __launch_bounds__(EX_THREADS) void edge_exact_kernel(const ExArgs<T> 
 #pragma unroll
             for (int c = 0; c < MB; ++c)
                 if (c < m_dim) z = ex_fma(w3[c], m[c], z);
+            if (p.drop_thr) z = egnn_drop_hash(ckey, (uint32_t)r) >= p.drop_thr ? z * (T)p.drop_inv_keep : (T)0;   // :203-208 (training mode)
             cw = ex_fma(p.W4[r], ex_silu(z), cw);
         }
         T inv = (T)1;
@@ -201,6 +210,9 @@ __global__ __launch_bounds__(EX_THREADS) void edge_exact_wide_kernel(const ExArg
     const int64_t bN = node / N * N;
     const int i = (int)(node - bN);
     const int j = p.idx ? p.idx[q] : k;
+    // (training-mode dropout: the fused kernels' hash masks -- row = global edge id -- of the edge_mlp and coors_mlp sites)
+    const uint32_t ekey = p.drop_thr ? egnn_drop_base(p.drop_seed, EGNN_DROP_SITE_EDGE, (uint32_t)(q + p.drop_eid0)) : 0u;
+    const uint32_t ckey = p.drop_thr ? egnn_drop_base(p.drop_seed, EGNN_DROP_SITE_COORS, (uint32_t)(q + p.drop_eid0)) : 0u;
     const T* const ci = p.coors + (bN + i) * C;
     const T* const cj = p.coors + (bN + j) * C;
     const T d = ex_sqdist(ci, cj, C);
@@ -227,6 +239,7 @@ __global__ __launch_bounds__(EX_THREADS) void edge_exact_wide_kernel(const ExArg
             T x = pi[h] + pj[h];
             const T* ws = p.Ws + (size_t)h * p.ldws;
             for (int s = 0; s < S; ++s) x = ex_fma(scal[s * EX_THREADS], ws[s], x);
+            if (p.drop_thr) x = egnn_drop_hash(ekey, (uint32_t)h) >= p.drop_thr ? x * (T)p.drop_inv_keep : (T)0;
             const T a = ex_silu(x);
             const T* w2 = p.W2 + (size_t)cb * H + h;
 #pragma unroll
@@ -259,6 +272,7 @@ __global__ __launch_bounds__(EX_THREADS) void edge_exact_wide_kernel(const ExArg
             T z = p.b3[r];
             const T* w3 = p.W3 + (size_t)r * m_dim;
             for (int c = 0; c < m_dim; ++c) z = ex_fma(w3[c], row[c] * gt, z);
+            if (p.drop_thr) z = egnn_drop_hash(ckey, (uint32_t)r) >= p.drop_thr ? z * (T)p.drop_inv_keep : (T)0;
             cw = ex_fma(p.W4[r], ex_silu(z), cw);
         }
         T inv = (T)1;
@@ -326,6 +340,7 @@ int edge_exact_launch(const egnn_edge_exact_args* args, void* stream)
     const int64_t E = (int64_t)a.B * a.N * a.K;
     const int64_t blocks = (E + EX_THREADS - 1) / EX_THREADS;
     if (blocks > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
+    if (a.drop_thr && (!(a.drop_inv_keep >= 1.f) || a.drop_eid0 < 0 || a.drop_eid0 + E > 0xffffffffLL)) return EGNN_E_SHAPE;      // (32-bit mask rows)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const ExArgs<T> p = ex_args<T>(a);
     const size_t lds = (size_t)(2 * a.fourier + 1 + a.edge_dim) * EX_THREADS * sizeof(T);
@@ -348,7 +363,46 @@ int edge_exact_launch(const egnn_edge_exact_args* args, void* stream)
     return egnn_launch_status();
 }
 
+// Z <- SiLU(dropout(Z)), element-wise (nn.Dropout between node_mlp's first Linear and its SiLU on this path, egnn_pytorch.py:196-201)
+template <typename T>
+__global__ __launch_bounds__(EX_THREADS) void drop_silu_kernel(T* __restrict__ Z, int64_t ld, int64_t rows, int cols, uint32_t thr, uint32_t seed,
+                                                               float inv_keep, int64_t row0)
+{
+    const int64_t total = rows * cols;
+    for (int64_t o = (int64_t)blockIdx.x * EX_THREADS + threadIdx.x; o < total; o += (int64_t)gridDim.x * EX_THREADS) {
+        const int64_t r = o / cols;
+        const int c = (int)(o - r * cols);
+        T z = Z[r * ld + c];
+        if (thr) z = egnn_drop_hash(egnn_drop_base(seed, EGNN_DROP_SITE_NODE, (uint32_t)(row0 + r)), (uint32_t)c) >= thr ? z * (T)inv_keep : (T)0;
+        Z[r * ld + c] = ex_silu(z);
+    }
+}
+
+template <typename T>
+int drop_silu_launch(void* Z, int64_t ld, int64_t rows, int cols, uint32_t thr, uint32_t seed, float inv_keep, int64_t row0, void* stream)
+{
+    if (!Z) return EGNN_E_NULLPTR;
+    if (rows <= 0 || cols <= 0 || ld < cols || row0 < 0 || row0 + rows > 0xffffffffLL) return EGNN_E_SHAPE;
+    if (thr && !(inv_keep >= 1.f)) return EGNN_E_SHAPE;
+    int64_t blocks = (rows * cols + EX_THREADS - 1) / EX_THREADS;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(drop_silu_kernel<T>, dim3((unsigned)blocks), dim3(EX_THREADS), 0, static_cast<hipStream_t>(stream), static_cast<T*>(Z), ld,
+                       rows, cols, thr, seed, inv_keep, row0);
+    return egnn_launch_status();
+}
+
 }  // namespace
+
+extern "C" int egnn_drop_silu_f32(void* Z, int64_t ld, int64_t rows, int cols, uint32_t drop_thr, uint32_t drop_seed, float drop_inv_keep,
+                                  int64_t row0, void* stream)
+{
+    return drop_silu_launch<float>(Z, ld, rows, cols, drop_thr, drop_seed, drop_inv_keep, row0, stream);
+}
+extern "C" int egnn_drop_silu_f64(void* Z, int64_t ld, int64_t rows, int cols, uint32_t drop_thr, uint32_t drop_seed, float drop_inv_keep,
+                                  int64_t row0, void* stream)
+{
+    return drop_silu_launch<double>(Z, ld, rows, cols, drop_thr, drop_seed, drop_inv_keep, row0, stream);
+}
 
 extern "C" size_t egnn_edge_exact_workspace_bytes(int B, int N, int K, int m_dim, int coor_dim)
 {

@@ -47,6 +47,9 @@ struct XbArgs {
     int64_t ldp, ldws;
     const int32_t* idx;
     T *A_T, *DZ_T, *g_scal;
+    uint32_t drop_thr, drop_seed;
+    float drop_inv_keep;
+    int64_t drop_eid0;
 };
 
 // MB: message channels whose gU the thread keeps in registers (16 / 32 / 64); 0: any m_dim, gU re-read per hidden unit
@@ -91,12 +94,18 @@ __global__ __launch_bounds__(XB_THREADS) void edge_exact_bwd_kernel(const XbArgs
 #pragma unroll
         for (int c = 0; c < MR; ++c) g[c] = c < m_dim ? gu[c] : (T)0;
     }
+    const uint32_t ekey = p.drop_thr ? egnn_drop_base(p.drop_seed, EGNN_DROP_SITE_EDGE, (uint32_t)(q + p.drop_eid0)) : 0u;
     T gd = (T)0;                                                         // S == 1: d/d (squared distance) stays in a register
     for (int h = 0; h < H; ++h) {
         T x = pi[h] + pj[h];
         const T* ws = p.Ws + (size_t)h * p.ldws;
         if (S == 1) x = xb_fma(d, ws[0], x);
         else for (int s = 0; s < S; ++s) x = xb_fma(scal[s * XB_THREADS], ws[s], x);
+        T dk = (T)1;                                                     // d (dropped pre-activation) / d (pre-activation)
+        if (p.drop_thr) {                                                // training-mode dropout (:178-184): the forward's mask of this row
+            dk = egnn_drop_hash(ekey, (uint32_t)h) >= p.drop_thr ? (T)p.drop_inv_keep : (T)0;
+            x *= dk;
+        }
         const T sig = (T)1 / ((T)1 + xb_exp(-x));
         const T a = x * sig;                                             // SiLU(x), as the forward (x / (1 + exp(-x)))
         const T* w2 = p.W2 + h;
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(XB_THREADS) void edge_exact_bwd_kernel(const XbArgs
         } else {
             for (int c = 0; c < m_dim; ++c) da = xb_fma(w2[(size_t)c * H], gu[c], da);
         }
-        const T dz = da * (sig * ((T)1 + x * ((T)1 - sig)));             // SiLU'(x) = sig (1 + x (1 - sig))
+        const T dz = da * (sig * ((T)1 + x * ((T)1 - sig))) * dk;        // SiLU'(x) = sig (1 + x (1 - sig))
         p.A_T[(size_t)h * E + q] = a;
         p.DZ_T[(size_t)h * E + q] = dz;
         if (S == 1) gd = xb_fma(dz, ws[0], gd);
@@ -164,6 +173,8 @@ int edge_exact_bwd_launch(const egnn_edge_exact_bwd_args* args, void* stream)
     p.coors = static_cast<const T*>(a.coors); p.edges = static_cast<const T*>(a.edges); p.gU = static_cast<const T*>(a.gU);
     p.ldp = a.ldp; p.ldws = a.ldws; p.idx = a.idx;
     p.A_T = static_cast<T*>(a.A_T); p.DZ_T = static_cast<T*>(a.DZ_T); p.g_scal = static_cast<T*>(a.g_scal);
+    if (a.drop_thr && (!(a.drop_inv_keep >= 1.f) || a.drop_eid0 < 0 || a.drop_eid0 + E > 0xffffffffLL)) return EGNN_E_SHAPE;
+    p.drop_thr = a.drop_thr; p.drop_seed = a.drop_seed; p.drop_inv_keep = a.drop_inv_keep; p.drop_eid0 = a.drop_eid0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     auto run = [&](auto kern) -> int {
         if (lds > 64 * 1024) {

@@ -73,14 +73,10 @@ def _rerun_exact_ok(module, *tensors):
     """A forward that tripped the range status word may be re-run in plain fp32: the word was read for THIS call (sync mode) and no
     stream capture is going on.  Under autograd too (round 5): the re-run's forward is the plain-fp32 kernels and its backward the
     recompute path -- plain fp32 ATen arithmetic over the neighbour list those kernels selected, no fp16 cast site anywhere -- so that
-    reference-legal inputs such as feats x 1e6 TRAIN instead of raising (slower: it is the wide-range path).  Not with training-mode
-    dropout, whose hash masks live in the fast kernels."""
+    reference-legal inputs such as feats x 1e6 TRAIN instead of raising (slower: it is the wide-range path).  With training-mode
+    dropout as well: the plain kernels evaluate the same hash masks (the re-run draws a fresh seed, like any other forward)."""
     if _ops.RANGE_CHECK != "sync" or exact_active():
         return False
-    if torch.is_grad_enabled() and (any(p.requires_grad for p in module.parameters()) or
-                                    any(torch.is_tensor(t) and t.is_floating_point() and t.requires_grad for t in tensors)):
-        if any(m.dropout_active() for m in module.modules() if isinstance(m, EGNN)):
-            return False
     return not torch.cuda.is_current_stream_capturing()
 # The kernels compute in fp32-class arithmetic (split-f16 products, fp32 accumulation: DESIGN.md §2).  Other floating dtypes
 # -- the reference is dtype-generic and its own tests run in float64 -- are accepted at the boundary: inputs are converted to
@@ -190,10 +186,6 @@ class EGNN(nn.Module):
             raise NotImplementedError("the gfx950 path supports coordinate dimensions 1..64 (beyond 8 on the plain kernels)")
         if feats.shape[-1] != self.dim:
             raise ValueError(f"feats last dim {feats.shape[-1]} != dim {self.dim}")
-        if self.training and self.dropout_p > 0 and (coors.shape[-1] > 8 or self.m_dim > 64 or 2 * self.fourier_features + 1 + self.edge_dim > 16):
-            raise NotImplementedError("training-mode dropout on the gfx950 path needs coordinate dimension <= 8, m_dim <= 64 and <= 16 per-edge scalars "
-                                      "(the hash masks live in the fused edge pass; wider shapes run -- and train -- on the plain kernels, "
-                                      "which carry no dropout); use dropout=0 or call .eval()")
         if (edges is not None) != (self.edge_dim > 0):
             raise ValueError("`edges` must be passed if and only if edge_dim > 0")
         b, n = feats.shape[:2]
@@ -254,8 +246,11 @@ class EGNN(nn.Module):
             if isinstance(edges, EdgeLookup):
                 raise NotImplementedError("float64 modules take the materialised (B,N,N,edge_dim) edge features")
             with torch.cuda.device(feats.device):
+                if self.dropout_active() and drop_seed is None:
+                    drop_seed = _dropout.draw_seed()
                 out = self._forward_exact(feats.double(), coors.double(), None if edges is None else edges.double(), mask, adj_mat,
-                                          dtype=torch.float64, want_u=want_u)
+                                          dtype=torch.float64, want_u=want_u,
+                                          drop=(self.dropout_p, drop_seed) if self.dropout_active() else None)
             if f_dtype != torch.float64 or c_dtype != torch.float64:
                 out = (out[0].to(f_dtype), out[1].to(c_dtype)) + tuple(out[2:])
             return out
@@ -279,9 +274,8 @@ class EGNN(nn.Module):
         return torch.float64 if (p is not None and p.dtype == torch.float64) else torch.float32
 
     def float64_kernels(self):
-        """A float64 module runs on the float64 kernels -- except with training-mode dropout, whose hash masks live in the fast
-        kernels only: that combination keeps the boundary conversion (fp32-class arithmetic, with the one-time warning)."""
-        return self.compute_dtype() == torch.float64 and not self.dropout_active()
+        """A float64 module runs on the float64 kernels (training-mode dropout included: the plain kernels evaluate the same hash masks)."""
+        return self.compute_dtype() == torch.float64
 
     def _select_neighbors(self, coors, mask, adj_mat, order_hint):
         """(idx, rank, order, slots, K, valid_radius) of egnn_pytorch.py:230-260 for fp32 coordinates on the device: the K nearest
@@ -364,9 +358,7 @@ class EGNN(nn.Module):
         # ... and heads wider than 64 message channels (the fused kernels hold up to four 16-channel accumulator tiles per edge tile)
         wide_shape = 2 * self.fourier_features + 1 + self.edge_dim > 16 or coors.shape[-1] > 8 or self.m_dim > 64
         if exact_active() or wide_shape:
-            if drop is not None:
-                raise NotImplementedError("the plain-fp32 (wide-range) kernels carry no training-mode dropout (its hash masks live in the fused edge pass)")
-            return self._forward_exact(feats, coors, edges, mask, adj_mat, want_u=want_u)
+            return self._forward_exact(feats, coors, edges, mask, adj_mat, want_u=want_u, drop=drop)
         b, n, dim = feats.shape
         w = self.packed_weights()
         feats = feats.contiguous()
@@ -489,10 +481,12 @@ class EGNN(nn.Module):
         return node_out, coors_out, order, idx, rank, valid_radius, u_pre, proj_kept
 
 
-    def _forward_exact(self, feats, coors, edges, mask, adj_mat, dtype=torch.float32, want_u=False):
+    def _forward_exact(self, feats, coors, edges, mask, adj_mat, dtype=torch.float32, want_u=False, drop=None):
         """The layer on the plain-fp32 kernels (include/egnn_hip.h, "The wide-range path"): exact-fp32 GEMMs, fp32 node_norm, the edge
         pass as fp32 VALU arithmetic on the module's own weight tensors.  Same neighbour selection, same return tuple as _forward_hip.
-        dtype = torch.float64: the same kernels instantiated for double ("The float64 path"; feats / coors / edges are float64)."""
+        dtype = torch.float64: the same kernels instantiated for double ("The float64 path"; feats / coors / edges are float64).
+        drop = (p, seed): training-mode dropout -- the fused kernels' hash masks at the three sites (egnn_edge_exact_args.drop_*,
+        egnn_drop_silu_*)."""
         esz = 8 if dtype == torch.float64 else 4
         b, n, dim = feats.shape
         feats = feats.contiguous()
@@ -567,6 +561,7 @@ class EGNN(nn.Module):
                 u_pre = _ops.empty(b * n * k, self.m_dim, dtype=dtype, device=feats.device)
                 a.U_out = u_pre.data_ptr()
                 proj_keep = (proj, False)
+            _ops.set_drop(a, drop)
             _ops.edge_exact(a, feats.device, dtype)
             del proj, keep
         elif self.node_mlp is not None:
@@ -576,7 +571,10 @@ class EGNN(nn.Module):
             node_in = _ops.node_prep_f32(feats2d, m_i, f32(ln.weight) if ln is not None else None,
                                          f32(ln.bias) if ln is not None else None, ln.eps if ln is not None else 1e-5, self.m_dim)
             n0, n3 = self.node_mlp[0], self.node_mlp[3]
-            hid = _ops.linear_f32(node_in, f32(n0.weight), 2 * dim, dim + self.m_dim, bias=f32(n0.bias), act=1, name="node_mlp0_f32")
+            if drop is None:
+                hid = _ops.linear_f32(node_in, f32(n0.weight), 2 * dim, dim + self.m_dim, bias=f32(n0.bias), act=1, name="node_mlp0_f32")
+            else:                                                        # Linear -> Dropout -> SiLU (egnn_pytorch.py:196-201)
+                hid = _ops.drop_silu_(_ops.linear_f32(node_in, f32(n0.weight), 2 * dim, dim + self.m_dim, bias=f32(n0.bias), name="node_mlp0_f32"), drop)
             node_out = _ops.linear_f32(hid, f32(n3.weight), dim, 2 * dim, bias=f32(n3.bias), residual=feats2d,
                                        name="node_mlp1_f32").view(b, n, dim)
         return node_out, coors_out, None, idx, rank, valid_radius, u_pre, proj_keep

@@ -313,7 +313,8 @@ typedef struct egnn_edge_args {
                                    order / valid_radius -- the setup reads them instead of walking order -> idx -> coors -> mask */
     /* training-mode dropout (egnn_pytorch.py:176, 178-184, 203-208; drop_thr = 0: off).  Element (edge, unit) of the pre-activation of
      * edge_mlp's and of coors_mlp's first SiLU is kept iff the counter-based hash of [seed, site, edge id, unit] is >= drop_thr (csrc/egnn_common.h;
-     * the torch twin is egnn_pytorch_amd/_dropout.py) and multiplied by drop_inv_keep = 1 / (1 - p), else zeroed.  coor_dim 3, m_dim <= 16. */
+     * the torch twin is egnn_pytorch_amd/_dropout.py) and multiplied by drop_inv_keep = 1 / (1 - p), else zeroed.  Every shape of this entry
+     * (coor_dim <= 8, m_dim <= 64, up to 16 scalars); the plain kernels carry the same masks (egnn_edge_exact_args.drop_*). */
     uint32_t drop_thr;          /* round(p * 2^32), p in (0, 1) */
     uint32_t drop_seed;
     float drop_inv_keep;
@@ -349,7 +350,8 @@ int egnn_edge_features_gather_f32(const float* edges, const int64_t* edge_tok, c
  *                              -> d loss / d scalars = sum over dim 0   (n_chunks = ceil(Hp / 32 / egnn_edge_bwd_chunk_steps()))
  * The all-edge contractions can ride with either pass (each edge appears once in both lists).  Every element of the outputs is
  * written (no zero-fill needed) except the unused rows of dWs_part at S > 1.  Limits: S <= 16 (beyond five scalars d/d s goes to the
- * matrix cores: WsTh; the all-edge contractions must then be split over the two passes and dropout is not instantiated), m_dim <= 16, B*N*K < 2^31, the P table and the partial rows below 4 GB each.  All pointers
+ * matrix cores: WsTh; the all-edge contractions must then be split over the two passes), m_dim <= 16 per call (wider heads: once per
+ * block of 16 channels), B*N*K < 2^31, the P table and the partial rows below 4 GB each.  All pointers
  * device memory. */
 typedef struct egnn_edge_bwd_args {
     int B, N, K;
@@ -611,10 +613,23 @@ typedef struct egnn_edge_exact_args {
     void* edge_ws;
     void* U_out;                /* optional (forward under autograd): (B*N*K, m_dim) u = edge_mlp.3(SiLU(edge_mlp.0(.))) incl. its bias, before the
                                    second SiLU (egnn_pytorch.py:181-183) -- what egnn_edge_exact_bwd_* and the per-edge tail differentiate from */
+    /* training-mode dropout behind the first Linear of edge_mlp and of coors_mlp (egnn_pytorch.py:178-184, 203-208; ABI 34): the same
+     * counter-based hash masks as the fused kernels (csrc/egnn_common.h: sites edge / coors, row = drop_eid0 + edge, column = hidden
+     * unit), kept values x drop_inv_keep; drop_thr = 0: none.  node_mlp's mask: egnn_drop_silu_f32 / _f64 between its two Linears. */
+    uint32_t drop_thr, drop_seed;
+    float drop_inv_keep;
+    int64_t drop_eid0;
 } egnn_edge_exact_args;
 
 size_t egnn_edge_exact_workspace_bytes(int B, int N, int K, int m_dim, int coor_dim);      /* fp32; twice that for egnn_edge_exact_f64 */
 int egnn_edge_exact_f32(const egnn_edge_exact_args* args, void* stream);
+/* Z (rows, ld >= cols) <- SiLU(dropout(Z)) in place: nn.Dropout between node_mlp's first Linear and its SiLU on the plain kernels
+ * (egnn_pytorch.py:196-201) -- element (row, col) kept iff the hash of [seed, site = node, row0 + row, col] >= drop_thr (csrc/egnn_common.h)
+ * and multiplied by drop_inv_keep, else zero; drop_thr = 0: plain SiLU. */
+int egnn_drop_silu_f32(void* Z, int64_t ld, int64_t rows, int cols, uint32_t drop_thr, uint32_t drop_seed, float drop_inv_keep, int64_t row0,
+                       void* stream);
+int egnn_drop_silu_f64(void* Z, int64_t ld, int64_t rows, int cols, uint32_t drop_thr, uint32_t drop_seed, float drop_inv_keep, int64_t row0,
+                       void* stream);
 
 /* The E x H work of the BACKWARD of that path (csrc/edge_exact_bwd.hip; autograd of egnn_pytorch.py:277-287): plain fp32 for calls that
  * were answered by the wide-range path and for the shapes beyond the fused kernels' limits, float64 for float64 modules (the reference's
@@ -641,6 +656,11 @@ typedef struct egnn_edge_exact_bwd_args {
     void* A_T;                  /* out (H, B*N*K) */
     void* DZ_T;                 /* out (H, B*N*K) */
     void* g_scal;               /* out (B*N*K, S), S = 2 fourier + 1 + edge_dim: [sin.., cos.., dist, edge features..] */
+    /* training-mode dropout behind edge_mlp's first Linear, as in `egnn_edge_exact_args` -- ABI 34: z is re-evaluated with the forward's
+     * mask, A_T = SiLU of the dropped pre-activation, DZ_T = the gradient with respect to the Linear's output */
+    uint32_t drop_thr, drop_seed;
+    float drop_inv_keep;
+    int64_t drop_eid0;
 } egnn_edge_exact_bwd_args;
 int egnn_edge_exact_bwd_f32(const egnn_edge_exact_bwd_args* args, void* stream);
 int egnn_edge_exact_bwd_f64(const egnn_edge_exact_bwd_args* args, void* stream);

@@ -80,6 +80,11 @@ CASES = [
     (dict(dim=32, dropout=0.3, m_dim=48, soft_edges=True), 24, False),
     (dict(dim=32, num_nearest_neighbors=8, dropout=0.2, norm_coors=True, cdim=5), 40, True),
     (dict(dim=24, num_nearest_neighbors=12, dropout=0.15, m_dim=24, edge_dim=2, cdim=2), 36, False),
+    # ... and the shapes of the plain kernels (csrc/edge_exact.hip: the same hash masks; egnn_drop_silu_f32 for node_mlp): more than 8
+    # coordinates, a head wider than 64 channels (the blocked kernel), more than 16 per-edge scalars
+    (dict(dim=24, num_nearest_neighbors=8, dropout=0.2, norm_coors=True, cdim=9), 30, True),
+    (dict(dim=16, num_nearest_neighbors=6, dropout=0.25, m_dim=80, soft_edges=True), 24, False),
+    (dict(dim=16, dropout=0.3, fourier_features=8, edge_dim=2, norm_feats=True), 14, True),
 ]
 
 
@@ -152,6 +157,11 @@ BWD_CASES = [
     (dict(dim=24, num_nearest_neighbors=6, dropout=0.15, fourier_features=4, edge_dim=4, cdim=4), 24, True, True),
     # no coors_mlp: the recompute path
     (dict(dim=24, num_nearest_neighbors=8, dropout=0.2, update_coors=False), 30, False, False),
+    # the plain kernels' shapes: `_backward_exact` with the masks re-evaluated (csrc/edge_exact_bwd.hip, the generic tail kernel; a head
+    # wider than 64 channels keeps the autograd tail with the hash's torch twin)
+    (dict(dim=24, num_nearest_neighbors=8, dropout=0.2, cdim=9, coor_weights_clamp_value=2.0), 30, True, "exact"),
+    (dict(dim=16, num_nearest_neighbors=6, dropout=0.25, m_dim=80, soft_edges=True), 24, False, "exact"),
+    (dict(dim=16, dropout=0.3, fourier_features=8, edge_dim=2, norm_feats=True, m_pool_method="mean"), 14, True, "exact"),
 ]
 
 
@@ -164,7 +174,10 @@ def test_training_mode_backward_differentiates_the_masked_layer(kw, n, use_mask,
     torch.manual_seed(21)
     layer = EGNN(**_layer_kw(kw))
     cdim = kw.get("cdim", 3)
-    assert (A._dropout_native_ok(layer) and cdim <= 8) == native
+    if native == "exact":                                   # the plain kernels: EGNNFunction takes `_backward_exact`
+        assert cdim > 8 or layer.m_dim > 64 or 2 * layer.fourier_features + 1 + layer.edge_dim > 16
+    else:
+        assert (A._dropout_native_ok(layer) and cdim <= 8) == native
     with torch.no_grad():
         for prm in layer.parameters():
             prm.mul_(40.0)
@@ -206,14 +219,33 @@ def test_training_mode_backward_differentiates_the_masked_layer(kw, n, use_mask,
 
 
 @pytest.mark.gpu
-def test_dropout_configurations_outside_the_fused_kernels_still_raise():
-    """Training-mode dropout covers every shape of the fused edge pass (m_dim <= 64, coordinate dimension <= 8); what runs on the plain
-    kernels -- wider heads, more coordinates -- carries no dropout and says so."""
-    from egnn_pytorch_amd import EGNN
+def test_dropout_runs_on_every_path_and_a_float64_module_trains_in_float64():
+    """Training-mode dropout has no shape limit left (round 5: the plain kernels evaluate the same hash masks), and a float64 module
+    with dropout computes -- and differentiates -- in float64: forward against the float64 restatement with the same masks at 1e-9."""
+    from egnn_pytorch_amd import EGNN, _dropout, autograd as A
     f = torch.randn(1, 12, 16).cuda()
-    with pytest.raises(NotImplementedError):
-        EGNN(dim=16, dropout=0.1).cuda().train()(f, torch.randn(1, 12, 9).cuda())
-    with pytest.raises(NotImplementedError):
-        EGNN(dim=16, dropout=0.1, m_dim=80).cuda().train()(f, torch.randn(1, 12, 3).cuda())
+    EGNN(dim=16, dropout=0.1).cuda().train()(f, torch.randn(1, 12, 9).cuda())
+    EGNN(dim=16, dropout=0.1, m_dim=80).cuda().train()(f, torch.randn(1, 12, 3).cuda())
     EGNN(dim=16, dropout=0.1, m_dim=80).cuda().eval()(f, torch.randn(1, 12, 3).cuda())      # eval: dropout is the identity
-    EGNN(dim=16, dropout=0.1, m_dim=32).cuda().train()(f, torch.randn(1, 12, 5).cuda())     # (round 5: covered)
+    EGNN(dim=16, dropout=0.1, m_dim=32).cuda().train()(f, torch.randn(1, 12, 5).cuda())
+    torch.manual_seed(5)
+    layer = EGNN(dim=16, num_nearest_neighbors=6, dropout=0.2, norm_coors=True, fourier_features=1).double().cuda().train()
+    g = torch.Generator().manual_seed(8)
+    feats, coors = torch.randn(2, 20, 16, generator=g, dtype=torch.float64).cuda(), torch.randn(2, 20, 3, generator=g, dtype=torch.float64).cuda()
+    torch.manual_seed(31)
+    seed = _dropout.draw_seed()
+    torch.manual_seed(31)
+    fq, cq = feats.clone().requires_grad_(True), coors.clone().requires_grad_(True)
+    node, co = layer(fq, cq)
+    assert node.dtype == torch.float64
+    got = torch.autograd.grad(node.sum() + (co * co).sum(), [fq, cq] + list(layer.parameters()), allow_unused=True)
+    with torch.no_grad():
+        idx, rank, radius = layer._forward_with_hint(feats, coors, None, None, None, None, drop_seed=seed)[3:6]
+    f2, c2 = feats.clone().requires_grad_(True), coors.clone().requires_grad_(True)
+    n2, co2 = A.layer_given_neighbors(layer, f2, c2, None, None, idx.long(), rank.double(), radius, drop=(0.2, seed))
+    assert float((node - n2).abs().max()) <= 1e-9 and float((co - co2).abs().max()) <= 1e-9
+    want = torch.autograd.grad(n2.sum() + (co2 * co2).sum(), [f2, c2] + list(layer.parameters()), allow_unused=True)
+    for a, r in zip(got, want):
+        assert (a is None) == (r is None)
+        if a is not None:
+            assert float((a - r).abs().max()) <= 1e-8 * max(1.0, float(r.abs().max()))
