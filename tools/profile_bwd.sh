@@ -16,7 +16,7 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES" 
 done
 cd "$REPO"
 python - "$OUT" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, re, sys, collections
 out = sys.argv[1]
 keep = ("edge_bwd_kernel", "edge_bwd_prep", "edge_tail_bwd", "edge_pool", "rows_gather_sum", "dest_lists", "dest_totals", "split_scaled", "absmax",
         "linear_hl_splitk", "silu_bwd", "unsplit_words", "sum_parts")
@@ -28,7 +28,10 @@ for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
         if k is None:
             continue
         if k == "edge_bwd_kernel":
-            k = "edge_bwd by_dest (+dW2)" if "true, false" in name.replace("ELb1ELb0", "true, false") or "Lb1ELb0" in name else "edge_bwd by_src (+dWs, ds)"
+            # template arguments <NM, ST, WANT_W2, WANT_S, ...>: the pass that carries d/d W_2 is the by-destination one
+            m = re.search(r"edge_bwd_kernel<\s*\d+,\s*\d+,\s*(true|false),\s*(true|false)", name) or re.search(r"edge_bwd_kernelILi\d+ELi\d+ELb([01])ELb([01])", name)
+            w2 = m is not None and m.group(1) in ("true", "1")
+            k = "edge_bwd by_dest (+dW2)" if w2 else "edge_bwd by_src (+dWs, ds)"
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as o:
     for k in sorted(acc):
