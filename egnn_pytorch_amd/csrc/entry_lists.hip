@@ -16,6 +16,10 @@
 namespace {
 
 constexpr int EL_MAX_THREADS = 1024;     // up to 16 waves per graph, each with its own histogram (as many as fit in LDS)
+#ifndef EGNN_EL_ROWS_AHEAD
+#define EGNN_EL_ROWS_AHEAD 16
+#endif
+constexpr int EL_ROWS_AHEAD = EGNN_EL_ROWS_AHEAD;   // rows whose index loads are in flight together (round 5, with the parallel scan below: 0.18 -> 0.09 ms per call at the north-star shape)
 
 // hist[w][j] = number of edges of wave w's rows that arrive at j;  then (pass 2) per destination j: deg, tiles, and the
 // graph-local exclusive scans first[j] (entries) / tseg[j] (tiles); returns the graph's totals through LDS slots
@@ -29,11 +33,24 @@ __device__ __forceinline__ void hist_and_scan(const int32_t* __restrict__ idx, i
     __syncthreads();
     const int rows_per_wave = (N + EL_WAVES - 1) / EL_WAVES;
     const int r0 = wave * rows_per_wave, r1 = (r0 + rows_per_wave) < N ? (r0 + rows_per_wave) : N;
-    for (int i = r0; i < r1; ++i)
-        for (int k = lane; k < K; k += 64) {
-            const int j = idx ? idx[((size_t)b * N + i) * K + k] : k;
-            atomicAdd(&hist[wave * N + j], 1);
+    // (K <= 64 -- one column per lane: four rows' indices in flight per step; the loop is bound by the latency of the index loads -- one
+    // workgroup per graph -- and only the LDS counters have to be bumped in row order)
+    if (idx && K <= 64) {
+        for (int i = r0; i < r1; i += EL_ROWS_AHEAD) {
+            int jv[EL_ROWS_AHEAD];
+#pragma unroll
+            for (int u = 0; u < EL_ROWS_AHEAD; ++u) jv[u] = (lane < K && i + u < r1) ? idx[((size_t)b * N + i + u) * K + lane] : -1;
+#pragma unroll
+            for (int u = 0; u < EL_ROWS_AHEAD; ++u)
+                if (jv[u] >= 0) atomicAdd(&hist[wave * N + jv[u]], 1);
         }
+    } else {
+        for (int i = r0; i < r1; ++i)
+            for (int k = lane; k < K; k += 64) {
+                const int j = idx ? idx[((size_t)b * N + i) * K + k] : k;
+                atomicAdd(&hist[wave * N + j], 1);
+            }
+    }
     __syncthreads();
     // per thread: a contiguous range of destinations; local sums, then a scan over the 256 threads
     const int per = (N + EL_THREADS - 1) / EL_THREADS;
@@ -45,18 +62,17 @@ __device__ __forceinline__ void hist_and_scan(const int32_t* __restrict__ idx, i
         se += deg;
         st += (deg + 15) >> 4;
     }
-    scan_e[tid] = se;
-    scan_t[tid] = st;
+    // exclusive scans over the workgroup's threads: inside the waves on the DPP network, the (up to 16) wave totals through LDS (round 5:
+    // this was one thread walking all 1024 entries -- half of the two kernels' time)
+    const int ie = egnn_wave_inclusive_scan(se), it = egnn_wave_inclusive_scan(st);
+    int* wtot = totals + 2;                              // [2][16]
+    if (lane == 63) { wtot[wave] = ie; wtot[16 + wave] = it; }
     __syncthreads();
-    if (tid == 0) {
-        int ae = 0, at = 0;
-        for (int t = 0; t < EL_THREADS; ++t) {
-            const int e = scan_e[t], x = scan_t[t];
-            scan_e[t] = ae; scan_t[t] = at;
-            ae += e; at += x;
-        }
-        totals[0] = ae; totals[1] = at;
-    }
+    int be = 0, bt = 0;
+    for (int w = 0; w < wave; ++w) { be += wtot[w]; bt += wtot[16 + w]; }
+    scan_e[tid] = be + ie - se;
+    scan_t[tid] = bt + it - st;
+    if (tid == EL_THREADS - 1) { totals[0] = be + ie; totals[1] = bt + it; }
     __syncthreads();
 }
 
@@ -83,7 +99,7 @@ __global__ __launch_bounds__(EL_MAX_THREADS) void dest_lists_kernel(const int32_
     int* scan_e = hist + EL_WAVES * N;
     int* scan_t = scan_e + EL_THREADS;
     int* totals = scan_t + EL_THREADS;
-    int* first = totals + 2;                         // [N] graph-local first entry of destination j in the csr list
+    int* first = totals + 2 + 32;                    // [N] graph-local first entry of destination j in the csr list (behind the wave totals)
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,14 +134,31 @@ __global__ __launch_bounds__(EL_MAX_THREADS) void dest_lists_kernel(const int32_
     // placement: rows in ascending order within the wave, the waves' row ranges in ascending order -> ascending edge id per destination
     const int rows_per_wave = (N + EL_WAVES - 1) / EL_WAVES;
     const int r0 = wave * rows_per_wave, r1 = (r0 + rows_per_wave) < N ? (r0 + rows_per_wave) : N;
-    for (int i = r0; i < r1; ++i)
-        for (int k = lane; k < K; k += 64) {
-            const int64_t eid = ebase + (int64_t)i * K + k;
-            const int j = idx ? idx[eid] : k;
-            const int pos = atomicAdd(&hist[wave * N + j], 1);       // distinct destinations within a row: no two lanes share a counter
-            ent[tbase * 16 + pos] = (int32_t)eid;
-            csr_order[ebase + first[j] + pos] = eid;
+    if (idx && K <= 64) {
+        // (as in the histogram pass: four rows' index loads in flight, the counters bumped in row order)
+        for (int i = r0; i < r1; i += EL_ROWS_AHEAD) {
+            int jv[EL_ROWS_AHEAD];
+#pragma unroll
+            for (int u = 0; u < EL_ROWS_AHEAD; ++u) jv[u] = (lane < K && i + u < r1) ? idx[ebase + (int64_t)(i + u) * K + lane] : -1;
+#pragma unroll
+            for (int u = 0; u < EL_ROWS_AHEAD; ++u) {
+                if (jv[u] < 0) continue;
+                const int64_t eid = ebase + (int64_t)(i + u) * K + lane;
+                const int pos = atomicAdd(&hist[wave * N + jv[u]], 1);   // distinct destinations within a row: no two lanes share a counter
+                ent[tbase * 16 + pos] = (int32_t)eid;
+                csr_order[ebase + first[jv[u]] + pos] = eid;
+            }
         }
+    } else {
+        for (int i = r0; i < r1; ++i)
+            for (int k = lane; k < K; k += 64) {
+                const int64_t eid = ebase + (int64_t)i * K + k;
+                const int j = idx ? idx[eid] : k;
+                const int pos = atomicAdd(&hist[wave * N + j], 1);       // distinct destinations within a row: no two lanes share a counter
+                ent[tbase * 16 + pos] = (int32_t)eid;
+                csr_order[ebase + first[j] + pos] = eid;
+            }
+    }
 }
 
 }  // namespace
@@ -149,7 +182,7 @@ extern "C" int egnn_dest_lists_i32(const int32_t* idx, int B, int N, int K, int3
     // (large graphs -- N beyond ~8000 -- trade waves for histogram space: 2 waves up to N = 13 500, 1 wave up to N = 20 400; the
     // forward's k-NN select stops at 8192 nodes per graph, dense graphs reach the int32 edge-id limit long before)
     int waves = 16;
-    auto lds_for = [&](int w) { return ((size_t)w * N + 2 * (size_t)w * 64 + 2 + N) * sizeof(int); };
+    auto lds_for = [&](int w) { return ((size_t)w * N + 2 * (size_t)w * 64 + 2 + 32 + N) * sizeof(int); };
     while (waves > 4 && lds_for(waves) > 96 * 1024) waves >>= 1;
     while (waves > 1 && lds_for(waves) > 160 * 1024) waves >>= 1;
     const size_t lds = lds_for(waves);
