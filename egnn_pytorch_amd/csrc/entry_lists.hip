@@ -104,9 +104,17 @@ __global__ __launch_bounds__(EL_MAX_THREADS) void dest_lists_kernel(const int32_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     hist_and_scan(idx, b, N, K, hist, scan_e, scan_t, totals);
-    // tiles of the graphs in front of this one (B is small: a few hundred at most)
+    // tiles of the graphs in front of this one: one graph per thread, summed over the workgroup (integer: any order gives the same sum)
     int64_t tbase = 0;
-    for (int g = 0; g < b; ++g) tbase += tiles_per_graph[g];
+    {
+        int part = 0;
+        for (int g = tid; g < b; g += EL_THREADS) part += (int)tiles_per_graph[g];
+        part = egnn_wave_inclusive_scan(part);
+        int* wtot = totals + 2;                              // (free again: hist_and_scan ended with a barrier behind its last use)
+        if (lane == 63) wtot[wave] = part;
+        __syncthreads();
+        for (int w = 0; w < EL_WAVES; ++w) tbase += wtot[w];
+    }
     const int64_t ebase = (int64_t)b * N * K;        // every graph has exactly N K edges
     // start offsets per (wave, destination): hist[w][j] <- position of wave w's first entry of j inside j's tiles (graph-local,
     // in entries), first[j] <- csr start; tile_seg / csr_seg of this graph's destinations
