@@ -481,7 +481,10 @@ int launch_knn_c(const float* coors, const uint8_t* mask, const uint8_t* adj, in
 {
     const int Npad = (N + 63) / 64 * 64;
     const int Kpad = K > KNN_SURVIVORS ? (K + 1) / 2 * 2 : KNN_SURVIVORS;      // the fast path parks up to 128 survivors
-    int rows_per_wg = 32;
+#ifndef EGNN_KNN_ROWS_PER_WG
+#define EGNN_KNN_ROWS_PER_WG 32
+#endif
+    int rows_per_wg = EGNN_KNN_ROWS_PER_WG;
     if (N < rows_per_wg) rows_per_wg = (N + 3) / 4 * 4;
     const size_t cbytes = (size_t)Npad * (4 * C + 1);
     const size_t coord_bytes = cbytes + 8 - cbytes % 8;
