@@ -86,6 +86,9 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 constexpr int EDGE_THREADS = EGNN_EDGE_THREADS;
 constexpr int EDGE_WAVES = EDGE_THREADS / 64;
 constexpr int TILES = 2;                 // MFMA tiles (16 edges) per wave
+#ifndef EGNN_EDGE_DENSE_TERMS
+#define EGNN_EDGE_DENSE_TERMS 1
+#endif
 constexpr int SLOTS_PER_WAVE = TILES * 16;
 constexpr int SLOTS_PER_ROUND = EDGE_WAVES * SLOTS_PER_WAVE;     // 256
 constexpr int HC = EGNN_EDGE_HC;          // hidden columns per LDS chunk (steps of 32)
@@ -175,6 +178,10 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
     // (wide heads -- m_dim > 16 -- and the generic coordinate dimension have no instantiation of their own for it: a run-time branch)
     constexpr bool WRITE_U = MODE == 1 || MODE == 3 || NB > 1 || CDM != 3;
     constexpr bool GDMA = EGNN_EDGE_GDMA && EGNN_EDGE_RING;           // gathers by LDS-DMA
+    // first-layer MFMAs: with P_i on the VALU (TPI == 0: K < 6) both words of a lane group's K-slots are free for scalar terms -- two
+    // terms per lane group and MFMA, half as many MFMAs (same table, read two words at a time; round 5, late)
+    constexpr bool DENSE_TERMS = EGNN_EDGE_DENSE_TERMS && TPI == 0 && NM > 1;
+    constexpr int NMX = DENSE_TERMS ? (NM + 1) / 2 : NM;
     constexpr int HC = EGNN_EDGE_RING ? HCT / 2 : HCT;     // columns per staged chunk (ring: two slots of HCT / 2)
     constexpr int NCH = nch_of(NB);
     constexpr int W2B = 64 * NB;                           // bytes of W2 fragments per hidden column: NB blocks x (hi | lo) x 16 channels
@@ -220,7 +227,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
         uint32_t pip[TILES];                                 // TPI == 0: byte offset of this lane's fp32 P_i row (+ 4 g)
         uint32_t piw[TPI == 1 ? TILES : 1] = {};             // byte offset of: TPI == 2: the wave's P_i row as (hi, lo) words
                                                              // (+ lane & 15); TPI == 1: per tile, the row of the tile's g-th node
-        u32x2 bq[TILES][NM];                                 // B fragments of the first-layer MFMAs (constant over the hidden loop)
+        u32x2 bq[TILES][NMX];                                // B fragments of the first-layer MFMAs (constant over the hidden loop)
         int ei[TILES], ej[TILES];                            // node / neighbour of this lane's edge: x_i - x_j is recomputed in the
                                                              // epilogue instead of living in 2 x CDM registers across the hidden loop
         bool fm[TILES];                                      // edge contributes (valid slot and unmasked)
@@ -280,35 +287,44 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             //     s' = s / ws_scale = 2^10 s1 + r_hi + r_lo      (s1 coarse; r the exact remainder, |s'| clamped to 6e7)
             // meeting the (hi, lo) weight pairs of egnn_pytorch_amd/_weights.py::scalar_table.
             const int F = p.fourier;
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const int tau = 4 * m + g;
+            // split term tau (scalar tau / 3, part tau % 3) of this lane's edge as the (fp16, fp16) word of a B fragment; 0 beyond the scalars
+            auto term_word = [&](const int tau) -> uint32_t {
                 const int sidx = tau / 3, kind = tau - 3 * sidx;
+                if (sidx >= S) return 0u;
+                float val;
+                if (NM == 1 && TPI != 2) val = d;                   // NM == 1 <=> S == 1: d is the only scalar (TPI == 2 keeps the generic
+                                                                    // form: the shortcut tips its register allocation into a spill)
+                else if (sidx < F) val = sinf(d * exp2f(-(float)sidx));
+                else if (sidx < 2 * F) val = cosf(d * exp2f(-(float)(sidx - F)));
+                else if (sidx == 2 * F) val = d;
+                else val = p.edges[(p.edges_by_k ? (bN + i) * (size_t)K + k : (bN + i) * (size_t)N + j) * p.edge_dim + (sidx - 2 * F - 1)];
+                // |s'| beyond 2^10 * 65504 = 6.7e7 does not fit the three fp16 parts: the coarse part overflows to inf and
+                // the edge's result is NaN (never a silently clamped number); the status word says why
+                val = val * p.ws_inv_scale;
+                egnn_flag_range(p.status, valid && fabsf(val) >= 6.0e7f && fabsf(val) < __builtin_inff(), EGNN_RANGE_SCALAR);
+                if (fabsf(val) >= 6.0e7f) val = __builtin_nanf("");
+                const _Float16 s1 = (_Float16)(val * (1.0f / 1024.0f));
+                const float r = val - (float)s1 * 1024.0f;
+                const _Float16 rh = (_Float16)r;
+                const _Float16 rl = (_Float16)(r - (float)rh);
+                return kind == 0 ? pack_h2(s1, s1) : (kind == 1 ? pack_h2(rh, rh) : pack_h2(rl, (_Float16)0.f));
+            };
+#pragma unroll
+            for (int m = 0; m < NMX; ++m) {
                 u32x2 bw = u32x2{0u, 0u};
-                if (sidx < S) {
-                    float val;
-                    if (NM == 1 && TPI != 2) val = d;                   // NM == 1 <=> S == 1: d is the only scalar (TPI == 2 keeps the generic
-                                                                        // form: the shortcut tips its register allocation into a spill)
-                    else if (sidx < F) val = sinf(d * exp2f(-(float)sidx));
-                    else if (sidx < 2 * F) val = cosf(d * exp2f(-(float)(sidx - F)));
-                    else if (sidx == 2 * F) val = d;
-                    else val = p.edges[(p.edges_by_k ? (bN + i) * (size_t)K + k : (bN + i) * (size_t)N + j) * p.edge_dim + (sidx - 2 * F - 1)];
-                    // |s'| beyond 2^10 * 65504 = 6.7e7 does not fit the three fp16 parts: the coarse part overflows to inf and
-                    // the edge's result is NaN (never a silently clamped number); the status word says why
-                    val = val * p.ws_inv_scale;
-                    egnn_flag_range(p.status, valid && fabsf(val) >= 6.0e7f && fabsf(val) < __builtin_inff(), EGNN_RANGE_SCALAR);
-                    if (fabsf(val) >= 6.0e7f) val = __builtin_nanf("");
-                    const _Float16 s1 = (_Float16)(val * (1.0f / 1024.0f));
-                    const float r = val - (float)s1 * 1024.0f;
-                    const _Float16 rh = (_Float16)r;
-                    const _Float16 rl = (_Float16)(r - (float)rh);
-                    bw[1] = kind == 0 ? pack_h2(s1, s1) : (kind == 1 ? pack_h2(rh, rh) : pack_h2(rl, (_Float16)0.f));
-                }
-                if (TPI == 2 && m == 0 && g == 0) bw[0] = pack_h2((_Float16)1.f, (_Float16)1.f);   // x (P_i hi, P_i lo)
-                if (TPI == 1 && m == 0) {
-                    // the tile's slots start in node nf and end at most 3 nodes later (K >= 6): lane group g carries node nf + g
-                    const int nf = (qwave + t * 16) / K;
-                    if (nl - nf == g) bw[0] = pack_h2((_Float16)1.f, (_Float16)1.f);
+                if constexpr (DENSE_TERMS) {
+                    // P_i is added on the VALU here (TPI == 0), so BOTH words of a lane group's K-slots carry scalar terms: terms 8 m + 2 g and
+                    // 8 m + 2 g + 1 -- half the first-layer MFMAs of the one-term-per-group form (c4: K = 3, five scalars: 4 -> 2)
+                    bw[0] = term_word(8 * m + 2 * g);
+                    bw[1] = term_word(8 * m + 2 * g + 1);
+                } else {
+                    bw[1] = term_word(4 * m + g);
+                    if (TPI == 2 && m == 0 && g == 0) bw[0] = pack_h2((_Float16)1.f, (_Float16)1.f);   // x (P_i hi, P_i lo)
+                    if (TPI == 1 && m == 0) {
+                        // the tile's slots start in node nf and end at most 3 nodes later (K >= 6): lane group g carries node nf + g
+                        const int nf = (qwave + t * 16) / K;
+                        if (nl - nf == g) bw[0] = pack_h2((_Float16)1.f, (_Float16)1.f);
+                    }
                 }
                 bq[t][m] = bw;
             }
@@ -397,6 +413,8 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
         // first-layer A fragments: row (hidden unit) e of the 16-block, split term 4 m + g
         const char* tl = wst + (e * (4 * NM) + (g ^ ((e >> 2) & 2))) * 4;      // (units 8 .. 15 of a block: term pairs swapped in the table, no bank conflict)
         constexpr int tstep = 16 * 4 * NM * 4;                          // bytes per 16 hidden units
+        // DENSE_TERMS: from this lane's one-word position to its two-word position (bytes; 8-byte aligned: even word index)
+        const int dense_delta = ((4 * (g >> 1) + 2 * ((g & 1) ^ ((e >> 3) & 1))) - (g ^ ((e >> 2) & 2))) * 4;
 
         f32x4 acc[TILES][NB];
 #pragma unroll
@@ -579,11 +597,23 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
                 __builtin_amdgcn_wave_barrier();
                 }
 
-                u32x2 av[NM][2];
+                u32x2 av[NMX][2];
+                if constexpr (DENSE_TERMS) {
+                    // two consecutive table words per lane group: logical 4-word group 2 m + (g >> 1), its words 2 (g & 1), 2 (g & 1) + 1
+                    // (units 8 .. 15 of a block store their word pairs swapped: _weights.py::swizzle_terms); a group beyond NM (odd NM): zero
 #pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    av[m][0] = u32x2{0u, *reinterpret_cast<const uint32_t*>(tlc + m * 16 + st * 2 * tstep)};
-                    av[m][1] = u32x2{0u, *reinterpret_cast<const uint32_t*>(tlc + m * 16 + st * 2 * tstep + tstep)};
+                    for (int m = 0; m < NMX; ++m) {
+                        const bool in = 2 * m + (g >> 1) < NM;
+                        const char* tp = tlc + dense_delta + m * 32 + st * 2 * tstep;
+                        av[m][0] = in ? *reinterpret_cast<const u32x2*>(tp) : u32x2{0u, 0u};
+                        av[m][1] = in ? *reinterpret_cast<const u32x2*>(tp + tstep) : u32x2{0u, 0u};
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        av[m][0] = u32x2{0u, *reinterpret_cast<const uint32_t*>(tlc + m * 16 + st * 2 * tstep)};
+                        av[m][1] = u32x2{0u, *reinterpret_cast<const uint32_t*>(tlc + m * 16 + st * 2 * tstep + tstep)};
+                    }
                 }
                 f16x8 whi[NB], wlo[NB];
 #pragma unroll
@@ -626,7 +656,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 #pragma unroll
                     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-                        for (int m = 0; m < NM; ++m)
+                        for (int m = 0; m < NMX; ++m)
 #if defined(EGNN_EDGE_ABL) && (EGNN_EDGE_ABL & 16)
                             x[t][hb][0] += __builtin_bit_cast(float, (m == 0 ? a0[t][hb] : av[m][hb])[0] ^ bq[t][m][1]);   // ablation: no first-layer MFMAs
 #else
