@@ -322,12 +322,24 @@ def version_key(layer):
     change (re-assignment; `_apply` with overwrite_module_params_on_conversion)."""
     cached = layer.__dict__.get("_param_cache")
     mods = layer.__dict__.get("_param_cache_mods")
-    if cached is None or any(m._parameters.get(n) is not p for (m, n), p in zip(mods, cached)):
-        mods, cached = [], []
+    tree = layer.__dict__.get("_param_cache_tree")
+    # the cache is valid while (a) every registered child of every module of the tree is still the object it was (a replaced submodule --
+    # `layer.node_norm = nn.LayerNorm(..)`, `edge_mlp[0] = new_linear`, an adapter swap -- keeps the OLD module's _parameters unchanged, so
+    # (b) alone would go on serving the stale packed tables) and no child was added or removed, and (b) every Parameter is the
+    # registered one
+    if (cached is None
+            or any(len(c._modules) != cnt for c, cnt, _ in tree)
+            or any(c._modules.get(n) is not ch for c, _, kids in tree for n, ch in kids)
+            or any(len(m._parameters) != cnt for m, cnt in layer.__dict__["_param_cache_counts"])
+            or any(m._parameters.get(n) is not p for (m, n), p in zip(mods, cached))):
+        mods, cached, tree, counts = [], [], [], []
         for m in layer.modules():
+            tree.append((m, len(m._modules), tuple(m._modules.items())))
+            counts.append((m, len(m._parameters)))
             for n, p in m._parameters.items():
                 if p is not None:
                     mods.append((m, n))
                     cached.append(p)
         layer.__dict__["_param_cache"], layer.__dict__["_param_cache_mods"] = cached, mods
+        layer.__dict__["_param_cache_tree"], layer.__dict__["_param_cache_counts"] = tree, counts
     return tuple((p.data_ptr(), p._version, p.device) for p in cached)

@@ -237,6 +237,27 @@ def test_packed_weights_cache_tracks_parameter_updates():
     assert b is not a and not torch.equal(a["Wcat"], b["Wcat"])
 
 
+def test_packed_weights_cache_tracks_replaced_submodules():
+    """A whole submodule replaced between two forwards (the old module's own _parameters never change): the packed tables must follow."""
+    from egnn_pytorch_amd import EGNN
+    torch.manual_seed(0)
+    layer = EGNN(dim=8, norm_feats=True)
+    a = layer.packed_weights()
+    assert layer.packed_weights() is a
+    new_first = torch.nn.Linear(layer.edge_mlp[0].in_features, layer.edge_mlp[0].out_features)
+    layer.edge_mlp[0] = new_first                                   # nn.Sequential.__setitem__
+    b = layer.packed_weights()
+    assert b is not a and not torch.equal(a["Wcat"], b["Wcat"])
+    assert layer.packed_weights() is b
+    norm = torch.nn.LayerNorm(8)
+    with torch.no_grad():
+        norm.weight.fill_(3.0)
+    layer.node_norm = norm                                          # nn.Module.__setattr__
+    c = layer.packed_weights()
+    assert c is not b and float(c["gamma"][0]) == 3.0
+    assert layer.packed_weights() is c
+
+
 def test_packed_tile_layout_matches_header_formula():
     """_weights.pack_tiles / unpack_tiles against the offset formula documented in include/egnn_hip.h."""
     from egnn_pytorch_amd import _weights
