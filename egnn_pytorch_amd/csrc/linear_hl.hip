@@ -28,6 +28,20 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // training-mode dropout between the Linear and its activation (egnn_linear_hl_drop_f32); thr = 0: off
 struct DropArgs { uint32_t thr, seed; float inv_keep; };
 
+// Build knobs (tools/variants.py build src=linear_hl ...).  Until round 6 the defaults of ILV and PRIO were defined BELOW the kernel body,
+// which therefore saw them undefined (= 0): the production library ran without either, whatever the comments said.
+#ifndef EGNN_HL_ILV
+#define EGNN_HL_ILV 0                        // classic loop: a K-tile's DMA issue spread over its three MFMA groups
+#endif
+#ifndef EGNN_HL_PRIO
+#define EGNN_HL_PRIO 0                       // s_setprio 3 for the K loop, 0 for the epilogue
+#endif
+#ifndef EGNN_HL_CFG
+#define EGNN_HL_CFG 1
+#endif
+#ifndef EGNN_HL_LOOP
+#define EGNN_HL_LOOP 2                       // 2: software-pipelined, hand-scheduled K loop (64 x 64 wave tiles); 0: the classic loop
+#endif
 constexpr int BK = 16;                       // one v_mfma_f32_32x32x16_f16 step per K-tile
 constexpr int ROWB = BK * 2;                 // bytes per LDS row (32)
 #ifndef EGNN_HL_GROUP_M
@@ -41,6 +55,25 @@ constexpr int GROUP_M = EGNN_HL_GROUP_M;
 //      streamed out of L2 (the 128 x 128 tile draws ~11 TB/s from L2 on the north-star projection, which is what
 //      holds its MFMA utilisation near 45 %)
 //   2: 256 x 256, 8 waves (2 x 4, 128 x 64 per wave), 4-deep ring of 32 KB -> 128 KB LDS, one workgroup per CU
+// ---- hand-scheduled K loop (EGNN_HL_LOOP == 2): LDS reads, LDS-DMA and their waits as inline assembly, hidden from the compiler's
+// wait-count model (cdna_hip_programming.md 5.7: asm loads are not counted, so every wait below is placed and counted by hand).
+template <int OFF>
+__device__ __forceinline__ void hl_lds_rd(f16x8& d, uint32_t addr)
+{
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF) : "memory");
+}
+// one LDS-DMA piece: lane l's 16 bytes at (sbase + voff) land at lds_dst + 16 l; wave-uniform 64-bit base in scalar registers
+__device__ __forceinline__ void hl_dma16(const char* sbase, uint32_t voff, uint32_t lds_dst)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
+__device__ __forceinline__ const char* hl_uniform_ptr(const void* p)
+{
+    const uint64_t a = (uint64_t)(size_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return reinterpret_cast<const char*>((size_t)(((uint64_t)hi << 32) | lo));
+}
+
 template <int CFG> struct Cfg;
 template <> struct Cfg<0> { static constexpr int BM = 128, BN = 128, WM = 2, WN = 2, TI = 2, TJ = 2, STAGES = 4; };
 template <> struct Cfg<1> { static constexpr int BM = 256, BN = 128, WM = 4, WN = 2, TI = 2, TJ = 2, STAGES = 3; };
@@ -157,19 +190,126 @@ __device__ __forceinline__ void linear_hl_body(
 
     // (split-K launches -- egnn_linear_hl_splitk_f32 -- give every workgroup a range [kt0, kt0 + kt_count) of the K-tiles)
     const int nk = kt_count < 0 ? nkt : kt_count;
+    constexpr bool HAND = EGNN_HL_LOOP == 2 && TI == 2 && TJ == 2 && DPW <= 4;      // the hand-scheduled loop: 64 x 64 wave tiles
     // prologue: tiles 0 .. S-2 in flight (dummies past the end keep the vmcnt bookkeeping uniform)
+    if constexpr (!HAND) {
 #pragma unroll
-    for (int t = 0; t < STAGES - 1; ++t) stage(kt0 + (t < nk ? t : nk - 1), t);
+        for (int t = 0; t < STAGES - 1; ++t) stage(kt0 + (t < nk ? t : nk - 1), t);
+    }
 
     int slot = 0;                                                      // ring slot of tile kt
 #if EGNN_HL_PRIO
     asm volatile("s_setprio 3");             // the K loop issues ahead of the CU's other workgroup when that one is in its epilogue
 #endif
-    for (int kt = 0; kt < nk; ++kt) {
+    auto wait_tile = [&]() {                 // this wave's DMAs of the oldest tile in flight have landed; its own LDS reads are complete
         if (STAGES == 4 && DPW == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else if (STAGES == 3 && DPW == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
         else if (STAGES == 3 && DPW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
+    // ---- The K loop, software-pipelined and hand-scheduled (round 6; profiles/r06_experiments/gemm_k_loop.txt).
+    // The classic loop (the else branch) puts the barrier at the HEAD of a K-tile: behind it every wave issues its DMA pieces, reads four
+    // fragments and waits for them before its first MFMA -- a few hundred cycles in which the wave feeds the matrix pipe nothing, per 384
+    // cycles of its own MFMA work, all eight waves of the workgroup at the same time.  Here the barrier that publishes tile kt+1 sits
+    // INSIDE tile kt, between its second and third MFMA group, and the hi fragments of tile kt+1 are read behind it into a second
+    // register set (+16 VGPRs: 114) while group 3 runs:
+    //     [ah, bh of tile kt in registers]
+    //     reads al0 al1 bl0 bl1 (tile kt)       outstanding: [ah' bh' x 4 of the previous tile's tail] + 4
+    //     lgkmcnt(4)  -> ah, bh                 g1: ah x bh
+    //     lgkmcnt(2)  -> al                     g2: al x bh
+    //     vmcnt((S-2) DPW) lgkmcnt(0); s_barrier         own reads of tile kt complete, own DMAs of tile kt+1 landed
+    //                                                    -> tile kt+1 visible, ring slot of tile kt free
+    //     reads ah' bh' (tile kt+1)             g3: ah x bl, the DMA pieces of tile kt+S (into the freed slot) between its MFMAs
+    // A wave arrives at the barrier with MFMAs in the pipe, has four more ready behind it, and every fragment read is issued at least one
+    // MFMA group (128 matrix-pipe cycles) ahead of its first use.  The same schedule written with compiler-visible loads does NOT come
+    // out this way: the register allocator re-uses fragment registers across the loop's back edge and the wait-count pass then puts
+    // lgkmcnt(0) right behind the reads, in front of the tile's first MFMA (measured: -3 % instead of -9 ... -11 %).  So the fragment reads
+    // and the DMA pieces are asm statements in program order (the compiler does not count them: cdna_hip_programming.md 5.7), the waits are
+    // counted by hand (LDS returns in order) and sched_barrier pins the MFMAs between them; DMA sources are a scalar base + one shared
+    // lane offset (no 64-bit vector address arithmetic per piece).  Same products in the same order per accumulator: the same bits.
+    if constexpr (HAND) {
+        const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem);
+        const char* sb[DPW];
+        uint32_t sdst[DPW];
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            sb[j] = hl_uniform_ptr(src[j] - lane * 8);
+            sdst[j] = lds0 + (uint32_t)dst[j];
+        }
+        const uint32_t voff = (uint32_t)lane * 16u;
+        const uint32_t a_addr = lds0 + (uint32_t)a_base, b_addr = lds0 + (uint32_t)b_base;
+        auto dma = [&](int kt_src, int sl, int j) {
+#if defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 4)
+            kt_src = 0;                                                // ablation: always the same (L1/L2-hot) tile
+#endif
+            hl_dma16(sb[j] + (size_t)kt_src * 1024, voff, sdst[j] + (uint32_t)(sl * BUF));
+        };
+#pragma unroll
+        for (int t = 0; t < STAGES - 1; ++t)
+#pragma unroll
+            for (int j = 0; j < DPW; ++j) dma(kt0 + (t < nk ? t : nk - 1), t, j);
+        wait_tile();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) dma(kt0 + (STAGES - 1 < nk ? STAGES - 1 : nk - 1), STAGES - 1, j);
+        f16x8 ahA[TI], bhA[TJ], ahB[TI], bhB[TJ];
+        hl_lds_rd<0>(ahA[0], a_addr); hl_lds_rd<32 * ROWB>(ahA[1], a_addr);
+        hl_lds_rd<0>(bhA[0], b_addr); hl_lds_rd<32 * ROWB>(bhA[1], b_addr);
+        auto tile = [&](f16x8 (&ah)[TI], f16x8 (&bh)[TJ], f16x8 (&ahn)[TI], f16x8 (&bhn)[TJ], const int kt) {
+            const uint32_t so = (uint32_t)(slot * BUF);
+            f16x8 al[TI], bl[TJ];
+            hl_lds_rd<AARR>(al[0], a_addr + so); hl_lds_rd<AARR + 32 * ROWB>(al[1], a_addr + so);
+            hl_lds_rd<WARR>(bl[0], b_addr + so); hl_lds_rd<WARR + 32 * ROWB>(bl[1], b_addr + so);
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[0]), "+v"(ah[1]), "+v"(bh[0]), "+v"(bh[1]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(al[0]), "+v"(al[1]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (STAGES == 4 && DPW == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" : "+v"(bl[0]), "+v"(bl[1]) :: "memory");
+            else if (STAGES == 3 && DPW == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" : "+v"(bl[0]), "+v"(bl[1]) :: "memory");
+            else if (STAGES == 3 && DPW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : "+v"(bl[0]), "+v"(bl[1]) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(bl[0]), "+v"(bl[1]) :: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const int nslot = slot + 1 == STAGES ? 0 : slot + 1;
+            const int nsrc = kt0 + (kt + STAGES < nk ? kt + STAGES : nk - 1);      // past the end: harmless re-fetch of the last tile
+            const uint32_t sn = (uint32_t)(nslot * BUF);
+            hl_lds_rd<0>(ahn[0], a_addr + sn); hl_lds_rd<32 * ROWB>(ahn[1], a_addr + sn);
+            hl_lds_rd<0>(bhn[0], b_addr + sn); hl_lds_rd<32 * ROWB>(bhn[1], b_addr + sn);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#if !(defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 8))                         // (ablation 8: no DMA in the loop -- timing only)
+                    if (i * TJ + j < DPW) dma(nsrc, slot, i * TJ + j);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            slot = nslot;
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            tile(ahA, bhA, ahB, bhB, kt);
+            if (kt + 1 < nk) tile(ahB, bhB, ahA, bhA, kt + 1);
+        }
+        // (the last tile's look-ahead reads: their destinations may not be re-used before they have landed)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ahA[0]), "+v"(ahA[1]), "+v"(bhA[0]), "+v"(bhA[1]), "+v"(ahB[0]), "+v"(ahB[1]), "+v"(bhB[0]), "+v"(bhB[1]) :: "memory");
+    } else {
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_tile();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const int nt = kt + STAGES - 1;
@@ -239,6 +379,7 @@ __device__ __forceinline__ void linear_hl_body(
         __builtin_amdgcn_sched_barrier(0);
 #endif
         slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the dummy DMAs before the LDS is released
 #if EGNN_HL_PRIO
@@ -484,16 +625,6 @@ int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi,
                        Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale, split_cols, status, drop, a_nkt);
     return egnn_launch_status();
 }
-
-#ifndef EGNN_HL_ILV
-#define EGNN_HL_ILV 1
-#endif
-#ifndef EGNN_HL_PRIO
-#define EGNN_HL_PRIO 1
-#endif
-#ifndef EGNN_HL_CFG
-#define EGNN_HL_CFG 1
-#endif
 
 template <int ACT, bool HAS_RES>
 int launch_hl(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, const _Float16* Wlo,
