@@ -209,9 +209,13 @@ def make_inputs(kwargs, b, n, device, seed):
     return feats.to(device), coors.to(device), mask.to(device)
 
 
+LAST_LOCAL_ELAPSED = [None]
+
+
 def timed_region(step, steps, warmup, sync, barrier, reduce_max):
     """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides;
-    returns the max over ranks of the elapsed seconds."""
+    returns the max over ranks of the elapsed seconds.  LAST_LOCAL_ELAPSED[0] = this rank's own K steps (its synchronize, before the
+    closing barrier): what the N-rank line reports per rank (min / max) so that a straggler shows as such, not only through the max."""
     for _ in range(warmup):
         step()
     sync()
@@ -221,6 +225,7 @@ def timed_region(step, steps, warmup, sync, barrier, reduce_max):
     for _ in range(steps):
         step()
     sync()
+    LAST_LOCAL_ELAPSED[0] = time.perf_counter() - t0
     barrier()
     sync()
     return reduce_max(time.perf_counter() - t0)
@@ -433,6 +438,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def per_rank_ms(steps):
+        """{"min", "max", "ranks": [...]}: every rank's own ms per step over the timed region (all_gather of LAST_LOCAL_ELAPSED)."""
+        mine = LAST_LOCAL_ELAPSED[0] / steps * 1e3
+        if dist is None:
+            vals = [mine]
+        else:
+            t = torch.tensor([mine], dtype=torch.float64, device=device)
+            parts = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            vals = [float(p.item()) for p in parts]
+        return {"min": round(min(vals), 4), "max": round(max(vals), 4), "ranks": [round(v, 4) for v in vals]}
+
     if standin:
         # the rank logic only (CPU, gloo): the module's REAL forward code above the kernels -- a small layer of the workload's kind on this
         # rank's shard, rank-dependent input seeds, parameters broadcast from rank 0 -- with the kernel layer replaced by the torch
@@ -458,10 +475,11 @@ def main():
             out = layer(feats, coors, mask=mask)
             return float(out[0].sum())
         elapsed = timed_region(standin_step, args.steps, args.warmup, lambda: None, barrier, reduce_max)
+        rank_ms = per_rank_ms(args.steps)
         if rank == 0:
             print(json.dumps({"metric": "EGNN.forward graphs/sec", "value": round(world * b * args.steps / elapsed, 2),
                               "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+                              "ms_per_step": round(elapsed / args.steps * 1e3, 4), "ms_per_step_by_rank": rank_ms, "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                               "data": f"STAND-IN ({args.standin_backend}, CPU, kernels stubbed by tests/_cpu_stub.py): rank logic only, not a measurement",
                               "config": {"workload": args.workload, "graphs_per_gpu": b, "global_batch": world * b}}), flush=True)
@@ -519,6 +537,7 @@ def main():
         check_range()
     _ops.RANGE_CHECK = mode0
     elapsed = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, reduce_max)
+    rank_ms = per_rank_ms(args.steps)                    # (a collective: every rank calls it)
     check_range()                                        # raises if any timed step left the representable range
 
     # the same K steps in the other mode of the range check, so that the line shows what the per-forward synchronisation costs
@@ -579,7 +598,7 @@ def main():
         out = {
             "metric": "EGNN.forward graphs/sec", "value": round(value, 2), "unit": "graphs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "ms_per_step_by_rank": rank_ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "edges_per_s": round(value * n * shp["K"] * depth, 1), "range_check": _ops.RANGE_CHECK, "priming_steps": PRIME_STEPS + 3,
             f"value_range_check_{other_mode}": None if value_other is None else round(value_other, 2),

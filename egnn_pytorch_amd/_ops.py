@@ -101,6 +101,21 @@ def side_stream(device):
     return st
 
 
+_fork_events = {}
+
+
+def fork_event(device):
+    """An event recorded NOW on the current stream of `device` (one cached event object per device and thread: a later record
+    replaces the earlier one, and whoever waits for it does so right behind the record -- layer.py::_forward_hip_impl)."""
+    import threading
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), threading.get_ident())
+    ev = _fork_events.get(key)
+    if ev is None:
+        ev = _fork_events[key] = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(torch.device("cuda", key[0])))
+    return ev
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 

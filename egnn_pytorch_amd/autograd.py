@@ -23,8 +23,7 @@ Backward, three paths:
            more than 16 per-edge scalars / 8 coordinates / 64 message channels.  The per-edge tail through autograd on E x m tensors,
            the E x H work on egnn_edge_exact_bwd_f32 / _f64 + egnn_edge_exact_node_sums_* (csrc/edge_exact_bwd.hip), every contraction on
            the exact GEMMs (egnn_linear_f32 / egnn_linear_f64), in the arithmetic of the forward.
-  `_backward_recompute` -- what is left: layers without coors_mlp or node_mlp in training-mode dropout (masks re-evaluated by the torch
-           twin of the kernels' hash), more per-edge scalars than the exact backward keeps in LDS (80 in fp32, 40 in float64), EGNN_NATIVE_BACKWARD=0 /
+  `_backward_recompute` -- what is left: more per-edge scalars than the exact backward keeps in LDS (80 in fp32, 40 in float64), EGNN_NATIVE_BACKWARD=0 /
            EGNN_NATIVE_BACKWARD_EXACT=0, CPU tensors (the tests); also the native paths' reference in the tests.  The whole layer
            re-evaluated a few graphs at a time as a differentiable chain of ATen ops over the neighbour list the HIP kernel selected,
            factorised like the forward, and differentiated by autograd.
@@ -330,9 +329,10 @@ def _dropout_native_ok(layer):
     drop_thr, the two tail kernels, egnn_silu_bwd_drop_f32) cover every shape of the fused forward kernels since round 5 -- heads up to 64
     channels, coordinate dimensions up to 8 (the generic tail kernel re-evaluates coors_mlp's mask), up to 16 per-edge scalars; the
     tuning switches that take pieces of the native backward away send the masked layer to the recompute path."""
+    # (round 6: layers without coors_mlp / node_mlp -- update_coors=False / update_feats=False -- take the generic tail kernel, which
+    # skips the absent module and its mask site; odd `dim`: egnn_silu_bwd_drop_f32 steps its (row, column) pair per element)
     return (_TAIL_KERNEL and _TAIL_REDUCE and _GRAD_GEMM and _FUSED_SPLIT == "dest" and _TAIL_GENERIC
             and 2 * layer.fourier_features + 1 + layer.edge_dim <= 16 and layer.m_dim <= 64
-            and layer.coors_mlp is not None and layer.node_mlp is not None and layer.dim % 2 == 0
             and os.environ.get("EGNN_TAIL_SCALAR", "0") != "1" and os.environ.get("EGNN_BWD_DROP_NATIVE", "1") != "0")
 
 
@@ -1245,7 +1245,7 @@ def _backward_native(ctx, g_node, g_coors):
 
 def _backward_recompute(ctx, g_node, g_coors):
     """The pure-ATen backward: chunked recompute of the whole layer through autograd (module docstring).  Used where neither native
-    path applies -- training-mode dropout without coors_mlp / node_mlp, more per-edge scalars than `_backward_exact` carries, CPU tensors,
+    path applies -- more per-edge scalars than `_backward_exact` carries, CPU tensors,
     the EGNN_NATIVE_BACKWARD* switches -- and as the native paths' reference in the tests."""
     layer = ctx.layer
     feats, coors, edges, mask, idx, rank = _unpack(ctx)

@@ -8,7 +8,7 @@
 //     w_ij   = W4 . SiLU(W3 * m_ij + b3) + b4                      (coors_mlp)
 //     mask, clamp, CoorsNorm;  x_i' = x_i + sum_k w_ij * rel_ij;  m_i = sum_k m_ij  (or mean)
 //
-// What bounds it on MI355X (tools/ubench/overlap_asm.hip, silu_seq.hip; measured): the E x H SiLU evaluations.  The
+// What bounds it on MI355X (tools/ubench/gen_overlap_asm.py, silu_seq.hip; measured): the E x H SiLU evaluations.  The
 // f32-input MFMA (v_mfma_f32_16x16x4_f32) executes on the SAME datapath as the f32 VALU -- MFMA time and VALU time add --
 // while f16/bf16 MFMAs run on the matrix cores and hide completely behind VALU work.  So BOTH Linears of edge_mlp run as
 // split-f16 products on the f16 matrix cores (fp32 accumulation: per-product error ~2^-22, i.e. f32 class) and the VALU

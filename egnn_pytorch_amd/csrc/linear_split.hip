@@ -1,6 +1,6 @@
 // C = act(A * W^T + bias) (+ residual), fp32 in / fp32 out, on the gfx950 MATRIX cores.
 //
-// Why not v_mfma_f32_32x32x2_f32: measured on MI355X (tools/ubench/overlap_asm.hip) the f32-input MFMA runs at
+// Why not v_mfma_f32_32x32x2_f32: measured on MI355X (tools/ubench/gen_overlap_asm.py) the f32-input MFMA runs at
 // the f32 vector rate on the vector datapath (157 TFLOP/s peak, blocks the VALU); the f16 MFMA runs on the matrix
 // cores at 16x that rate.  So every fp32 product is evaluated as a 3-term split-f16 product with fp32 accumulation:
 //     a = a_hi + a_lo,  w = w_hi + w_lo   (f16 pairs: 22 significant bits)

@@ -214,8 +214,9 @@ __global__ __launch_bounds__(256) void silu_bwd_kernel(const float* z, const flo
         f32x4 av, dv;
         uint32_t key = 0u;
         int col0 = 0;
-        if (drop_thr) {                                          // (cols % 4 == 0: a quad stays inside one row)
-            const int64_t row = (q * 4) / cols;
+        int64_t row = 0;
+        if (drop_thr) {
+            row = (q * 4) / cols;
             col0 = (int)(q * 4 - row * cols);
             key = egnn_drop_base(drop_seed, EGNN_DROP_SITE_NODE, (uint32_t)(row0 + row));
         }
@@ -223,6 +224,10 @@ __global__ __launch_bounds__(256) void silu_bwd_kernel(const float* z, const flo
         for (int u = 0; u < 4; ++u) {
             float zz = zv[u], gk = 1.0f;
             if (drop_thr) {
+                if (u && col0 + u == cols) {                     // cols % 4 != 0 (node_mlp's hidden width 2 dim with an odd dim): the quad
+                    col0 -= cols;                                // crosses into the next row
+                    key = egnn_drop_base(drop_seed, EGNN_DROP_SITE_NODE, (uint32_t)(row0 + ++row));
+                }
                 const bool keep = egnn_drop_hash(key, (uint32_t)(col0 + u)) >= drop_thr;
                 zz = keep ? zz * drop_inv_keep : 0.f;
                 gk = keep ? drop_inv_keep : 0.f;
@@ -378,7 +383,7 @@ extern "C" int egnn_silu_bwd_f32(const float* z, const float* g, float* a_out, f
 extern "C" int egnn_silu_bwd_drop_f32(const float* z, const float* g, float* a_out, float* gz_out, int64_t count, uint32_t* amax_bits,
                                       uint32_t drop_thr, uint32_t drop_seed, float drop_inv_keep, int64_t row0, int cols, void* stream)
 {
-    if (drop_thr && (!(drop_inv_keep >= 1.f) || cols <= 0 || (cols % 4) != 0 || row0 < 0 || row0 + count / cols > 0xffffffffLL)) return EGNN_E_SHAPE;
+    if (drop_thr && (!(drop_inv_keep >= 1.f) || cols < 4 || (count % cols) != 0 || row0 < 0 || row0 + count / cols > 0xffffffffLL)) return EGNN_E_SHAPE;
     if (!z || !g || !a_out || !gz_out) return EGNN_E_NULLPTR;
     if (count <= 0 || (count % 4) != 0) return EGNN_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(a_out) | reinterpret_cast<uintptr_t>(gz_out)) & 15)

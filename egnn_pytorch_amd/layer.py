@@ -41,6 +41,7 @@ _EDGE_ALGO = int(os.environ.get("EGNN_EDGE_ALGO", "0"))
 _PRECISION = os.environ.get("EGNN_PRECISION", "fast")
 _DENSE_PW = os.environ.get("EGNN_DENSE_PW", "1") != "0"            # dense layers with N % 32 == 0 on the wave-per-node edge kernel
 _SHARED_FEATS_IMAGE = os.environ.get("EGNN_SHARED_FEATS_IMAGE", "1") != "0"   # 0: a second packed image of feats for the projection
+_ENTRY_FORK = os.environ.get("EGNN_ENTRY_FORK", "1") != "0"        # ... which then waits for an event recorded at the layer's entry, not for them
 _LATE_SELECT = os.environ.get("EGNN_LATE_SELECT", "1") != "0"      # node-level launches before the neighbour selection (see _forward_hip)
 _exact_now = contextvars.ContextVar("egnn_exact_now", default=False)       # per thread / context: concurrent forwards do not see each other's
 _warned_rerun = False
@@ -277,10 +278,24 @@ class EGNN(nn.Module):
         """A float64 module runs on the float64 kernels (training-mode dropout included: the plain kernels evaluate the same hash masks)."""
         return self.compute_dtype() == torch.float64
 
-    def _select_neighbors(self, coors, mask, adj_mat, order_hint):
+    def _select_outputs(self, coors, adj_mat, order_hint, k):
+        """The four outputs of the k-NN selection (idx, rank, order or None, slots or None), allocated on the LAUNCH stream."""
+        b, n = coors.shape[:2]
+        dev = coors.device
+        want_order = adj_mat is None and 64 <= n <= 4096 and _SPATIAL_ORDER and coors.shape[-1] == 3
+        have_hint = order_hint is not None and tuple(order_hint.shape) == (b, n)
+        return (_ops.empty(b, n, k, dtype=torch.int32, device=dev), _ops.empty(b, n, k, dtype=torch.float32, device=dev),
+                _ops.empty(b, n, dtype=torch.int32, device=dev) if (want_order and not have_hint) else None,
+                _ops.empty(b * n * k, 4, dtype=torch.int32, device=dev) if (_SLOT_PREP and coors.shape[-1] == 3) else None)
+
+    def _select_neighbors(self, coors, mask, adj_mat, order_hint, fork=None):
         """(idx, rank, order, slots, K, valid_radius) of egnn_pytorch.py:230-260 for fp32 coordinates on the device: the K nearest
         neighbours (None, None, None, None, N on the dense path), the Morton order the edge pass schedules by, the per-slot records.
-        Launched on the side stream (EGNN_SIDE_STREAM=0: the current one); whoever consumes the result joins that stream first."""
+        Launched on the side stream (EGNN_SIDE_STREAM=0: the current one); whoever consumes the result joins that stream first.
+        fork = (outputs of _select_outputs, event): the side stream waits for that EVENT of the launch stream -- recorded at the layer's
+        entry, before its node-level launches -- instead of for the stream's tail, so the selection runs beside node_prep and the
+        projection although it is enqueued behind them (the outputs were allocated at the same point: a block the allocator recycles
+        from a tensor freed AFTER the event could still be in use by a launch the side stream does not wait for)."""
         b, n = coors.shape[:2]
         num_nearest = self.num_nearest_neighbors
         valid_radius = self.valid_radius
@@ -317,11 +332,7 @@ class EGNN(nn.Module):
             # side stream before it reads them, so when they are freed every use is ordered before the launch stream's later work and the
             # allocator may reuse the blocks at once.  (Allocated inside the fork they belonged to the side stream's pool and needed
             # record_stream(): four calls per forward and frees deferred to events.)
-            dev = coors.device
-            idx_o = _ops.empty(b, n, k, dtype=torch.int32, device=dev)
-            rank_o = _ops.empty(b, n, k, dtype=torch.float32, device=dev)
-            order_o = _ops.empty(b, n, dtype=torch.int32, device=dev) if (want_order and not have_hint) else None
-            slots_o = _ops.empty(b * n * k, 4, dtype=torch.int32, device=dev) if (_SLOT_PREP and coors.shape[-1] == 3) else None
+            idx_o, rank_o, order_o, slots_o = fork[0] if fork is not None else self._select_outputs(coors, adj_mat, order_hint, k)
 
             def select():
                 idx_, rank_ = _ops.knn_select(coors, mask, adj_mat, k, out=(idx_o, rank_o))
@@ -334,8 +345,10 @@ class EGNN(nn.Module):
             use_side = _SIDE_STREAM and _ops._timer is None
             side = _ops.side_stream(coors.device) if use_side else None
             if side is not None:
-                cur = torch.cuda.current_stream()
-                side.wait_stream(cur)
+                if fork is not None and fork[1] is not None:
+                    side.wait_event(fork[1])
+                else:
+                    side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     idx, rank, order, slots = select()
             else:
@@ -385,6 +398,10 @@ class EGNN(nn.Module):
                        and not (adj_mat is not None and self.only_sparse_neighbors))
         if sel is None and not late_select:
             sel = self._select_neighbors(coors, mask, adj_mat, order_hint)
+        fork = None
+        if late_select and _SIDE_STREAM and _ENTRY_FORK and _ops._timer is None:
+            # the selection is enqueued behind the node-level launches but depends on nothing they write: fork point = here
+            fork = (self._select_outputs(coors, adj_mat, order_hint, self.num_nearest_neighbors), _ops.fork_event(feats.device))
         idx = rank = order = slots = None
         k, valid_radius = self.num_nearest_neighbors, self.valid_radius
         if sel is not None:
@@ -414,7 +431,7 @@ class EGNN(nn.Module):
                                   split_cols=hp if pi_split else 0)
             del feats_hl
             if sel is None:
-                sel = self._select_neighbors(coors, mask, adj_mat, order_hint)
+                sel = self._select_neighbors(coors, mask, adj_mat, order_hint, fork=fork)
             idx, rank, order, slots, k_sel, valid_radius = sel
             assert k_sel == k
             side_join = use_nearest and k > 0 and _SIDE_STREAM and _ops._timer is None

@@ -215,7 +215,8 @@ int64_t egnn_split_scaled_colsum_rows(int64_t rows, int KpT);
 int egnn_silu_bwd_f32(const float* z, const float* g, float* a_out, float* gz_out, int64_t count, uint32_t* amax_bits, void* stream);
 /* ... with training-mode dropout between the Linear and the SiLU (node_mlp, egnn_pytorch.py:196-201): z (rows, cols) is the Linear's
  * output; the forward's mask (egnn_linear_hl_drop_f32: site node, row = row0 + r, column c) is re-evaluated: z_d = keep ? z *
- * drop_inv_keep : 0, a_out = SiLU(z_d), gz_out = g SiLU'(z_d) (keep ? drop_inv_keep : 0).  cols % 4 == 0. */
+ * drop_inv_keep : 0, a_out = SiLU(z_d), gz_out = g SiLU'(z_d) (keep ? drop_inv_keep : 0).  cols >= 4, count % cols == 0 (count % 4 == 0 as
+ * above: the array is walked four elements at a time, across row ends). */
 int egnn_silu_bwd_drop_f32(const float* z, const float* g, float* a_out, float* gz_out, int64_t count, uint32_t* amax_bits,
                            uint32_t drop_thr, uint32_t drop_seed, float drop_inv_keep, int64_t row0, int cols, void* stream);
 int egnn_linear_hl_splitk_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo, float w_inv_scale, float* C_parts,

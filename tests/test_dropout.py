@@ -155,8 +155,14 @@ BWD_CASES = [
     (dict(dim=24, num_nearest_neighbors=8, dropout=0.2, m_dim=32, fourier_features=3), 30, False, True),
     (dict(dim=32, num_nearest_neighbors=20, dropout=0.25, fourier_features=4, norm_coors=True), 40, True, True),
     (dict(dim=24, num_nearest_neighbors=6, dropout=0.15, fourier_features=4, edge_dim=4, cdim=4), 24, True, True),
-    # no coors_mlp: the recompute path
-    (dict(dim=24, num_nearest_neighbors=8, dropout=0.2, update_coors=False), 30, False, False),
+    # round 6: layers without coors_mlp / without node_mlp and an odd `dim` on the native backward too (the generic tail kernel skips the
+    # absent module and its mask site; node_mlp's hidden width 2 dim is no multiple of 4 when dim is odd: egnn_silu_bwd_drop_f32 walks
+    # across row ends)
+    (dict(dim=24, num_nearest_neighbors=8, dropout=0.2, update_coors=False), 30, False, True),
+    (dict(dim=24, num_nearest_neighbors=8, dropout=0.2, update_feats=False, norm_coors=True), 30, True, True),
+    (dict(dim=32, num_nearest_neighbors=32, dropout=0.25, update_feats=False), 64, False, True),
+    (dict(dim=33, num_nearest_neighbors=8, dropout=0.2), 30, True, True),
+    (dict(dim=17, num_nearest_neighbors=6, dropout=0.3, update_coors=False, m_dim=20), 26, False, True),
     # the plain kernels' shapes: `_backward_exact` with the masks re-evaluated (csrc/edge_exact_bwd.hip, the generic tail kernel; a head
     # wider than 64 channels keeps the autograd tail with the hash's torch twin)
     (dict(dim=24, num_nearest_neighbors=8, dropout=0.2, cdim=9, coor_weights_clamp_value=2.0), 30, True, "exact"),
@@ -193,13 +199,17 @@ def test_training_mode_backward_differentiates_the_masked_layer(kw, n, use_mask,
     seed = _dropout.draw_seed()
     torch.manual_seed(77)
     f, c = feats.clone().requires_grad_(True), coors.clone().requires_grad_(True)
-    saved = A._FUSED_MAX_GRAPHS
+    saved, saved_rc = A._FUSED_MAX_GRAPHS, A._backward_recompute
     A._FUSED_MAX_GRAPHS = 2                                  # two chunks of graphs: the masks' rows are global edge / node ids
+    if native:                                               # a native case must not fall back to the ATen recompute, silently
+        def _no_recompute(*a_, **k_):
+            raise AssertionError("this configuration is expected on a native backward, not on _backward_recompute")
+        A._backward_recompute = _no_recompute
     try:
         node, co = layer(f, c, edges, mask)
         got = torch.autograd.grad((node * rn).sum() + (co * rc).sum(), [f, c] + list(layer.parameters()), allow_unused=True)
     finally:
-        A._FUSED_MAX_GRAPHS = saved
+        A._FUSED_MAX_GRAPHS, A._backward_recompute = saved, saved_rc
     with torch.no_grad():
         idx, rank, radius = layer._forward_hip_checked(feats, coors, edges, mask, None, None, drop_seed=seed)[3:6]
     l64 = copy.deepcopy(layer).double()
@@ -213,8 +223,9 @@ def test_training_mode_backward_differentiates_the_masked_layer(kw, n, use_mask,
         if a is not None:
             assert float((a.double() - r).abs().max()) <= 1e-4 * max(1.0, float(r.abs().max()))
     # two training-mode calls draw different masks
+    o = 0 if kw.get("update_feats", True) else 1             # (update_feats=False: the features pass through, the coordinates carry the masks)
     with torch.no_grad():
-        a1, a2 = layer(feats, coors, edges, mask)[0], layer(feats, coors, edges, mask)[0]
+        a1, a2 = layer(feats, coors, edges, mask)[o], layer(feats, coors, edges, mask)[o]
     assert not torch.allclose(a1, a2, atol=1e-3)
 
 

@@ -179,6 +179,10 @@ def test_bench_rank_logic_end_to_end_with_gloo_standin():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 2 * d["config"]["graphs_per_gpu"] and d["value"] > 0
     assert "STAND-IN" in d["data"]
+    # every rank's own time per step beside the max over ranks (a straggler must show as one): two ranks, min <= max <= the region's
+    by_rank = d["ms_per_step_by_rank"]
+    assert len(by_rank["ranks"]) == 2 and by_rank["min"] == min(by_rank["ranks"]) and by_rank["max"] == max(by_rank["ranks"])
+    assert 0 < by_rank["min"] <= by_rank["max"] <= d["ms_per_step"] * 1.001 + 1e-3
     # the driver's own command line -- `python bench.py --gpus 2 ...` WITHOUT a launcher -- spawns the two ranks itself (VERDICT r2
     # weak #6: it used to exit with "needs torch.distributed.run") and prints the same single line
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
