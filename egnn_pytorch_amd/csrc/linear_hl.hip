@@ -17,6 +17,7 @@
 //     -> conflict-free ds_read_b128.
 // Tiles 256 x 256 (8 waves, 2 x 4) or 128 x 128 (4 waves, 2 x 2), K-tile 16; XCD-contiguous, M-grouped block -> tile
 // map.  Optional second output: the result re-split into (hi, lo) f16 for the next GEMM of the chain.
+#include <cstdlib>
 #include "egnn_common.h"
 
 namespace {
@@ -38,6 +39,12 @@ struct DropArgs { uint32_t thr, seed; float inv_keep; };
 #endif
 #ifndef EGNN_HL_CFG
 #define EGNN_HL_CFG 1
+#endif
+#ifndef EGNN_HL_NT
+#define EGNN_HL_NT 0                         // experiment: `nt` on the LDS-DMA pieces of the hand-scheduled loop (1: A pieces, 2: all)
+#endif
+#ifndef EGNN_HL_DMAPOS
+#define EGNN_HL_DMAPOS 0                     // experiment: 1 = a tile's DMA pieces right behind the barrier instead of between group 3's MFMAs
 #endif
 #ifndef EGNN_HL_LOOP
 #define EGNN_HL_LOOP 2                       // 2: software-pipelined, hand-scheduled K loop (64 x 64 wave tiles); 0: the classic loop
@@ -63,9 +70,13 @@ __device__ __forceinline__ void hl_lds_rd(f16x8& d, uint32_t addr)
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF) : "memory");
 }
 // one LDS-DMA piece: lane l's 16 bytes at (sbase + voff) land at lds_dst + 16 l; wave-uniform 64-bit base in scalar registers
+template <bool NT = false>
 __device__ __forceinline__ void hl_dma16(const char* sbase, uint32_t voff, uint32_t lds_dst)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+    if constexpr (NT)                        // (experiment EGNN_HL_NT: non-temporal policy for the streamed operand)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 __device__ __forceinline__ const char* hl_uniform_ptr(const void* p)
 {
@@ -96,7 +107,7 @@ __device__ __forceinline__ void linear_hl_body(
     const float* __restrict__ bias, const float* __restrict__ R, int64_t ldr,
     float* __restrict__ C, int64_t ldc, _Float16* __restrict__ Chi, _Float16* __restrict__ Clo, int nkt_out,
     int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, int32_t* __restrict__ status, char* smem, const int bid,
-    const int kt0 = 0, const int kt_count = -1, const DropArgs drop = DropArgs{0u, 0u, 1.f}, const int a_nkt = 0)
+    const int kt0 = 0, const int kt_count = -1, const DropArgs drop = DropArgs{0u, 0u, 1.f}, const int a_nkt = 0, const int group_m = GROUP_M)
 {
     using C_ = Cfg<CFG>;
     constexpr int BM = C_::BM, BN = C_::BN, TI = C_::TI, TJ = C_::TJ, STAGES = C_::STAGES;
@@ -118,10 +129,10 @@ __device__ __forceinline__ void linear_hl_body(
     const int q = nblk >> 3, rr = nblk & 7;
     const int xcd = bid & 7;
     const int v = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-    const int width = GROUP_M * ntn;
+    const int width = group_m * ntn;
     const int gid = v / width;
-    const int first_m = gid * GROUP_M;
-    const int gsz = (ntm - first_m) < GROUP_M ? (ntm - first_m) : GROUP_M;
+    const int first_m = gid * group_m;
+    const int gsz = (ntm - first_m) < group_m ? (ntm - first_m) : group_m;
     const int tile_m = first_m + (v % width) % gsz;
     const int tile_n = (v % width) / gsz;
     const int64_t m0 = (int64_t)tile_m * BM;
@@ -242,7 +253,15 @@ __device__ __forceinline__ void linear_hl_body(
 #if defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 4)
             kt_src = 0;                                                // ablation: always the same (L1/L2-hot) tile
 #endif
-            hl_dma16(sb[j] + (size_t)kt_src * 1024, voff, sdst[j] + (uint32_t)(sl * BUF));
+            // (piece j of every wave is an A piece for WAVES j < 2 ARB, a W piece behind that)
+#if EGNN_HL_NT == 2
+            hl_dma16<true>(sb[j] + (size_t)kt_src * 1024, voff, sdst[j] + (uint32_t)(sl * BUF));
+#elif EGNN_HL_NT == 1
+            if (WAVES * j < 2 * ARB) hl_dma16<true>(sb[j] + (size_t)kt_src * 1024, voff, sdst[j] + (uint32_t)(sl * BUF));
+            else hl_dma16<false>(sb[j] + (size_t)kt_src * 1024, voff, sdst[j] + (uint32_t)(sl * BUF));
+#else
+            hl_dma16<false>(sb[j] + (size_t)kt_src * 1024, voff, sdst[j] + (uint32_t)(sl * BUF));
+#endif
         };
 #pragma unroll
         for (int t = 0; t < STAGES - 1; ++t)
@@ -288,13 +307,17 @@ __device__ __forceinline__ void linear_hl_body(
             const uint32_t sn = (uint32_t)(nslot * BUF);
             hl_lds_rd<0>(ahn[0], a_addr + sn); hl_lds_rd<32 * ROWB>(ahn[1], a_addr + sn);
             hl_lds_rd<0>(bhn[0], b_addr + sn); hl_lds_rd<32 * ROWB>(bhn[1], b_addr + sn);
+#if EGNN_HL_DMAPOS == 1
+#pragma unroll
+            for (int j = 0; j < DPW; ++j) dma(nsrc, slot, j);
+#endif
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-#if !(defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 8))                         // (ablation 8: no DMA in the loop -- timing only)
+#if !(defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 8)) && EGNN_HL_DMAPOS == 0  // (ablation 8: no DMA in the loop -- timing only)
                     if (i * TJ + j < DPW) dma(nsrc, slot, i * TJ + j);
 #endif
                     __builtin_amdgcn_sched_barrier(0);
@@ -560,11 +583,12 @@ __global__ __launch_bounds__(Cfg<CFG>::WM * Cfg<CFG>::WN * 64, 2) void linear_hl
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
     const float* __restrict__ bias, const float* __restrict__ R, int64_t ldr,
     float* __restrict__ C, int64_t ldc, _Float16* __restrict__ Chi, _Float16* __restrict__ Clo, int nkt_out,
-    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, int32_t* __restrict__ status, const DropArgs drop, const int a_nkt)
+    int64_t M, int N, int Kp, int ntm, int ntn, float out_scale, int split_cols, int32_t* __restrict__ status, const DropArgs drop, const int a_nkt,
+    const int group_m)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // STAGES x BUF
     linear_hl_body<CFG, ACT, HAS_RES, DROP>(Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, ntm, ntn,
-                                            out_scale, split_cols, status, smem, blockIdx.x, 0, -1, drop, a_nkt);
+                                            out_scale, split_cols, status, smem, blockIdx.x, 0, -1, drop, a_nkt, group_m);
 }
 
 // Split-K: blockIdx.y = part; the part's partial product goes to its own (M, ldc) slab (summed afterwards in fixed order)
@@ -593,6 +617,23 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
     }
 }
 
+// M-tiles per group of the block -> tile map (the tiles of a group -- group_m M-tiles x all N-tiles, M fastest -- are consecutive block
+// indices of one XCD).  EGNN_HL_GROUP_M in the environment overrides the build default (tools/gemm_lab.py gm=... sweeps it in one process).
+// Measured in round 6 (profiles/r06_experiments/gemm_group_m.txt, every value on every GEMM shape of the north star, c3 and c5 in one
+// process): the best group holds ~128 tiles -- 4 M-tiles for the projection's 33 N-tiles (-3 % against the former constant 8), 16 for
+// node_mlp.0's 8 (-3 %), flat for four N-tiles and fewer, 32 M-tiles always worse.
+static int hl_group_m(int ntm, int ntn)
+{
+    (void)ntm;
+    if (const char* e = getenv("EGNN_HL_GROUP_M")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 1024) return v;
+    }
+    if (ntn <= 4) return GROUP_M;
+    const int g = (128 + ntn / 2) / ntn;
+    return g < 2 ? 2 : (g > 16 ? 16 : g);
+}
+
 template <int CFG, int ACT, bool HAS_RES>
 int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi, const _Float16* Wlo,
                   const float* bias, const float* R, int64_t ldr, float* C, int64_t ldc, _Float16* Chi, _Float16* Clo,
@@ -604,6 +645,7 @@ int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi,
     const int64_t ntn = (N + C_::BN - 1) / C_::BN;
     if (ntm * ntn > 0x7fffffffLL) return EGNN_E_UNSUPPORTED;
     const size_t lds = (size_t)C_::STAGES * (2 * C_::BM + 2 * C_::BN) * ROWB;
+    const int gm = hl_group_m((int)ntm, (int)ntn);
     // (the dropout epilogue -- a hash per output element -- is its own instantiation: as a run-time branch in the common kernel it cost
     // the residual GEMM 18 % (0.25 -> 0.30 ms) through register pressure alone)
     if constexpr (ACT == 1 && !HAS_RES) {
@@ -612,7 +654,7 @@ int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
             hipLaunchKernelGGL((linear_hl_kernel<CFG, ACT, HAS_RES, true>), dim3((unsigned)(ntm * ntn)), dim3(C_::WM * C_::WN * 64), lds, s,
-                               Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale, split_cols, status, drop, a_nkt);
+                               Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale, split_cols, status, drop, a_nkt, gm);
             return egnn_launch_status();
         }
     } else if (drop.thr) {
@@ -622,7 +664,7 @@ int launch_hl_cfg(const _Float16* Ahi, const _Float16* Alo, const _Float16* Whi,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((linear_hl_kernel<CFG, ACT, HAS_RES>), dim3((unsigned)(ntm * ntn)), dim3(C_::WM * C_::WN * 64), lds, s,
-                       Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale, split_cols, status, drop, a_nkt);
+                       Ahi, Alo, Whi, Wlo, bias, R, ldr, C, ldc, Chi, Clo, nkt_out, M, N, Kp, (int)ntm, (int)ntn, out_scale, split_cols, status, drop, a_nkt, gm);
     return egnn_launch_status();
 }
 

@@ -12,7 +12,7 @@ python - <<PY
 import json
 d = json.load(open("$OUT/bench.json"))
 print("value", d["value"], "ms/step", d["ms_per_step"], "deferred", d.get("value_range_check_deferred"))
-print({k["name"]: k["avg_ms"] for k in d.get("kernels", [])})
+print({k["kernel"]: k["avg_ms"] for k in d.get("kernels", [])})
 PY
 if [ "$TRACE" = 1 ]; then
   cd /tmp
