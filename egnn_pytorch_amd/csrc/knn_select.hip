@@ -38,6 +38,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 #ifndef EGNN_KNN_PAIR
 #define EGNN_KNN_PAIR 1                      // two query rows per wave on the standard shape (see process_pair; 0: one row per wave everywhere)
 #endif
+#ifndef EGNN_KNN_ADJ_FAST
+#define EGNN_KNN_ADJ_FAST 1                  // rows with >= K - 1 adjacent nodes straight from the adjacency row (see the row loop)
+#endif
 constexpr int KNN_PREFIX_BITS = EGNN_KNN_BITS;   // key bits resolved by the pruning threshold of the fast path
 constexpr int KNN_SURVIVORS = 128;               // ... and survivors the fast path ranks directly (two per lane)
 constexpr int KNN_THREADS = 256;
@@ -65,13 +68,74 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
     uint64_t* selbuf = selall + (size_t)wave * Kpad;
 
     const float* cb = coors + (size_t)b * N * C;
-    for (int j = tid; j < Npad; j += KNN_THREADS) {
-        for (int c = 0; c < C; ++c) xs[c * Npad + j] = j < N ? cb[j * C + c] : 0.f;
-        ms[j] = j < N ? (mask ? mask[(size_t)b * N + j] : (uint8_t)1) : (uint8_t)0;
+    if constexpr (CDM == 3) {
+        // the graph's 3 N floats as one flat, coalesced stream, a batch of loads in flight at a time (round 6: one 12-byte-strided load
+        // per coordinate with its LDS store behind it was eight dependent L2 round trips per workgroup at N = 2048 -- two thirds of
+        // what was left of the kernel once the adjacency decides most rows)
+        constexpr int BL = 12;
+        const int total = 3 * Npad;
+        for (int f0 = 0; f0 < total; f0 += BL * KNN_THREADS) {
+            float v[BL];
+#pragma unroll
+            for (int t = 0; t < BL; ++t) {
+                const int f = f0 + t * KNN_THREADS + tid;
+                v[t] = f < 3 * N ? cb[f] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < BL; ++t) {
+                const int f = f0 + t * KNN_THREADS + tid;
+                if (f < total) {
+                    const int j = f / 3;
+                    xs[(f - 3 * j) * Npad + j] = v[t];
+                }
+            }
+        }
+        for (int j = tid; j < Npad; j += KNN_THREADS) ms[j] = j < N ? (mask ? mask[(size_t)b * N + j] : (uint8_t)1) : (uint8_t)0;
+    } else {
+        for (int j = tid; j < Npad; j += KNN_THREADS) {
+            for (int c = 0; c < C; ++c) xs[c * Npad + j] = j < N ? cb[j * C + c] : 0.f;
+            ms[j] = j < N ? (mask ? mask[(size_t)b * N + j] : (uint8_t)1) : (uint8_t)0;
+        }
     }
     __syncthreads();
 
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+#if EGNN_KNN_ADJ_FAST
+    // bit r: some OTHER node has the first coordinate of this workgroup's row r (then a non-adjacent node could sit at distance exactly
+    // 0.0 and tie with the adjacent ones: the row takes the general path) -- once per workgroup, every thread its <= 8 candidates
+    // against the <= 32 rows (branch-free; per row and wave it was two thirds of a decided row's instructions)
+    uint32_t* const dupflags = reinterpret_cast<uint32_t*>(selall + (size_t)KNN_WAVES * Kpad);
+    if constexpr (CPL % 4 == 0 && CPL <= 32) {
+        if (adj) {                                                       // (uniform)
+            if (tid == 0) *dupflags = 0u;
+            __syncthreads();
+            uint32_t m = rows_per_wg > 32 ? 0xFFFFFFFFu : 0u;
+            if (rows_per_wg <= 32) {
+                constexpr int PT = CPL / 4;                              // candidates per thread: N <= 64 CPL = 256 PT
+                float xc[PT];
+#pragma unroll
+                for (int t = 0; t < PT; ++t) xc[t] = xs[tid + KNN_THREADS * t];          // (past N: pad zeros / the next plane, masked below)
+                // lane r holds the first coordinate of row r; v_readlane hands it to every lane (no LDS round trip per row)
+                const int xrow_bits = __float_as_int((lane < 32 && row0 + lane < N) ? xs[row0 + lane] : 0.f);
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const int i = row0 + r;
+                    const float xi = __int_as_float(__builtin_amdgcn_readlane(xrow_bits, r));
+                    uint32_t hit = 0u;
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) {
+                        const int j = tid + KNN_THREADS * t;
+                        hit |= (uint32_t)(xc[t] == xi) & (uint32_t)(j != i) & (uint32_t)(j < N);
+                    }
+                    if (r < rows_per_wg && i < N) m |= hit << r;         // (uniform)
+                }
+            }
+            if (m) atomicOr(dupflags, m);
+            __syncthreads();
+        }
+    }
+#endif
 
 #if EGNN_KNN_PAIR
     // Two query rows per wave (round 5): the candidates' coordinates and mask bytes are read from LDS once for both rows, and the two
@@ -184,6 +248,78 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_select_kernel(
             continue;
         }
 
+#if EGNN_KNN_ADJ_FAST
+        // ---- rows the adjacency alone decides (round 6).  With an adjacency matrix the ranking row is -1 for the node itself, 0 for
+        // every adjacent node and a distance >= 0 (or 1e5) for the others (:255-256), and ties go by ascending index: a row with at
+        // least K - 1 adjacent nodes is [i, its first K - 1 adjacent nodes in index order] with ranks -1, 0, 0, ... whatever the
+        // coordinates are -- unless a NON-adjacent node sits at distance exactly 0.0 and ties with them, which a row rules out by
+        // finding no candidate with the query's first coordinate (checked conservatively: any j != i; only rows of unmasked nodes can
+        // have such a tie, a masked row's non-adjacent pairs are all 1e5).  The chain adjacency of BASELINE.json's c4 (K = 3,
+        // N = 2048): every interior row, 2046 of 2048 -- no distance, no key, no threshold search for them.
+        // Adjacent nodes are counted from whole-line loads of the row's 0 / 1 bytes with one wave scan for the positions -- no per-chunk
+        // ballots, which run on the CU's one scalar unit.
+#if defined(EGNN_KNN_ABL) && (EGNN_KNN_ABL & 1)
+        if (adjrow) continue;                                             // timing-only ablation: prologue only
+#endif
+        if constexpr (CPL % 4 == 0 && CPL <= 32) {
+            if (adjrow && (N & 15) == 0 && (reinterpret_cast<uintptr_t>(adjrow) & 15) == 0) {
+                // the row's N 0 / 1 bytes in chunks of 1 KB: lane l holds bytes [16 l, 16 l + 16) of every chunk -- one fully coalesced
+                // 16-byte load per lane and chunk (as dwords at a 32-byte lane stride the same bytes cost eight instructions of sixteen
+                // partly used lines each: 59 of the kernel's 93 us at c4's shape)
+                constexpr int NCH = (CPL * 64 + 1023) / 1024;            // chunks: 1 (N <= 1024) or 2
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                uint32_t nz[NCH][4];
+                int cl[NCH];
+#pragma unroll
+                for (int h = 0; h < NCH; ++h) {
+                    const int jb = 1024 * h + 16 * lane;                  // (N % 16 == 0: a lane's 16 bytes are inside the row or outside it)
+                    u32x4 w4 = u32x4{0u, 0u, 0u, 0u};
+                    if (jb < N) w4 = *reinterpret_cast<const u32x4*>(adjrow + jb);
+                    cl[h] = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t w = w4[q];
+                        w = (((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w) & 0x80808080u;       // bit 8 t + 7: byte t is non-zero
+                        const int d = i - (jb + 4 * q);
+                        if ((unsigned)d < 4u) w &= ~(0x80u << (8 * d));                  // the diagonal is cleared (:252-254)
+                        nz[h][q] = w;
+                        cl[h] += __popc(w);
+                    }
+                }
+                // both chunks' prefix sums in one scan (a lane has at most 16 adjacent nodes per chunk)
+                const int packed = cl[0] | ((NCH > 1 ? cl[NCH - 1] : 0) << 16);
+                const int incl = egnn_wave_inclusive_scan(packed);
+                const int tot = __builtin_amdgcn_readlane(incl, 63);
+                const int total0 = tot & 0xffff, total = total0 + (tot >> 16);
+                bool decided = total >= K - 1;                            // wave-uniform
+                if (decided && mi) decided = ((*dupflags >> r) & 1u) == 0u;      // (no other node with this row's first coordinate)
+#if defined(EGNN_KNN_ABL) && (EGNN_KNN_ABL & 2)
+                if (decided || total == 12345) continue;                   // timing-only ablation: no emission, no general rows
+#endif
+                if (decided) {
+                    const size_t ob = ((size_t)b * N + i) * K;
+                    if (lane == 0) { idx_out[ob] = i; rank_out[ob] = -1.0f; }
+#pragma unroll
+                    for (int h = 0; h < NCH; ++h) {
+                        int pos = h == 0 ? (incl & 0xffff) - cl[0] : total0 + (incl >> 16) - cl[NCH - 1];
+                        const int jb = 1024 * h + 16 * lane;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            uint32_t w = nz[h][q];
+                            while (w && pos < K - 1) {
+                                const int t = __builtin_ctz(w) >> 3;
+                                w &= w - 1;
+                                idx_out[ob + 1 + pos] = jb + 4 * q + t;
+                                rank_out[ob + 1 + pos] = 0.0f;
+                                ++pos;
+                            }
+                        }
+                    }
+                    continue;
+                }
+            }
+        }
+#endif
         uint32_t key[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
@@ -488,7 +624,7 @@ int launch_knn_c(const float* coors, const uint8_t* mask, const uint8_t* adj, in
     if (N < rows_per_wg) rows_per_wg = (N + 3) / 4 * 4;
     const size_t cbytes = (size_t)Npad * (4 * C + 1);
     const size_t coord_bytes = cbytes + 8 - cbytes % 8;
-    const size_t lds = coord_bytes + (size_t)KNN_WAVES * Kpad * 8;
+    const size_t lds = coord_bytes + (size_t)KNN_WAVES * Kpad * 8 + 8;          // (+ the duplicate-coordinate flags of the adjacency path)
     if (lds > 160 * 1024) return EGNN_E_UNSUPPORTED;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_select_kernel<CPL, CDM>),

@@ -64,6 +64,43 @@ def test_knn_select_bit_exact(n, k, use_mask, adj_kind):
     np.testing.assert_array_equal(ref_idx.astype(np.int32), idx)
 
 
+@pytest.mark.parametrize("n,band,k,use_mask,three_d,with_diag", [
+    (2048, 1, 3, True, False, True),        # BASELINE.json's c4: chain with the diagonal, K = max degree: every interior row is decided
+    (2048, 1, 3, False, True, False),       # no diagonal in adj_mat: self + K adjacent tie for K slots (the first K - 1 by index)
+    (512, 2, 5, True, False, True), (1024, 3, 4, True, True, True), (256, 1, 8, False, False, True),     # K - 1 > degree: distances decide
+    (300, 2, 5, True, False, True),         # N % 64 != 0
+    (130, 1, 3, False, False, True),        # N % 4 != 0: the general path
+])
+def test_knn_select_rows_decided_by_the_adjacency(n, band, k, use_mask, three_d, with_diag):
+    """only_sparse_neighbors-style selections (egnn_pytorch.py:248-256): rows with at least K - 1 adjacent nodes come straight from
+    the adjacency row (csrc/knn_select.hip, round 6) -- bit-identical to the oracle's ranking + stable top-k, including the rows that
+    must NOT take the shortcut: fewer adjacent nodes than K - 1, and a non-adjacent node at distance exactly 0 (it ties with the
+    adjacent ones at rank 0.0 and wins by index)."""
+    from egnn_pytorch_amd import _ops
+    rng = np.random.default_rng(n + 7 * k)
+    b = 2
+    coors = rng.standard_normal((b, n, 3)).astype(np.float32)
+    # exact duplicates of unmasked, non-adjacent nodes: 5 <-> 40 (lower index wins a slot of row 40), 90 <- 17 in graph 1
+    coors[0, 40] = coors[0, 5]
+    coors[1, 90] = coors[1, 17]
+    coors[1, 91, 0] = coors[1, 20, 0]                                    # equal first coordinate only: the conservative check falls back
+    mask = (np.arange(n)[None, :] < np.array([[n], [n - n // 5]])) if use_mask else None
+    i = np.arange(n)
+    adj = np.abs(i[:, None] - i[None, :]) <= band
+    if not with_diag:
+        adj = adj & (i[:, None] != i[None, :])
+    if three_d:
+        adj = np.stack([adj, adj.copy()])
+        adj[1, 7, :] = False                                             # an isolated row in graph 1: everything by distance
+        adj[1, :, 7] = False
+    _, dist = O.pairwise(coors)
+    ranking, _ = O.build_ranking(dist, mask, adj)
+    ref_val, ref_idx = O.topk_smallest(ranking, k)
+    idx, rank = _ops.knn_select(_dev(coors), _dev(mask), _dev(adj), k)
+    np.testing.assert_array_equal(ref_val.view(np.uint32), rank.cpu().numpy().view(np.uint32))
+    np.testing.assert_array_equal(ref_idx.astype(np.int32), idx.cpu().numpy())
+
+
 def test_knn_select_large_graph_other_coordinate_dimensions():
     """N = 4500 with 5-D coordinates (a wave keeps at most 4096 such candidates): the workgroup-per-row kernel with the reference's
     summation order for C = 5 (s0, s4, s1, s2, s3)."""
