@@ -46,6 +46,9 @@ struct DropArgs { uint32_t thr, seed; float inv_keep; };
 #ifndef EGNN_HL_DMAPOS
 #define EGNN_HL_DMAPOS 0                     // experiment: 1 = a tile's DMA pieces right behind the barrier instead of between group 3's MFMAs
 #endif
+#ifndef EGNN_HL_NTSTORE
+#define EGNN_HL_NTSTORE 2                    // non-temporal output stores in the staged epilogue: 0 never, 1 always, 2 the projection table only
+#endif
 #ifndef EGNN_HL_LOOP
 #define EGNN_HL_LOOP 2                       // 2: software-pipelined, hand-scheduled K loop (64 x 64 wave tiles); 0: the classic loop
 #endif
@@ -487,7 +490,13 @@ __device__ __forceinline__ void linear_hl_body(
                         }
                     }
 #if !(defined(EGNN_HL_ABL) && (EGNN_HL_ABL & 1))
-                    *reinterpret_cast<f32x4*>(C + gm * ldc + gn) = v;
+                    // the projection table (the call with split_cols: 1.09 GB at the north-star shape, read back by the edge pass long
+                    // after it has left every cache) goes out non-temporal: its lines no longer push the A / W panels out of L2 (round 6,
+                    // one process: north star -2.7 %, c5 -5 %, c3 -13 %; node_mlp's outputs, which the next kernel reads at once: +4 %, left alone)
+                    if (EGNN_HL_NTSTORE == 1 || (EGNN_HL_NTSTORE == 2 && split_cols > 0))
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(C + gm * ldc + gn));
+                    else
+                        *reinterpret_cast<f32x4*>(C + gm * ldc + gn) = v;
 #else
                     if (v[0] == 123.456f) *reinterpret_cast<f32x4*>(C + gm * ldc + gn) = v;
 #endif
@@ -519,8 +528,13 @@ __device__ __forceinline__ void linear_hl_body(
                         l8[u] = (_Float16)(x - (float)h);
                     }
                     const size_t o = (size_t)((rbg * nkt_out + (nw0 >> 4) + kt) * 512 + lane * 8);
+#if EGNN_HL_NTSTORE == 1
+                    __builtin_nontemporal_store(h8, reinterpret_cast<f16x8*>(Chi + o));
+                    __builtin_nontemporal_store(l8, reinterpret_cast<f16x8*>(Clo + o));
+#else
                     *reinterpret_cast<f16x8*>(Chi + o) = h8;
                     *reinterpret_cast<f16x8*>(Clo + o) = l8;
+#endif
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the strip is read before the next 32 rows overwrite it
