@@ -75,6 +75,10 @@ def model_counts(kwargs, b, n):
         "node_mlp0": dict(bound="mfma", flops=2.0 * bn * (dim + m) * 2 * dim,
                           bytes=4 * (bn * (dim + m) + 2 * dim * (dim + m) + bn * 2 * dim)),
         "node_mlp1": dict(bound="mfma", flops=2.0 * bn * 2 * dim * dim, bytes=4 * (bn * 2 * dim + 2 * dim * dim + 2 * bn * dim)),
+        # narrow layers (dim <= 256): both Linears in one launch (csrc/node_mlp_fused.hip) -- the hidden activation never reaches memory:
+        # reads [LayerNorm(h) | m_i] and the residual, writes the output rows
+        "node_mlp": dict(bound="mfma", flops=2.0 * bn * ((dim + m) * 2 * dim + 2 * dim * dim),
+                         bytes=4 * (bn * (dim + m) + 2 * bn * dim + 2 * dim * (dim + m) + 2 * dim * dim)),
         # one pass over feats: read fp32 rows once, write [node_norm(feats) | 0] as a (hi, lo) pair -- and the raw rows as a second pair
         # only when node_norm is a LayerNorm (the projection reads the one image otherwise: egnn_linear_hl_lda_f32)
         "node_prep": dict(bound="hbm", bytes=4 * bn * dim + (4 * bn * dim if kwargs.get("norm_feats") else 0) + 4 * bn * (dim + m),
@@ -137,6 +141,7 @@ _TRAFFIC_KERNELS = {
     "node_proj": (r"linear_hl_kernelILi\d+ELi0ELb0E", r"linear_hl_kernel<\d+, 0, false"),
     "node_mlp0": (r"linear_hl_kernelILi\d+ELi1ELb0E", r"linear_hl_kernel<\d+, 1, false"),
     "node_mlp1": (r"linear_hl_kernelILi\d+ELi0ELb1E", r"linear_hl_kernel<\d+, 0, true"),
+    "node_mlp": (r"node_mlp_fused_kernel",),
 }
 
 

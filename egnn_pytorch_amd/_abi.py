@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 34
+ABI_VERSION = 35
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -35,6 +35,7 @@ SYMBOLS = (
     "egnn_knn_select_f64", "egnn_linear_f64", "egnn_node_prep_f64", "egnn_edge_exact_f64",
     "egnn_edge_exact_bwd_f32", "egnn_edge_exact_bwd_f64", "egnn_edge_exact_node_sums_f32", "egnn_edge_exact_node_sums_f64",
     "egnn_edge_tail_exact_bwd_f32", "egnn_edge_tail_exact_bwd_f64", "egnn_status_publish",
+    "egnn_node_mlp_fused_halves", "egnn_node_mlp_fused_pack_f16", "egnn_node_mlp_fused_f32",
 )
 
 
@@ -253,6 +254,13 @@ def load():
     lib.egnn_linear_hl_drop_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p,
                                             c_int64, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int,
                                             ctypes.c_uint32, ctypes.c_uint32, c_float, c_void_p, c_void_p]
+    lib.egnn_node_mlp_fused_halves.restype = c_int64
+    lib.egnn_node_mlp_fused_halves.argtypes = [c_int, c_int]
+    lib.egnn_node_mlp_fused_pack_f16.restype = c_int
+    lib.egnn_node_mlp_fused_pack_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.egnn_node_mlp_fused_f32.restype = c_int
+    lib.egnn_node_mlp_fused_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64,
+                                            c_int, c_int, c_void_p, c_void_p]
     lib.egnn_split_f16.restype = c_int
     lib.egnn_split_f16.argtypes = [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.egnn_node_prep_hl.restype = c_int

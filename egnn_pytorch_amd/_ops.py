@@ -426,6 +426,36 @@ def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32
     return out if out_hl else c
 
 
+def node_mlp_fused_supported(dim, m_dim):
+    """egnn_node_mlp_fused_f32 is built for this layer width (m_dim = 16, dim in {32, 64, 128, 256})."""
+    return _abi.load().egnn_node_mlp_fused_halves(int(dim), int(m_dim)) > 0
+
+
+def node_mlp_fused_image(w5_split, w6_split, dim, m_dim):
+    """The fused kernel's weight image (fp16 tensor) from the two packed (hi, lo) weight images of egnn_linear_hl_f32."""
+    lib = _abi.load()
+    n = lib.egnn_node_mlp_fused_halves(int(dim), int(m_dim))
+    assert n > 0
+    img = empty(n, dtype=torch.float16, device=w5_split[0].device)
+    rc = lib.egnn_node_mlp_fused_pack_f16(_ptr(w5_split[0]), _ptr(w5_split[1]), _ptr(w6_split[0]), _ptr(w6_split[1]), int(dim), int(m_dim),
+                                          _ptr(img), _stream())
+    _abi.check(rc, "egnn_node_mlp_fused_pack_f16")
+    return img
+
+
+def node_mlp_fused(node_in: "PackedHL", image, w5_inv, b5, w6_inv, b6, residual, dim, m_dim):
+    """W6 SiLU(W5 [LayerNorm(h) | m_i] + b5) + b6 + residual in one launch (egnn_node_mlp_fused_f32): (rows, dim) fp32."""
+    m = node_in.rows
+    assert residual.shape == (m, dim) and residual.is_contiguous() and node_in.kp == _kpad(dim + m_dim)
+    out = empty(m, dim, dtype=torch.float32, device=residual.device)
+    with _timed("node_mlp"):
+        rc = _abi.load().egnn_node_mlp_fused_f32(_ptr(node_in.hi), _ptr(node_in.lo), _ptr(image), float(w5_inv), _ptr(b5), float(w6_inv),
+                                                 _ptr(b6), _ptr(residual), _ptr(out), m, int(dim), int(m_dim),
+                                                 _status_ptr(residual.device), _stream())
+    _abi.check(rc, "egnn_node_mlp_fused_f32")
+    return out
+
+
 # ---- the wide-range path: the same layer in plain fp32 (include/egnn_hip.h, "The wide-range path")
 def linear_f32(a, w, n, k, bias=None, residual=None, act=0, out=None, name="linear_f32"):
     """act(a @ w[:n, :k].T + bias) (+ residual) in exact fp32 (v_mfma_f32_32x32x2_f32) -- egnn_linear_f32.  a (M, >= k) and w

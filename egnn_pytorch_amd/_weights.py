@@ -133,6 +133,35 @@ def split_f16(w: torch.Tensor):
     return pack_tiles(hi), pack_tiles(lo), 1.0 / scale, npad
 
 
+def node_mlp_fused_supported(dim: int, m: int) -> bool:
+    """Mirror of egnn_node_mlp_fused_halves(dim, m_dim) > 0 (csrc/node_mlp_fused.hip: the widths the one-launch node_mlp is built for)."""
+    return m == 16 and dim in (32, 64, 128, 256)
+
+
+def node_mlp_fused_image(w5_split, w6_split, dim: int, m: int) -> torch.Tensor:
+    """Tensor-op twin of egnn_node_mlp_fused_pack_f16 (the specification the kernel is tested against, and what a CPU module packs):
+    per block hb of 32 hidden units  [W5 fragments (ht, ks, hi|lo, lane, 8)] [W6 fragments (dt, hi|lo, lane, 8)]  of
+    v_mfma_f32_16x16x32_f16 A operands -- lane = 16 kq + r holds row r of its 16-row tile and K-slots 8 kq .. 8 kq + 7; W5's rows are
+    hidden units 32 hb + 16 ht + r with k = 32 ks + slot; W6's rows are output features 16 dt + r and slot s carries hidden unit
+    32 hb + pi(s), pi(8 q + t) = 4 q + t (t < 4), 16 + 4 q + (t - 4) -- the order in which the first product's accumulators hold them."""
+    assert node_mlp_fused_supported(dim, m)
+    ndt = nhb = dim // 16
+    kp1 = (dim + m + 31) // 32 * 32
+    k1s = kp1 // 32
+    pi = torch.tensor([4 * (s_ >> 3) + (s_ & 7) if (s_ & 7) < 4 else 16 + 4 * (s_ >> 3) + (s_ & 7) - 4 for s_ in range(32)],
+                      device=w5_split[0].device)
+    f5, f6 = [], []
+    for part in (0, 1):
+        w5 = unpack_tiles(w5_split[part], w5_split[3], kp1)[:2 * dim]                    # (2 dim, Kp1) fp16, scaled
+        w6 = unpack_tiles(w6_split[part], w6_split[3], 2 * dim)[:dim]                    # (dim, 2 dim)
+        f5.append(w5.reshape(nhb, 2, 16, k1s, 4, 8).permute(0, 1, 3, 4, 2, 5).reshape(nhb, 2, k1s, 64, 8))      # (hb, ht, ks, kq r, e)
+        g = w6.reshape(ndt, 16, nhb, 32)[..., pi].reshape(ndt, 16, nhb, 4, 8)            # (dt, r, hb, kq, e)
+        f6.append(g.permute(2, 0, 3, 1, 4).reshape(nhb, ndt, 64, 8))
+    f5 = torch.stack(f5, dim=3).reshape(nhb, -1)                                          # (hb, ht, ks, part, lane, e)
+    f6 = torch.stack(f6, dim=2).reshape(nhb, -1)                                          # (hb, dt, part, lane, e)
+    return torch.cat((f5, f6), dim=1).reshape(-1).contiguous()
+
+
 def _f32_mul(a: float, b: float) -> float:
     """a * b rounded to fp32 (what max |w * b| is for fp32 tensors when a = max |w|: rounding is monotone)."""
     import numpy as np
@@ -309,6 +338,12 @@ def _pack(layer) -> dict:
             out["W6_split"] = split_f16(w6)
             out["W5T_split"] = split_f16(w5.t().contiguous())
             out["W6T_split"] = split_f16(w6.t().contiguous())
+        if node_mlp_fused_supported(dim, m):                       # narrow layers: node_mlp in one launch (csrc/node_mlp_fused.hip)
+            if on_dev:
+                from . import _ops
+                out["nmf_img"] = _ops.node_mlp_fused_image(out["W5_split"], out["W6_split"], dim, m)
+            else:
+                out["nmf_img"] = node_mlp_fused_image(out["W5_split"], out["W6_split"], dim, m)
         if layer.norm_feats:
             out.update(gamma=layer.node_norm.weight.detach().float().contiguous(),
                        beta=layer.node_norm.bias.detach().float().contiguous(),

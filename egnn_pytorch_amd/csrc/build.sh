@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -Wno-inline-a
 rm -rf "$HERE/obj"
 mkdir -p "$HERE/obj"
 pids=()
-for f in knn_select spatial_order adj_expand linear_hl edge_fused edge_pw edge_exact edge_exact_bwd edge_bwd edge_tail node_ops layer_api segment_sum entry_lists global_attn linear_f32 node_prep_f32 fp64 linear_split; do
+for f in knn_select spatial_order adj_expand linear_hl node_mlp_fused edge_fused edge_pw edge_exact edge_exact_bwd edge_bwd edge_tail node_ops layer_api segment_sum entry_lists global_attn linear_f32 node_prep_f32 fp64 linear_split; do
   EXTRA=""
   # the ranking kernel must reproduce the reference's un-fused ((dx*dx+dy*dy)+dz*dz) bit for bit
   [ "$f" = knn_select ] && EXTRA="-ffp-contract=off"

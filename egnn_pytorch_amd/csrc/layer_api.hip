@@ -248,7 +248,7 @@ extern "C" int egnn_pack_weights_host(const egnn_layer_desc* desc, const egnn_la
 namespace {
 
 struct Workspace {
-    size_t idx, rank, order, slots, raw_hi, raw_lo, node_hi, node_lo, proj, hid_hi, hid_lo, bytes;
+    size_t idx, rank, order, slots, raw_hi, raw_lo, node_hi, node_lo, proj, hid_hi, hid_lo, nmf_img, bytes;
 };
 
 Workspace carve(const egnn_layer_desc* d, const Dims& x, int64_t B, int64_t N, int64_t K)
@@ -266,8 +266,13 @@ Workspace carve(const egnn_layer_desc* d, const Dims& x, int64_t B, int64_t N, i
     if (d->update_feats) {
         take(w.node_hi, (size_t)egnn_packed_halves(rows, x.kp_node) * 2);
         take(w.node_lo, (size_t)egnn_packed_halves(rows, x.kp_node) * 2);
-        take(w.hid_hi, (size_t)egnn_packed_halves(rows, x.kp_hid) * 2);
-        take(w.hid_lo, (size_t)egnn_packed_halves(rows, x.kp_hid) * 2);
+        if (egnn_node_mlp_fused_halves(x.dim, x.m) > 0) {
+            // narrow layers: node_mlp in one launch (csrc/node_mlp_fused.hip) -- no hidden image, the fused weight image instead
+            take(w.nmf_img, (size_t)egnn_node_mlp_fused_halves(x.dim, x.m) * 2);
+        } else {
+            take(w.hid_hi, (size_t)egnn_packed_halves(rows, x.kp_hid) * 2);
+            take(w.hid_lo, (size_t)egnn_packed_halves(rows, x.kp_hid) * 2);
+        }
     }
     w.bytes = off;
     return w;
@@ -391,7 +396,14 @@ extern "C" int egnn_layer_forward_f32(const egnn_layer_desc* desc, const egnn_pa
     }
 
     // ---- node update (:335-337)
-    if (desc->update_feats) {
+    if (desc->update_feats && egnn_node_mlp_fused_halves(dim, x.m) > 0) {
+        // (the Python module packs the fused image once per parameter version; this entry keeps no state between calls and re-derives
+        // it -- ~1 MB -- from the blob's two packed images)
+        EGNN_TRY(egnn_node_mlp_fused_pack_f16(blob + info->w5_hi, blob + info->w5_lo, blob + info->w6_hi, blob + info->w6_lo, dim, x.m,
+                                              ws + w.nmf_img, stream));
+        EGNN_TRY(egnn_node_mlp_fused_f32(node_hi, node_lo, ws + w.nmf_img, info->w5_inv_scale, F(info->b5), info->w6_inv_scale, F(info->b6),
+                                         feats, feats_out, rows, dim, x.m, status, stream));
+    } else if (desc->update_feats) {
         if (x.kp_hid != 2 * dim) {                                             // pad columns must read as zero in the next GEMM
             if (hipMemsetAsync(ws + w.hid_hi, 0, (size_t)egnn_packed_halves(rows, x.kp_hid) * 2, s) != hipSuccess) return (int)hipGetLastError();
             if (hipMemsetAsync(ws + w.hid_lo, 0, (size_t)egnn_packed_halves(rows, x.kp_hid) * 2, s) != hipSuccess) return (int)hipGetLastError();

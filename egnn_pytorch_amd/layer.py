@@ -41,6 +41,7 @@ _EDGE_ALGO = int(os.environ.get("EGNN_EDGE_ALGO", "0"))
 _PRECISION = os.environ.get("EGNN_PRECISION", "fast")
 _DENSE_PW = os.environ.get("EGNN_DENSE_PW", "1") != "0"            # dense layers with N % 32 == 0 on the wave-per-node edge kernel
 _SHARED_FEATS_IMAGE = os.environ.get("EGNN_SHARED_FEATS_IMAGE", "1") != "0"   # 0: a second packed image of feats for the projection
+_NODE_MLP_FUSED = os.environ.get("EGNN_NODE_MLP_FUSED", "1") != "0"   # node_mlp of narrow layers in one launch (csrc/node_mlp_fused.hip)
 _ENTRY_FORK = os.environ.get("EGNN_ENTRY_FORK", "1") != "0"        # ... which then waits for an event recorded at the layer's entry, not for them
 _LATE_SELECT = os.environ.get("EGNN_LATE_SELECT", "1") != "0"      # node-level launches before the neighbour selection (see _forward_hip)
 _exact_now = contextvars.ContextVar("egnn_exact_now", default=False)       # per thread / context: concurrent forwards do not see each other's
@@ -493,9 +494,14 @@ class EGNN(nn.Module):
 
         # ---- node update (egnn_pytorch.py:335-337)
         if self.node_mlp is not None:
-            hid = _ops.linear_hl(node_in, w["W5_split"], 2 * dim, w["b5"], act=1, out_f32=False, out_hl=True,
-                                 name="node_mlp0", drop=drop)
-            node_out = _ops.linear_hl(hid, w["W6_split"], dim, w["b6"], residual=feats2d, name="node_mlp1").view(b, n, dim)
+            if _NODE_MLP_FUSED and drop is None and "nmf_img" in w:
+                # narrow layers (dim <= 256): both Linears in one launch, the hidden activation stays in registers
+                node_out = _ops.node_mlp_fused(node_in, w["nmf_img"], w["W5_split"][2], w["b5"], w["W6_split"][2], w["b6"], feats2d,
+                                               dim, self.m_dim).view(b, n, dim)
+            else:
+                hid = _ops.linear_hl(node_in, w["W5_split"], 2 * dim, w["b5"], act=1, out_f32=False, out_hl=True,
+                                     name="node_mlp0", drop=drop)
+                node_out = _ops.linear_hl(hid, w["W6_split"], dim, w["b6"], residual=feats2d, name="node_mlp1").view(b, n, dim)
         return node_out, coors_out, order, idx, rank, valid_radius, u_pre, proj_kept
 
 

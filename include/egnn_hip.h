@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 34
+#define EGNN_ABI_VERSION 35
 
 enum {
     EGNN_OK = 0,
@@ -227,6 +227,23 @@ int egnn_absmax_f32(const float* X, int64_t count, uint32_t* out_bits, void* str
  * into the fp32 values hi + lo IN PLACE, for the backward kernels, which read both halves as fp32: the table the forward used is kept
  * for the backward instead of being recomputed.  cols % 4 == 0, ldx % 4 == 0, X 16-byte aligned. */
 int egnn_unsplit_words_f32(float* X, int64_t ldx, int64_t rows, int cols, void* stream);
+
+/* node_mlp in one launch for narrow layers (reference: egnn_pytorch.py:196-201, 336-337) -- csrc/node_mlp_fused.hip:
+ *     out = W6 SiLU(W5 x + b5) + b6 + residual,   x = the packed [LayerNorm(h) | m_i] image of egnn_node_prep_hl (Kp = pad32(dim + 16))
+ * with the hidden activation (rows x 2 dim) kept in registers instead of written out as a packed image and read back by a second
+ * egnn_linear_hl_f32.  Built for m_dim = 16 and dim in {32, 64, 128, 256} (egnn_node_mlp_fused_halves returns 0 otherwise; the two-launch
+ * path serves every shape).  Same arithmetic as that path (3-term split-fp16 products, fp32 accumulation, bias / SiLU in fp32); results
+ * differ from it by the order of the fp32 sums only.  An activation beyond fp16's range sets EGNN_RANGE_A_OPERAND.
+ *   egnn_node_mlp_fused_halves: fp16 elements of the fused weight image.
+ *   egnn_node_mlp_fused_pack_f16: the image from the packed (hi, lo) images of scale5 * W5 (2 dim rows, Kp = pad32(dim + 16)) and
+ *     scale6 * W6 (dim rows, Kp = 2 dim) that egnn_linear_hl_f32 takes (power-of-two scales; their inverses are passed to the kernel).
+ *   egnn_node_mlp_fused_f32: residual / out (M, dim) fp32 contiguous, 16-byte aligned; b5 (2 dim), b6 (dim). */
+int64_t egnn_node_mlp_fused_halves(int dim, int m_dim);
+int egnn_node_mlp_fused_pack_f16(const void* W5_hi, const void* W5_lo, const void* W6_hi, const void* W6_lo, int dim, int m_dim,
+                                 void* image, void* stream);
+int egnn_node_mlp_fused_f32(const void* X_hi, const void* X_lo, const void* image, float w5_inv_scale, const float* b5,
+                            float w6_inv_scale, const float* b6, const float* residual, float* out, int64_t M, int dim, int m_dim,
+                            int32_t* status, void* stream);
 
 /* X (rows, cols) fp32 row-major -> packed (rows, Kp) images hi = fp16(x), lo = fp16(x - hi); pads zero; Kp % 32 == 0,
  * Kp >= cols.  |X| >= 65504 (finite) sets EGNN_RANGE_A_OPERAND in *status (optional) and turns into inf / NaN. */

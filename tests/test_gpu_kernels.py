@@ -668,6 +668,34 @@ def test_split_scaled_both_equals_the_two_single_splits(rows, cols):
     assert float(_ops.GradOperand(torch.zeros_like(x), colsum=True).colsum.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dim,rows", [(32, 100), (64, 4096), (128, 5000), (256, 1300)])
+def test_node_mlp_fused_matches_float64_and_the_two_launch_path(dim, rows):
+    """csrc/node_mlp_fused.hip (narrow layers: W6 SiLU(W5 x + b5) + b6 + h in one launch, the hidden activation in registers): its weight
+    image equals the tensor-op twin bit for bit (the permutation of W6's K-slots is the specification's), the output equals float64 at
+    fp32-class accuracy and the two-launch path to the rounding of the fp32 sums; rows % 128 != 0 (a workgroup's tail) included."""
+    from egnn_pytorch_amd import _ops, _weights
+    g = torch.Generator().manual_seed(dim + rows)
+    m = 16
+    w5 = torch.randn(2 * dim, dim + m, generator=g) / (dim + m) ** 0.5
+    w6 = torch.randn(dim, 2 * dim, generator=g) / (2 * dim) ** 0.5
+    b5, b6 = torch.randn(2 * dim, generator=g), torch.randn(dim, generator=g)
+    x = torch.randn(rows, dim + m, generator=g)
+    res = torch.randn(rows, dim, generator=g)
+    s5, s6 = _weights.split_f16(w5), _weights.split_f16(w6)
+    want_img = _weights.node_mlp_fused_image(s5, s6, dim, m)
+    s5d, s6d = tuple(t.cuda() if torch.is_tensor(t) else t for t in s5), tuple(t.cuda() if torch.is_tensor(t) else t for t in s6)
+    img = _ops.node_mlp_fused_image(s5d, s6d, dim, m)
+    assert torch.equal(img.cpu(), want_img)
+    node_in = _ops.split_f16(x.cuda())
+    out = _ops.node_mlp_fused(node_in, img, s5[2], b5.cuda(), s6[2], b6.cuda(), res.cuda(), dim, m)
+    ref = torch.nn.functional.silu(x.double() @ w5.double().t() + b5.double()) @ w6.double().t() + b6.double() + res.double()
+    assert float((out.double().cpu() - ref).abs().max()) <= 3e-5 * max(1.0, float(ref.abs().max()))
+    hid = _ops.linear_hl(node_in, s5d, 2 * dim, b5.cuda(), act=1, out_f32=False, out_hl=True)
+    two = _ops.linear_hl(hid, s6d, dim, b6.cuda(), residual=res.cuda())
+    assert float((out - two).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(out, _ops.node_mlp_fused(node_in, img, s5[2], b5.cuda(), s6[2], b6.cuda(), res.cuda(), dim, m))     # bit-reproducible
+
+
 def test_silu_bwd_matches_autograd():
     """egnn_silu_bwd_f32: a = SiLU(z) and gz = g SiLU'(z) in place, against torch autograd in float64."""
     from egnn_pytorch_amd import _ops

@@ -18,7 +18,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "egnn_pytorch_amd", "csrc")
 VDIR = os.path.join(ROOT, "build_variants")
-PROD = ("knn_select", "spatial_order", "adj_expand", "linear_hl", "node_ops", "edge_fused", "edge_pw", "edge_exact", "edge_exact_bwd", "edge_fused_d", "edge_fused_cd", "linear_f32", "node_prep_f32", "fp64", "edge_fused_c", "edge_bwd", "edge_tail",
+PROD = ("knn_select", "spatial_order", "adj_expand", "linear_hl", "node_mlp_fused", "node_ops", "edge_fused", "edge_pw", "edge_exact", "edge_exact_bwd", "edge_fused_d", "edge_fused_cd", "linear_f32", "node_prep_f32", "fp64", "edge_fused_c", "edge_bwd", "edge_tail",
         "layer_api", "segment_sum", "entry_lists", "global_attn")
 
 TIMER = r'''
