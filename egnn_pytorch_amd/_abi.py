@@ -189,7 +189,11 @@ class EGNNHipError(RuntimeError):
 
 class EGNNRangeError(EGNNHipError):
     """A finite value left the range the split-fp16 arithmetic of the gfx950 path can carry (include/egnn_hip.h:
-    EGNN_RANGE_*).  The outputs of that call are non-finite; the reference (plain fp32) has no such limit."""
+    EGNN_RANGE_*).  The outputs of that call are non-finite; the reference (plain fp32) has no such limit.
+    origin: "call" (this forward), "backward" (bits an earlier backward left: the forward that reports them is valid and is not
+    re-run) or "earlier" (deferred mode: some earlier call); bits: the status bits."""
+    origin = "call"
+    bits = 0
 
 
 RANGE_BITS = {

@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import contextlib
 import contextvars
+import threading
+import time
 import os
 from ctypes import byref
 
@@ -138,7 +140,7 @@ def _u8(t):
 #   EGNN_RANGE_CHECK=off       never read (outputs are still non-finite when it happens)
 RANGE_CHECK = os.environ.get("EGNN_RANGE_CHECK", "sync")
 _SPIN = os.environ.get("EGNN_RANGE_SPIN", "1") != "0"
-_SPIN_LIMIT = 50_000_000                                # ~ seconds of spinning before the copy + synchronise fallback
+_SPIN_SECONDS = float(os.environ.get("EGNN_RANGE_SPIN_SECONDS", "2.0"))   # spinning on the pinned word, then the copy + synchronise fallback
 _status = {}
 
 
@@ -154,6 +156,7 @@ class _Status:
         self.pub = torch.zeros(4, dtype=torch.int32).pin_memory()
         self.pub_np = self.pub.numpy()
         self.seq = 0
+        self.lock = threading.Lock()
 
 
 _status_slot = contextvars.ContextVar("egnn_status_slot", default=0)
@@ -181,12 +184,14 @@ def status_word(device):
     return st
 
 
-def _raise_range(bits, when):
+def _raise_range(bits, when, origin="call"):
     what = "; ".join(msg for bit, msg in _abi.RANGE_BITS.items() if bits & bit)
-    raise _abi.EGNNRangeError(
+    err = _abi.EGNNRangeError(
         f"egnn_pytorch_amd ({when}): a value left the range of the split-fp16 arithmetic of the gfx950 path: {what}. "
         f"The outputs of that call are non-finite. (The reference computes in plain fp32 and has no such limit; rescale the "
         f"inputs / weights, or see DESIGN.md section 2.)")
+    err.origin, err.bits = origin, int(bits)
+    raise err
 
 
 def range_check_after_forward(device, mode=None):
@@ -201,15 +206,26 @@ def range_check_after_forward(device, mode=None):
         # on was measured too: no faster -- what the synchronisation costs is the host time from forward() entry to its first launch)
         fwd = bwd = None
         if _SPIN:
-            st.seq = (st.seq % 0x7ffffff0) + 1
-            with torch.cuda.device(st.dev.device):
-                rc = _abi.load().egnn_status_publish(st.dev.data_ptr(), st.pub.data_ptr(), 2, st.seq, _stream())
-            _abi.check(rc, "egnn_status_publish")
-            view, seq, spins = st.pub_np, st.seq, 0
-            while view[2] != seq and spins < _SPIN_LIMIT:
-                spins += 1
-            if view[2] == seq:
-                fwd, bwd = int(view[0]), int(view[1])
+            # publish + spin under the device's lock: the sequence number and the pinned words are per device, and two threads running
+            # forwards on one device would overwrite each other's (one of them then spun out its whole limit).  The spin is bounded by
+            # TIME (a count of Python iterations is seconds on one host and minutes on another); past it: the copy + synchronise below.
+            with st.lock:
+                st.seq = (st.seq % 0x7ffffff0) + 1
+                with torch.cuda.device(st.dev.device):
+                    rc = _abi.load().egnn_status_publish(st.dev.data_ptr(), st.pub.data_ptr(), 2, st.seq, _stream())
+                _abi.check(rc, "egnn_status_publish")
+                view, seq, spins = st.pub_np, st.seq, 0
+                deadline = None
+                while view[2] != seq:
+                    spins += 1
+                    if (spins & 0xFFF) == 0:
+                        now = time.perf_counter()
+                        if deadline is None:
+                            deadline = now + _SPIN_SECONDS
+                        elif now > deadline:
+                            break
+                if view[2] == seq:
+                    fwd, bwd = int(view[0]), int(view[1])
         if fwd is None:                                 # (EGNN_RANGE_SPIN=0, or the pinned word never changed: copy + synchronise)
             st.host.copy_(st.dev, non_blocking=True)
             torch.cuda.current_stream(st.dev.device).synchronize()
@@ -218,7 +234,7 @@ def range_check_after_forward(device, mode=None):
             st.dev.zero_()
             st.host.zero_()
         if bwd and not fwd:                             # left by an earlier backward: not this call's, never a reason to re-run it
-            _raise_range(bwd, "an earlier backward")
+            _raise_range(bwd, "an earlier backward", origin="backward")
         if fwd:
             _raise_range(fwd | bwd, "this call")
         return
@@ -253,7 +269,7 @@ def check_range(device=None, wait=True):
         if bits:
             st.dev.zero_()
             st.host.zero_()
-            _raise_range(bits, "an earlier call")
+            _raise_range(bits, "an earlier call", origin="earlier")
 
 
 def knn_select(coors, mask, adj_mat, k, out=None):

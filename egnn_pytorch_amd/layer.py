@@ -200,13 +200,15 @@ class EGNN(nn.Module):
             raise ValueError(f"mask shape {tuple(mask.shape)} != {(b, n)}")
 
     def forward(self, feats, coors, edges=None, mask=None, adj_mat=None):
+        out = None
         try:
             out = self._call(feats, coors, edges, mask, adj_mat, None)[:2]
             _ops.range_check_after_forward(feats.device)            # EGNN_RANGE_CHECK: sync (default) | deferred | off
         except _abi.EGNNRangeError as err:
-            if "an earlier backward" in str(err) or not _rerun_exact_ok(self, feats, coors, edges):
+            if err.origin == "backward" or not _rerun_exact_ok(self, feats, coors, edges):
                 raise
             _warn_rerun(err)
+            out = None                                              # (under autograd the first attempt holds u and the projection table)
             with exact_arithmetic():                                # reference-legal inputs beyond the fp16 cast sites: plain fp32
                 out = self._call(feats, coors, edges, mask, adj_mat, None)[:2]
         return out
@@ -668,7 +670,7 @@ class EGNN_Network(nn.Module):
                 out = self._forward(feats, coors, adj_mat, edges, mask, return_coor_changes)
             _ops.range_check_after_forward(coors.device)            # once per network forward, not per layer
         except _abi.EGNNRangeError as err:
-            if "an earlier backward" in str(err) or not _rerun_exact_ok(self, feats, coors, edges):
+            if err.origin == "backward" or not _rerun_exact_ok(self, feats, coors, edges):
                 raise
             _warn_rerun(err)
             with exact_arithmetic(), (torch.enable_grad() if grad else torch.no_grad()):    # the whole stack again, in plain fp32
