@@ -14,7 +14,7 @@ import re
 ROLE = {r"linear_hl_kernel<\d+, 0, false": "node_proj", r"linear_hl_kernel<\d+, 1, false": "node_mlp0",
         r"linear_hl_kernel<\d+, 0, true": "node_mlp1", r"edge_kernel": "edge_fused", r"edge_pw_kernel": "edge_fused", r"knn_select_kernel": "knn_select",
         r"node_prep_hl_kernel": "node_prep", r"split_f16_kernel": "split_f16", r"spatial_order_kernel": "spatial_order",
-        r"slot_prep_kernel": "slot_prep"}
+        r"slot_prep_kernel": "slot_prep", r"node_mlp_fused_kernel": "node_mlp"}
 
 
 def short(name):
