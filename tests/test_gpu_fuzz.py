@@ -20,7 +20,8 @@ def _dev(x):
 def _draw(seed):
     rng = np.random.default_rng(1000 + seed)
     pick = lambda xs: xs[int(rng.integers(len(xs)))]                                      # noqa: E731
-    kw = dict(dim=pick([8, 16, 24, 40, 64]), m_dim=pick([4, 16, 16, 16, 20, 32, 48]), edge_dim=pick([0, 0, 1, 3]),
+    # (dim 32 / 64 / 128 with m_dim 16: node_mlp in one launch, csrc/node_mlp_fused.hip)
+    kw = dict(dim=pick([8, 16, 24, 32, 40, 64, 128]), m_dim=pick([4, 16, 16, 16, 20, 32, 48]), edge_dim=pick([0, 0, 1, 3]),
               fourier_features=pick([0, 0, 1, 2]), norm_feats=bool(rng.integers(2)), norm_coors=bool(rng.integers(2)),
               m_pool_method=pick(["sum", "mean"]), soft_edges=bool(rng.integers(2)),
               coor_weights_clamp_value=pick([None, None, 0.5, 2.0]), valid_radius=pick([float("inf"), float("inf"), 2.5]))
@@ -28,6 +29,8 @@ def _draw(seed):
     kw["update_feats"], kw["update_coors"] = upd != "coors", upd != "feats"
     mode = pick(["dense", "knn", "knn", "knn", "sparse", "knn_adj"])
     n = int(rng.integers(6, 90))
+    if mode in ("sparse", "knn_adj") and rng.integers(3) == 0:
+        n = pick([144, 160, 256, 272])                       # (N % 16 == 0 beyond 128 nodes: rows the adjacency decides, csrc/knn_select.hip)
     if mode in ("knn", "knn_adj"):
         kw["num_nearest_neighbors"] = min(n, pick([3, 5, 8, 16, 32, 32, 64]))
     if mode == "sparse":
