@@ -142,52 +142,86 @@ _TRAFFIC_KERNELS = {
     "node_mlp0": (r"linear_hl_kernelILi\d+ELi1ELb0E", r"linear_hl_kernel<\d+, 1, false"),
     "node_mlp1": (r"linear_hl_kernelILi\d+ELi0ELb1E", r"linear_hl_kernel<\d+, 0, true"),
     "node_mlp": (r"node_mlp_fused_kernel",),
+    "knn_select": (r"knn_select_kernel",),
+    "node_prep": (r"node_prep_hl_kernel",),
+    "slot_prep": (r"slot_prep_kernel",),
+    "spatial_order": (r"spatial_order_kernel",),
 }
 
 
-def live_traffic(workload, kernel, timeout_s=150):
-    """HBM traffic of `kernel` per launch, measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE
-    cannot share a pass; PMC collection cannot run inside the timed process), collected and corrected as MI355X_MICROARCH.md's HBM
-    section prescribes -- both counters in KiB, FETCH_SIZE doubled on gfx950 (it reports half the bytes of 16-byte-per-lane coalesced
-    reads).  Returns (bytes per launch, note) or (None, why not)."""
+def _pmc_child(workload, counter, timeout_s):
+    """One child run of this script under `rocprofv3 --kernel-trace --pmc <counter>` (PMC collection cannot run inside the timed process):
+    the rows of its counter CSV as (kernel name, value, dispatch ns), or a string saying why there are none."""
     import csv
     import glob
-    import re
     import shutil
     import subprocess
     import tempfile
     rp = shutil.which("rocprofv3")
-    pats = _TRAFFIC_KERNELS.get(kernel)
-    if rp is None or pats is None:
-        return None, "rocprofv3 not on PATH" if rp is None else f"no kernel pattern for {kernel}"
-    vals = {}
+    if rp is None:
+        return "rocprofv3 not on PATH"
+    # (a plain single-process child: nothing of a launcher's rendezvous may leak into it)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
+           and not k.startswith("TORCHELASTIC")}
+    env.update(TMPDIR="/tmp", EGNN_BENCH_TRAFFIC_CHILD="1")
+    rows = []
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
-        # (a plain single-process child: nothing of a launcher's rendezvous may leak into it)
-        env = {k: v for k, v in os.environ.items()
-               if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
-               and not k.startswith("TORCHELASTIC")}
-        env.update(TMPDIR="/tmp", EGNN_BENCH_TRAFFIC_CHILD="1")
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            cmd = [rp, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
-                   os.path.abspath(__file__), "--workload", workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-train-step",
-                   "--no-live-traffic"]
-            try:
-                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
-            except Exception as ex:                      # (never fatal: the line falls back to the committed profile)
-                return None, f"rocprofv3 --pmc {counter}: {type(ex).__name__}"
-            got = []
-            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                with open(f) as fh:
-                    for row in csv.DictReader(fh):
-                        if row["Counter_Name"] == counter and any(re.search(p, row["Kernel_Name"]) for p in pats):
-                            got.append(float(row["Counter_Value"]))
-            if not got:
-                return None, f"no {counter} rows for {kernel}"
-            vals[counter] = sum(got) / len(got)
+        cmd = [rp, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
+               os.path.abspath(__file__), "--workload", workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-train-step",
+               "--no-live-traffic"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+        except Exception as ex:                      # (never fatal: the line falls back to the committed profile)
+            return f"rocprofv3 --pmc {counter}: {type(ex).__name__}"
+        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if row["Counter_Name"] == counter:
+                        rows.append((row["Kernel_Name"], float(row["Counter_Value"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+    return rows or f"no {counter} rows"
+
+
+def live_traffic(workload, kernel, timeout_s=150):
+    """HBM traffic of `kernel` per launch, measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE
+    cannot share a pass), collected and corrected as MI355X_MICROARCH.md's HBM section prescribes -- both counters in KiB, FETCH_SIZE
+    doubled on gfx950 (it reports half the bytes of 16-byte-per-lane coalesced reads).  Returns (bytes per launch, note) or (None, why not)."""
+    import re
+    pats = _TRAFFIC_KERNELS.get(kernel)
+    if pats is None:
+        return None, f"no kernel pattern for {kernel}"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        rows = _pmc_child(workload, counter, timeout_s)
+        if isinstance(rows, str):
+            return None, rows
+        got = [v for name, v, _ in rows if any(re.search(p, name) for p in pats)]
+        if not got:
+            return None, f"no {counter} rows for {kernel}"
+        vals[counter] = sum(got) / len(got)
     return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), \
         "measured in this run: two child runs of this command under rocprofv3 --kernel-trace --pmc (FETCH_SIZE, WRITE_SIZE: separate " \
         "passes), (2 FETCH_SIZE + WRITE_SIZE) * 1024 per launch (MI355X_MICROARCH.md: KiB units, gfx950 FETCH_SIZE correction)"
+
+
+def live_clocks(workload, timeout_s=150):
+    """Effective shader clock of each kernel of the step, measured NOW (MI355X_MICROARCH.md, "DVFS give-back": the chip clocks to its
+    power budget; effective clock = GRBM_GUI_ACTIVE / kernel wall time): one more child run under `rocprofv3 --pmc GRBM_GUI_ACTIVE`.
+    rocprofv3 sums the counter over the 8 XCDs and its sampling window is wider than the dispatch: the smallest value of the pass (a
+    few-microsecond copy kernel) is subtracted as that fixed part; wall time = the dispatch's own timestamps in that pass.
+    Returns ({kernel: GHz}, note) or (None, why not).  The roofline peaks (2.5 PFLOP/s dense f16) assume 2.4 GHz."""
+    import re
+    rows = _pmc_child(workload, "GRBM_GUI_ACTIVE", timeout_s)
+    if isinstance(rows, str):
+        return None, rows
+    floor = min(v for _, v, _ in rows)
+    out = {}
+    for kernel, pats in _TRAFFIC_KERNELS.items():
+        got = [(v - floor) / 8.0 / ns for name, v, ns in rows if ns > 20000 and any(re.search(p, name) for p in pats)]
+        if got:
+            out[kernel] = round(sum(got) / len(got), 3)
+    return (out or None), "GRBM_GUI_ACTIVE (summed over 8 XCDs; the pass's smallest value subtracted as the sampling window's fixed part) " \
+        "/ 8 / dispatch wall time, one child run of this command under rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE"
 
 
 def git_head():
@@ -598,6 +632,19 @@ def main():
                 src = (src or "none") + f" [live measurement unavailable: {note}]"
         dominant["traffic"] = traffic
         dominant["traffic_source"] = src
+        # the clock each kernel actually ran at (the chip clocks to its power budget: the MFMA peak of 2.5 PFLOP/s assumes 2.4 GHz)
+        if world == 1 and not args.no_live_traffic and os.environ.get("EGNN_BENCH_TRAFFIC_CHILD") != "1" and not under_profiler:
+            clocks, cnote = live_clocks(args.workload)
+            if clocks:
+                for kr in kernels + [dominant]:
+                    ghz = clocks.get(kr["kernel"])
+                    if ghz:
+                        kr["effective_clock_ghz"] = ghz
+                        if kr["bound"] == "mfma":
+                            kr["frac_at_clock"] = round(kr["frac"] * 2.4 / ghz, 4)
+                dominant["clock_source"] = cnote
+            else:
+                dominant["clock_source"] = f"unavailable: {cnote}"
         graphs = world * b * args.steps
         value = graphs / elapsed
         out = {

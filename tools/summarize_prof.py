@@ -66,6 +66,31 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
             for cname, vals in cs.items():
                 print(f"{os.path.basename(d):6s} {k:44s} {cname:28s} n={len(vals):4d} avg={sum(vals)/len(vals):16.1f}")
 
+# ---- effective shader clock per kernel (MI355X_MICROARCH.md, "DVFS give-back": GRBM_GUI_ACTIVE / kernel wall time).  rocprofv3 sums the
+# counter over the eight XCDs, and its sampling window is wider than the dispatch: the smallest value any dispatch of the pass reports
+# (a few-microsecond copy kernel) is taken as that fixed part.  Wall time = the dispatch's own timestamps in the same pass.
+XCDS = 8
+clocks = {}
+for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        rows = []
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                    rows.append((short(row["Kernel_Name"]), float(row["Counter_Value"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+        if not rows:
+            continue
+        floor = min(v for _, v, _ in rows)
+        print(f"\n== effective clock (GRBM_GUI_ACTIVE pass; counter summed over {XCDS} XCDs, fixed part {floor:.0f} subtracted)")
+        agg = defaultdict(list)
+        for k, v, ns in rows:
+            if ns > 20000:
+                agg[k].append(((v - floor) / XCDS / ns, ns))
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(n for _, n in kv[1])):
+            ghz = sum(g for g, _ in v) / len(v)
+            clocks[k.split(" [")[0]] = round(ghz, 3)
+            print(f"clock  {k:44s} n={len(v):4d} wall_ns={sum(n for _, n in v)/len(v):10.0f} effective_GHz={ghz:.3f}  (peak figures assume 2.400: x{ghz/2.4:.3f})")
+
 # ---- HBM traffic per launch for bench.py's roofline.traffic (MI355X_MICROARCH.md, HBM section):
 # FETCH_SIZE / WRITE_SIZE are in KiB and come from separate passes; on gfx950 FETCH_SIZE reports one half of the
 # bytes of a wide (16 B/lane) coalesced read, so it is doubled; WRITE_SIZE is taken as is (uncalibrated).
@@ -95,5 +120,7 @@ except Exception:
     traffic["_head"] = None
 if len(sys.argv) > 3 and sys.argv[3]:
     traffic["_head"] = sys.argv[3]
+if clocks:
+    traffic["_clock_ghz"] = {k: v for k, v in clocks.items() if k in ROLE.values()}
 with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
     json.dump({workload: traffic}, fh, indent=1)
