@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 35
+ABI_VERSION = 36
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -26,7 +26,7 @@ SYMBOLS = (
     "egnn_adj_max_degree_u8",
     "egnn_edge_fused_f32", "egnn_spatial_order_f32", "egnn_linear_hl_f32", "egnn_split_f16", "egnn_node_prep_hl",
     "egnn_packed_halves", "egnn_adj_expand_u8", "egnn_adj_expand_workspace_bytes", "egnn_edge_mfmas",
-    "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32",
+    "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32", "egnn_layer_forward_opts_f32",
     "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_bwd_work_bytes", "egnn_edge_tail_bwd_f32", "egnn_edge_tail_part_floats", "egnn_edge_pool_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
     "egnn_induced_attn_f32", "egnn_token_attn_f32", "egnn_slot_prep_f32", "egnn_struct_bytes",
     "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32", "egnn_split_scaled_both_f16", "egnn_split_scaled_colsum_rows", "egnn_drop_silu_f32", "egnn_drop_silu_f64", "egnn_silu_bwd_f32", "egnn_silu_bwd_drop_f32",
@@ -164,6 +164,12 @@ class PackedInfo(Structure):
                 ("wcat_inv_scale", c_float), ("ws_inv_scale", c_float), ("w2_inv_scale", c_float), ("w3_inv_scale", c_float),
                 ("w5_inv_scale", c_float), ("w6_inv_scale", c_float)] + \
                [(f, ctypes.c_uint64) for f in INFO_OFFSETS] + [("bytes", ctypes.c_uint64)]
+
+
+class ForwardOpts(Structure):
+    """Mirror of `struct egnn_forward_opts`."""
+    _fields_ = [("side_stream", c_void_p), ("ev_fork", c_void_p), ("ev_join", c_void_p), ("order", c_void_p), ("nmf_img", c_void_p),
+                ("order_is_hint", c_int32), ("reserved", c_int32)]
 
 
 def layer_desc(layer) -> "LayerDesc":
@@ -339,6 +345,8 @@ def load():
     lib.egnn_layer_forward_f32.argtypes = [POINTER(LayerDesc), POINTER(PackedInfo), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                            c_void_p, c_void_p]
+    lib.egnn_layer_forward_opts_f32.restype = c_int
+    lib.egnn_layer_forward_opts_f32.argtypes = lib.egnn_layer_forward_f32.argtypes + [POINTER(ForwardOpts)]
 
     lib.egnn_linear_f32.restype = c_int
     lib.egnn_linear_f32.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
@@ -373,7 +381,8 @@ def load():
         raise EGNNHipError(f"{path}: ABI version {lib.egnn_abi_version()} != {ABI_VERSION}; rebuild it")
     lib.egnn_struct_bytes.restype = c_int64
     lib.egnn_struct_bytes.argtypes = [c_int]
-    for which, mirror in enumerate((EdgeArgs, EdgeBwdArgs, EdgeTailArgs, LayerDesc, PackedInfo, EdgeExactArgs, EdgeExactBwdArgs, EdgeTailExactArgs)):
+    for which, mirror in enumerate((EdgeArgs, EdgeBwdArgs, EdgeTailArgs, LayerDesc, PackedInfo, EdgeExactArgs, EdgeExactBwdArgs, EdgeTailExactArgs,
+                                    ForwardOpts)):
         if lib.egnn_struct_bytes(which) != ctypes.sizeof(mirror):
             raise EGNNHipError(f"{path}: sizeof({mirror.__name__}) = {ctypes.sizeof(mirror)} here, {lib.egnn_struct_bytes(which)} in the "
                                f"library: the ctypes mirror in _abi.py and include/egnn_hip.h disagree")

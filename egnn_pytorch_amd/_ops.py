@@ -103,6 +103,24 @@ def side_stream(device):
     return st
 
 
+_side_handles = {}
+
+
+def side_handles(device):
+    """(raw hipStream_t of the side stream, raw hipEvent_t fork, raw hipEvent_t join) for the C whole-layer entry (egnn_forward_opts);
+    one pair of events per device and thread, kept alive here (an event may be re-recorded once the call that used it is enqueued)."""
+    import threading
+    key = (device.index, threading.get_ident())
+    h = _side_handles.get(key)
+    if h is None:
+        side = side_stream(device)
+        evs = (torch.cuda.Event(), torch.cuda.Event())
+        for ev in evs:
+            ev.record(side)                                   # (torch creates the hipEvent_t at the first record)
+        h = _side_handles[key] = (side.cuda_stream, evs[0].cuda_event, evs[1].cuda_event, side, evs)
+    return h[:3]
+
+
 _fork_events = {}
 
 

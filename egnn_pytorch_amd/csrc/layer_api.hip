@@ -295,7 +295,23 @@ extern "C" int egnn_layer_forward_f32(const egnn_layer_desc* desc, const egnn_pa
                                       float* feats_out, float* coors_out, void* workspace, size_t workspace_bytes,
                                       int32_t* status, void* stream)
 {
+    return egnn_layer_forward_opts_f32(desc, info, blob_dev, feats, coors, edges, mask, adj, adj_batch_stride, B, N, K, coor_dim, feats_out,
+                                       coors_out, workspace, workspace_bytes, status, stream, nullptr);
+}
+
+#define EGNN_HIP_TRY(call) do { const hipError_t e__ = (call); if (e__ != hipSuccess) return (int)e__; } while (0)
+
+extern "C" int egnn_layer_forward_opts_f32(const egnn_layer_desc* desc, const egnn_packed_info* info, const void* blob_dev,
+                                           const float* feats, const float* coors, const float* edges, const uint8_t* mask,
+                                           const uint8_t* adj, int64_t adj_batch_stride, int B, int N, int K, int coor_dim,
+                                           float* feats_out, float* coors_out, void* workspace, size_t workspace_bytes,
+                                           int32_t* status, void* stream, const egnn_forward_opts* opts)
+{
     if (!desc || !info || !blob_dev || !feats || !coors || !feats_out || !coors_out || !workspace) return EGNN_E_NULLPTR;
+    // the neighbour selection on a second stream (opts->side_stream): it reads the coordinates only, so it forks at THIS call's entry
+    // (ev_fork, recorded before the node-level launches) and is joined in front of the edge pass (ev_join)
+    hipStream_t side = opts ? static_cast<hipStream_t>(opts->side_stream) : nullptr;
+    if (side && (!opts->ev_fork || !opts->ev_join)) return EGNN_E_NULLPTR;
     const Dims x = dims_of(desc);
     if (!x.ok) return EGNN_E_UNSUPPORTED;
     if (B <= 0 || N <= 0 || K < 0 || coor_dim < 1 || coor_dim > 8) return EGNN_E_SHAPE;
@@ -329,7 +345,6 @@ extern "C" int egnn_layer_forward_f32(const egnn_layer_desc* desc, const egnn_pa
         if (K > 0) {
             idx = reinterpret_cast<int32_t*>(ws + w.idx);
             rank = reinterpret_cast<float*>(ws + w.rank);
-            EGNN_TRY(egnn_knn_select_f32(coors, mask, adj, adj_batch_stride, B, N, K, coor_dim, idx, rank, stream));
         }
     }
     const float* gamma = desc->update_feats && desc->norm_feats ? F(info->gamma) : nullptr;
@@ -337,6 +352,7 @@ extern "C" int egnn_layer_forward_f32(const egnn_layer_desc* desc, const egnn_pa
     void *node_hi = desc->update_feats ? ws + w.node_hi : nullptr, *node_lo = desc->update_feats ? ws + w.node_lo : nullptr;
 
     if (K > 0) {
+        if (side && idx) EGNN_HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opts->ev_fork), s));
         // ---- operand prep + node-level projections P = feats [W_i ; W_j]^T + [b1 ; 0]
         // (node_norm = Identity, the reference's default: [feats | 0] for node_mlp and feats for the projection hold the same values --
         // one packed image, the projection contracts over its first kp_dim columns: egnn_linear_hl_lda_f32)
@@ -374,15 +390,26 @@ extern "C" int egnn_layer_forward_f32(const egnn_layer_desc* desc, const egnn_pa
         }
         if (desc->norm_coors) a.coors_scale = F(info->coors_scale);
         a.coors = coors; a.coor_dim = coor_dim; a.edges = edges; a.mask = mask; a.idx = idx; a.rank = rank;
+        // ---- neighbour selection (:230-260), enqueued BEHIND the node-level launches (with a side stream it runs beside them: it
+        // waits for the entry event only) -- the first kernel of the forward starts earlier, and nothing it writes is read before the
+        // edge pass
+        void* sel_stream = (side && idx) ? static_cast<void*>(side) : stream;
+        if (side && idx) EGNN_HIP_TRY(hipStreamWaitEvent(side, static_cast<hipEvent_t>(opts->ev_fork), 0));
+        if (idx) EGNN_TRY(egnn_knn_select_f32(coors, mask, adj, adj_batch_stride, B, N, K, coor_dim, idx, rank, sel_stream));
         if (idx && !adj && N >= 64 && N <= 4096 && coor_dim == 3) {            // scheduling aid only
-            int32_t* order = reinterpret_cast<int32_t*>(ws + w.order);
-            EGNN_TRY(egnn_spatial_order_f32(coors, B, N, order, stream));
+            int32_t* order = (opts && opts->order) ? opts->order : reinterpret_cast<int32_t*>(ws + w.order);
+            if (!(opts && opts->order && opts->order_is_hint))                 // (a stack of layers reuses the first layer's order)
+                EGNN_TRY(egnn_spatial_order_f32(coors, B, N, order, sel_stream));
             a.order = order;
         }
         if (idx && coor_dim == 3) {                                             // the setup's index chain, flattened (egnn_slot_prep_f32)
             EGNN_TRY(egnn_slot_prep_f32(coors, mask, idx, rank, a.order, valid_radius < 3.0e38f ? valid_radius : 3.0e38f, B, N, K,
-                                        ws + w.slots, stream));
+                                        ws + w.slots, sel_stream));
             a.slots = ws + w.slots;
+        }
+        if (side && idx) {
+            EGNN_HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opts->ev_join), side));
+            EGNN_HIP_TRY(hipStreamWaitEvent(s, static_cast<hipEvent_t>(opts->ev_join), 0));
         }
         a.valid_radius = valid_radius < 3.0e38f ? valid_radius : 3.0e38f;
         a.clamp = desc->coor_weights_clamp_value < 0.f ? -1.f : desc->coor_weights_clamp_value;
@@ -399,9 +426,11 @@ extern "C" int egnn_layer_forward_f32(const egnn_layer_desc* desc, const egnn_pa
     if (desc->update_feats && egnn_node_mlp_fused_halves(dim, x.m) > 0) {
         // (the Python module packs the fused image once per parameter version; this entry keeps no state between calls and re-derives
         // it -- ~1 MB -- from the blob's two packed images)
-        EGNN_TRY(egnn_node_mlp_fused_pack_f16(blob + info->w5_hi, blob + info->w5_lo, blob + info->w6_hi, blob + info->w6_lo, dim, x.m,
-                                              ws + w.nmf_img, stream));
-        EGNN_TRY(egnn_node_mlp_fused_f32(node_hi, node_lo, ws + w.nmf_img, info->w5_inv_scale, F(info->b5), info->w6_inv_scale, F(info->b6),
+        const void* img = (opts && opts->nmf_img) ? opts->nmf_img : ws + w.nmf_img;
+        if (!(opts && opts->nmf_img))
+            EGNN_TRY(egnn_node_mlp_fused_pack_f16(blob + info->w5_hi, blob + info->w5_lo, blob + info->w6_hi, blob + info->w6_lo, dim, x.m,
+                                                  ws + w.nmf_img, stream));
+        EGNN_TRY(egnn_node_mlp_fused_f32(node_hi, node_lo, img, info->w5_inv_scale, F(info->b5), info->w6_inv_scale, F(info->b6),
                                          feats, feats_out, rows, dim, x.m, status, stream));
     } else if (desc->update_feats) {
         if (x.kp_hid != 2 * dim) {                                             // pad columns must read as zero in the next GEMM

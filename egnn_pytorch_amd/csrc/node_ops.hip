@@ -454,6 +454,7 @@ extern "C" int64_t egnn_struct_bytes(int which)
     case 5: return (int64_t)sizeof(egnn_edge_exact_args);
     case 6: return (int64_t)sizeof(egnn_edge_exact_bwd_args);
     case 7: return (int64_t)sizeof(egnn_edge_tail_exact_args);
+    case 8: return (int64_t)sizeof(egnn_forward_opts);
     default: return -1;
     }
 }

@@ -44,6 +44,11 @@ _SHARED_FEATS_IMAGE = os.environ.get("EGNN_SHARED_FEATS_IMAGE", "1") != "0"   # 
 _NODE_MLP_FUSED = os.environ.get("EGNN_NODE_MLP_FUSED", "1") != "0"   # node_mlp of narrow layers in one launch (csrc/node_mlp_fused.hip)
 _ENTRY_FORK = os.environ.get("EGNN_ENTRY_FORK", "1") != "0"        # ... which then waits for an event recorded at the layer's entry, not for them
 _LATE_SELECT = os.environ.get("EGNN_LATE_SELECT", "1") != "0"      # node-level launches before the neighbour selection (see _forward_hip)
+# Inference forwards as ONE call of the C whole-layer entry (egnn_layer_forward_opts_f32: the same kernels in the same order, enqueued from
+# C) instead of a dozen Python-side launches: ~200 us of host time per forward become a few tens.  Only with every scheduling switch
+# above at its default -- the C entry implements the default policy -- and never while per-kernel timing is on.
+_C_FORWARD = (os.environ.get("EGNN_C_FORWARD", "1") != "0" and _SPATIAL_ORDER and _SLOT_PREP and _EDGE_ALGO == 0 and _SHARED_FEATS_IMAGE
+              and _NODE_MLP_FUSED and _ENTRY_FORK and _LATE_SELECT and not _PREFETCH)
 _exact_now = contextvars.ContextVar("egnn_exact_now", default=False)       # per thread / context: concurrent forwards do not see each other's
 _warned_rerun = False
 
@@ -233,14 +238,16 @@ class EGNN(nn.Module):
         """(node_out, coors_out, order, idx, rank, valid_radius, u, proj) -- what autograd.EGNNFunction.forward needs; u = the
         (B*N*K, 16) pre-activation of edge_mlp's second SiLU when `want_u` (the native backward differentiates from it), proj =
         ((B*N, 2 Hp) projection table P_i | P_j, pi_split) the edge pass read (kept for the backward instead of a second GEMM)."""
-        return self._forward_with_hint(feats, coors, edges, mask, adj_mat, order_hint, want_u=want_u, drop_seed=drop_seed)
+        return self._forward_with_hint(feats, coors, edges, mask, adj_mat, order_hint, want_u=want_u, drop_seed=drop_seed, selection=True)
 
     def dropout_active(self):
         """training mode with dropout > 0: every forward draws a fresh mask seed (egnn_pytorch_amd/_dropout.py)"""
         return self.training and self.dropout_p > 0
 
-    def _forward_with_hint(self, feats, coors, edges, mask, adj_mat, order_hint, want_u=False, drop_seed=None, presel=None, prefetch=None):
-        """forward + the scheduling permutation it used (EGNN_Network hands layer 0's on to the next layers)."""
+    def _forward_with_hint(self, feats, coors, edges, mask, adj_mat, order_hint, want_u=False, drop_seed=None, presel=None, prefetch=None,
+                           selection=False):
+        """forward + the scheduling permutation it used (EGNN_Network hands layer 0's on to the next layers).  selection: the caller
+        reads the neighbour list (idx, rank) from the returned tuple -- the one-call C forward keeps it in its workspace."""
         self._check_inputs(feats, coors, edges, mask, adj_mat)
         _abi.load()
         f_dtype, c_dtype = feats.dtype, coors.dtype
@@ -260,6 +267,11 @@ class EGNN(nn.Module):
             return out
         if f_dtype == torch.float64 or c_dtype == torch.float64:
             _warn_float64_once()
+        if (_C_FORWARD and not want_u and not selection and drop_seed is None and presel is None and prefetch is None and f_dtype == torch.float32
+                and c_dtype == torch.float32 and _ops._timer is None and not self.dropout_active() and not exact_active()):
+            out = self._forward_c(feats, coors, edges, mask, adj_mat, order_hint)
+            if out is not None:
+                return out
         with torch.cuda.device(feats.device):
             if self.dropout_active() and drop_seed is None:
                 drop_seed = _dropout.draw_seed()
@@ -358,6 +370,97 @@ class EGNN(nn.Module):
             else:
                 idx, rank, order, slots = select()
         return idx, rank, order, slots, k, valid_radius
+
+    def _c_state(self, device):
+        """(desc, info, blob on `device`, fused node_mlp image or None) of the C whole-layer entry for the current parameters; None when the
+        C entry does not cover this layer's shape."""
+        key = (_weights.version_key(self), device)
+        st = self.__dict__.get("_c_packed")
+        if st is None or st[0] != key:
+            try:
+                desc, info, blob = _ops.pack_weights_c(self)
+            except _abi.EGNNHipError:
+                st = (key, None)
+            else:
+                blob_dev = blob.to(device)
+                img = None
+                lib = _abi.load()
+                halves = lib.egnn_node_mlp_fused_halves(self.dim, self.m_dim) if self.node_mlp is not None else 0
+                if halves > 0:
+                    img = torch.empty(halves, dtype=torch.float16, device=device)
+                    base = blob_dev.data_ptr()
+                    with torch.cuda.device(device):
+                        _abi.check(lib.egnn_node_mlp_fused_pack_f16(base + info.w5_hi, base + info.w5_lo, base + info.w6_hi, base + info.w6_lo,
+                                                                    self.dim, self.m_dim, img.data_ptr(), _ops._stream()),
+                                   "egnn_node_mlp_fused_pack_f16")
+                st = (key, (desc, info, blob_dev, img))
+            self.__dict__["_c_packed"] = st
+        return st[1]
+
+    def _forward_c(self, feats, coors, edges, mask, adj_mat, order_hint):
+        """The fp32 inference forward as one call of egnn_layer_forward_opts_f32 (include/egnn_hip.h; csrc/layer_api.hip mirrors
+        `_forward_hip_impl` launch for launch, so the outputs are the same bits).  Returns `_forward_hip`'s tuple, or None when the call is
+        outside what the C entry covers (edge look-up tables, wide shapes, the wave-per-node kernel on dense batches, empty inputs, another
+        current device): the Python launch sequence below then runs it."""
+        b, n, dim = feats.shape
+        cdim = coors.shape[-1]
+        use_nearest = self.num_nearest_neighbors > 0 or self.only_sparse_neighbors
+        dev = feats.device
+        if (isinstance(edges, EdgeLookup) or b == 0 or n == 0 or cdim > 8 or self.m_dim > 64
+                or 2 * self.fourier_features + 1 + self.edge_dim > 16 or dev.index != torch.cuda.current_device()
+                or (adj_mat is not None and (not adj_mat.is_cuda or adj_mat.dtype != torch.bool))):
+            return None
+        if not use_nearest and (b * n >= 8192 and n % 32 == 0 and 32 <= n <= 4096 and cdim == 3 and self.m_dim <= 16 and self.edge_dim == 0
+                                and self.fourier_features == 0 and _DENSE_PW and b * n * n * 16 <= (1 << 28)):
+            return None                                             # (dense batches that fill the chip: the wave-per-node kernel)
+        st = self._c_state(dev)
+        if st is None:
+            return None
+        desc, info, blob_dev, img = st
+        valid_radius = self.valid_radius
+        if use_nearest:
+            k = self.num_nearest_neighbors
+            if adj_mat is not None and self.only_sparse_neighbors:
+                k = _ops.adj_max_degree(adj_mat)                    # host sync, as upstream (:249)
+                valid_radius = 0.0
+            if k > n:
+                raise RuntimeError("selected index k out of range")  # torch.topk's error upstream
+            if k == 0:
+                return None
+        else:
+            k = n
+        feats, coors = feats.contiguous(), coors.contiguous()
+        if edges is not None:
+            edges = edges.contiguous().float()
+        m8, a8 = _ops._u8(mask), _ops._u8(adj_mat)
+        stride = n * n if (a8 is not None and a8.dim() == 3) else 0
+        lib = _abi.load()
+        nbytes = lib.egnn_workspace_bytes(desc, b, n, k)
+        # every buffer is allocated HERE, on the launch stream (the side stream writes the selection's part of the workspace between the
+        # two events of this call: `_select_neighbors` has the argument)
+        ws = _ops.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        node_out = _ops.empty(b, n, dim, dtype=torch.float32, device=dev) if self.node_mlp is not None else feats
+        coors_out = _ops.empty(b, n, cdim, dtype=torch.float32, device=dev) if self.coors_mlp is not None else coors
+        opts = _abi.ForwardOpts()
+        order = None
+        if use_nearest and adj_mat is None and 64 <= n <= 4096 and cdim == 3:
+            if order_hint is not None and tuple(order_hint.shape) == (b, n) and order_hint.dtype == torch.int32 and order_hint.is_contiguous():
+                order, opts.order_is_hint = order_hint, 1
+            else:
+                order = _ops.empty(b, n, dtype=torch.int32, device=dev)
+            opts.order = order.data_ptr()
+        if use_nearest and _SIDE_STREAM:
+            opts.side_stream, opts.ev_fork, opts.ev_join = _ops.side_handles(dev)
+        if img is not None:
+            opts.nmf_img = img.data_ptr()
+        rc = lib.egnn_layer_forward_opts_f32(desc, info, blob_dev.data_ptr(), feats.data_ptr(), coors.data_ptr(), _ops._ptr(edges), _ops._ptr(m8),
+                                             _ops._ptr(a8), stride, b, n, k, cdim, node_out.data_ptr(), coors_out.data_ptr(), ws.data_ptr(),
+                                             nbytes, _ops._status_ptr(dev), _ops._stream(), opts)
+        if rc != 0 and opts.side_stream:
+            # the selection may still be writing into the workspace on the side stream: join it before the buffers are freed
+            torch.cuda.current_stream().wait_stream(_ops.side_stream(dev))
+        _abi.check(rc, "egnn_layer_forward_opts_f32")
+        return node_out, coors_out, order, None, None, valid_radius, None, None
 
     def _forward_hip(self, feats, coors, edges, mask, adj_mat, order_hint=None, want_u=False, drop=None, presel=None, prefetch=None):
         try:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 35
+#define EGNN_ABI_VERSION 36
 
 enum {
     EGNN_OK = 0,
@@ -54,7 +54,8 @@ enum {
 
 int egnn_abi_version(void);
 /* sizeof of the argument structs as this library was compiled -- 0: egnn_edge_args, 1: egnn_edge_bwd_args, 2: egnn_edge_tail_args,
- * 3: egnn_layer_desc, 4: the packed-weights info struct, 5: egnn_edge_exact_args, 6: egnn_edge_exact_bwd_args, 7: egnn_edge_tail_exact_args; -1 otherwise -- so that a binding that mirrors them (ctypes, cgo, JNI) can verify its
+ * 3: egnn_layer_desc, 4: the packed-weights info struct, 5: egnn_edge_exact_args, 6: egnn_edge_exact_bwd_args, 7: egnn_edge_tail_exact_args,
+ * 8: egnn_forward_opts; -1 otherwise -- so that a binding that mirrors them (ctypes, cgo, JNI) can verify its
  * layout at load time instead of corrupting a call. */
 int64_t egnn_struct_bytes(int which);
 /* Hands `nwords` (<= 8) int32 status words to the host without a copy engine and without a stream synchronisation: a one-thread kernel on
@@ -561,6 +562,36 @@ int egnn_layer_forward_f32(const egnn_layer_desc* desc, const egnn_packed_info* 
                            const uint8_t* adj, int64_t adj_batch_stride, int B, int N, int K, int coor_dim,
                            float* feats_out, float* coors_out, void* workspace, size_t workspace_bytes,
                            int32_t* status, void* stream);
+
+/* The same forward with what a binding that calls it per layer of a running model wants (round 6: the shipped Python module's
+ * inference path is this one call -- egnn_pytorch_amd/layer.py::_forward_c -- instead of a dozen Python-side launches: the host
+ * time of a forward falls from ~200 us to a few tens, which is what a synchronous range check exposes per call and what bounds
+ * small graphs).  NULL opts = egnn_layer_forward_f32.  All handles belong to the caller; the library still creates nothing.
+ *   side_stream: a second hipStream_t for the neighbour selection (k-NN select, Morton order, slot records: they read the
+ *                coordinates only) -- it waits for ev_fork, which this call records on `stream` at its entry, runs beside the
+ *                operand prep and the projection GEMM, and is joined in front of the edge pass through ev_join (both hipEvent_t,
+ *                required with side_stream; reusable by the next call once this one has been enqueued).  The workspace must have been
+ *                allocated in `stream`'s order (the side stream touches it only between the two events).
+ *   order / order_is_hint: (B,N) int32 buffer for the Morton order instead of the workspace's -- written by this call, or, with
+ *                order_is_hint = 1, read as is (a stack of layers reuses the first layer's order: scheduling only, any permutation
+ *                of each graph's nodes is valid);
+ *   nmf_img:     the fused node_mlp weight image (egnn_node_mlp_fused_pack_f16) kept by the caller across calls; NULL: re-derived
+ *                from the blob into the workspace at every call. */
+typedef struct egnn_forward_opts {
+    void* side_stream;
+    void* ev_fork;
+    void* ev_join;
+    int32_t* order;
+    const void* nmf_img;
+    int32_t order_is_hint;
+    int32_t reserved;
+} egnn_forward_opts;
+
+int egnn_layer_forward_opts_f32(const egnn_layer_desc* desc, const egnn_packed_info* info, const void* blob_dev,
+                                const float* feats, const float* coors, const float* edges, const uint8_t* mask,
+                                const uint8_t* adj, int64_t adj_batch_stride, int B, int N, int K, int coor_dim,
+                                float* feats_out, float* coors_out, void* workspace, size_t workspace_bytes,
+                                int32_t* status, void* stream, const egnn_forward_opts* opts);
 
 
 /* =============================================================================================

@@ -79,11 +79,16 @@ def test_c_program_reproduces_golden(c_program, tmp_path, name):
                                         (dict(dim=32, edge_dim=3, fourier_features=2, soft_edges=True, norm_coors=True,
                                               norm_feats=True, m_pool_method="mean"), 40, dict(mask=True, edges=True)),
                                         (dict(dim=48, only_sparse_neighbors=True, edge_dim=2), 64, dict(mask=True, edges=True, adj=True)),
-                                        (dict(dim=32, m_dim=40, num_nearest_neighbors=16, soft_edges=True), 80, dict(mask=True))])
+                                        (dict(dim=32, m_dim=40, num_nearest_neighbors=16, soft_edges=True), 80, dict(mask=True)),
+                                        (dict(dim=128, num_nearest_neighbors=32, norm_feats=True), 96, dict(mask=True)),
+                                        (dict(dim=24, num_nearest_neighbors=8, update_feats=False), 70, dict()),
+                                        (dict(dim=24, num_nearest_neighbors=8, update_coors=False, valid_radius=1.5), 70, dict(mask=True)),
+                                        (dict(dim=40, num_nearest_neighbors=6, coor_weights_clamp_value=0.5), 64, dict(adj=True))])
 def test_c_layer_forward_matches_module(kw, n, flags):
-    """egnn_layer_forward_f32 (weights re-laid by the C host packer) and the Python module (torch packer, 7 separate calls)
-    launch the same kernels on the same operands: bit-identical outputs."""
-    from egnn_pytorch_amd import EGNN, _ops
+    """Three ways to one forward, bit-identical outputs: the Python launch sequence (`EGNN._forward_hip`: torch packer, a dozen separate
+    C-ABI calls), egnn_layer_forward_f32 on the C host packer's blob (`_ops.forward_c`: what a binding without torch does), and the
+    module's own inference path (`EGNN._forward_c`: egnn_layer_forward_opts_f32 with the side stream, one call per forward)."""
+    from egnn_pytorch_amd import EGNN, _ops, layer as L
     torch.manual_seed(3)
     layer = EGNN(**kw).cuda().eval()
     with torch.no_grad():
@@ -100,7 +105,53 @@ def test_c_layer_forward_matches_module(kw, n, flags):
         i = torch.arange(n)
         adj = ((i[:, None] - i[None, :]).abs() <= 2).cuda()
     with torch.no_grad():
-        want = layer(feats, coors, edges, mask, adj)
+        want = layer._forward_hip(feats, coors, edges, mask, adj)[:2]          # the Python launch sequence
+        assert L._C_FORWARD
+        calls = []
+        orig = L.EGNN._forward_c
+        L.EGNN._forward_c = lambda self, *a: calls.append(1) or orig(self, *a)
+        try:
+            mod = layer(feats, coors, edges, mask, adj)                         # the module: one C call
+        finally:
+            L.EGNN._forward_c = orig
+        assert calls, "the module's inference forward did not take the one-call path"
     got = _ops.forward_c(layer, feats, coors, edges, mask, adj)
     torch.cuda.synchronize()
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert torch.equal(mod[0], want[0]) and torch.equal(mod[1], want[1])
+
+
+def test_one_call_forward_in_a_network_reuses_the_first_layers_order():
+    """EGNN_Network on the one-call path: layer 0 writes the Morton order into a buffer of the caller, the next layers read it as a hint
+    (egnn_forward_opts.order / order_is_hint) -- same outputs, bit for bit, as the Python launch sequence (EGNN_C_FORWARD=0)."""
+    from egnn_pytorch_amd import EGNN_Network, layer as L
+    torch.manual_seed(5)
+    net = EGNN_Network(depth=3, dim=32, num_nearest_neighbors=8, norm_coors=True).cuda().eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(30.0)
+    g = torch.Generator().manual_seed(2)
+    feats, coors = torch.randn(2, 128, 32, generator=g).cuda(), torch.randn(2, 128, 3, generator=g).cuda()
+    mask = (torch.arange(128)[None] < torch.tensor([[128], [77]])).cuda()
+    hints = []
+    orig = L.EGNN._forward_c
+
+    def spy(self, feats, coors, edges, mask, adj_mat, order_hint):
+        hints.append(order_hint)
+        return orig(self, feats, coors, edges, mask, adj_mat, order_hint)
+
+    with torch.no_grad():
+        L.EGNN._forward_c = spy
+        try:
+            fast = net(feats, coors, mask=mask)
+        finally:
+            L.EGNN._forward_c = orig
+        assert len(hints) == 3 and hints[0] is None and hints[1] is not None and hints[2] is hints[1]
+        was = L._C_FORWARD
+        L._C_FORWARD = False
+        try:
+            slow = net(feats, coors, mask=mask)
+        finally:
+            L._C_FORWARD = was
+    torch.cuda.synchronize()
+    assert torch.equal(fast[0], slow[0]) and torch.equal(fast[1], slow[1])
