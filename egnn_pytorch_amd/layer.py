@@ -172,6 +172,15 @@ class EGNN(nn.Module):
         self._packed = None
         self._packed_key = None
 
+    def __getstate__(self):
+        """copy.deepcopy / pickle / torch.save(module): without the kernel-side caches (re-laid-out weights on the device, the C entry's
+        blob, the cached parameter list) -- they are rebuilt at the copy's first forward."""
+        st = self.__dict__.copy()
+        st["_packed"] = st["_packed_key"] = None
+        for k in ("_c_packed", "_param_cache", "_param_cache_mods", "_param_cache_tree", "_param_cache_counts"):
+            st.pop(k, None)
+        return st
+
     # ------------------------------------------------------------------ kernel-side weights
     def packed_weights(self):
         key = _weights.version_key(self)

@@ -355,3 +355,26 @@ def test_host_read_and_lazy_destination_lists_on_the_cpu():
                         _ops.HostRead(torch.tensor([20], dtype=torch.int64)))
     assert dl.ent.numel() == 384 and dl.ent.numel() == 384            # 20 tiles x 16 entries, whole 128-entry rounds; resolved once
     assert _ops.DestLists(ent[:256], None, None, None).ent.numel() == 256
+
+
+def test_copies_and_pickles_of_a_module_leave_the_kernel_side_caches_behind():
+    """copy.deepcopy / pickle / torch.save of an EGNN carry the reference's state only: the re-laid-out weights, the C entry's blob and
+    the cached parameter list (device tensors, ctypes structs, references to the ORIGINAL's Parameter objects) are rebuilt by the copy."""
+    import copy
+    import io
+    import pickle
+    from egnn_pytorch_amd import EGNN, _weights
+    layer = EGNN(dim=16, num_nearest_neighbors=4, norm_feats=True)
+    _weights.version_key(layer)                                   # (fills the parameter-list cache)
+    layer.__dict__["_c_packed"] = (("key",), None)
+    layer._packed, layer._packed_key = {"stale": 1}, ("key",)
+    for make in (copy.deepcopy, lambda m: pickle.loads(pickle.dumps(m)),
+                 lambda m: (lambda b: (torch.save(m, b), b.seek(0), torch.load(b, weights_only=False))[2])(io.BytesIO())):
+        twin = make(layer)
+        assert twin._packed is None and twin._packed_key is None
+        assert not any(k in twin.__dict__ for k in ("_c_packed", "_param_cache", "_param_cache_mods", "_param_cache_tree", "_param_cache_counts"))
+        assert all(torch.equal(a, b) for a, b in zip(layer.state_dict().values(), twin.state_dict().values()))
+        # the copy's key is built from ITS parameters
+        assert all(p is q for p, q in zip(twin.__dict__.get("_param_cache") or (_weights.version_key(twin) and twin.__dict__["_param_cache"]),
+                                          twin.parameters()))
+    assert layer.__dict__["_c_packed"] == (("key",), None) and layer._packed == {"stale": 1}      # (the original keeps its caches)
