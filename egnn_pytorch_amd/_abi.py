@@ -26,7 +26,7 @@ SYMBOLS = (
     "egnn_adj_max_degree_u8",
     "egnn_edge_fused_f32", "egnn_spatial_order_f32", "egnn_linear_hl_f32", "egnn_split_f16", "egnn_node_prep_hl",
     "egnn_packed_halves", "egnn_adj_expand_u8", "egnn_adj_expand_workspace_bytes", "egnn_edge_mfmas",
-    "egnn_packed_weights_bytes", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32", "egnn_layer_forward_opts_f32",
+    "egnn_packed_weights_bytes", "egnn_packed_layout", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32", "egnn_layer_forward_opts_f32",
     "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_bwd_work_bytes", "egnn_edge_tail_bwd_f32", "egnn_edge_tail_part_floats", "egnn_edge_pool_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
     "egnn_induced_attn_f32", "egnn_token_attn_f32", "egnn_slot_prep_f32", "egnn_struct_bytes",
     "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32", "egnn_split_scaled_both_f16", "egnn_split_scaled_colsum_rows", "egnn_drop_silu_f32", "egnn_drop_silu_f64", "egnn_silu_bwd_f32", "egnn_silu_bwd_drop_f32",
@@ -337,6 +337,8 @@ def load():
 
     lib.egnn_packed_weights_bytes.restype = c_size_t
     lib.egnn_packed_weights_bytes.argtypes = [POINTER(LayerDesc)]
+    lib.egnn_packed_layout.restype = c_int
+    lib.egnn_packed_layout.argtypes = [POINTER(LayerDesc), POINTER(PackedInfo)]
     lib.egnn_pack_weights_host.restype = c_int
     lib.egnn_pack_weights_host.argtypes = [POINTER(LayerDesc), POINTER(LayerParams), c_void_p, POINTER(PackedInfo)]
     lib.egnn_workspace_bytes.restype = c_size_t

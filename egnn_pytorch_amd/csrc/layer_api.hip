@@ -117,6 +117,15 @@ float split_packed(const float* w, int n, int k, int64_t ld, int rows_p, int kp,
 
 }  // namespace
 
+extern "C" int egnn_packed_layout(const egnn_layer_desc* desc, egnn_packed_info* info)
+{
+    if (!desc || !info) return EGNN_E_NULLPTR;
+    const Dims x = dims_of(desc);
+    if (!x.ok) return EGNN_E_UNSUPPORTED;
+    layout(desc, x, info);
+    return EGNN_OK;
+}
+
 extern "C" size_t egnn_packed_weights_bytes(const egnn_layer_desc* desc)
 {
     const Dims x = dims_of(desc);

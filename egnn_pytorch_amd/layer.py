@@ -383,26 +383,17 @@ class EGNN(nn.Module):
     def _c_state(self, device):
         """(desc, info, blob on `device`, fused node_mlp image or None) of the C whole-layer entry for the current parameters; None when the
         C entry does not cover this layer's shape."""
-        key = (_weights.version_key(self), device)
+        w = self.packed_weights()                                    # (re-laid out on the device once per parameter version)
+        key = (self._packed_key, device)
         st = self.__dict__.get("_c_packed")
         if st is None or st[0] != key:
             try:
-                desc, info, blob = _ops.pack_weights_c(self)
+                desc, info, blob_dev = _ops.pack_weights_blob(self, w, device)
             except _abi.EGNNHipError:
                 st = (key, None)
             else:
-                blob_dev = blob.to(device)
-                img = None
-                lib = _abi.load()
-                halves = lib.egnn_node_mlp_fused_halves(self.dim, self.m_dim) if self.node_mlp is not None else 0
-                if halves > 0:
-                    img = torch.empty(halves, dtype=torch.float16, device=device)
-                    base = blob_dev.data_ptr()
-                    with torch.cuda.device(device):
-                        _abi.check(lib.egnn_node_mlp_fused_pack_f16(base + info.w5_hi, base + info.w5_lo, base + info.w6_hi, base + info.w6_lo,
-                                                                    self.dim, self.m_dim, img.data_ptr(), _ops._stream()),
-                                   "egnn_node_mlp_fused_pack_f16")
-                st = (key, (desc, info, blob_dev, img))
+                img = w.get("nmf_img")
+                st = (key, (desc, info, blob_dev, img.to(device) if img is not None else None))
             self.__dict__["_c_packed"] = st
         return st[1]
 

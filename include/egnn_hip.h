@@ -535,6 +535,12 @@ typedef struct egnn_packed_info {
 /* Size of the packed blob for a layer (0 on an invalid descriptor). */
 size_t egnn_packed_weights_bytes(const egnn_layer_desc* desc);
 
+/* The blob's layout alone: dimensions, padded row counts, byte offsets and `bytes` of `info`; the scales are left 0.  For a binding
+ * that re-lays the weights itself ON THE DEVICE in the formats of egnn_pack_weights_host (the shipped module does: its torch packer
+ * needs ~1.5 ms where the host function needs 60 ms at dim 512, which matters when the parameters change between forwards) and only
+ * has to place the pieces where egnn_layer_forward_f32 looks for them. */
+int egnn_packed_layout(const egnn_layer_desc* desc, egnn_packed_info* info);
+
 /* The weight re-layout of egnn_pytorch_amd/_weights.py::pack as a HOST function (pure CPU work, no HIP call): factorised
  * first Linear of edge_mlp (W_i | W_j | W_s, x -log2 e), fp16 (hi, lo) splits with power-of-two scales, packed tile-major
  * GEMM operands, MFMA fragment orders (see egnn_edge_args).  `blob` (host, egnn_packed_weights_bytes bytes) is what the

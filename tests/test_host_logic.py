@@ -378,3 +378,23 @@ def test_copies_and_pickles_of_a_module_leave_the_kernel_side_caches_behind():
         assert all(p is q for p, q in zip(twin.__dict__.get("_param_cache") or (_weights.version_key(twin) and twin.__dict__["_param_cache"]),
                                           twin.parameters()))
     assert layer.__dict__["_c_packed"] == (("key",), None) and layer._packed == {"stale": 1}      # (the original keeps its caches)
+
+
+@pytest.mark.parametrize("kw", [dict(dim=24, num_nearest_neighbors=6), dict(dim=32, edge_dim=3, fourier_features=2, soft_edges=True, norm_coors=True,
+                                                                               norm_feats=True), dict(dim=16, update_feats=False),
+                                dict(dim=16, update_coors=False, m_dim=40), dict(dim=64, norm_feats=True)])
+def test_blob_assembled_from_the_torch_packer_equals_the_c_host_packer(kw):
+    """_ops.pack_weights_blob (the module's own re-laid-out tensors copied to the offsets of egnn_packed_layout: what the one-call inference
+    forward runs on) == egnn_pack_weights_host's blob, byte for byte, and the same info struct."""
+    from egnn_pytorch_amd import EGNN, _abi, _ops, _weights
+    torch.manual_seed(2)
+    layer = EGNN(**kw)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(torch.randn_like(p) * 0.2)
+    desc_c, info_c, blob_c = _ops.pack_weights_c(layer)
+    desc_t, info_t, blob_t = _ops.pack_weights_blob(layer, _weights.pack(layer), torch.device("cpu"))
+    assert bytes(desc_c) == bytes(desc_t)
+    for name, _ in _abi.PackedInfo._fields_:
+        assert getattr(info_c, name) == getattr(info_t, name), name
+    assert blob_c.numel() == blob_t.numel() and torch.equal(blob_c, blob_t)
