@@ -224,6 +224,24 @@ def live_clocks(workload, timeout_s=150):
         "/ 8 / dispatch wall time, one child run of this command under rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE"
 
 
+def unprimed_value(args, timeout_s=120):
+    """`value` of a FRESH process that skips the priming steps (EGNN_BENCH_PRIME=0: only the contract's W warm-up steps in front of the
+    timed region), as BENCH_r01 ... r04 were taken: a child run of this command without the CPU baseline, the training step and the PMC
+    passes.  Returns (graphs/s, None) or (None, why not).  Secondary figure: what the priming changes is visible in the line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
+           and not k.startswith("TORCHELASTIC")}
+    env.update(EGNN_BENCH_PRIME="0", EGNN_BENCH_TRAFFIC_CHILD="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--no-cpu-baseline", "--no-train-step", "--no-live-traffic"] + (["--ragged-mask"] if args.ragged_mask else [])
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s, check=True)
+        return float(json.loads(r.stdout.strip().splitlines()[-1])["value"]), None
+    except Exception as ex:                                  # (never fatal)
+        return None, f"{type(ex).__name__}"
+
+
 def git_head():
     """Commit of the tree that printed the line: `git rev-parse`, or -- the GPU boxes get a snapshot without .git -- the file `.head`
     that tools/stamp_head.sh writes before a gpurun call."""
@@ -566,7 +584,8 @@ def main():
     # north-star line is not affected (22.4 - 22.6 k with and without).
     mode0 = _ops.RANGE_CHECK
     PRIME_STEPS = int(os.environ.get("EGNN_BENCH_PRIME", "24"))   # (0: no priming)
-    for m_, cnt in (("deferred", PRIME_STEPS), ("sync", 3)):
+    PRIME_SYNC = 3 if PRIME_STEPS > 0 else 0
+    for m_, cnt in (("deferred", PRIME_STEPS), ("sync", PRIME_SYNC)):
         if mode0 == "off":
             break
         _ops.RANGE_CHECK = m_
@@ -652,7 +671,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "ms_per_step_by_rank": rank_ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "edges_per_s": round(value * n * shp["K"] * depth, 1), "range_check": _ops.RANGE_CHECK, "priming_steps": PRIME_STEPS + 3,
+            "edges_per_s": round(value * n * shp["K"] * depth, 1), "range_check": _ops.RANGE_CHECK, "priming_steps": PRIME_STEPS + PRIME_SYNC,
             f"value_range_check_{other_mode}": None if value_other is None else round(value_other, 2),
             "config": {"workload": workload_label(kwargs, b, n, shp["K"]), "name": args.workload,
                        "graphs_per_gpu": b, "nodes": n, "neighbors": shp["K"], "layers": depth, "global_batch": world * b,
@@ -664,6 +683,11 @@ def main():
             "other_kernels_ms_per_step": other,
             "sum_kernel_ms": round(sum(per_kernel[k] * launches[k] for k in per_kernel), 4),
         }
+        if world == 1 and PRIME_STEPS > 0 and not args.no_live_traffic and os.environ.get("EGNN_BENCH_TRAFFIC_CHILD") != "1" and not under_profiler:
+            uv, why = unprimed_value(args)
+            out["value_unprimed"] = round(uv, 2) if uv is not None else None
+            if uv is None:
+                out["value_unprimed_note"] = f"child run failed: {why}"
         if dist is not None:
             out["process_group"] = {"backend": dist.get_backend(), "world_size": world}
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed at N = 1 only
