@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
-ABI_VERSION = 36
+ABI_VERSION = 37
 _LIB_NAME = "libegnn_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -28,7 +28,7 @@ SYMBOLS = (
     "egnn_packed_halves", "egnn_adj_expand_u8", "egnn_adj_expand_workspace_bytes", "egnn_edge_mfmas",
     "egnn_packed_weights_bytes", "egnn_packed_layout", "egnn_pack_weights_host", "egnn_workspace_bytes", "egnn_layer_forward_f32", "egnn_layer_forward_opts_f32",
     "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_bwd_work_bytes", "egnn_edge_tail_bwd_f32", "egnn_edge_tail_part_floats", "egnn_edge_pool_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
-    "egnn_induced_attn_f32", "egnn_token_attn_f32", "egnn_slot_prep_f32", "egnn_struct_bytes",
+    "egnn_induced_attn_f32", "egnn_token_attn_f32", "egnn_slot_prep_f32", "egnn_spatial_order_masked_f32", "egnn_struct_bytes",
     "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32", "egnn_split_scaled_both_f16", "egnn_split_scaled_colsum_rows", "egnn_drop_silu_f32", "egnn_drop_silu_f64", "egnn_silu_bwd_f32", "egnn_silu_bwd_drop_f32",
     "egnn_linear_hl_drop_f32", "egnn_linear_hl_lda_f32",
     "egnn_linear_f32", "egnn_node_prep_f32", "egnn_edge_exact_f32", "egnn_edge_exact_workspace_bytes",
@@ -278,6 +278,8 @@ def load():
                                       c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]
     lib.egnn_spatial_order_f32.restype = c_int
     lib.egnn_spatial_order_f32.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.egnn_spatial_order_masked_f32.restype = c_int
+    lib.egnn_spatial_order_masked_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.egnn_slot_prep_f32.restype = c_int
     lib.egnn_slot_prep_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.egnn_dest_lists_capacity.restype = c_size_t

@@ -317,13 +317,14 @@ def knn_select(coors, mask, adj_mat, k, out=None):
     return idx, rank
 
 
-def spatial_order(coors, out=None):
-    """(B,N) int32 Morton permutation -- egnn_spatial_order_f32 (scheduling aid for the edge pass)."""
+def spatial_order(coors, out=None, mask8=None):
+    """(B,N) int32 Morton permutation -- egnn_spatial_order_masked_f32 (scheduling aid for the edge pass; the padded nodes of mask8,
+    (B,N) bytes, behind the real ones)."""
     b, n, _ = coors.shape
     order = out if out is not None else empty(b, n, dtype=torch.int32, device=coors.device)
     with _timed("spatial_order"):
-        rc = _abi.load().egnn_spatial_order_f32(_ptr(coors), b, n, _ptr(order), _stream())
-    _abi.check(rc, "egnn_spatial_order_f32")
+        rc = _abi.load().egnn_spatial_order_masked_f32(_ptr(coors), _ptr(mask8), b, n, _ptr(order), _stream())
+    _abi.check(rc, "egnn_spatial_order_masked_f32")
     return order
 
 

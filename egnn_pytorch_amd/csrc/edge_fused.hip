@@ -253,7 +253,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
             const int i = p.order ? p.order[bN + pos] : pos;
             u32x4v rec = u32x4v{0u, 0u, 0u, 0u};
             if (slot_rec) rec = slot_rec[(bN + pos) * (size_t)K + k];
-            const int j = slot_rec ? (int)(rec[0] & 0x7fffffffu) : (p.idx ? p.idx[(bN + i) * K + k] : k);
+            const int j = slot_rec ? (int)(rec[0] & 0x3fffffffu) : (p.idx ? p.idx[(bN + i) * K + k] : k);
 #endif
             const int C = (CDM == 3) ? 3 : p.coor_dim;
             const float* ci = p.coors + (bN + i) * C;
@@ -373,7 +373,7 @@ __device__ __forceinline__ void edge_body(const egnn_edge_args& p, const int G, 
 #else
             int j2;
             if (slot_rec) {
-                j2 = (int)(reinterpret_cast<const uint32_t*>(slot_rec + ((bN + pos) * (size_t)K + k))[0] & 0x7fffffffu);
+                j2 = (int)(reinterpret_cast<const uint32_t*>(slot_rec + ((bN + pos) * (size_t)K + k))[0] & 0x3fffffffu);
             } else {
                 const int i2 = p.order ? p.order[bN + pos] : pos;
                 j2 = p.idx ? p.idx[(bN + i2) * K + k] : k;

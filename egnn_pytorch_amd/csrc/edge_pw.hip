@@ -50,6 +50,9 @@ typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 #ifndef EGNN_PW_WGS
 #define EGNN_PW_WGS 5                        // workgroups per CU the register allocation must allow
 #endif
+#ifndef EGNN_PW_SKIP_MASKED
+#define EGNN_PW_SKIP_MASKED 1                // a round none of whose 32 edges contributes (a padded node: mask_i = 0) skips its hidden loop
+#endif
 #ifndef EGNN_PW_RESID4
 #define EGNN_PW_RESID4 1                     // residual of the split on v_mfma_f32_4x4x4_16B_f16 (0: v_mfma_f32_16x16x16_f16)
 #endif
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
         uint32_t goff[4];
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            const uint32_t j2 = *reinterpret_cast<const uint32_t*>(rb + (8 * qq + (lane >> 3)) * 16) & 0x7fffffffu;
+            const uint32_t j2 = *reinterpret_cast<const uint32_t*>(rb + (8 * qq + (lane >> 3)) * 16) & 0x3fffffffu;   // (bit 31: pair mask, bit 30: group flag)
             // the DMA drops lane l's 16 bytes at position l & 7 of row 8 qq + (l >> 3); the exchange rows' swizzle (chunk c at position
             // c ^ ((row >> 1) & 7)) moves to the global side: fetch the chunk that belongs at that position
             const uint32_t gchunk = (uint32_t)(((lane & 7) ^ ((4 * qq + (lane >> 4)) & 7)) * 16);
@@ -311,6 +314,20 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
         f32x4 acc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // A round whose 32 edges are all masked out (the node is padding -- mask_i = 0 --, or past the grid's last node) contributes exact
+        // zeros to m_i and to the coordinate update whatever its hidden values are (the epilogue drops masked edges): its hidden loop
+        // -- gathers, first-layer MFMAs, 32 x 2080 SiLUs, second-layer MFMAs -- is skipped; the wave keeps its part of the workgroup's
+        // staging ring and barriers.  Not under autograd (U_out: the backward reads u of every edge).  Wave-uniform.
+        // When all FOUR nodes of the workgroup's group are padding (bit 30 of the first record of every round: egnn_slot_prep_f32 sets it
+        // from the four nodes' masks, so the four waves read the same answer), the ring is left alone as well: no barrier, no staging --
+        // chunk 0 stays where the previous round (or the prologue) put it.  The Morton order lists padded nodes last (egnn_spatial_order_
+        // masked_f32), so that padding fills whole groups.
+#if EGNN_PW_SKIP_MASKED
+        const bool skip_round = pa->U_out == nullptr && __builtin_amdgcn_ballot_w64(fm[0] || fm[1]) == 0ull;
+        const bool skip_group = skip_round && ((__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(rb)) >> 30) & 1) != 0;
+#else
+        constexpr bool skip_round = false, skip_group = false;
+#endif
 
         // ------------------------------------------------------------------ hidden loop
         const bool last_round = rho + 1 == total_rounds;
@@ -467,6 +484,19 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
 #elif EGNN_PW_PRIO == 2
         asm volatile("s_setprio 3");
 #endif
+        if (skip_group) {
+        } else if (skip_round) {
+            // the ring's protocol without the steps: wait for the chunk, meet the other waves, request this wave's share of the next one
+            for (int c = 0; c < nchunks; ++c, ++ring) {
+                const int slot = ring & 1;
+#if !(EGNN_PW_ABL & 128)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (c + 1 < nchunks) stage(c + 1, slot ^ 1);
+                else if (!last_round) stage(0, slot ^ 1);
+#endif
+            }
+        } else
         for (int c = 0; c < nchunks; ++c, ++ring) {
             const int slot = ring & 1;
             const int c0 = c * PW_HC;
@@ -497,6 +527,14 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
         int32_t* const status = pe->status;
         const float* const gate_w = pe->gate_w;
         const float* const coors_scale = pe->coors_scale;
+        if (skip_round) {
+            // every edge of the round is masked out: its sums are exact zeros (what the code below computes for masked edges)
+            if (!MULTI) {
+                nms = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ncs[c] = 0.f;
+            }
+        } else {
         f32x4 b2r, gwr = f32x4{0.f, 0.f, 0.f, 0.f};
         float gb = 0.f;
         const int g4 = pw_opaque(4) * g;                                     // (opaque: see pw_opaque)
@@ -635,6 +673,7 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
             for (int u = 0; u < 4; ++u) nms[u] = 0.f + ms[u];
 #pragma unroll
             for (int c = 0; c < 4; ++c) ncs[c] = 0.f + cs[c];
+        }
         }
 
         // ------------------------------------------------------------------ node outputs (after the node's last round)

@@ -408,7 +408,7 @@ extern "C" int egnn_layer_forward_opts_f32(const egnn_layer_desc* desc, const eg
         if (idx && !adj && N >= 64 && N <= 4096 && coor_dim == 3) {            // scheduling aid only
             int32_t* order = (opts && opts->order) ? opts->order : reinterpret_cast<int32_t*>(ws + w.order);
             if (!(opts && opts->order && opts->order_is_hint))                 // (a stack of layers reuses the first layer's order)
-                EGNN_TRY(egnn_spatial_order_f32(coors, B, N, order, sel_stream));
+                EGNN_TRY(egnn_spatial_order_masked_f32(coors, mask, B, N, order, sel_stream));
             a.order = order;
         }
         if (idx && coor_dim == 3) {                                             // the setup's index chain, flattened (egnn_slot_prep_f32)

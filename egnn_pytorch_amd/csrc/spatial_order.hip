@@ -21,7 +21,7 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) {          // 10 bits ->
     return v;
 }
 
-__global__ __launch_bounds__(256) void spatial_order_kernel(const float* __restrict__ coors, int N, int Np,
+__global__ __launch_bounds__(256) void spatial_order_kernel(const float* __restrict__ coors, const uint8_t* __restrict__ mask, int N, int Np,
                                                             int32_t* __restrict__ order)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -63,6 +63,9 @@ __global__ __launch_bounds__(256) void spatial_order_kernel(const float* __restr
                 q = fminf(fmaxf(q, 0.f), 1023.f);                    // NaN -> 0
                 code |= spread3((uint32_t)q) << a;
             }
+            // padded nodes (mask = 0) behind the real ones: the edge pass skips a group of four whose nodes are all padding (bit 62; the
+            // padding entries of the sort carry ~0 and stay last)
+            if (mask && !mask[(size_t)b * N + i]) code |= 0x40000000u;
             k = ((uint64_t)code << 32) | (uint32_t)i;
         }
         keys[i] = k;
@@ -89,6 +92,7 @@ __global__ __launch_bounds__(256) void slot_prep_kernel(const float* __restrict_
 {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= total) return;
+    const int64_t total_nodes = total / K;
     const int64_t node = q / K;                              // b * N + pos
     const int k = (int)(q - node * K);
     const int64_t bN = node / N * N;
@@ -104,6 +108,20 @@ __global__ __launch_bounds__(256) void slot_prep_kernel(const float* __restrict_
     }
     uint4 r;
     r.x = (uint32_t)j | (ok ? 0x80000000u : 0u);
+    if (mask && (k & 31) == 0) {
+        // bit 30 of the first record of every 32-slot round: all four nodes of this node's group (positions 4 (node / 4) .. + 3 of the
+        // consumption order, over the whole batch) are padding -- the wave-per-node edge kernel (csrc/edge_pw.hip) then skips the
+        // workgroup's round without touching its staging ring.  The same four masks for the four nodes of a group, by construction.
+        const int64_t g0 = node & ~(int64_t)3;
+        bool dead = true;
+        for (int m = 0; m < 4; ++m) {
+            const int64_t nm = g0 + m < total_nodes ? g0 + m : total_nodes - 1;
+            const int64_t bm = nm / N * N;
+            const int im = order ? order[nm] : (int)(nm - bm);
+            dead = dead && !mask[bm + im];
+        }
+        if (dead) r.x |= 0x40000000u;
+    }
     r.y = __float_as_uint(ci[0] - cj[0]);
     r.z = __float_as_uint(ci[1] - cj[1]);
     r.w = __float_as_uint(ci[2] - cj[2]);
@@ -128,13 +146,18 @@ extern "C" int egnn_slot_prep_f32(const float* coors, const uint8_t* mask, const
 
 extern "C" int egnn_spatial_order_f32(const float* coors, int B, int N, int32_t* order_out, void* stream)
 {
+    return egnn_spatial_order_masked_f32(coors, nullptr, B, N, order_out, stream);
+}
+
+extern "C" int egnn_spatial_order_masked_f32(const float* coors, const uint8_t* mask, int B, int N, int32_t* order_out, void* stream)
+{
     if (!coors || !order_out) return EGNN_E_NULLPTR;
     if (B <= 0 || N <= 0) return EGNN_E_SHAPE;
     if (N > 4096) return EGNN_E_UNSUPPORTED;
     int Np = 2;
     while (Np < N) Np <<= 1;
     const size_t lds = (size_t)Np * 8 + 6 * 256 * sizeof(float);
-    hipLaunchKernelGGL(spatial_order_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), coors, N, Np,
+    hipLaunchKernelGGL(spatial_order_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), coors, mask, N, Np,
                        order_out);
     return egnn_launch_status();
 }

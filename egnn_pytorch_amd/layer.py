@@ -47,8 +47,13 @@ _LATE_SELECT = os.environ.get("EGNN_LATE_SELECT", "1") != "0"      # node-level 
 # Inference forwards as ONE call of the C whole-layer entry (egnn_layer_forward_opts_f32: the same kernels in the same order, enqueued from
 # C) instead of a dozen Python-side launches: ~200 us of host time per forward become a few tens.  Only with every scheduling switch
 # above at its default -- the C entry implements the default policy -- and never while per-kernel timing is on.
-_C_FORWARD = (os.environ.get("EGNN_C_FORWARD", "1") != "0" and _SPATIAL_ORDER and _SLOT_PREP and _EDGE_ALGO == 0 and _SHARED_FEATS_IMAGE
-              and _NODE_MLP_FUSED and _ENTRY_FORK and _LATE_SELECT and not _PREFETCH)
+_C_FORWARD = os.environ.get("EGNN_C_FORWARD", "1") != "0"
+
+
+def _default_policy():
+    """every scheduling switch at its default (read at call time: tests flip them on the module)"""
+    return (_SPATIAL_ORDER and _SLOT_PREP and _EDGE_ALGO == 0 and _SHARED_FEATS_IMAGE and _NODE_MLP_FUSED and _ENTRY_FORK and _LATE_SELECT
+            and not _PREFETCH)
 _exact_now = contextvars.ContextVar("egnn_exact_now", default=False)       # per thread / context: concurrent forwards do not see each other's
 _warned_rerun = False
 
@@ -276,7 +281,7 @@ class EGNN(nn.Module):
             return out
         if f_dtype == torch.float64 or c_dtype == torch.float64:
             _warn_float64_once()
-        if (_C_FORWARD and not want_u and not selection and drop_seed is None and presel is None and prefetch is None and f_dtype == torch.float32
+        if (_C_FORWARD and _default_policy() and not want_u and not selection and drop_seed is None and presel is None and prefetch is None and f_dtype == torch.float32
                 and c_dtype == torch.float32 and _ops._timer is None and not self.dropout_active() and not exact_active()):
             out = self._forward_c(feats, coors, edges, mask, adj_mat, order_hint)
             if out is not None:
@@ -361,7 +366,7 @@ class EGNN(nn.Module):
             def select():
                 # (the Morton order launched AHEAD of the selection was measured in round 6: +- 0.3 %, not kept)
                 idx_, rank_ = _ops.knn_select(coors, mask, adj_mat, k, out=(idx_o, rank_o))
-                order_ = (order_hint if have_hint else _ops.spatial_order(coors, out=order_o)) if want_order else None
+                order_ = (order_hint if have_hint else _ops.spatial_order(coors, out=order_o, mask8=mask8)) if want_order else None
                 # the edge pass's setup as one coalesced record per slot instead of a chain of dependent loads
                 slots_ = _ops.slot_prep(coors, mask8, idx_, rank_, order_, valid_radius, out=slots_o) if slots_o is not None else None
                 return idx_, rank_, order_, slots_

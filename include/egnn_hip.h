@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EGNN_ABI_VERSION 36
+#define EGNN_ABI_VERSION 37
 
 enum {
     EGNN_OK = 0,
@@ -99,6 +99,9 @@ int egnn_adj_max_degree_u8(const uint8_t* adj, int64_t rows, int N, int32_t* out
 /* Scheduling aid for egnn_edge_fused_f32 (no reference counterpart): per-graph Morton (Z-order) permutation of
  * the nodes, order_out (B,N) int32.  N <= 4096. */
 int egnn_spatial_order_f32(const float* coors, int B, int N, int32_t* order_out, void* stream);
+/* The same with the padded nodes (mask (B,N) bytes = 0; NULL: none) listed BEHIND the real ones of their graph: padding then fills whole
+ * groups of four consecutive positions, which the wave-per-node edge kernel skips (egnn_slot_prep_f32's bit 30). */
+int egnn_spatial_order_masked_f32(const float* coors, const uint8_t* mask, int B, int N, int32_t* order_out, void* stream);
 
 /* The transposed neighbour list of the backward (autograd of the gather at egnn_pytorch.py:275): the edge ids (b, i, k) -> b N K + i K + k
  * sorted stably by destination node b N + idx[b,i,k] (idx NULL: dense, destination = k, K = N), in two forms:
@@ -118,9 +121,13 @@ int egnn_dest_lists_i32(const int32_t* idx, int B, int N, int K, int32_t* ent, s
  * only the other workgroups of its CU can cover (~0.2 ms of 1.47 at the north-star shape).  This pass does
  * them once per edge slot, in the order the edge pass consumes the slots (position pos of `order`, neighbour k), and leaves one
  * 16-byte record per slot:
- *     slots[(b*N + pos)*K + k] = { j | (pair_ok << 31),  x_i - x_j  (3 floats, the reference's :232 subtraction bit for bit) }
- * with i = order ? order[b,pos] : pos, j = idx[b,i,k], pair_ok = mask ? mask[b,i] && mask[b,j] && (rank ? rank[b,i,k] <= valid_radius : 1) : 1
- * (:292-300).  The edge pass then needs one coalesced load per slot (egnn_edge_args.slots).  slots: B*N*K records of 4 dwords.
+ *     slots[(b*N + pos)*K + k] = { j | (pair_ok << 31) | (group_dead << 30),  x_i - x_j  (3 floats, the reference's :232 subtraction bit for bit) }
+ * with i = order ? order[b,pos] : pos, j = idx[b,i,k] (< 2^30), pair_ok = mask ? mask[b,i] && mask[b,j] && (rank ? rank[b,i,k] <= valid_radius : 1) : 1
+ * (:292-300); group_dead (records with k % 32 == 0 only, 0 elsewhere and without a mask; round 6): the four nodes at positions
+ * 4 ((b*N + pos) / 4) .. + 3 of the consumption order are ALL padding (mask = 0) -- every edge of theirs is masked out, their pooled
+ * messages are exact zeros and their coordinates unchanged whatever the hidden values are, so the wave-per-node edge kernel, whose
+ * workgroup owns exactly those four nodes, skips the round (a single padded node among real ones skips its own hidden loop and keeps
+ * the workgroup's barriers).  The edge pass then needs one coalesced load per slot (egnn_edge_args.slots).  slots: B*N*K records of 4 dwords.
  * idx NULL = the dense all-pairs layer (K == N, j = k): with the records a dense layer with N % 32 == 0 runs the wave-per-node edge kernel. */
 int egnn_slot_prep_f32(const float* coors, const uint8_t* mask, const int32_t* idx, const float* rank, const int32_t* order,
                        float valid_radius, int B, int N, int K, void* slots, void* stream);

@@ -507,7 +507,8 @@ def test_slot_prep_records_bit_exact(b, n, k, use_mask, use_order):
     if mask is not None:
         ok = mask[bi, o][:, :, None] & mask[bi[:, :, None], idx_o] & (rank_o <= radius)
     want_w0 = idx_o.to(torch.int32) | (ok.to(torch.int32) << 31)
-    assert torch.equal(slots[..., 0], want_w0)
+    # (bit 30 = the group flag of padded nodes: test_padded_nodes_last_in_the_order_and_the_group_flag_of_the_slot_records)
+    assert torch.equal(slots[..., 0] & ~(1 << 30), want_w0)
     assert torch.equal(slots[..., 1:].view(torch.float32), rel)
     # the layer with and without the records
     torch.manual_seed(3)
@@ -852,3 +853,54 @@ def test_wave_per_node_kernel_writes_the_same_u_for_the_backward(b, n, k, dim, r
     assert res[0][2] is not None and res[0][2].shape == (b * n * k, 16)
     for x, y in zip(res[0], res[1]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("n,k", [(96, 32), (130, 64), (64, 64)])
+def test_padded_nodes_last_in_the_order_and_the_group_flag_of_the_slot_records(n, k):
+    """egnn_spatial_order_masked_f32: a permutation of each graph's nodes with every real node in front of every padded one (and the
+    unmasked order when there is no mask); egnn_slot_prep_f32: bit 30 exactly on the records with k % 32 == 0 of the nodes whose group
+    of four consecutive positions (over the whole batch) is all padding, bits 31 / j / x_i - x_j as before."""
+    from egnn_pytorch_amd import _ops
+    b = 3
+    g = torch.Generator().manual_seed(n + k)
+    coors = torch.randn(b, n, 3, generator=g).cuda()
+    mask = (torch.rand(b, n, generator=g) < 0.5)
+    mask[1, : n // 2] = True
+    mask[1, n // 2:] = False
+    mask_d = mask.cuda()
+    m8 = _ops._u8(mask_d)
+    plain = _ops.spatial_order(coors).cpu()
+    order = _ops.spatial_order(coors, mask8=m8).cpu()
+    assert torch.equal(_ops.spatial_order(coors, mask8=None).cpu(), plain)
+    for gi in range(b):
+        perm = order[gi].long()
+        assert torch.equal(torch.sort(perm).values, torch.arange(n))
+        real = mask[gi][perm]
+        nreal = int(mask[gi].sum())
+        assert bool(real[:nreal].all()) and not bool(real[nreal:].any())
+        # (within the real nodes and within the padded ones: the Morton order of the unmasked call)
+        pl = plain[gi].long()
+        assert torch.equal(perm[:nreal], pl[mask[gi][pl]]) and torch.equal(perm[nreal:], pl[~mask[gi][pl]])
+    idx, rank = _ops.knn_select(coors, mask_d, None, k)
+    rec = _ops.slot_prep(coors, m8, idx, rank, order.cuda(), float("inf")).cpu().view(b * n, k, 4)
+    rec_nomask = _ops.slot_prep(coors, None, idx, rank, order.cuda(), float("inf")).cpu().view(b * n, k, 4)
+    w0 = rec[..., 0].long() & 0xffffffff
+    node_real = torch.stack([mask[gi][order[gi].long()] for gi in range(b)]).reshape(-1)          # in consumption order
+    dead = ~node_real.view(-1, 4).any(dim=1) if (b * n) % 4 == 0 else None
+    for node in range(b * n):
+        grp = node // 4
+        members = node_real[4 * grp: 4 * grp + 4]
+        want = not bool(members.any())
+        for kk in range(k):
+            flag = (int(w0[node, kk]) >> 30) & 1
+            assert flag == (1 if (want and kk % 32 == 0) else 0), (node, kk)
+    assert not bool(((rec_nomask[..., 0].long() >> 30) & 1).any())
+    assert torch.equal(rec[..., 0].long() & 0x3fffffff, rec_nomask[..., 0].long() & 0x3fffffff)   # j
+    assert torch.equal(rec[..., 1:], rec_nomask[..., 1:])                                          # x_i - x_j
+    ok = (w0 >> 31) & 1
+    i_of = torch.stack([order[gi].long() for gi in range(b)]).reshape(-1)
+    for node in range(0, b * n, 7):
+        gi = node // n
+        ii = int(i_of[node])
+        jj = idx.cpu()[gi, ii].long()
+        assert torch.equal(ok[node].bool(), mask[gi, ii] & mask[gi][jj])

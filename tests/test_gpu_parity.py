@@ -820,3 +820,45 @@ def test_network_without_layers_returns_its_embeddings():
         feats, out_coors = net(tokens, coors)
         want = net.token_emb(tokens) + net.pos_emb(torch.arange(9, device="cuda"))[None]
     assert torch.equal(feats, want) and torch.equal(out_coors, coors)
+
+
+@pytest.mark.parametrize("pattern", ["ragged", "scattered", "one_graph_empty", "few_real", "blocks_of_four"])
+@pytest.mark.parametrize("kwargs", [dict(dim=64, num_nearest_neighbors=32), dict(dim=32, num_nearest_neighbors=64, norm_coors=True, soft_edges=True,
+                                                                               m_pool_method="mean", norm_feats=True)],
+                         ids=["k32", "k64_flags"])
+def test_padded_nodes_are_skipped_without_changing_anything(kwargs, pattern):
+    """The wave-per-node edge kernel skips rounds whose edges are all masked out (padded nodes; whole workgroups when four consecutive
+    positions of the Morton order are padding -- the order lists padded nodes last): the outputs of real AND padded nodes against the
+    oracle (padded rows: node_mlp([LN(h) | 0]) + h and the input coordinates, bit for bit), for masks that are contiguous, scattered,
+    empty for a whole graph, and nearly empty."""
+    b, n, dim = 4, 160, kwargs["dim"]
+    rng = np.random.default_rng(zlib.crc32((pattern + str(dim)).encode()))
+    cfg = O.EGNNConfig(**kwargs)
+    params = O.random_params(cfg, seed=23)
+    feats = rng.standard_normal((b, n, dim)).astype(np.float32)
+    coors = rng.standard_normal((b, n, 3)).astype(np.float32)
+    k = kwargs["num_nearest_neighbors"]
+    if pattern == "ragged":
+        mask = np.arange(n)[None, :] < np.array([n, n - 37, n // 2 + 1, k + 3])[:, None]
+    elif pattern == "scattered":
+        mask = rng.random((b, n)) < 0.6
+    elif pattern == "one_graph_empty":
+        mask = rng.random((b, n)) < 0.8
+        mask[2] = False
+    elif pattern == "few_real":
+        mask = np.zeros((b, n), dtype=bool)
+        for g in range(b):
+            mask[g, rng.choice(n, size=k + 1 + g, replace=False)] = True
+    else:                                                                 # real nodes in aligned blocks of four positions
+        mask = np.repeat(rng.random((b, n // 4)) < 0.5, 4, axis=1)
+    ref_node, ref_co = O.egnn_forward(cfg, params, feats, coors, None, mask, None)
+    net = _module("layer", kwargs, params)
+    node, co = net(_dev(feats), _dev(coors), None, _dev(mask), None)
+    node, co = node.cpu().numpy(), co.cpu().numpy()
+    np.testing.assert_allclose(node, ref_node, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(co, ref_co, atol=ATOL, rtol=0)
+    assert np.array_equal(co[~mask], coors[~mask])                        # padded nodes do not move: the same bits
+    # ... and a padded node's features do not depend on anything but its own row (m_i = 0 exactly): move every other node
+    coors2 = coors + np.where(mask[..., None], rng.standard_normal((b, n, 3)).astype(np.float32), 0).astype(np.float32)
+    node2, _ = net(_dev(feats), _dev(coors2), None, _dev(mask), None)
+    assert np.array_equal(node2.cpu().numpy()[~mask], node[~mask])
