@@ -30,7 +30,7 @@ SYMBOLS = (
     "egnn_edge_bwd_pass_f32", "egnn_edge_bwd_chunk_steps", "egnn_edge_bwd_work_bytes", "egnn_edge_tail_bwd_f32", "egnn_edge_tail_part_floats", "egnn_edge_pool_f32", "egnn_rows_gather_sum_f32", "egnn_edge_features_gather_f32",
     "egnn_induced_attn_f32", "egnn_token_attn_f32", "egnn_slot_prep_f32", "egnn_spatial_order_masked_f32", "egnn_struct_bytes",
     "egnn_dest_lists_capacity", "egnn_dest_lists_i32", "egnn_split_scaled_f16", "egnn_linear_hl_splitk_f32", "egnn_sum_parts_f32", "egnn_absmax_f32", "egnn_unsplit_words_f32", "egnn_split_scaled_both_f16", "egnn_split_scaled_colsum_rows", "egnn_drop_silu_f32", "egnn_drop_silu_f64", "egnn_silu_bwd_f32", "egnn_silu_bwd_drop_f32",
-    "egnn_linear_hl_drop_f32", "egnn_linear_hl_lda_f32",
+    "egnn_linear_hl_drop_f32", "egnn_linear_hl_lda_f32", "egnn_linear_hl_lda_rows_f32", "egnn_edge_pw_covers",
     "egnn_linear_f32", "egnn_node_prep_f32", "egnn_edge_exact_f32", "egnn_edge_exact_workspace_bytes",
     "egnn_knn_select_f64", "egnn_linear_f64", "egnn_node_prep_f64", "egnn_edge_exact_f64",
     "egnn_edge_exact_bwd_f32", "egnn_edge_exact_bwd_f64", "egnn_edge_exact_node_sums_f32", "egnn_edge_exact_node_sums_f64",
@@ -260,6 +260,12 @@ def load():
     lib.egnn_linear_hl_lda_f32.restype = c_int
     lib.egnn_linear_hl_lda_f32.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p,
                                            c_int64, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.egnn_edge_pw_covers.restype = c_int
+    lib.egnn_edge_pw_covers.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64]
+    lib.egnn_linear_hl_lda_rows_f32.restype = c_int
+    lib.egnn_linear_hl_lda_rows_f32.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p,
+                                                c_int64, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                                c_void_p]
     lib.egnn_linear_hl_drop_f32.restype = c_int
     lib.egnn_linear_hl_drop_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p,
                                             c_int64, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int,

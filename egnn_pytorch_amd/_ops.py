@@ -411,10 +411,12 @@ def split_f16(x2d):
 
 
 def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32=True, out_hl=False, name="linear",
-              split_cols=0, drop=None):
+              split_cols=0, drop=None, row_mask=None):
     """act(A @ W.T + bias) (+ residual) with pre-split packed fp16 (hi, lo) operands -- egnn_linear_hl_f32.
     Returns fp32 C, or a PackedHL (padded to 32 columns for the next GEMM) when out_hl, or both.
-    split_cols: columns [0, split_cols) of C hold (fp16 hi, fp16 lo) words instead of fp32 values."""
+    split_cols: columns [0, split_cols) of C hold (fp16 hi, fp16 lo) words instead of fp32 values.
+    row_mask: (M,) bytes -- M-tiles without a set row are skipped, their rows of C stay unwritten (egnn_linear_hl_lda_rows_f32: the
+    projection table of a padded batch, inference only)."""
     whi, wlo, inv, w_rows = wsplit
     m, kp = a.rows, a.kp
     kp_a = 0
@@ -437,7 +439,13 @@ def linear_hl(a: "PackedHL", wsplit, n, bias=None, residual=None, act=0, out_f32
         assert residual.shape == (m, n) and residual.is_contiguous()
         ldr = n
     with _timed(name):
-        if kp_a:
+        if row_mask is not None:
+            assert drop is None and row_mask.numel() == m and row_mask.is_contiguous()
+            rc = _abi.load().egnn_linear_hl_lda_rows_f32(_ptr(a.hi), _ptr(a.lo), kp_a, _ptr(whi), _ptr(wlo), float(inv), _ptr(bias),
+                                                         _ptr(residual), ldr, _ptr(c), n, _ptr(out.hi) if out else None,
+                                                         _ptr(out.lo) if out else None, kp_out, m, n, kp, w_rows, act, int(split_cols),
+                                                         _ptr(row_mask), _status_ptr(dev), _stream())
+        elif kp_a:
             rc = _abi.load().egnn_linear_hl_lda_f32(_ptr(a.hi), _ptr(a.lo), kp_a, _ptr(whi), _ptr(wlo), float(inv), _ptr(bias),
                                                     _ptr(residual), ldr, _ptr(c), n, _ptr(out.hi) if out else None,
                                                     _ptr(out.lo) if out else None, kp_out, m, n, kp, w_rows, act, int(split_cols),

@@ -767,15 +767,25 @@ __global__ __launch_bounds__(PW_THREADS, EGNN_PW_WGS) void edge_pw_kernel(const 
 }  // namespace
 
 // internal (called by egnn_edge_fused_f32's dispatcher, edge_fused.hip): EGNN_E_UNSUPPORTED = "not this kernel's shape, use the general one"
+// 1 when egnn_edge_fused_f32 (algo = 0) runs THIS kernel for a layer of the given shape -- provided it is handed slot records
+// (egnn_slot_prep_f32), a split P_i table (K >= 6) and no training-mode dropout; else the general kernel runs.  Exported: callers that
+// skip the projection rows of padded nodes (egnn_linear_hl_lda_rows_f32) may do so only here -- the general kernel's tiles mix the P_i
+// rows of several nodes in one MFMA operand, where an unwritten (NaN) row would reach the edges of its neighbours in the tile.
+extern "C" int egnn_edge_pw_covers(int B, int N, int K, int S, int fourier, int edge_dim, int m_dim, int coor_dim, int64_t ldp)
+{
+    if (coor_dim != 3 || K < 32 || (K % 32) != 0 || K > 4096) return 0;
+    if (S != 1 || fourier != 0 || edge_dim != 0 || m_dim > 16) return 0;
+    if ((int64_t)B * N * K * 16 > 0xffffffffLL) return 0;                 // slot records behind one 32-bit buffer resource
+    if ((int64_t)N * ldp * 4 > 0xffffffffLL) return 0;
+    return 1;
+}
+
 int egnn_edge_pw_launch(const egnn_edge_args* args, void* stream)
 {
     const egnn_edge_args& a = *args;
-    if (a.coor_dim != 3 || a.K < 32 || (a.K % 32) != 0 || a.K > 4096) return EGNN_E_UNSUPPORTED;
-    if (a.S != 1 || a.fourier != 0 || a.edge_dim != 0 || a.m_dim > 16 || a.wst_terms != 4) return EGNN_E_UNSUPPORTED;
+    if (!egnn_edge_pw_covers(a.B, a.N, a.K, a.S, a.fourier, a.edge_dim, a.m_dim, a.coor_dim, a.ldp) || a.wst_terms != 4) return EGNN_E_UNSUPPORTED;
     if (!a.slots || !a.pi_split || (!a.idx && a.K != a.N)) return EGNN_E_UNSUPPORTED;       // (idx NULL: the dense all-pairs layer, records with j = k)
     if (a.drop_thr) return EGNN_E_UNSUPPORTED;                            // training-mode dropout keeps the general kernel (its MODE 3)
-    if ((int64_t)a.B * a.N * a.K * 16 > 0xffffffffLL) return EGNN_E_UNSUPPORTED;       // slot records behind one 32-bit buffer resource
-    if ((int64_t)a.N * a.ldp * 4 > 0xffffffffLL) return EGNN_E_UNSUPPORTED;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         return (int)hipGetLastError();

@@ -376,14 +376,18 @@ extern "C" int egnn_layer_forward_opts_f32(const egnn_layer_desc* desc, const eg
             EGNN_TRY(egnn_split_f16(feats, dim, rows, dim, ws + w.raw_hi, ws + w.raw_lo, x.kp_dim, status, stream));
         const int pi_split = K >= 6;
         float* proj = reinterpret_cast<float*>(ws + w.proj);
+        // (mask: a padded node's rows of P are read by masked-out edges only -- M-tiles of padded nodes are not computed; only where the
+        // wave-per-node edge kernel runs: egnn_edge_pw_covers)
+        const uint8_t* row_mask = (mask && idx && coor_dim == 3 && pi_split &&
+                                   egnn_edge_pw_covers(B, N, K, x.S, x.F, x.edge_dim, x.m, coor_dim, 2 * (int64_t)x.Hp)) ? mask : nullptr;
         if (shared)
-            EGNN_TRY(egnn_linear_hl_lda_f32(node_hi, node_lo, x.kp_node, blob + info->wcat_hi, blob + info->wcat_lo, info->wcat_inv_scale,
-                                            F(info->bcat), nullptr, 0, proj, 2 * x.Hp, nullptr, nullptr, 0, rows, 2 * x.Hp, x.kp_dim,
-                                            info->wcat_rows, 0, pi_split ? x.Hp : 0, status, stream));
+            EGNN_TRY(egnn_linear_hl_lda_rows_f32(node_hi, node_lo, x.kp_node, blob + info->wcat_hi, blob + info->wcat_lo, info->wcat_inv_scale,
+                                                 F(info->bcat), nullptr, 0, proj, 2 * x.Hp, nullptr, nullptr, 0, rows, 2 * x.Hp, x.kp_dim,
+                                                 info->wcat_rows, 0, pi_split ? x.Hp : 0, row_mask, status, stream));
         else
-            EGNN_TRY(egnn_linear_hl_f32(ws + w.raw_hi, ws + w.raw_lo, blob + info->wcat_hi, blob + info->wcat_lo, info->wcat_inv_scale,
-                                        F(info->bcat), nullptr, 0, proj, 2 * x.Hp, nullptr, nullptr, 0, rows, 2 * x.Hp, x.kp_dim,
-                                        info->wcat_rows, 0, pi_split ? x.Hp : 0, status, stream));
+            EGNN_TRY(egnn_linear_hl_lda_rows_f32(ws + w.raw_hi, ws + w.raw_lo, 0, blob + info->wcat_hi, blob + info->wcat_lo,
+                                                 info->wcat_inv_scale, F(info->bcat), nullptr, 0, proj, 2 * x.Hp, nullptr, nullptr, 0, rows,
+                                                 2 * x.Hp, x.kp_dim, info->wcat_rows, 0, pi_split ? x.Hp : 0, row_mask, status, stream));
         egnn_edge_args a;
         std::memset(&a, 0, sizeof(a));
         a.B = B; a.N = N; a.K = K; a.dim = dim; a.m_dim = x.m; a.H = x.H; a.Hp = x.Hp;

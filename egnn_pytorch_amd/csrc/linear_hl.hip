@@ -27,7 +27,10 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
 // training-mode dropout between the Linear and its activation (egnn_linear_hl_drop_f32); thr = 0: off
-struct DropArgs { uint32_t thr, seed; float inv_keep; };
+struct DropArgs {
+    uint32_t thr, seed; float inv_keep;
+    const uint8_t* row_mask;     // (M) bytes or NULL: an M-tile none of whose rows is set is not computed (egnn_linear_hl_lda_rows_f32)
+};
 
 // Build knobs (tools/variants.py build src=linear_hl ...).  Until round 6 the defaults of ILV and PRIO were defined BELOW the kernel body,
 // which therefore saw them undefined (= 0): the production library ran without either, whatever the comments said.
@@ -140,6 +143,16 @@ __device__ __forceinline__ void linear_hl_body(
     const int tile_n = (v % width) / gsz;
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
+    if (drop.row_mask) {
+        // rows nobody reads: every wave looks at the tile's BM flags and comes to the same answer (no barrier has been passed yet)
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < BM / 64; ++j) {
+            const int64_t row = m0 + lane + 64 * j;
+            any = any || (row < M && drop.row_mask[row] != 0);
+        }
+        if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;
+    }
 
     // ---- LDS-DMA pieces: piece d = wave + WAVES * j (j < DPW) of the list [Ah blocks | Al blocks | Wh blocks | Wl blocks].
     // In the packed layout a (row block, K-tile) piece is 1 KB of contiguous memory that is ALREADY the LDS image
@@ -752,6 +765,19 @@ extern "C" int egnn_linear_hl_lda_f32(const void* A_hi, const void* A_lo, int Kp
 {
     return linear_hl_entry(A_hi, A_lo, W_hi, W_lo, w_inv_scale, bias, residual, ldr, C, ldc, C_hi, C_lo, Kp_out, M, N, Kp, w_rows, act,
                            split_cols, status, stream, DropArgs{0u, 0u, 1.f}, Kp_a);
+}
+
+// ... and with a row mask: M-tiles (128 or 256 rows) none of whose rows has row_mask != 0 are skipped -- their rows of C are NOT written.
+// For the projection table of a padded batch (egnn_pytorch.py:279-287 factorised): a padded node's rows are read by masked-out edges
+// only, whose values the edge pass drops by select (csrc/edge_pw.hip, csrc/edge_fused.hip), never under autograd (the backward
+// differentiates through every edge's u).
+extern "C" int egnn_linear_hl_lda_rows_f32(const void* A_hi, const void* A_lo, int Kp_a, const void* W_hi, const void* W_lo,
+                                           float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
+                                           float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
+                                           int w_rows, int act, int split_cols, const uint8_t* row_mask, int32_t* status, void* stream)
+{
+    return linear_hl_entry(A_hi, A_lo, W_hi, W_lo, w_inv_scale, bias, residual, ldr, C, ldc, C_hi, C_lo, Kp_out, M, N, Kp, w_rows, act,
+                           split_cols, status, stream, DropArgs{0u, 0u, 1.f, row_mask}, Kp_a);
 }
 
 extern "C" int egnn_linear_hl_drop_f32(const void* A_hi, const void* A_lo, const void* W_hi, const void* W_lo,

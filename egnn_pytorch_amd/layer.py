@@ -48,12 +48,13 @@ _LATE_SELECT = os.environ.get("EGNN_LATE_SELECT", "1") != "0"      # node-level 
 # C) instead of a dozen Python-side launches: ~200 us of host time per forward become a few tens.  Only with every scheduling switch
 # above at its default -- the C entry implements the default policy -- and never while per-kernel timing is on.
 _C_FORWARD = os.environ.get("EGNN_C_FORWARD", "1") != "0"
+_PROJ_ROW_MASK = os.environ.get("EGNN_PROJ_ROW_MASK", "1") != "0"     # projection GEMM skips M-tiles of padded nodes (inference)
 
 
 def _default_policy():
     """every scheduling switch at its default (read at call time: tests flip them on the module)"""
     return (_SPATIAL_ORDER and _SLOT_PREP and _EDGE_ALGO == 0 and _SHARED_FEATS_IMAGE and _NODE_MLP_FUSED and _ENTRY_FORK and _LATE_SELECT
-            and not _PREFETCH)
+            and not _PREFETCH and _PROJ_ROW_MASK)
 _exact_now = contextvars.ContextVar("egnn_exact_now", default=False)       # per thread / context: concurrent forwards do not see each other's
 _warned_rerun = False
 
@@ -539,8 +540,15 @@ class EGNN(nn.Module):
                                                           self.m_dim, with_raw=True)
             else:
                 feats_hl = _ops.split_f16(feats2d)
+            # (a padded batch: the rows of padded nodes are read by masked-out edges only -- whole tiles of them are not computed.
+            # Not under autograd: the backward differentiates through every edge)
             proj = _ops.linear_hl(feats_hl, w["Wcat_split"], 2 * hp, w["bcat"], name="node_proj",
-                                  split_cols=hp if pi_split else 0)
+                                  split_cols=hp if pi_split else 0,
+                                  row_mask=mask8.view(-1) if (mask8 is not None and not want_u and drop is None and _PROJ_ROW_MASK
+                                                              and use_nearest and pi_split and _SLOT_PREP and _EDGE_ALGO == 0
+                                                              and _abi.load().egnn_edge_pw_covers(b, n, k, w["S"], self.fourier_features,
+                                                                                                  self.edge_dim, self.m_dim, coors.shape[-1],
+                                                                                                  2 * hp) == 1) else None)
             del feats_hl
             if sel is None:
                 sel = self._select_neighbors(coors, mask, adj_mat, order_hint, fork=fork)

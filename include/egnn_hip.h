@@ -186,6 +186,18 @@ int egnn_linear_hl_lda_f32(const void* A_hi, const void* A_lo, int Kp_a, const v
                            float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
                            float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
                            int w_rows, int act, int split_cols, int32_t* status, void* stream);
+/* The same (Kp_a = 0: a plain A image) with a row mask (round 6): M-tiles -- 128 or 256 consecutive rows -- none of whose rows has
+ * row_mask[row] != 0 are skipped, their rows of C are NOT written.  Made for the projection table of a padded batch: a padded node's rows
+ * are read by masked-out edges only, whose values both edge kernels drop by select; with padding at the end of every graph about a
+ * tile in five is skipped at the parity protocol's ragged masks.  Inference only (the backward differentiates through every edge's u). */
+/* (1 when egnn_edge_fused_f32 runs the wave-per-node kernel for a layer of this shape, given slot records, K >= 6 and no dropout: the
+ * one case in which a caller may hand the projection a row mask -- the general kernel's tiles mix the P_i rows of several nodes in one
+ * MFMA operand, where an unwritten row would reach its tile neighbours' edges.) */
+int egnn_edge_pw_covers(int B, int N, int K, int S, int fourier, int edge_dim, int m_dim, int coor_dim, int64_t ldp);
+int egnn_linear_hl_lda_rows_f32(const void* A_hi, const void* A_lo, int Kp_a, const void* W_hi, const void* W_lo,
+                                float w_inv_scale, const float* bias, const float* residual, int64_t ldr,
+                                float* C, int64_t ldc, void* C_hi, void* C_lo, int Kp_out, int64_t M, int N, int Kp,
+                                int w_rows, int act, int split_cols, const uint8_t* row_mask, int32_t* status, void* stream);
 /* The same with training-mode dropout between the Linear and the activation (node_mlp, egnn_pytorch.py:196-201): element (row, col) of
  * A W^T + bias is kept iff the hash of [seed, site = node, row, col] (csrc/egnn_common.h) is >= drop_thr and multiplied by drop_inv_keep,
  * else zeroed. */

@@ -904,3 +904,43 @@ def test_padded_nodes_last_in_the_order_and_the_group_flag_of_the_slot_records(n
         ii = int(i_of[node])
         jj = idx.cpu()[gi, ii].long()
         assert torch.equal(ok[node].bool(), mask[gi, ii] & mask[gi][jj])
+
+
+def test_projection_gemm_skips_the_tiles_of_padded_rows_only():
+    """egnn_linear_hl_lda_rows_f32: an M-tile is skipped -- its rows of C stay as they were -- exactly when none of its rows is set in the
+    row mask; every other row equals the unmasked product bit for bit (set or not: tiles are computed whole).  And the predicate that says
+    where a caller may use it (egnn_edge_pw_covers) for the BASELINE shapes."""
+    from egnn_pytorch_amd import _abi, _ops, _weights
+    g = torch.Generator().manual_seed(11)
+    m, k, n = 2048 + 70, 64, 384
+    a = torch.randn(m, k, generator=g).cuda()
+    w = (torch.randn(n, k, generator=g) / 8).cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    ws = _weights.split_f16(w)
+    full = _ops.linear_hl(_ops.split_f16(a), ws, n, bias)
+    mask = torch.zeros(m, dtype=torch.uint8)
+    mask[5] = 1                    # one row of the first tile
+    mask[700:900] = 1              # rows across a tile boundary
+    mask[m - 1] = 1                # the ragged last tile
+    got = _ops.linear_hl(_ops.split_f16(a), ws, n, bias, row_mask=mask.cuda())        # (C comes poisoned: tests/conftest.py)
+    torch.cuda.synchronize()
+    written = ~torch.isnan(got).any(dim=1).cpu()
+    assert torch.equal(got[written.cuda()], full[written.cuda()])
+    assert bool(written[mask.bool()].all())                                            # every set row was computed
+    # tiles are 128 or 256 rows: a row is written iff its tile (of either size, whichever the library chose) holds a set row
+    for bm in (128, 256):
+        tiles = torch.zeros((m + bm - 1) // bm, dtype=torch.bool)
+        tiles[torch.nonzero(mask).flatten() // bm] = True
+        if torch.equal(written, tiles.repeat_interleave(bm)[:m]):
+            break
+    else:
+        raise AssertionError("the written rows are not a union of whole M-tiles that hold a set row")
+    assert not bool(written.all())                                                     # (something was skipped)
+    lib = _abi.load()
+    hp = lib.egnn_padded_hidden(2 * (2 * 512 + 1))
+    assert lib.egnn_edge_pw_covers(64, 1024, 32, 1, 0, 0, 16, 3, 2 * hp) == 1          # north star
+    assert lib.egnn_edge_pw_covers(64, 1024, 64, 1, 0, 0, 16, 3, 2 * hp) == 1
+    assert lib.egnn_edge_pw_covers(32, 2048, 3, 5, 0, 4, 16, 3, 2 * hp) == 0           # c4: K = 3, edge features -> the general kernel
+    assert lib.egnn_edge_pw_covers(64, 1024, 32, 1, 0, 0, 16, 5, 2 * hp) == 0          # other coordinate dimensions
+    assert lib.egnn_edge_pw_covers(64, 1024, 32, 1, 0, 0, 32, 3, 2 * hp) == 0          # wide heads
+    assert lib.egnn_edge_pw_covers(64, 1024, 40, 1, 0, 0, 16, 3, 2 * hp) == 0          # K % 32 != 0
