@@ -17,6 +17,9 @@ python bench.py --reference-eager --train-step > $OUT/bench_line.json 2> $OUT/be
 python -c "
 import json; d=json.load(open('$OUT/bench_line.json')); print(d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'], d['cpu_baseline']['value'], d.get('reference_gpu_eager', {}).get('value'), d.get('train_step'))"
 python bench.py --ragged-mask --no-cpu-baseline --no-live-traffic > $OUT/bench_ragged_mask.json 2>> $OUT/bench_line.err
+for w in c3_network c5_shard; do   # padded batches (the parity protocol's ragged masks): what the padded-node skips are worth
+  python bench.py --workload $w --ragged-mask --no-cpu-baseline --no-live-traffic --no-train-step > $OUT/bench_ragged_mask_$w.json 2>> $OUT/bench_line.err
+done
 for w in c2_dense c3_network c4_sparse c5_shard; do
   HG="--hipgraph"; [ $w = c4_sparse ] && HG=""
   python bench.py --workload $w $HG > $OUT/bench_$w.json 2>> $OUT/bench_line.err; head -c 160 $OUT/bench_$w.json; echo
