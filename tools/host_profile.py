@@ -1,6 +1,6 @@
 """Where the host's time goes in one `EGNN.forward` call (north-star shape): cProfile over calls issued back to back with the range check
 deferred (the host never waits for the device), so the totals are pure launch-path cost; then, with the synchronous check, the wall time
-per call against the device time of its kernels.     python tools/host_profile.py [calls=300] [workload=north_star|c3_network|c5_shard|c2_dense]"""
+per call against the device time of its kernels.     python tools/host_profile.py [calls=300] [workload=north_star|c1_tiny|c2_dense|c3_network|c5_shard]"""
 import cProfile
 import os
 import pstats
@@ -18,6 +18,7 @@ calls = int(opts.get("calls", 300))
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 kw, B, N = {"north_star": (dict(dim=512, num_nearest_neighbors=32), 64, 1024), "c2_dense": (dict(dim=512), 8, 256),
+            "c1_tiny": (dict(dim=32), 1, 16),
             "c3_network": (dict(depth=3, dim=128, num_nearest_neighbors=32), 64, 1024),
             "c5_shard": (dict(depth=6, dim=256, num_nearest_neighbors=32, norm_coors=True), 64, 1024)}[opts.get("workload", "north_star")]
 net = "depth" in kw
