@@ -74,6 +74,11 @@ constexpr float DZ_UP = 256.f;               // dz (scaled units, < 2^7) x 2^8 b
 #ifndef EGNN_BWD_LO_MFMA
 #define EGNN_BWD_LO_MFMA 1
 #endif
+#ifndef EGNN_BWD_SKIP_DEAD
+#define EGNN_BWD_SKIP_DEAD 0                 // 1: a wave's round whose 32 entries all carry gU = 0 (padded nodes' edges, list padding) writes zeros and
+                                             // moves on.  Measured (profiles/r06_experiments/padded_nodes.txt): ragged masks -0.25 ms of 13.4, all-true
+                                             // masks +0.3 ms (the branch changes the loop's code) -- off
+#endif
 #ifndef EGNN_BWD_VALU_TILE_SUM
 #define EGNN_BWD_VALU_TILE_SUM 1
 #endif
@@ -348,6 +353,50 @@ __global__ __launch_bounds__(BW_THREADS, ((WANT_W2 && WANT_S) || ((WANT_W2 || WA
 #pragma unroll
             for (int m = 0; m < NM; ++m) bq[t][m] = u32x2{0u, w.sq[((size_t)q * NM + m) * 4 + g]};
         }
+#if EGNN_BWD_SKIP_DEAD
+        {
+            // Every entry of the wave's two tiles has gU = 0 -- the edges of a padded node (mask = 0: their messages reach no output), or
+            // list padding: dz = (W2^T gU) SiLU'(z) is an exact zero whatever z is, and so is everything contracted from it.  The wave
+            // writes the zeros the pass owes for these entries (their partial rows, d/d s) and takes the next round; the waves of a
+            // workgroup meet only after the loop.  A batch of ragged graphs spends a fifth of both passes here.
+            const u32x2 z0 = __builtin_bit_cast(u32x2, guhi[0]), z1 = __builtin_bit_cast(u32x2, guhi[1]);
+            const u32x2 z2 = __builtin_bit_cast(u32x2, gulo[0]), z3 = __builtin_bit_cast(u32x2, gulo[1]);
+            // (sign bits aside: a masked edge's gU is (+0) x SiLU'(u), which is -0 where SiLU' is negative)
+            const uint32_t nz = (z0[0] | z0[1] | z1[0] | z1[1] | z2[0] | z2[1] | z3[0] | z3[1]) & 0x7fff7fffu;
+            if (__builtin_amdgcn_ballot_w64(nz != 0u) == 0ull) {
+                for (int st = 0; st < nst; ++st)
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {
+                        const int col4 = ((st0 + st) * 32 + 16 * hb) * 4;
+                        if constexpr (PAIR) {
+                            buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)q0 >> 5) * row_bytes) + col4, 0.f);
+                        } else {
+                            buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)q0 >> 4) * row_bytes) + col4, 0.f);
+                            buf_store1f(rows_rsrc, hq4, (int)(((uint32_t)(q0 + 16) >> 4) * row_bytes) + col4, 0.f);
+                        }
+                    }
+                if constexpr (WANT_S) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        if constexpr (DSM) {
+                            const int eid = p.ent[q0 + 16 * t + hq];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (eid >= 0 && 4 * g + r < S) p.ds_part[((size_t)chunk * p.E + eid) * S + 4 * g + r] = 0.f;
+                        } else {
+                            const i32x4 e4 = *reinterpret_cast<const i32x4*>(p.ent + q0 + 16 * t + 4 * g);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                for (int c = 0; c < ST; ++c)
+                                    if (hq == 0 && c < S && e4[r] >= 0) p.ds_part[((size_t)chunk * p.E + e4[r]) * S + c] = 0.f;
+                        }
+                    }
+                }
+                continue;
+            }
+        }
+#endif
         // per register r: entry 16 t + 4 g + r (the edges this lane's data registers belong to).  The 16 entries of a tile share
         // their key node (the host pads every node's entries to whole tiles): one own row and one partial row per tile.
         int ownoff[2];                             // byte offset of the tile's own row: wave-uniform, rides in the scalar offset
