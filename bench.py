@@ -224,6 +224,23 @@ def live_clocks(workload, timeout_s=150):
         "/ 8 / dispatch wall time, one child run of this command under rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE"
 
 
+def child_value(args, extra_flags, env_extra=None, timeout_s=120):
+    """`value` of a child run of this command (same workload / steps / warm-up, no CPU baseline, training step or PMC passes) with
+    `extra_flags`: (graphs/s, None) or (None, why not).  For secondary figures of the line; never fatal."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
+           and not k.startswith("TORCHELASTIC")}
+    env.update(EGNN_BENCH_TRAFFIC_CHILD="1", **(env_extra or {}))
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--no-cpu-baseline", "--no-train-step", "--no-live-traffic"] + list(extra_flags)
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s, check=True)
+        return float(json.loads(r.stdout.strip().splitlines()[-1])["value"]), None
+    except Exception as ex:
+        return None, f"{type(ex).__name__}"
+
+
 def unprimed_value(args, timeout_s=120):
     """`value` of a FRESH process that skips the priming steps (EGNN_BENCH_PRIME=0: only the contract's W warm-up steps in front of the
     timed region), as BENCH_r01 ... r04 were taken: a child run of this command without the CPU baseline, the training step and the PMC
@@ -688,6 +705,14 @@ def main():
             out["value_unprimed"] = round(uv, 2) if uv is not None else None
             if uv is None:
                 out["value_unprimed_note"] = f"child run failed: {why}"
+        if (world == 1 and not args.ragged_mask and not args.no_live_traffic and os.environ.get("EGNN_BENCH_TRAFFIC_CHILD") != "1"
+                and not under_profiler and not kwargs.get("only_sparse_neighbors")):
+            # a padded batch (the parity protocol's ragged masks, SURVEY.md section 8d: len ~ U{N/2..N}): the edge pass and the projection
+            # skip the padded nodes.  Secondary figure; `value` is the all-true batch the metric is defined on.
+            rv, why = child_value(args, ["--ragged-mask"])
+            out["value_ragged_masks"] = round(rv, 2) if rv is not None else None
+            if rv is None:
+                out["value_ragged_masks_note"] = f"child run failed: {why}"
         if dist is not None:
             out["process_group"] = {"backend": dist.get_backend(), "world_size": world}
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed at N = 1 only
