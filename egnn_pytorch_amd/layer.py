@@ -218,6 +218,10 @@ class EGNN(nn.Module):
             raise ValueError(f"edges shape {tuple(edges.shape)} != {(b, n, n, self.edge_dim)}")
         if mask is not None and tuple(mask.shape) != (b, n):
             raise ValueError(f"mask shape {tuple(mask.shape)} != {(b, n)}")
+        # the kernels take raw device pointers: a tensor on another device (or on the host) would be read as garbage, not rejected
+        for name, t in (("coors", coors), ("mask", mask), ("adj_mat", adj_mat), ("edges", None if isinstance(edges, EdgeLookup) else edges)):
+            if t is not None and t.device != feats.device:
+                raise RuntimeError(f"Expected all tensors to be on the same device: feats is on {feats.device}, {name} on {t.device}")
 
     def forward(self, feats, coors, edges=None, mask=None, adj_mat=None):
         out = None

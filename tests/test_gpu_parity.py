@@ -862,3 +862,18 @@ def test_padded_nodes_are_skipped_without_changing_anything(kwargs, pattern):
     coors2 = coors + np.where(mask[..., None], rng.standard_normal((b, n, 3)).astype(np.float32), 0).astype(np.float32)
     node2, _ = net(_dev(feats), _dev(coors2), None, _dev(mask), None)
     assert np.array_equal(node2.cpu().numpy()[~mask], node[~mask])
+
+
+def test_inputs_on_another_device_are_rejected_not_read():
+    """The kernels take raw device pointers: a mask / coors / adj_mat / edges tensor left on the host must raise (as torch's own
+    device-mismatch error would upstream), not be dereferenced on the GPU."""
+    from egnn_pytorch_amd import EGNN
+    layer = EGNN(dim=16, num_nearest_neighbors=4).cuda().eval()
+    feats, coors = torch.randn(2, 8, 16).cuda(), torch.randn(2, 8, 3).cuda()
+    mask = torch.ones(2, 8, dtype=torch.bool)
+    for kw in (dict(mask=mask), dict(adj_mat=torch.eye(8, dtype=torch.bool))):
+        with pytest.raises(RuntimeError, match="same device"):
+            layer(feats, coors, **kw)
+    with pytest.raises(RuntimeError, match="same device"):
+        layer(feats, coors.cpu())
+    layer(feats, coors, mask=mask.cuda())
